@@ -814,6 +814,14 @@ void mgo_get_mt(const MgoEnv* e, uint32_t* mt624, int32_t* pos) {
 }
 
 void mgo_set_agent_dir(MgoEnv* e, int32_t k, int32_t dir) { e->adir[k] = ((dir % 4) + 4) % 4; }
+void mgo_set_carrying(MgoEnv* e, int32_t k, int32_t obj) { e->acarry[k] = obj; }
+
+/* test helper: a fresh `_gen_grid` with every agent lifted off the grid (pos None, lists empty);
+ * dir / active / done / carrying are kept.  The caller re-seats agents with mgo_place_agent_at. */
+int32_t mgo_regen_grid(MgoEnv* e, int32_t which_gen) {
+    for (int k = 0; k < e->sh->cfg.n_agents; k++) { e->ag_nagents[k] = 0; e->ax[k] = e->ay[k] = -1; }
+    return gen_grid(e, which_gen);
+}
 
 int32_t mgo_place_agent_at(MgoEnv* e, int32_t k, int32_t x, int32_t y) {
     if (!in_grid(e, x, y)) return MGO_ERR_ASSERT;

@@ -117,9 +117,11 @@ void mgo_occlude(int32_t vs, int32_t ax, int32_t ay, const uint8_t* transp, uint
 void mgo_get_state(const MgoEnv* e, uint8_t* base, int32_t* agents7, int32_t* step_count);
 void mgo_get_mt(const MgoEnv* e, uint32_t* mt624, int32_t* pos);
 void mgo_set_agent_dir(MgoEnv* e, int32_t k, int32_t dir);
+void mgo_set_carrying(MgoEnv* e, int32_t k, int32_t obj);
 /* test helper: overwrite a cell with a non-agent object id (env.put_obj, base.py:655-662) */
 int32_t mgo_put_obj(MgoEnv* e, int32_t obj, int32_t x, int32_t y);
 /* test helper: teleport an (already placed) agent; re-seats stacks like a fresh placement */
+int32_t mgo_regen_grid(MgoEnv* e, int32_t which_gen);
 int32_t mgo_place_agent_at(MgoEnv* e, int32_t k, int32_t x, int32_t y);
 
 /* ---- batch (OpenMP over envs): cpu_baseline leg of bench.py ---- */

@@ -117,6 +117,8 @@ def lib():
         L.mgo_get_state.argtypes = [vp, u8p, i32p, i32p]
         L.mgo_get_mt.argtypes = [vp, u32p, i32p]
         L.mgo_set_agent_dir.argtypes = [vp, C.c_int32, C.c_int32]
+        L.mgo_set_carrying.argtypes = [vp, C.c_int32, C.c_int32]
+        L.mgo_regen_grid.argtypes = [vp, C.c_int32]
         L.mgo_put_obj.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
         L.mgo_place_agent_at.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
         L.mgo_mt_init_by_array.argtypes = [u32p, i32p, u32p, C.c_int32]
@@ -380,6 +382,14 @@ class OracleEnv(object):
 
     def set_dir(self, k, d):
         self.L.mgo_set_agent_dir(self.h, k, d)
+
+    def set_carrying(self, k, obj):
+        self.L.mgo_set_carrying(self.h, k, obj)
+
+    def regen_grid(self):
+        """fresh `_gen_grid` of the reset program with agents lifted off (test scenes only; the
+        caller re-places agents with place_agent_at)."""
+        _raise(self.L.mgo_regen_grid(self.h, 1))
 
     def put_obj(self, obj, x, y):
         _raise(self.L.mgo_put_obj(self.h, obj, x, y))

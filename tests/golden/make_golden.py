@@ -1,0 +1,281 @@
+#!/usr/bin/env python
+"""Generate the golden vectors in tests/golden/*.npz by EXECUTING THE REAL REFERENCE
+(/root/reference, imported through tests/golden/refshim).  Build container only.
+
+    python tests/golden/make_golden.py            # regenerate everything
+
+What is captured (SURVEY.md section 4 fixture plan):
+  atlas.npz      — sprite tiles via MultiGrid.render_tile for ts in {5,8,11,32}
+  rng.npz        — seeded MT19937 states for seeds 1337..1337+63, raw draws, randint / shuffle
+  occlusion.npz  — random transparency grids -> occlude_mask outputs
+  traj_<scenario>.npz — seeded trajectories: actions, shuffle order, canonical state, rewards,
+                        done, grid.encode(), obs (full for 2 seeds, CRC32 for all), final MT state
+  interact.npz   — hand-built pickup / drop / toggle / error scenes
+The reference's arrays are data; no reference source text is stored.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import refload  # noqa: E402
+import refstate  # noqa: E402
+import scenarios  # noqa: E402
+
+TRAJ = {  # scenario -> (n_seeds, n_steps, n_full_obs_seeds)
+    "MarlGrid-2AgentEmpty9x9-v0": (8, 120, 2),
+    "MarlGrid-3AgentCluttered11x11-v0": (12, 150, 2),
+    "MarlGrid-4AgentEmpty9x9-v0": (8, 120, 2),
+    "MarlGrid-3AgentCluttered15x15-v0": (16, 200, 2),
+    "Custom-8AgentCluttered30x30": (4, 80, 1),
+    "MarlGrid-1AgentCluttered15x15-v0": (6, 120, 1),
+    "Goalcycle-demo-solo-v0": (6, 150, 1),
+    "Test-3AgentCluttered11x11-noghost": (8, 150, 1),
+    "Test-4AgentEmpty5x5-crowded": (8, 150, 2),
+    "Test-4AgentEmpty5x5-crowded-noghost": (8, 150, 1),
+    "Test-2AgentCluttered9x9-offset2-ts5": (6, 120, 2),
+    "Test-2AgentEmpty7x7-see-through": (4, 60, 2),
+}
+CANON = ("base_enc", "pos", "dir", "active", "done", "carry_enc", "ordinal")
+
+
+def gen_atlas(m, out):
+    from marlgrid.base import MultiGrid
+    from marlgrid.objects import Wall, Goal, BonusTile, Box, Door, COLORS
+    from marlgrid.agents import GridAgentInterface
+    d = {}
+    colors = [c for c in COLORS if c not in ("prestige", "shadow")]
+    for ts in (5, 8, 11, 32):
+        d["empty_ts%d" % ts] = MultiGrid.render_tile(None, tile_size=ts).astype(np.uint8)
+        d["wall_ts%d" % ts] = MultiGrid.render_tile(Wall(), tile_size=ts).astype(np.uint8)
+        d["goal_ts%d" % ts] = MultiGrid.render_tile(Goal(color="green", reward=1), tile_size=ts).astype(np.uint8)
+        d["bonus_ts%d" % ts] = MultiGrid.render_tile(BonusTile(color="yellow", reward=1), tile_size=ts).astype(np.uint8)
+        d["box_yellow_ts%d" % ts] = MultiGrid.render_tile(Box("yellow"), tile_size=ts).astype(np.uint8)
+        d["door_yellow_open_ts%d" % ts] = MultiGrid.render_tile(Door(color="yellow", state=1), tile_size=ts).astype(np.uint8)
+        d["door_yellow_locked_ts%d" % ts] = MultiGrid.render_tile(Door(color="yellow", state=3), tile_size=ts).astype(np.uint8)
+        sprites = np.zeros((len(colors), 4, ts, ts, 3), np.uint8)
+        blends = np.zeros((len(colors), 4, ts, ts, 3), np.uint8)
+        for ci, c in enumerate(colors):
+            for dr in range(4):
+                a = GridAgentInterface(color=c, view_size=3, view_tile_size=ts)
+                a.activate()
+                a.dir = dr
+                sprites[ci, dr] = MultiGrid.render_tile(a, tile_size=ts)
+                g = Goal(color="green", reward=1)
+                g.agents.append(a)
+                blends[ci, dr] = MultiGrid.render_tile(g, tile_size=ts)
+        d["agent_ts%d" % ts] = sprites
+        d["goal_blend_ts%d" % ts] = blends
+    d["colors"] = np.array(colors)
+    np.savez_compressed(out, **d)
+
+
+def gen_rng(out):
+    from gym.utils import seeding
+    seeds = np.arange(1337, 1337 + 64)
+    keys = np.zeros((64, 624), np.uint32)
+    for i, s in enumerate(seeds):
+        rng, _ = seeding.np_random(int(s))
+        st = rng.get_state()
+        assert st[2] == 624
+        keys[i] = st[1]
+    d = dict(seeds=seeds, mt_key=keys)
+    # raw tempered 32-bit draws + bounded draws for a few seeds
+    raw = np.zeros((4, 2000), np.uint32)
+    for i in range(4):
+        rng, _ = seeding.np_random(int(seeds[i]))
+        raw[i] = rng.randint(0, 2 ** 32, size=2000, dtype=np.uint32)   # one word per draw
+    d["raw_draws"] = raw
+    ri = np.zeros((4, 300, 2), np.int64)
+    sh = np.zeros((4, 300, 8), np.int64)
+    for i in range(4):
+        rng, _ = seeding.np_random(int(seeds[i]))
+        for t in range(300):
+            ri[i, t] = rng.randint((0, 0), (15, 11))
+            x = np.arange(8)
+            rng.shuffle(x)
+            sh[i, t] = x
+    d["randint_0_0_15_11"] = ri
+    d["shuffle8"] = sh
+    # big / special seeds through the hashing path
+    special = np.array([0, 1, 2 ** 31, 2 ** 32 + 5, 1337 * 1337, 2 ** 63 + 11], dtype=np.uint64)
+    sk = np.zeros((len(special), 624), np.uint32)
+    for i, s in enumerate(special):
+        rng, _ = seeding.np_random(int(s))
+        sk[i] = rng.get_state()[1]
+    d["special_seeds"] = special
+    d["special_mt_key"] = sk
+    np.savez_compressed(out, **d)
+
+
+def gen_occlusion(m, out):
+    from marlgrid.agents import occlude_mask
+    rng = np.random.RandomState(7)
+    d = {}
+    for vs in (3, 5, 7, 9, 11):
+        for off in (0, 1, 2):
+            if vs - 1 - off < 0:
+                continue
+            N = 300
+            T = rng.rand(N, vs, vs) < rng.choice([0.5, 0.7, 0.85, 0.95], size=(N, 1, 1))
+            M = np.zeros((N, vs, vs), bool)
+            for i in range(N):
+                M[i] = occlude_mask(T[i].copy(), (vs // 2, vs - 1 - off))
+            d["T_vs%d_off%d" % (vs, off)] = np.packbits(T)
+            d["M_vs%d_off%d" % (vs, off)] = np.packbits(M)
+    np.savez_compressed(out, **d)
+
+
+def gen_traj(name, out):
+    spec = scenarios.registered(name)
+    recipe = scenarios.ref_recipe(name)
+    S, T, F = TRAJ[name]
+    n, W, H = len(spec["agents"]), spec["W"], spec["H"]
+    P = spec["view_size"] * spec["tile_size"]
+    seeds = 1337 + np.arange(S)
+    arng = np.random.RandomState(4242)
+    # mostly navigation, all 7 ids present (pickup/drop/toggle/done are no-ops in these scenes)
+    actions = arng.choice(7, size=(S, T, n), p=[.2, .2, .4, .05, .05, .05, .05]).astype(np.int8)
+    d = dict(seeds=seeds, actions=actions)
+    rec = {k: [] for k in CANON}
+    ctor = {k: [] for k in CANON}
+    rst = {k: [] for k in CANON}
+    rewards = np.zeros((S, T, n), np.float64)
+    ep_done = np.zeros((S, T), bool)
+    reset_after = np.zeros((S, T), bool)
+    order = np.zeros((S, T, n), np.int8)
+    enc = np.zeros((S, T, W, H, 3), np.uint8)
+    crc = np.zeros((S, T, n), np.uint32)
+    crc_reset = np.zeros((S, n), np.uint32)
+    crc_ctor = np.zeros((S, n), np.uint32)
+    obs_full = np.zeros((F, T, n, P, P, 3), np.uint8)
+    obs_reset_full = np.zeros((F, n, P, P, 3), np.uint8)
+    mt_final = np.zeros((S, 624), np.uint32)
+    mt_final_pos = np.zeros(S, np.int32)
+    for si, seed in enumerate(seeds):
+        env = refstate.make_ref_env(spec, recipe, seed=int(seed))
+        c = refstate.canonical(env)
+        for k in CANON:
+            ctor[k].append(c[k])
+        o = env.gen_obs()
+        crc_ctor[si] = [refstate.crc(x) for x in o]
+        o = env.reset()
+        c = refstate.canonical(env)
+        for k in CANON:
+            rst[k].append(c[k])
+        crc_reset[si] = [refstate.crc(x) for x in o]
+        if si < F:
+            obs_reset_full[si] = np.stack(o)
+        spy = refstate.OrderSpy(env.np_random)
+        env.np_random = spy
+        per = {k: [] for k in CANON}
+        for t in range(T):
+            o, r, dn, _ = env.step(actions[si, t])
+            assert all(x.min() >= 0 and x.max() <= 255 for x in o)
+            c = refstate.canonical(env)
+            for k in CANON:
+                per[k].append(c[k])
+            rewards[si, t], ep_done[si, t] = r, dn
+            order[si, t] = spy.last
+            enc[si, t] = env.grid.encode()
+            crc[si, t] = [refstate.crc(x) for x in o]
+            if si < F:
+                obs_full[si, t] = np.stack(o)
+            if dn:
+                env.reset()          # caller-side reset after done (README loop)
+                reset_after[si, t] = True
+        for k in CANON:
+            rec[k].append(np.stack(per[k]))
+        st = spy._rng.get_state()
+        mt_final[si], mt_final_pos[si] = st[1], st[2]
+    for k in CANON:
+        d["step_" + k] = np.stack(rec[k])
+        d["ctor_" + k] = np.stack(ctor[k])
+        d["reset_" + k] = np.stack(rst[k])
+    d.update(rewards=rewards, ep_done=ep_done, reset_after=reset_after, order=order, encode=enc,
+             obs_crc=crc, obs_crc_reset=crc_reset, obs_crc_ctor=crc_ctor, obs_full=obs_full,
+             obs_reset_full=obs_reset_full, mt_final=mt_final, mt_final_pos=mt_final_pos)
+    np.savez_compressed(out, **d)
+
+
+def gen_interact(m, out):
+    """Hand-built pickup/drop/toggle scenes (base.py:587-617 — 'TODO: verify' in the reference).
+    Each scene: EmptyMultiGrid 7x7, 2 agents teleported via a fresh grid + put_obj; scripted
+    actions for agent 0 (agent 1 idles with 'done'); records canonical state + encode + obs CRC
+    per step, or the exception name raised."""
+    from marlgrid.objects import Box, Door, Key
+    spec = scenarios.interact_spec()
+    recipe = ("EmptyMultiGrid", dict(grid_size=7))
+    scenes = scenarios.interact_scenes()
+    d = {}
+    for sname, sc in scenes.items():
+        env = refstate.make_ref_env(spec, recipe, seed=1337)
+        env.reset()
+        # rebuild a deterministic layout: fresh walls+goal grid (EmptyMultiGrid._gen_grid draws
+        # no random numbers), agents at fixed cells facing fixed dirs
+        env._gen_grid(env.width, env.height)
+        for k, (x, y, dr) in enumerate(sc["agents"]):
+            a = env.agents[k]
+            a.agents = []
+            a.pos = None
+            assert env.try_place_obj(a, np.array([x, y]))
+            a.dir = dr
+        mk = {"Box": lambda c, s: Box(c), "Door": lambda c, s: Door(color=c, state=s), "Key": lambda c, s: Key(c)}
+        for (oid, x, y) in sc["objects"]:
+            o = spec["objects"][oid]
+            env.put_obj(mk[o["type"]](o["color"], o.get("state", 0)), x, y)
+        for k, oid in sc.get("carrying", {}).items():
+            o = spec["objects"][oid]
+            env.agents[k].carrying = mk[o["type"]](o["color"], o.get("state", 0))
+        per = {k: [] for k in CANON}
+        encs, crcs, errs, rews = [], [], [], []
+        for t, act in enumerate(sc["actions"]):
+            try:
+                o, r, dn, _ = env.step(act)
+                err = ""
+            except Exception as ex:       # noqa: BLE001 — the exception type is the golden
+                err = type(ex).__name__
+                o, r = None, np.zeros(len(env.agents))
+            errs.append(err)
+            c = refstate.canonical(env)
+            for k in CANON:
+                per[k].append(c[k])
+            encs.append(env.grid.encode())
+            rews.append(np.asarray(r, np.float64))
+            crcs.append([refstate.crc(x) for x in o] if o is not None else [0] * len(env.agents))
+        for k in CANON:
+            d["%s/step_%s" % (sname, k)] = np.stack(per[k])
+        d["%s/encode" % sname] = np.stack(encs)
+        d["%s/obs_crc" % sname] = np.array(crcs, np.uint32)
+        d["%s/error" % sname] = np.array(errs)
+        d["%s/rewards" % sname] = np.stack(rews)
+    np.savez_compressed(out, **d)
+
+
+def main():
+    m = refload.load()
+    which = sys.argv[1:] or ["atlas", "rng", "occlusion", "traj", "interact"]
+    if "atlas" in which:
+        gen_atlas(m, os.path.join(HERE, "atlas.npz"))
+    if "rng" in which:
+        gen_rng(os.path.join(HERE, "rng.npz"))
+    if "occlusion" in which:
+        gen_occlusion(m, os.path.join(HERE, "occlusion.npz"))
+    if "traj" in which:
+        for name in TRAJ:
+            gen_traj(name, os.path.join(HERE, "traj_%s.npz" % name))
+            print("traj", name, flush=True)
+    if "interact" in which:
+        gen_interact(m, os.path.join(HERE, "interact.npz"))
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print("%-60s %8d B" % (f, os.path.getsize(os.path.join(HERE, f))))
+
+
+if __name__ == "__main__":
+    main()

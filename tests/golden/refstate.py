@@ -1,0 +1,74 @@
+"""Reference-side helpers (build container only): construct a reference env for a scenario spec
+and dump its state in the id-free canonical form that the oracle and the HIP path are compared in.
+"""
+import zlib
+
+import numpy as np
+
+import refload
+
+
+def make_ref_env(spec, recipe, seed=1337):
+    m = refload.load()
+    from marlgrid.agents import GridAgentInterface
+    import marlgrid.envs as E
+    cls_name, kwargs = recipe
+    agents = [GridAgentInterface(color=a["color"], view_size=spec["view_size"],
+                                 view_tile_size=spec["tile_size"], view_offset=spec["view_offset"],
+                                 see_through_walls=spec["see_through_walls"])
+              for a in spec["agents"]]
+    kw = dict(kwargs)
+    kw.setdefault("max_steps", spec["max_steps"])
+    kw["seed"] = seed
+    return getattr(E, cls_name)(agents=agents, **kw)
+
+
+def canonical(env):
+    """id-free canonical state of a reference env."""
+    W, H, n = env.width, env.height, len(env.agents)
+    base_enc = np.zeros((W, H, 3), np.uint8)
+    for i in range(W):
+        for j in range(H):
+            o = env.grid.get(i, j)
+            if o is not None and not o.is_agent:
+                base_enc[i, j] = o.encode()
+    pos = np.full((n, 2), -1, np.int16)
+    d = np.zeros(n, np.int8)
+    active = np.zeros(n, bool)
+    done = np.zeros(n, bool)
+    carry = np.zeros((n, 3), np.uint8)
+    ordinal = np.full(n, -1, np.int8)
+    for k, a in enumerate(env.agents):
+        d[k], active[k], done[k] = a.dir, a.active, a.done
+        if a.carrying is not None:
+            carry[k] = a.carrying.encode()
+        if a.pos is not None:
+            pos[k] = a.pos
+            o = env.grid.get(*a.pos)
+            if o is a:
+                ordinal[k] = 0
+            elif o.is_agent:
+                ordinal[k] = 1 + o.agents.index(a)
+            else:
+                ordinal[k] = o.agents.index(a)
+    return dict(base_enc=base_enc, pos=pos, dir=d, active=active, done=done, carry_enc=carry,
+                ordinal=ordinal, step_count=int(env.step_count))
+
+
+class OrderSpy(object):
+    """Proxy around env.np_random recording each shuffled iteration order (base.py:514-516)."""
+
+    def __init__(self, rng):
+        self._rng = rng
+        self.last = None
+
+    def shuffle(self, x):
+        self._rng.shuffle(x)
+        self.last = np.array(x).copy()
+
+    def __getattr__(self, k):
+        return getattr(self._rng, k)
+
+
+def crc(a):
+    return zlib.crc32(np.ascontiguousarray(a, dtype=np.uint8).tobytes()) & 0xFFFFFFFF

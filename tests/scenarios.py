@@ -83,3 +83,97 @@ def registered(name):
             colors=["red", "blue", "purple", "orange", "olive", "pink", "cyan", "yellow"]),
     }
     return table[name]()
+
+
+# ---------------------------------------------------------------------------------------------
+# how to build the same scenario with the *reference* classes (used only where /root/reference
+# exists: golden generation + live-parity tests).  (env_class name, env kwargs); agents are built
+# from spec["agents"] + view_size/tile_size/view_offset.
+# ---------------------------------------------------------------------------------------------
+
+def ref_recipe(name):
+    t = {
+        "MarlGrid-1AgentCluttered15x15-v0": ("ClutteredMultiGrid", dict(grid_size=11, n_clutter=30)),
+        "MarlGrid-3AgentCluttered11x11-v0": ("ClutteredMultiGrid", dict(grid_size=11, clutter_density=0.15)),
+        "MarlGrid-3AgentCluttered15x15-v0": ("ClutteredMultiGrid", dict(grid_size=15, clutter_density=0.15)),
+        "MarlGrid-2AgentEmpty9x9-v0": ("EmptyMultiGrid", dict(grid_size=9)),
+        "MarlGrid-3AgentEmpty9x9-v0": ("EmptyMultiGrid", dict(grid_size=9)),
+        "MarlGrid-4AgentEmpty9x9-v0": ("EmptyMultiGrid", dict(grid_size=9)),
+        "Goalcycle-demo-solo-v0": ("ClutteredGoalCycleEnv", dict(grid_size=13, clutter_density=0.1, n_bonus_tiles=3)),
+        "Custom-8AgentCluttered30x30": ("ClutteredMultiGrid", dict(grid_size=30, clutter_density=0.15)),
+        "Test-3AgentCluttered11x11-noghost": ("ClutteredMultiGrid", dict(grid_size=11, clutter_density=0.15, ghost_mode=False)),
+        "Test-4AgentEmpty5x5-crowded": ("EmptyMultiGrid", dict(grid_size=5)),
+        "Test-4AgentEmpty5x5-crowded-noghost": ("EmptyMultiGrid", dict(grid_size=5, ghost_mode=False)),
+        "Test-2AgentCluttered9x9-offset2-ts5": ("ClutteredMultiGrid", dict(grid_size=9, n_clutter=8, randomize_goal=True)),
+        "Test-2AgentEmpty7x7-see-through": ("EmptyMultiGrid", dict(grid_size=7)),
+    }
+    return t[name]
+
+
+_registered_base = registered
+
+
+def registered(name):   # noqa: F811  (extends the table above with test-only scenarios)
+    extra = {
+        "Test-3AgentCluttered11x11-noghost": lambda: cluttered_spec(3, 11, 7, clutter_density=0.15, ghost_mode=False),
+        "Test-4AgentEmpty5x5-crowded": lambda: empty_spec(4, 5, 5),
+        "Test-4AgentEmpty5x5-crowded-noghost": lambda: empty_spec(4, 5, 5, ghost_mode=False),
+        "Test-2AgentCluttered9x9-offset2-ts5": lambda: cluttered_spec(2, 9, 5, n_clutter=8, randomize_goal=True,
+                                                                        tile_size=5, view_offset=2),
+        "Test-2AgentEmpty7x7-see-through": lambda: empty_spec(2, 7, 3, see_through_walls=True, tile_size=11),
+    }
+    if name in extra:
+        return extra[name]()
+    return _registered_base(name)
+
+
+ALL_SCENARIOS = [
+    "MarlGrid-2AgentEmpty9x9-v0", "MarlGrid-3AgentCluttered11x11-v0", "MarlGrid-4AgentEmpty9x9-v0",
+    "MarlGrid-3AgentCluttered15x15-v0", "Custom-8AgentCluttered30x30",
+    "MarlGrid-1AgentCluttered15x15-v0", "MarlGrid-3AgentEmpty9x9-v0", "Goalcycle-demo-solo-v0",
+    "Test-3AgentCluttered11x11-noghost", "Test-4AgentEmpty5x5-crowded",
+    "Test-4AgentEmpty5x5-crowded-noghost", "Test-2AgentCluttered9x9-offset2-ts5",
+    "Test-2AgentEmpty7x7-see-through",
+]
+
+
+# ---------------------------------------------------------------------------------------------
+# hand-built interaction scenes (pickup / drop / toggle / errors; base.py:587-620)
+# ---------------------------------------------------------------------------------------------
+
+def interact_spec():
+    s = empty_spec(2, 7, 7)
+    s["objects"] = [None, WALL, GOAL,
+                    dict(type="Box", color="yellow", state=0),            # 3
+                    dict(type="Door", color="yellow", state=1),           # 4 open
+                    dict(type="Door", color="yellow", state=2),           # 5 closed
+                    dict(type="Door", color="yellow", state=3),           # 6 locked
+                    dict(type="Key", color="yellow", state=0),            # 7
+                    dict(type="Key", color="red", state=0)]               # 8
+    return s
+
+
+def interact_scenes():
+    """name -> dict(agents=[(x, y, dir)], objects=[(obj_id, x, y)], carrying={agent: obj_id},
+    actions=[[a0, a1], ...]).  Keys / closed doors are kept out of sight where the reference's
+    renderer would crash (objects.py:309,370)."""
+    L, R, F, PICK, DROP, TOG, DONE = 0, 1, 2, 3, 4, 5, 6
+    return {
+        "box_pickup_drop": dict(agents=[(2, 3, 0), (1, 1, 0)], objects=[(3, 3, 3)],
+                                actions=[[F, DONE], [PICK, DONE], [PICK, DONE], [F, DONE], [DROP, DONE],
+                                         [DROP, DONE], [F, DONE], [PICK, L], [R, DONE], [DROP, DONE],
+                                         [L, DONE], [TOG, DONE]]),
+        "door_locked_nokey": dict(agents=[(2, 3, 0), (1, 1, 0)], objects=[(6, 3, 3)],
+                                  actions=[[TOG, DONE], [F, DONE], [PICK, DONE], [TOG, DONE]]),
+        "door_locked_wrongkey": dict(agents=[(2, 3, 0), (1, 1, 0)], objects=[(6, 3, 3)], carrying={0: 8},
+                                     actions=[[TOG, DONE], [F, DONE]]),
+        "door_locked_key": dict(agents=[(2, 3, 0), (1, 1, 0)], objects=[(6, 3, 3)], carrying={0: 7},
+                                actions=[[TOG, DONE], [TOG, DONE], [F, DONE], [TOG, DONE], [F, DONE],
+                                         [L, DONE], [L, DONE], [TOG, DONE]]),
+        "open_door_two_agents": dict(agents=[(2, 3, 0), (3, 2, 1)], objects=[(4, 3, 3)],
+                                     actions=[[F, DONE], [DONE, F], [L, R], [F, DONE], [DONE, F],
+                                              [DONE, DONE]]),
+        "drop_blocked": dict(agents=[(2, 3, 0), (3, 3, 2)], objects=[], carrying={0: 3},
+                             actions=[[DROP, DONE], [L, DONE], [DROP, DONE], [PICK, DONE]]),
+        "bad_action": dict(agents=[(2, 3, 0), (1, 1, 0)], objects=[], actions=[[9, DONE]]),
+    }
