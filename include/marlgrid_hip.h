@@ -1,0 +1,180 @@
+/*
+ * marlgrid_hip.h — C ABI of the MI355X-native batched MarlGrid step engine
+ * (libmarlgrid_hip.so, built from marlgrid_amd/csrc by hipcc --offload-arch=gfx950).
+ *
+ * The reference (kandouss/marlgrid v0.0.5) is pure Python with no FFI; the boundary this library
+ * sits behind is the Python class contract of `MultiGridEnv` (marlgrid/base.py:334-708).  Each
+ * entry point below names the reference method(s) it replaces for a BATCH of B independent envs:
+ *
+ *   mg_mt_seed      MultiGridEnv.seed -> gym.utils.seeding.np_random -> RandomState.seed(list)
+ *                                                                       (base.py:371-374)
+ *   mg_reset        MultiGridEnv.reset + _gen_grid + place_obj/try_place_obj
+ *                                       (base.py:402-416, 664-708; envs/empty.py:9-16,
+ *                                        envs/cluttered.py:25-36, envs/goalcycle.py:30-51)
+ *   mg_step         MultiGridEnv.step action loop, rewards, done  (base.py:501-649)
+ *   mg_render_obs   MultiGridEnv.gen_obs / gen_agent_obs / gen_obs_grid, MultiGrid.slice,
+ *                   MultiGrid.opacity, GridAgentInterface.process_vis / occlude_mask,
+ *                   MultiGrid.render / render_tile / blend_tiles
+ *                                       (base.py:418-474, 123-147, 103-106, 275-331;
+ *                                        agents.py:233-266, 290-343)
+ *   mg_encode       MultiGrid.encode    (base.py:196-214; objects.py:90-99)
+ *   mg_put_obj      MultiGridEnv.put_obj (base.py:655-662)
+ *
+ * Conventions: plain pointers and sizes only (no torch types).  Every buffer is owned by the
+ * caller and lives in device memory (HBM) unless marked HOST; kernels never allocate.  All calls
+ * are asynchronous on `stream` (a hipStream_t passed as void*; NULL = the default stream) and
+ * return 0 or a negative MG_E_* code for argument errors detected on the host.  Per-env runtime
+ * errors (the reference's exceptions) are recorded in MgState.error[b] (first error sticks) and
+ * surfaced by the host wrapper as the matching Python exception.  Re-entrant: no mutable globals.
+ *
+ * HBM layout (struct-of-arrays over the env batch, sized for 288 GB):
+ *   grid        uint8  [B][cells_stride]      object id per cell, index x*H + y (= MultiGrid.grid[i,j]);
+ *                                            cells_stride = W*H rounded up to 16
+ *   agents      uint64 [B][n_agents]          packed record, see MG_AG_* below
+ *   mt          uint32 [B][624] + mt_pos[B]   per-env MT19937 (numpy RandomState stream), *lazy*
+ *                                            form: word mt_pos is the next one to regenerate
+ *   step_count  int32  [B];  done uint8 [B];  error int32 [B]
+ *   obs         uint8  [B][n_agents][P][P][3] with P = view_size*tile_size
+ */
+#ifndef MARLGRID_HIP_H
+#define MARLGRID_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MG_ABI_VERSION 1
+#define MG_MAX_AGENTS 16
+#define MG_MAX_OBJ 64
+#define MG_MAX_GEN 16
+#define MG_MAX_VIEW 15
+#define MG_KEY_WORDS 2
+#define MG_MT_N 624
+
+/* host-side argument errors (return values) */
+#define MG_OK 0
+#define MG_E_ARG (-100)
+#define MG_E_UNSUPPORTED (-101)
+#define MG_E_LAUNCH (-102)
+
+/* per-env runtime errors (MgState.error), mirroring the reference's exceptions */
+#define MG_ERR_VALUE 1     /* ValueError: unknown action               base.py:619-620 */
+#define MG_ERR_RECURSION 2 /* RecursionError: rejection sampling failed base.py:705-706 */
+#define MG_ERR_TYPE 3      /* TypeError: Box.toggle arity               objects.py:381-382 */
+#define MG_ERR_ASSERT 4    /* AssertionError: grid.get out of bounds    base.py:154-156 */
+
+/* packed agent record (uint64, little endian bytes) */
+#define MG_AG_X 0      /* byte 0: x */
+#define MG_AG_Y 1      /* byte 1: y */
+#define MG_AG_DIR 2    /* byte 2: dir 0..3 (agent.state % 4, objects.py:132-142); survives reset */
+#define MG_AG_FLAGS 3  /* byte 3: MG_AF_* */
+#define MG_AG_CARRY 4  /* byte 4: carried object id (0 = None) */
+#define MG_AG_RANK 5   /* byte 5: arrival rank among the env's agents (stack order = rank order) */
+#define MG_AG_BONUS 6  /* byte 6: bonus_state, 0xFF = None (agents.py:169) */
+#define MG_AF_ACTIVE 1
+#define MG_AF_DONE 2
+#define MG_AF_PLACED 4
+
+/* object descriptor flags */
+#define MG_OF_CAN_OVERLAP 1
+#define MG_OF_CAN_PICKUP 2
+#define MG_OF_SEE_BEHIND 4
+#define MG_OF_ENDS_EPISODE 8 /* isinstance(fwd_cell, (Lava, Goal))  base.py:584 */
+#define MG_OF_IS_KEY 16
+#define MG_OF_IS_DOOR 32
+#define MG_OF_IS_BOX 64
+#define MG_OF_DOOR_LOCKED 128
+
+/* one entry per object id (id 0 = None); 32 bytes */
+typedef struct MgObjDesc {
+    uint8_t type_idx, color_idx, state, flags; /* WorldObj.encode + predicates, objects.py:75-99 */
+    uint8_t reward_kind;                       /* 0 none, 1 Goal (constant), 2 BonusTile */
+    uint8_t toggle_next;                       /* Door closed<->open successor id */
+    uint8_t unlock_next;                       /* Door locked->closed successor id */
+    uint8_t ovl_slot;                          /* atlas slot for "object + agent on top", 0xFF none */
+    uint8_t bonus_id, n_bonus, bonus_flags, pad0; /* bonus_flags: 1 initial_reward, 2 reset_on_mistake */
+    uint32_t pad1;
+    double reward;                             /* Goal.reward / BonusTile.reward */
+    double penalty;                            /* BonusTile.penalty */
+} MgObjDesc;
+
+typedef struct MgConfig {
+    int32_t B, W, H, n_agents;
+    int32_t view_size, tile_size, view_offset, see_through_walls; /* agents.py:19-35 (uniform) */
+    int32_t max_steps, reward_decay, ghost_mode, respawn;         /* base.py:341-346 */
+    int32_t cells_stride;                                         /* bytes per env in `grid` */
+    int32_t n_obj;                                                /* valid object ids: 0..n_obj-1 */
+    int32_t n_ovl_slots;                                          /* slot 0 = empty cell */
+    int32_t n_tiles;                                              /* 1 + n_obj + n_ovl_slots*n_agents*4 */
+    int32_t agent_type_idx;                                       /* 13 */
+    int32_t auto_reset;                                           /* reserved */
+    uint8_t agent_color_idx[MG_MAX_AGENTS];
+    const MgObjDesc* obj;   /* device, [n_obj] */
+    const uint8_t* atlas;   /* device, [4 orientations][n_tiles][tile_size*tile_size*3], pre-rotated.
+                             * tile 0 = shadow; 1+o = object o alone (o=0: empty tile);
+                             * 1+n_obj+(slot*n_agents+k)*4+d = slot's object with agent k facing d */
+} MgConfig;
+
+typedef struct MgState {
+    uint8_t* grid;
+    uint64_t* agents;
+    uint32_t* mt;
+    int32_t* mt_pos;
+    int32_t* step_count;
+    uint8_t* done;
+    int32_t* error;
+} MgState;
+
+/* `_gen_grid` as data: a static template (walls / put_obj results) + ordered random placements */
+typedef struct MgGenOp {
+    int32_t obj, count, max_tries;
+} MgGenOp;
+typedef struct MgGenProgram {
+    const uint8_t* template_grid; /* device, [cells_stride] */
+    int32_t n_ops;
+    MgGenOp ops[MG_MAX_GEN];      /* place_obj(obj, max_tries) x count, in order */
+    int32_t agent_max_tries;      /* 100000 (place_obj default 1e5, base.py:690-691) */
+} MgGenProgram;
+
+int32_t mg_abi_version(void);
+const char* mg_error_string(int32_t code);
+
+/* keys: device uint32 [B][MG_KEY_WORDS] (sha512-derived words, host computed), key_len: device
+ * int32 [B] (1 or 2).  Writes mt [B][624] and mt_pos [B] (= 0: first draw regenerates word 0). */
+int32_t mg_mt_seed(int32_t B, const uint32_t* keys, const int32_t* key_len, uint32_t* mt,
+                   int32_t* mt_pos, void* stream);
+
+/* env_mask: device uint8 [B] or NULL (= all); only envs with mask != 0 are reset. */
+int32_t mg_reset(const MgConfig* cfg, const MgState* st, const MgGenProgram* prog,
+                 const uint8_t* env_mask, void* stream);
+
+/* actions: device [B][n_agents], element size `action_bytes` in {1,4,8} (little-endian ints).
+ * rewards: device float32 [B][n_agents].  Sets st->done[b]. */
+int32_t mg_step(const MgConfig* cfg, const MgState* st, const void* actions, int32_t action_bytes,
+                float* rewards, void* stream);
+
+/* obs: device uint8 [B][n][P][P][3].  Optional debug outputs (NULL to skip):
+ * view_cells uint8 [B][n][vs][vs] (object id of the rotated sub-grid, index [i][j]),
+ * view_agent uint8 [B][n][vs][vs] (shown agent index or 0xFF), vis_mask uint8 [B][n][vs][vs]. */
+int32_t mg_render_obs(const MgConfig* cfg, const MgState* st, uint8_t* obs, uint8_t* view_cells,
+                      uint8_t* view_agent, uint8_t* vis_mask, void* stream);
+
+/* out: device uint8 [B][W][H][3]; vis_mask: device uint8 [B][W][H] or NULL. */
+int32_t mg_encode(const MgConfig* cfg, const MgState* st, const uint8_t* vis_mask, uint8_t* out,
+                  void* stream);
+
+/* env_mask as in mg_reset. Replaces whatever is in the cell (base.py:655-662). */
+int32_t mg_put_obj(const MgConfig* cfg, const MgState* st, int32_t obj, int32_t x, int32_t y,
+                   const uint8_t* env_mask, void* stream);
+
+/* timing helper for bench.py: average duration (ms) of `iters` back-to-back mg_render_obs
+ * launches on `stream`, bracketed by HIP events recorded on that same stream. */
+int32_t mg_time_render_obs(const MgConfig* cfg, const MgState* st, uint8_t* obs, int32_t iters,
+                           float* avg_ms, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,102 @@
+"""ctypes binding of libmarlgrid_hip.so (C ABI: include/marlgrid_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or does not load, importing
+this module raises.  Build it with `python -c "import __graft_entry__ as g; g.build()"` or
+`marlgrid_amd/csrc/build.sh`.
+"""
+import ctypes as C
+import os
+
+MAX_AGENTS, MAX_OBJ, MAX_GEN, MAX_VIEW, KEY_WORDS, MT_N = 16, 64, 16, 15, 2, 624
+
+OK = 0
+ERR_VALUE, ERR_RECURSION, ERR_TYPE, ERR_ASSERT = 1, 2, 3, 4
+ERR_EXC = {ERR_VALUE: ValueError, ERR_RECURSION: RecursionError, ERR_TYPE: TypeError,
+           ERR_ASSERT: AssertionError}
+
+AG_X, AG_Y, AG_DIR, AG_FLAGS, AG_CARRY, AG_RANK, AG_BONUS = range(7)
+AF_ACTIVE, AF_DONE, AF_PLACED = 1, 2, 4
+OF_CAN_OVERLAP, OF_CAN_PICKUP, OF_SEE_BEHIND, OF_ENDS_EPISODE = 1, 2, 4, 8
+OF_IS_KEY, OF_IS_DOOR, OF_IS_BOX, OF_DOOR_LOCKED = 16, 32, 64, 128
+
+
+class ObjDesc(C.Structure):
+    _fields_ = [("type_idx", C.c_uint8), ("color_idx", C.c_uint8), ("state", C.c_uint8), ("flags", C.c_uint8),
+                ("reward_kind", C.c_uint8), ("toggle_next", C.c_uint8), ("unlock_next", C.c_uint8),
+                ("ovl_slot", C.c_uint8),
+                ("bonus_id", C.c_uint8), ("n_bonus", C.c_uint8), ("bonus_flags", C.c_uint8), ("pad0", C.c_uint8),
+                ("pad1", C.c_uint32), ("reward", C.c_double), ("penalty", C.c_double)]
+
+
+assert C.sizeof(ObjDesc) == 32
+
+
+class Config(C.Structure):
+    _fields_ = [("B", C.c_int32), ("W", C.c_int32), ("H", C.c_int32), ("n_agents", C.c_int32),
+                ("view_size", C.c_int32), ("tile_size", C.c_int32), ("view_offset", C.c_int32),
+                ("see_through_walls", C.c_int32),
+                ("max_steps", C.c_int32), ("reward_decay", C.c_int32), ("ghost_mode", C.c_int32),
+                ("respawn", C.c_int32),
+                ("cells_stride", C.c_int32), ("n_obj", C.c_int32), ("n_ovl_slots", C.c_int32),
+                ("n_tiles", C.c_int32), ("agent_type_idx", C.c_int32), ("auto_reset", C.c_int32),
+                ("agent_color_idx", C.c_uint8 * MAX_AGENTS),
+                ("obj", C.c_void_p), ("atlas", C.c_void_p)]
+
+
+class State(C.Structure):
+    _fields_ = [("grid", C.c_void_p), ("agents", C.c_void_p), ("mt", C.c_void_p), ("mt_pos", C.c_void_p),
+                ("step_count", C.c_void_p), ("done", C.c_void_p), ("error", C.c_void_p)]
+
+
+class GenOp(C.Structure):
+    _fields_ = [("obj", C.c_int32), ("count", C.c_int32), ("max_tries", C.c_int32)]
+
+
+class GenProgram(C.Structure):
+    _fields_ = [("template_grid", C.c_void_p), ("n_ops", C.c_int32), ("ops", GenOp * MAX_GEN),
+                ("agent_max_tries", C.c_int32)]
+
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmarlgrid_hip.so")
+
+# every symbol include/marlgrid_hip.h declares
+SYMBOLS = ["mg_abi_version", "mg_error_string", "mg_mt_seed", "mg_reset", "mg_step", "mg_render_obs",
+           "mg_encode", "mg_put_obj", "mg_time_render_obs"]
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library (after torch, so that the HIP runtime torch ships is the one bound)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  — loads libamdhip64 first; our .so resolves against the same runtime
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("marlgrid_amd: %s is missing — build it (marlgrid_amd/csrc/build.sh); there is "
+                          "no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32 = C.c_void_p, C.c_int32
+    L.mg_abi_version.restype = i32
+    L.mg_error_string.restype = C.c_char_p
+    L.mg_error_string.argtypes = [i32]
+    L.mg_mt_seed.argtypes = [i32, vp, vp, vp, vp, vp]
+    L.mg_reset.argtypes = [C.POINTER(Config), C.POINTER(State), C.POINTER(GenProgram), vp, vp]
+    L.mg_step.argtypes = [C.POINTER(Config), C.POINTER(State), vp, i32, vp, vp]
+    L.mg_render_obs.argtypes = [C.POINTER(Config), C.POINTER(State), vp, vp, vp, vp, vp]
+    L.mg_encode.argtypes = [C.POINTER(Config), C.POINTER(State), vp, vp, vp]
+    L.mg_put_obj.argtypes = [C.POINTER(Config), C.POINTER(State), i32, i32, i32, vp, vp]
+    L.mg_time_render_obs.argtypes = [C.POINTER(Config), C.POINTER(State), vp, i32, C.POINTER(C.c_float), vp]
+    for f in SYMBOLS:
+        getattr(L, f)
+        if f not in ("mg_error_string",):
+            getattr(L, f).restype = i32
+    if L.mg_abi_version() != 1:
+        raise ImportError("marlgrid_amd: ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("libmarlgrid_hip: %s (%d)" % (lib().mg_error_string(rc).decode(), rc))

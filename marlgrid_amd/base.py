@@ -1,0 +1,713 @@
+"""Batched multi-agent gridworld: the gym-style `MultiGridEnv.reset()/step()` surface of
+kandouss/marlgrid (`marlgrid/base.py:334-708`) with a leading env-batch dimension B, the state in
+HBM and every per-step operation a hand-written HIP kernel (libmarlgrid_hip.so, C ABI in
+include/marlgrid_hip.h).  This module is host-side plumbing only: argument handling, the
+`_gen_grid` recorder, table/atlas upload and kernel launches on torch's current stream.  There is
+no CPU fallback.
+
+State layout (all torch tensors on one MI355X; struct-of-arrays over B):
+    grid_state   uint8  (B, cells_stride)   object id per cell, index x*H + y  (MultiGrid.grid[i, j])
+    agent_state  int64  (B, n)              packed 8-byte agent records (MG_AG_* in the C header)
+    mt_state     int32  (B, 624) + mt_pos   per-env MT19937, numpy RandomState stream
+    step_count   int32  (B,), done uint8 (B,), error int32 (B,)
+    obs          uint8  (B, n, P, P, 3),   rewards float32 (B, n)
+
+Differences from the reference that the batch forces (documented in DESIGN.md):
+  * obs / rewards / done are tensors with a leading B (the reference returns a list of n arrays,
+    a float64 ndarray and a bool); obs values are identical, dtype is uint8 as the declared
+    observation space says (the reference actually returns int64 arrays, base.py:305);
+  * `_gen_grid` is *recorded* once per reset (walls / put_obj -> static template, place_obj ->
+    ordered rejection-sampling program) and replayed on the device for every env with that env's
+    own RNG, so scenario subclasses written against the reference API keep working as long as
+    their layout logic does not branch on random draws in Python;
+  * per-env runtime errors (the reference's exceptions) are collected in `error` and raised as the
+    matching Python exception after the step (strict=True) or on `check_errors()`.
+"""
+import ctypes as C
+import threading
+
+import numpy as np
+
+from . import _native as N
+from . import rendering, seeding, spaces
+from .agents import GridAgentInterface
+from .objects import COLOR_TO_IDX, OBJECT_TYPES, BonusTile, Box, Door, Goal, Key, Wall, WorldObj
+
+TILE_PIXELS = 32
+
+_trace = threading.local()
+
+
+class ObjectRegistry(object):
+    """object kind <-> uint8 id (the reference keeps instance <-> key maps per grid,
+    base.py:19-64; here ids index the device object table and are stable for the env's life)."""
+
+    def __init__(self, max_num_objects=N.MAX_OBJ):
+        self.objs = [None]
+        self.key_to_id = {}
+        self.max_num_objects = max_num_objects
+        self.version = 0
+
+    def __len__(self):
+        return len(self.objs)
+
+    def get_key(self, obj):
+        if obj is None:
+            return 0
+        if not isinstance(obj, WorldObj) or obj.is_agent:
+            raise ValueError("only non-agent WorldObj instances can be put in the grid")
+        k = obj.key()
+        if k in self.key_to_id:
+            return self.key_to_id[k]
+        if len(self.objs) >= self.max_num_objects:
+            raise ValueError("Object registry full.")
+        self.objs.append(obj)
+        self.key_to_id[k] = len(self.objs) - 1
+        self.version += 1
+        for r in obj.related():
+            self.get_key(r)
+        return self.key_to_id[k]
+
+    def obj_of_key(self, key):
+        return self.objs[int(key)]
+
+    def find(self, obj):
+        return self.key_to_id.get(obj.key(), 0)
+
+
+class MultiGrid(object):
+    """The grid container (base.py:83-331).  Constructed inside `_gen_grid`, where it records the
+    static part of the layout; afterwards it is a view on the env's HBM grid."""
+
+    def __init__(self, shape, obj_reg=None, orientation=0):
+        env = getattr(_trace, "env", None)
+        if env is None:
+            raise RuntimeError("MultiGrid(...) is constructed inside MultiGridEnv._gen_grid")
+        if not isinstance(shape, tuple):
+            raise ValueError("Must create grid from shape tuple.")
+        self.width, self.height = shape
+        if self.width < 3 or self.height < 3:
+            raise ValueError("Grid needs width, height >= 3")
+        if (self.width, self.height) != (env.width, env.height):
+            raise ValueError("_gen_grid must build a grid of the env's own (width, height)")
+        self.orientation = orientation
+        self._env = env
+        self.obj_reg = env.obj_reg
+        self._template = np.zeros((self.width, self.height), np.uint8)
+        env._tr_begin(self)
+
+    # ---- layout recording / live edits --------------------------------------------------------
+    def set(self, i, j, obj):
+        assert i >= 0 and i < self.width
+        assert j >= 0 and j < self.height
+        env = self._env
+        if env._tracing:
+            env._tr_static(("put", self.obj_reg.get_key(obj), int(i), int(j)))
+            self._template[i, j] = self.obj_reg.get_key(obj)
+        else:
+            env.put_obj(obj, i, j)
+
+    def horz_wall(self, x, y, length=None, obj_type=Wall):
+        if length is None:
+            length = self.width - x
+        self._wall(("horz_wall", int(x), int(y), int(length)), [(x + i, y) for i in range(length)], obj_type)
+
+    def vert_wall(self, x, y, length=None, obj_type=Wall):
+        if length is None:
+            length = self.height - y
+        self._wall(("vert_wall", int(x), int(y), int(length)), [(x, y + j) for j in range(length)], obj_type)
+
+    def wall_rect(self, x, y, w, h, obj_type=Wall):
+        cells = ([(x + i, y) for i in range(w)] + [(x + i, y + h - 1) for i in range(w)]
+                 + [(x, y + j) for j in range(h)] + [(x + w - 1, y + j) for j in range(h)])
+        self._wall(("wall_rect", int(x), int(y), int(w), int(h)), cells, obj_type)
+
+    def _wall(self, sym, cells, obj_type):
+        env = self._env
+        if obj_type is Wall and env._tracing:
+            key = self.obj_reg.get_key(Wall())
+            env._tr_static(sym)
+            for (i, j) in cells:
+                assert 0 <= i < self.width and 0 <= j < self.height
+                self._template[i, j] = key
+        else:
+            for (i, j) in cells:
+                self.set(i, j, obj_type())
+
+    # ---- live views -----------------------------------------------------------------------------
+    @property
+    def grid(self):
+        """(B, W, H) uint8 object ids (live HBM view)"""
+        e = self._env
+        return e.grid_state[:, :e.width * e.height].view(e.batch_size, e.width, e.height)
+
+    def get(self, i, j, env=0):
+        """the non-agent object kind in cell (i, j) of env `env` (host sync; debugging aid)"""
+        assert i >= 0 and i < self.width
+        assert j >= 0 and j < self.height
+        return self.obj_reg.obj_of_key(int(self.grid[env, i, j].item()))
+
+    def encode(self, vis_mask=None):
+        """(B, W, H, 3) uint8 — batched MultiGrid.encode (base.py:196-214)"""
+        return self._env._encode(vis_mask)
+
+    @classmethod
+    def decode(cls, array):
+        raise NotImplementedError      # as upstream (base.py:216-218)
+
+
+class MultiGridEnv(object):
+    """See module docstring.  Constructor keeps the reference's kwargs (base.py:335-347) and adds
+    `batch_size`, `device`, `seeds`, `auto_reset`, `strict`."""
+
+    metadata = {}
+
+    def __init__(self, agents=[], grid_size=None, width=None, height=None, max_steps=100,
+                 reward_decay=True, seed=1337, respawn=False, ghost_mode=True, agent_spawn_kwargs={},
+                 batch_size=1, device=None, seeds=None, auto_reset=False, strict=True, _dry=False):
+        if grid_size is not None:
+            assert width is None and height is None
+            width, height = grid_size, grid_size
+        self.respawn = respawn
+        self.window = None
+        self.width, self.height = int(width), int(height)
+        self.max_steps = int(max_steps)
+        self.reward_decay = reward_decay
+        self.agent_spawn_kwargs = agent_spawn_kwargs
+        self.ghost_mode = ghost_mode
+        self.batch_size = int(batch_size)
+        self.auto_reset = bool(auto_reset)
+        self.strict = bool(strict)
+        self._dry = bool(_dry)
+        if self.batch_size < 1:
+            raise ValueError("batch_size must be >= 1")
+        if self.width > 255 or self.height > 255:
+            raise ValueError("grid dimensions are limited to 255")
+
+        self.agents = []
+        for agent in agents:
+            self.add_agent(agent)
+        self._check_agents()
+
+        self.obj_reg = ObjectRegistry()
+        self._tables_version = -1
+        self._tracing = False
+        self._prog_cache = {}
+        self._spec_ctor = None
+        self._spec_last = None
+        self.grid = None
+
+        if not self._dry:
+            import torch
+            if not torch.cuda.is_available():
+                raise RuntimeError("marlgrid_amd needs an MI355X (HIP device): there is no CPU fallback")
+            self.device = torch.device(device if device is not None else "cuda")
+            if self.device.type != "cuda":
+                raise RuntimeError("marlgrid_amd runs on HIP devices only (got %r)" % (device,))
+            if self.device.index is None:
+                self.device = torch.device("cuda", torch.cuda.current_device())
+            self._lib = N.lib()
+            self._alloc_state()
+        self._seeds_arg = seeds
+        self.seed(seed=seed)
+        self.reset()
+        self._spec_ctor = self._spec_last     # the constructor-time `_gen_grid` (base.py:369)
+        self._retrace = True
+
+    # ---- configuration ----------------------------------------------------------------------------
+    def add_agent(self, agent_interface):
+        if isinstance(agent_interface, dict):
+            self.agents.append(GridAgentInterface(**agent_interface))
+        elif isinstance(agent_interface, GridAgentInterface):
+            self.agents.append(agent_interface)
+        else:
+            raise ValueError(
+                "To add an agent to a marlgrid environment, call add_agent with either a "
+                "GridAgentInterface object or a dictionary that can be used to initialize one.")
+
+    def _check_agents(self):
+        n = len(self.agents)
+        if n < 1 or n > N.MAX_AGENTS:
+            raise ValueError("the batched engine supports 1..%d agents (got %d)" % (N.MAX_AGENTS, n))
+        a0 = self.agents[0]
+        for a in self.agents:
+            if (a.view_size, a.view_tile_size, a.view_offset, a.see_through_walls) != (
+                    a0.view_size, a0.view_tile_size, a0.view_offset, a0.see_through_walls):
+                raise NotImplementedError("all agents must share view_size / view_tile_size / view_offset / "
+                                          "see_through_walls (one (B, n, P, P, 3) observation tensor)")
+            if a.spawn_delay != 0:
+                raise NotImplementedError("spawn_delay > 0 is not supported by the batched engine")
+            if a.color == "prestige":
+                raise NotImplementedError("the data-dependent 'prestige' colour is not supported")
+            if len(a.hide_item_types) > 0:
+                raise NotImplementedError("hide_item_types is not supported")
+        if a0.view_size % 2 == 0 or a0.view_size > N.MAX_VIEW:
+            raise NotImplementedError("view_size must be odd and <= %d" % N.MAX_VIEW)
+        if not (0 <= a0.view_offset < a0.view_size):
+            raise ValueError("view_offset out of range")
+        self.view_size, self.tile_size = a0.view_size, a0.view_tile_size
+        self.view_offset, self.see_through_walls = a0.view_offset, a0.see_through_walls
+        self.obs_pixels = self.view_size * self.tile_size
+
+    @property
+    def num_agents(self):
+        return len(self.agents)
+
+    @property
+    def action_space(self):
+        return spaces.Tuple([agent.action_space for agent in self.agents])
+
+    @property
+    def observation_space(self):
+        return spaces.Tuple([agent.observation_space for agent in self.agents])
+
+    # ---- device state -------------------------------------------------------------------------------
+    def _alloc_state(self):
+        import torch
+        B, n, dev = self.batch_size, self.num_agents, self.device
+        self.cells_stride = (self.width * self.height + 15) // 16 * 16
+        P = self.obs_pixels
+        with torch.cuda.device(dev):
+            self.grid_state = torch.zeros((B, self.cells_stride), dtype=torch.uint8, device=dev)
+            self.agent_state = torch.zeros((B, n), dtype=torch.int64, device=dev)
+            self.mt_state = torch.zeros((B, N.MT_N), dtype=torch.int32, device=dev)
+            self.mt_pos = torch.zeros((B,), dtype=torch.int32, device=dev)
+            self.step_count_t = torch.zeros((B,), dtype=torch.int32, device=dev)
+            self.done_t = torch.zeros((B,), dtype=torch.uint8, device=dev)
+            self.error_t = torch.zeros((B,), dtype=torch.int32, device=dev)
+            self.obs = torch.zeros((B, n, P, P, 3), dtype=torch.uint8, device=dev)
+            self.rewards = torch.zeros((B, n), dtype=torch.float32, device=dev)
+        self._state = N.State(self.grid_state.data_ptr(), self.agent_state.data_ptr(), self.mt_state.data_ptr(),
+                              self.mt_pos.data_ptr(), self.step_count_t.data_ptr(), self.done_t.data_ptr(),
+                              self.error_t.data_ptr())
+
+    def _stream(self):
+        import torch
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def seed(self, seed=1337):
+        """Seed every env's RNG (base.py:371-374).  Env b gets `seed + b` unless explicit per-env
+        `seeds` were given to the constructor."""
+        if self._seeds_arg is not None:
+            seeds = [int(s) for s in np.asarray(self._seeds_arg).reshape(-1)]
+            if len(seeds) != self.batch_size:
+                raise ValueError("seeds must have batch_size entries")
+        else:
+            seeds = [int(seed) + b for b in range(self.batch_size)]
+        self.seeds = seeds
+        if not self._dry:
+            import torch
+            keys, lens = seeding.batch_keys(seeds)
+            k = torch.from_numpy(keys.view(np.int32)).to(self.device)
+            kl = torch.from_numpy(lens).to(self.device)
+            N.check(self._lib.mg_mt_seed(self.batch_size, k.data_ptr(), kl.data_ptr(), self.mt_state.data_ptr(),
+                                         self.mt_pos.data_ptr(), self._stream()))
+            torch.cuda.current_stream(self.device).synchronize()    # k / kl die here
+        return [seed]
+
+    # ---- `_gen_grid` recording ----------------------------------------------------------------------
+    def _gen_grid(self, width, height):
+        raise NotImplementedError("subclasses build self.grid here (see marlgrid_amd/envs)")
+
+    def _tr_begin(self, grid):
+        if not self._tracing:
+            raise RuntimeError("MultiGrid(...) is constructed inside _gen_grid")
+        self._tr_grid = grid
+        self._tr_sym = []
+        self._tr_ops = []
+
+    def _tr_static(self, sym):
+        if self._tr_ops:
+            raise NotImplementedError("static layout edits after a random place_obj are not supported: "
+                                      "put walls / fixed objects first")
+        self._tr_sym.append(sym)
+
+    def _trace_gen_grid(self):
+        self._tracing = True
+        self._tr_grid = None
+        _trace.env = self
+        try:
+            self._gen_grid(self.width, self.height)
+        finally:
+            _trace.env = None
+            self._tracing = False
+        g = self._tr_grid
+        if g is None or self.grid is not g:
+            raise RuntimeError("_gen_grid must assign self.grid = MultiGrid((width, height))")
+        if len(self._tr_ops) > N.MAX_GEN:
+            raise NotImplementedError("more than %d placement groups in _gen_grid" % N.MAX_GEN)
+        self._spec_last = dict(sym=list(self._tr_sym), ops=list(self._tr_ops))
+        return g._template, list(self._tr_ops)
+
+    def put_obj(self, obj, i, j, env_mask=None):
+        """Put an object at a specific position, replacing what is there (base.py:655-662)."""
+        if self._tracing:
+            self._tr_grid.set(i, j, obj)
+            return True
+        assert 0 <= i < self.width and 0 <= j < self.height
+        key = self.obj_reg.get_key(obj)
+        if not self._dry:
+            self._sync_tables()
+            N.check(self._lib.mg_put_obj(C.byref(self._cfg), C.byref(self._state), key, int(i), int(j),
+                                         self._mask_ptr(env_mask), self._stream()))
+        return True
+
+    def place_obj(self, obj, top=None, size=None, reject_fn=None, max_tries=1e5):
+        """Rejection-sample a free cell for `obj` (base.py:690-708).  Inside `_gen_grid` this records
+        one placement; the draw happens on the device, per env."""
+        if not self._tracing:
+            raise NotImplementedError("place_obj outside _gen_grid is not supported by the batched engine")
+        if isinstance(obj, GridAgentInterface):
+            raise NotImplementedError("agents are placed by reset() itself")
+        if reject_fn is not None or (top not in (None, (0, 0))) or size is not None:
+            raise NotImplementedError("place_obj(top=, size=, reject_fn=) is not supported")
+        max_tries = int(max(1, min(max_tries, 1e5)))
+        key = self.obj_reg.get_key(obj)
+        if self._tr_ops and self._tr_ops[-1][0] == key and self._tr_ops[-1][2] == max_tries:
+            self._tr_ops[-1] = (key, self._tr_ops[-1][1] + 1, max_tries)
+        else:
+            self._tr_ops.append((key, 1, max_tries))
+        return None
+
+    def try_place_obj(self, obj, pos):
+        raise NotImplementedError("try_place_obj is folded into the device reset / place kernels")
+
+    def place_agents(self, top=None, size=None, rand_dir=True, max_tries=1000):
+        pass    # deprecated no-op upstream as well (base.py:710-712)
+
+    # ---- tables: object descriptors + atlas -----------------------------------------------------------
+    def _obj_table(self):
+        objs = self.obj_reg.objs
+        tab = (N.ObjDesc * len(objs))()
+        for i, o in enumerate(objs):
+            if o is None:
+                continue
+            d = tab[i]
+            t, c, s = o.encode()
+            d.type_idx, d.color_idx, d.state = t, c, s
+            f = 0
+            f |= N.OF_CAN_OVERLAP if o.can_overlap() else 0
+            f |= N.OF_CAN_PICKUP if o.can_pickup() else 0
+            f |= N.OF_SEE_BEHIND if o.see_behind() else 0
+            f |= N.OF_ENDS_EPISODE if o.ends_episode else 0
+            f |= N.OF_IS_KEY if isinstance(o, Key) else 0
+            f |= N.OF_IS_BOX if isinstance(o, Box) else 0
+            if isinstance(o, Door):
+                f |= N.OF_IS_DOOR
+                if o.state == Door.LOCKED:
+                    f |= N.OF_DOOR_LOCKED
+                d.unlock_next = self.obj_reg.find(Door(o.color, Door.CLOSED))
+                d.toggle_next = self.obj_reg.find(Door(o.color, Door.OPEN if o.state == Door.CLOSED else Door.CLOSED))
+            d.flags = f
+            if isinstance(o, Goal):
+                d.reward_kind, d.reward = 1, float(o.reward)
+            elif isinstance(o, BonusTile):
+                d.reward_kind, d.reward, d.penalty = 2, float(o.reward), float(o.penalty)
+                d.bonus_id, d.n_bonus = o.bonus_id, o.n_bonus
+                d.bonus_flags = (1 if o.initial_reward else 0) | (2 if o.reset_on_mistake else 0)
+        return tab
+
+    def _sync_tables(self):
+        if self._dry or self._tables_version == self.obj_reg.version:
+            return
+        import torch
+        objs = self.obj_reg.objs
+        atlas, ovl_slot, n_slots = rendering.build_atlas(objs, [a.color for a in self.agents], self.tile_size)
+        tab = self._obj_table()
+        for i in range(len(objs)):
+            tab[i].ovl_slot = ovl_slot[i]
+        raw = np.frombuffer(bytes(tab), dtype=np.uint8).copy()
+        flat = atlas.reshape(-1)
+        pad = (-flat.size) % 16
+        flat = np.concatenate([flat, np.zeros(pad + 16, np.uint8)])
+        self._obj_dev = torch.from_numpy(raw).to(self.device)
+        self._atlas_dev = torch.from_numpy(flat).to(self.device)
+        self.atlas = atlas
+        cfg = N.Config()
+        cfg.B, cfg.W, cfg.H, cfg.n_agents = self.batch_size, self.width, self.height, self.num_agents
+        cfg.view_size, cfg.tile_size = self.view_size, self.tile_size
+        cfg.view_offset, cfg.see_through_walls = self.view_offset, int(self.see_through_walls)
+        cfg.max_steps, cfg.reward_decay = self.max_steps, int(bool(self.reward_decay))
+        cfg.ghost_mode = int(self.ghost_mode is not False)        # base.py:541 `is False`
+        cfg.respawn = int(bool(self.respawn))
+        cfg.cells_stride = self.cells_stride
+        cfg.n_obj, cfg.n_ovl_slots, cfg.n_tiles = len(objs), n_slots, atlas.shape[1]
+        cfg.agent_type_idx = OBJECT_TYPES.index(GridAgentInterface)
+        cfg.auto_reset = int(self.auto_reset)
+        for k, a in enumerate(self.agents):
+            cfg.agent_color_idx[k] = COLOR_TO_IDX[a.color]
+        cfg.obj, cfg.atlas = self._obj_dev.data_ptr(), self._atlas_dev.data_ptr()
+        self._cfg = cfg
+        self._tables_version = self.obj_reg.version
+        self._prog_cache = {}
+
+    def _program(self, template, ops):
+        import torch
+        key = (template.tobytes(), tuple(ops))
+        hit = self._prog_cache.get(key)
+        if hit is not None:
+            return hit[0]
+        t = np.zeros(self.cells_stride, np.uint8)
+        t[:self.width * self.height] = template.reshape(-1)
+        t_dev = torch.from_numpy(t).to(self.device)
+        prog = N.GenProgram()
+        prog.template_grid = t_dev.data_ptr()
+        prog.n_ops = len(ops)
+        for i, (obj, count, max_tries) in enumerate(ops):
+            prog.ops[i].obj, prog.ops[i].count, prog.ops[i].max_tries = obj, count, max_tries
+        prog.agent_max_tries = 100000
+        self._prog_cache[key] = (prog, t_dev)
+        return prog
+
+    def _mask_ptr(self, env_mask):
+        if env_mask is None:
+            return None
+        import torch
+        m = torch.as_tensor(env_mask, device=self.device)
+        if m.shape != (self.batch_size,):
+            raise ValueError("env_mask must have shape (batch_size,)")
+        self._mask_keep = m.to(torch.uint8).contiguous()
+        return C.c_void_p(self._mask_keep.data_ptr())
+
+    # ---- the gym surface -----------------------------------------------------------------------------
+    def reset(self, env_mask=None, **kwargs):
+        """Start a new episode in every env (or those selected by `env_mask`) and return the
+        observation tensor (B, n, P, P, 3) — base.py:402-416."""
+        template, ops = self._trace_gen_grid()
+        if self._dry:
+            return None
+        self._sync_tables()
+        prog = self._program(template, ops)
+        self._reset_prog, self._retrace = prog, False
+        N.check(self._lib.mg_reset(C.byref(self._cfg), C.byref(self._state), C.byref(prog),
+                                   self._mask_ptr(env_mask), self._stream()))
+        self._render()
+        if self.strict:
+            self.check_errors()
+        return self.obs
+
+    def step(self, actions):
+        """actions: (B, n) integer tensor (device preferred) or array-like -> (obs, rewards, done, {})
+        with obs (B, n, P, P, 3) uint8, rewards (B, n) float32, done (B,) bool — base.py:501-653."""
+        import torch
+        if not torch.is_tensor(actions):
+            actions = torch.as_tensor(np.asarray(actions))
+        if actions.dim() == 1 and self.batch_size == 1:
+            actions = actions.unsqueeze(0)
+        assert actions.dim() == 2 and actions.shape[1] == len(self.agents) and actions.shape[0] == self.batch_size, \
+            "actions must have shape (batch_size, n_agents)"                            # base.py:508
+        if actions.dtype not in (torch.int64, torch.int32, torch.uint8):
+            actions = actions.to(torch.int64)
+        actions = actions.to(self.device).contiguous()
+        N.check(self._lib.mg_step(C.byref(self._cfg), C.byref(self._state), actions.data_ptr(),
+                                  actions.element_size(), self.rewards.data_ptr(), self._stream()))
+        done = self.done_t.to(torch.bool)
+        if self.auto_reset:
+            # envs that just finished start their next episode before the obs is rendered (their
+            # returned obs is the first obs of the new episode; `done` still reports the end).  The
+            # done flags themselves are the device-side reset mask: no host sync.
+            if self._retrace:
+                # first step after construction: subclass constructors finish configuring the
+                # scenario after the base constructor's reset (cluttered.py:13-20)
+                template, ops = self._trace_gen_grid()
+                self._sync_tables()
+                self._reset_prog = self._program(template, ops)
+                self._retrace = False
+            N.check(self._lib.mg_reset(C.byref(self._cfg), C.byref(self._state), C.byref(self._reset_prog),
+                                       C.c_void_p(self.done_t.data_ptr()), self._stream()))
+        self._render()
+        if self.strict:
+            self.check_errors()
+        return self.obs, self.rewards, done, {}
+
+    def _render(self, debug=False):
+        import torch
+        if debug:
+            B, n, vs = self.batch_size, self.num_agents, self.view_size
+            cells = torch.zeros((B, n, vs, vs), dtype=torch.uint8, device=self.device)
+            shown = torch.zeros_like(cells)
+            vis = torch.zeros_like(cells)
+            N.check(self._lib.mg_render_obs(C.byref(self._cfg), C.byref(self._state), self.obs.data_ptr(),
+                                            cells.data_ptr(), shown.data_ptr(), vis.data_ptr(), self._stream()))
+            return cells, shown, vis
+        N.check(self._lib.mg_render_obs(C.byref(self._cfg), C.byref(self._state), self.obs.data_ptr(), None, None,
+                                        None, self._stream()))
+        return None
+
+    def gen_obs(self):
+        """(B, n, P, P, 3) uint8 (base.py:473-474)"""
+        self._render()
+        return self.obs
+
+    def gen_agent_obs(self, agent):
+        """agent: a GridAgentInterface of this env or its index -> (B, P, P, 3) (base.py:453-471)"""
+        k = agent if isinstance(agent, int) else self.agents.index(agent)
+        self._render()
+        a = self.agents[k]
+        pov = self.obs[:, k]
+        if a.observation_style == "image":
+            return pov
+        import torch
+        ret = {"pov": pov}
+        if a.observe_rewards:
+            ret["reward"] = torch.zeros(self.batch_size, device=self.device)   # always 0 upstream (base.py:464,519)
+        if a.observe_position:
+            wh = torch.tensor([self.width, self.height], dtype=torch.float32, device=self.device)
+            pos = self.agent_pos[:, k].to(torch.float32)
+            placed = (self.agent_flags[:, k] & N.AF_PLACED) != 0
+            ret["position"] = torch.where(placed[:, None], pos, torch.zeros_like(pos)) / wh
+        if a.observe_orientation:
+            ret["orientation"] = self.agent_dir[:, k]
+        return ret
+
+    def gen_obs_grid(self, agent):
+        """(view cells (B, vs, vs) object ids indexed [i, j], visibility mask (B, vs, vs) bool) for one
+        agent — base.py:418-451"""
+        k = agent if isinstance(agent, int) else self.agents.index(agent)
+        cells, _shown, vis = self._render(debug=True)
+        return cells[:, k], vis[:, k].bool()
+
+    def _encode(self, vis_mask=None):
+        import torch
+        out = torch.empty((self.batch_size, self.width, self.height, 3), dtype=torch.uint8, device=self.device)
+        vm = None
+        if vis_mask is not None:
+            vm = torch.as_tensor(vis_mask, device=self.device).to(torch.uint8).expand(
+                self.batch_size, self.width, self.height).contiguous()
+        N.check(self._lib.mg_encode(C.byref(self._cfg), C.byref(self._state),
+                                    None if vm is None else C.c_void_p(vm.data_ptr()), out.data_ptr(), self._stream()))
+        return out
+
+    def check_errors(self):
+        """Raise the reference's exception for the first env that hit one (host sync)."""
+        import torch
+        bad = torch.nonzero(self.error_t)
+        if bad.numel():
+            b = int(bad[0].item())
+            code = int(self.error_t[b].item())
+            self.error_t.zero_()
+            msgs = {N.ERR_VALUE: "Environment can't handle action (env %d)." % b,
+                    N.ERR_RECURSION: "Rejection sampling failed in place_obj (env %d)." % b,
+                    N.ERR_TYPE: "toggle() takes 1 positional argument but 3 were given (Box, env %d)" % b,
+                    N.ERR_ASSERT: "grid access out of bounds (env %d)" % b}
+            raise N.ERR_EXC[code](msgs[code])
+
+    # ---- agent state views (per-env state lives in HBM, not on the agent objects) -------------------------
+    def _rec_byte(self, i):
+        return ((self.agent_state >> (8 * i)) & 0xFF)
+
+    @property
+    def agent_pos(self):
+        """(B, n, 2) int64"""
+        import torch
+        return torch.stack([self._rec_byte(N.AG_X), self._rec_byte(N.AG_Y)], dim=-1)
+
+    @property
+    def agent_dir(self):
+        return self._rec_byte(N.AG_DIR)
+
+    @property
+    def agent_flags(self):
+        return self._rec_byte(N.AG_FLAGS)
+
+    @property
+    def agent_active(self):
+        return (self.agent_flags & N.AF_ACTIVE) != 0
+
+    @property
+    def agent_done(self):
+        return (self.agent_flags & N.AF_DONE) != 0
+
+    @property
+    def agent_carrying(self):
+        return self._rec_byte(N.AG_CARRY)
+
+    @property
+    def agent_rank(self):
+        return self._rec_byte(N.AG_RANK)
+
+    @property
+    def step_count(self):
+        return self.step_count_t
+
+    def set_agent(self, k, x=None, y=None, dir=None, carrying=None, env_mask=None):
+        """Test / scenario-building helper: overwrite fields of agent k's record in the selected envs.
+        Moving an agent this way gives it the highest arrival rank (as a fresh placement would)."""
+        import torch
+        m = torch.ones(self.batch_size, dtype=torch.bool, device=self.device) if env_mask is None else \
+            torch.as_tensor(env_mask, device=self.device).bool()
+        rec = self.agent_state
+
+        def setb(col, i, v):
+            return (col & ~(0xFF << (8 * i))) | (int(v) << (8 * i))
+        if x is not None or y is not None:
+            n = self.num_agents
+            old = self._rec_byte(N.AG_RANK)[:, k:k + 1]
+            rk = self._rec_byte(N.AG_RANK)
+            rk = torch.where(rk > old, rk - 1, rk)
+            rk[:, k] = n - 1
+            new = (rec & ~(0xFF << (8 * N.AG_RANK))) | (rk << (8 * N.AG_RANK))
+            rec[m] = new[m]
+        col = rec[:, k].clone()
+        if x is not None:
+            col = setb(col, N.AG_X, x)
+        if y is not None:
+            col = setb(col, N.AG_Y, y)
+        if dir is not None:
+            col = setb(col, N.AG_DIR, dir % 4)
+        if carrying is not None:
+            col = setb(col, N.AG_CARRY, self.obj_reg.get_key(carrying) if isinstance(carrying, WorldObj) else carrying)
+        rec[:, k] = torch.where(m, col, rec[:, k])
+
+    # ---- RNG state exchange with numpy (tests / checkpoints) -------------------------------------------
+    def numpy_rng_state(self, b=0):
+        """env b's generator as `np.random.RandomState.get_state()` would report it.  The device
+        keeps the *lazy* form (word mt_pos is regenerated when consumed); numpy regenerates whole
+        blocks, so the not-yet-consumed tail is advanced here."""
+        mt = self.mt_state[b].cpu().numpy().view(np.uint32).copy()
+        pos = int(self.mt_pos[b].item())
+        if pos == 0:
+            return mt, 624
+        for kk in range(pos, 624):
+            y = (int(mt[kk]) & 0x80000000) | (int(mt[(kk + 1) % 624]) & 0x7fffffff)
+            mt[kk] = int(mt[(kk + 397) % 624]) ^ (y >> 1) ^ (0x9908b0df if y & 1 else 0)
+        return mt, pos
+
+    def state_dict(self):
+        keys = ("grid_state", "agent_state", "mt_state", "mt_pos", "step_count_t", "done_t", "error_t")
+        return {k: getattr(self, k).clone() for k in keys}
+
+    def load_state_dict(self, sd):
+        for k, v in sd.items():
+            getattr(self, k).copy_(v)
+
+    # ---- plain-data description (parity tests hand this to the oracle) -----------------------------------
+    def scenario_spec(self):
+        def ospec(o):
+            if o is None:
+                return None
+            d = dict(type=o.__class__.__name__, color=o.color, state=o.state)
+            if isinstance(o, Goal):
+                d["reward"] = o.reward
+            if isinstance(o, BonusTile):
+                d.update(reward=o.reward, penalty=o.penalty, bonus_id=o.bonus_id, n_bonus=o.n_bonus,
+                         initial_reward=o.initial_reward, reset_on_mistake=o.reset_on_mistake)
+            return d
+
+        def prog(p):
+            return list(p["sym"]) + [("place", k, c, t) for (k, c, t) in p["ops"]]
+        return dict(W=self.width, H=self.height, agents=[dict(color=a.color) for a in self.agents],
+                    view_size=self.view_size, tile_size=self.tile_size, view_offset=self.view_offset,
+                    see_through_walls=self.see_through_walls, max_steps=self.max_steps,
+                    reward_decay=bool(self.reward_decay), ghost_mode=self.ghost_mode is not False,
+                    respawn=bool(self.respawn), objects=[ospec(o) for o in self.obj_reg.objs],
+                    wall_obj=self.obj_reg.find(Wall()), gen_ctor=prog(self._spec_ctor or self._spec_last),
+                    gen_reset=prog(self._spec_last))
+
+    def render(self, *args, **kwargs):
+        raise NotImplementedError("full-frame human rendering is out of scope for the batched engine "
+                                  "(SURVEY.md section 8f, row F2)")
+
+    def __str__(self):
+        return "<%s B=%d %dx%d n_agents=%d>" % (self.__class__.__name__, self.batch_size, self.width,
+                                                self.height, self.num_agents)

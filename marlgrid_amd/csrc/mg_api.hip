@@ -1,0 +1,134 @@
+// mg_api.hip — the C ABI of libmarlgrid_hip.so (include/marlgrid_hip.h): argument checks and
+// launches only; every buffer is caller-owned device memory, every call is asynchronous on the
+// caller's stream.
+#include "mg_device.h"
+#include "mg_launch.h"
+
+namespace {
+
+int check_cfg(const MgConfig* c) {
+    if (!c) return MG_E_ARG;
+    if (c->B < 0 || c->W < 3 || c->H < 3 || c->W > 255 || c->H > 255) return MG_E_ARG;
+    if (c->n_agents < 1 || c->n_agents > MG_MAX_AGENTS) return MG_E_UNSUPPORTED;
+    if (c->view_size < 1 || c->view_size > MG_MAX_VIEW || (c->view_size & 1) == 0) return MG_E_UNSUPPORTED;
+    if (c->tile_size < 1 || c->tile_size > 64) return MG_E_UNSUPPORTED;
+    if (c->view_offset < 0 || c->view_offset >= c->view_size) return MG_E_ARG;
+    if (c->cells_stride < c->W * c->H || (c->cells_stride & 15)) return MG_E_ARG;
+    if (c->n_obj < 1 || c->n_obj > MG_MAX_OBJ) return MG_E_UNSUPPORTED;
+    if (c->n_tiles != 1 + c->n_obj + c->n_ovl_slots * c->n_agents * 4) return MG_E_ARG;
+    if (!c->obj || !c->atlas) return MG_E_ARG;
+    if (c->max_steps < 1) return MG_E_ARG;
+    return MG_OK;
+}
+
+int check_state(const MgState* s) {
+    if (!s || !s->grid || !s->agents || !s->mt || !s->mt_pos || !s->step_count || !s->done || !s->error)
+        return MG_E_ARG;
+    return MG_OK;
+}
+
+int rc(hipError_t e) { return e == hipSuccess ? MG_OK : MG_E_LAUNCH; }
+
+}  // namespace
+
+extern "C" {
+
+int32_t mg_abi_version(void) { return MG_ABI_VERSION; }
+
+const char* mg_error_string(int32_t code) {
+    switch (code) {
+    case MG_OK: return "ok";
+    case MG_E_ARG: return "invalid argument";
+    case MG_E_UNSUPPORTED: return "unsupported configuration";
+    case MG_E_LAUNCH: return "HIP launch failed";
+    case MG_ERR_VALUE: return "ValueError: environment can't handle action";
+    case MG_ERR_RECURSION: return "RecursionError: rejection sampling failed in place_obj";
+    case MG_ERR_TYPE: return "TypeError: toggle() arity (Box)";
+    case MG_ERR_ASSERT: return "AssertionError: grid access out of bounds";
+    default: return "unknown";
+    }
+}
+
+int32_t mg_mt_seed(int32_t B, const uint32_t* keys, const int32_t* key_len, uint32_t* mt, int32_t* mt_pos,
+                   void* stream) {
+    if (B < 0 || !keys || !key_len || !mt || !mt_pos) return MG_E_ARG;
+    return rc(mg::launch_mt_seed(B, keys, key_len, mt, mt_pos, (hipStream_t)stream));
+}
+
+int32_t mg_reset(const MgConfig* cfg, const MgState* st, const MgGenProgram* prog, const uint8_t* env_mask,
+                 void* stream) {
+    int e = check_cfg(cfg);
+    if (e) return e;
+    e = check_state(st);
+    if (e) return e;
+    if (!prog || !prog->template_grid || prog->n_ops < 0 || prog->n_ops > MG_MAX_GEN) return MG_E_ARG;
+    for (int i = 0; i < prog->n_ops; i++)
+        if (prog->ops[i].obj <= 0 || prog->ops[i].obj >= cfg->n_obj || prog->ops[i].count < 0) return MG_E_ARG;
+    return rc(mg::launch_reset(*cfg, *st, *prog, env_mask, (hipStream_t)stream));
+}
+
+int32_t mg_step(const MgConfig* cfg, const MgState* st, const void* actions, int32_t action_bytes, float* rewards,
+                void* stream) {
+    int e = check_cfg(cfg);
+    if (e) return e;
+    e = check_state(st);
+    if (e) return e;
+    if (!actions || !rewards) return MG_E_ARG;
+    if (action_bytes != 1 && action_bytes != 4 && action_bytes != 8) return MG_E_ARG;
+    if (cfg->respawn) return MG_E_UNSUPPORTED;
+    return rc(mg::launch_step(*cfg, *st, actions, action_bytes, rewards, (hipStream_t)stream));
+}
+
+int32_t mg_render_obs(const MgConfig* cfg, const MgState* st, uint8_t* obs, uint8_t* view_cells,
+                      uint8_t* view_agent, uint8_t* vis_mask, void* stream) {
+    int e = check_cfg(cfg);
+    if (e) return e;
+    e = check_state(st);
+    if (e) return e;
+    if (!obs) return MG_E_ARG;
+    return rc(mg::launch_render(*cfg, *st, obs, view_cells, view_agent, vis_mask, (hipStream_t)stream));
+}
+
+int32_t mg_encode(const MgConfig* cfg, const MgState* st, const uint8_t* vis_mask, uint8_t* out, void* stream) {
+    int e = check_cfg(cfg);
+    if (e) return e;
+    e = check_state(st);
+    if (e) return e;
+    if (!out) return MG_E_ARG;
+    return rc(mg::launch_encode(*cfg, *st, vis_mask, out, (hipStream_t)stream));
+}
+
+int32_t mg_put_obj(const MgConfig* cfg, const MgState* st, int32_t obj, int32_t x, int32_t y,
+                   const uint8_t* env_mask, void* stream) {
+    int e = check_cfg(cfg);
+    if (e) return e;
+    e = check_state(st);
+    if (e) return e;
+    if (obj < 0 || obj >= cfg->n_obj || x < 0 || x >= cfg->W || y < 0 || y >= cfg->H) return MG_E_ARG;
+    return rc(mg::launch_put_obj(*cfg, *st, obj, x, y, env_mask, (hipStream_t)stream));
+}
+
+int32_t mg_time_render_obs(const MgConfig* cfg, const MgState* st, uint8_t* obs, int32_t iters, float* avg_ms,
+                           void* stream) {
+    int e = check_cfg(cfg);
+    if (e) return e;
+    e = check_state(st);
+    if (e) return e;
+    if (!obs || !avg_ms || iters < 1) return MG_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t t0, t1;
+    if (hipEventCreate(&t0) != hipSuccess || hipEventCreate(&t1) != hipSuccess) return MG_E_LAUNCH;
+    hipError_t err = mg::launch_render(*cfg, *st, obs, nullptr, nullptr, nullptr, s);   // warm
+    (void)hipEventRecord(t0, s);
+    for (int i = 0; i < iters && err == hipSuccess; i++) err = mg::launch_render(*cfg, *st, obs, nullptr, nullptr, nullptr, s);
+    (void)hipEventRecord(t1, s);
+    (void)hipEventSynchronize(t1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, t0, t1);
+    *avg_ms = ms / (float)iters;
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    return rc(err);
+}
+
+}  // extern "C"

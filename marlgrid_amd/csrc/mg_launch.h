@@ -1,0 +1,20 @@
+// mg_launch.h — host-side launchers implemented by the individual kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "marlgrid_hip.h"
+
+namespace mg {
+hipError_t launch_mt_seed(int B, const uint32_t* keys, const int32_t* key_len, uint32_t* mt, int32_t* mt_pos,
+                          hipStream_t s);
+hipError_t launch_reset(const MgConfig& cfg, const MgState& st, const MgGenProgram& prog, const uint8_t* mask,
+                        hipStream_t s);
+hipError_t launch_step(const MgConfig& cfg, const MgState& st, const void* actions, int action_bytes,
+                       float* rewards, hipStream_t s);
+hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, uint8_t* view_cells,
+                         uint8_t* view_agent, uint8_t* vis_mask, hipStream_t s);
+hipError_t launch_encode(const MgConfig& cfg, const MgState& st, const uint8_t* vis_mask, uint8_t* out,
+                         hipStream_t s);
+hipError_t launch_put_obj(const MgConfig& cfg, const MgState& st, int obj, int x, int y, const uint8_t* mask,
+                          hipStream_t s);
+}  // namespace mg

@@ -1,0 +1,319 @@
+// mg_render.hip — the observation raster: batched MultiGridEnv.gen_obs (marlgrid/base.py:418-474)
+//   = get_view_exts + MultiGrid.slice + rotate_grid   (agents.py:237-266, base.py:123-147, 67-80)
+//   + MultiGrid.opacity + occlude_mask                 (base.py:103-106, agents.py:290-343)
+//   + MultiGrid.render / render_tile / blend_tiles     (base.py:275-331)
+// producing obs[B][n][P][P][3] uint8.  This is the HBM-write-bound kernel of the engine: 9 408 B
+// (view 7, tile 8) per agent-step out, ~60 B in.
+//
+// Mapping (CDNA4): ONE WAVEFRONT PER ENV, 4 waves per workgroup, persistent grid-stride over envs.
+//   * the whole pre-rotated sprite atlas ([4 orientations][n_tiles][ts*ts*3] bytes, ~21 KB for the
+//     3-agent configs) is staged once per workgroup in LDS;
+//   * per env, the wave stages the env's grid (W*H bytes) and agent records in LDS, derives the
+//     n view_size x view_size egocentric neighbourhoods (base object, shown agent, transparency)
+//     cooperatively, lanes 0..n-1 run the shadow-casting pass as row bit-masks (log-step floods),
+//     and the wave writes a per-view-cell atlas offset map (tmap) to LDS;
+//   * the store loop then emits the env's n*P*P*3 contiguous output bytes as 16-byte
+//     (global_store_dwordx4) chunks, consecutive lanes -> consecutive chunks, each chunk assembled
+//     from 4 LDS dword look-ups atlas[tmap[cell] + row*TD + k].  Because (ts*3) % 4 == 0 every
+//     dword of the image lies inside exactly one tile row, so there is no byte shuffling at all.
+// No MFMA: there is no contraction anywhere in this path.
+#include "mg_device.h"
+#include "mg_launch.h"
+
+namespace mg {
+
+// ---- shadow casting (agents.py:298-343) as row bit-masks ---------------------------------------
+// bit i of row j == mask[i, j].  The reference sweeps each row rightwards from the agent column
+// and leftwards from agent column + 1, propagating to the row above (first loop nest) or below
+// (second); out-of-range accesses of the unchecked numba code read False / are dropped.
+__device__ __forceinline__ uint32_t flood_right(uint32_t m, uint32_t p) {
+    // set bit i+1 whenever bit i is set and p[i] (p = transparency restricted to [ax, vs-2])
+    m |= (m & p) << 1;
+    uint32_t q = p & (p >> 1);
+    m |= (m & q) << 2;
+    q = q & (q >> 2);
+    m |= (m & q) << 4;
+    q = q & (q >> 4);
+    m |= (m & q) << 8;
+    return m;
+}
+__device__ __forceinline__ uint32_t flood_left(uint32_t m, uint32_t p) {
+    // set bit i-1 whenever bit i is set and p[i] (p = transparency restricted to [1, ax+1])
+    m |= (m & p) >> 1;
+    uint32_t q = p & (p << 1);
+    m |= (m & q) >> 2;
+    q = q & (q << 2);
+    m |= (m & q) >> 4;
+    q = q & (q << 4);
+    m |= (m & q) >> 8;
+    return m;
+}
+
+template <int VS_>
+__device__ __forceinline__ void occlude_rows(int vs_rt, int off, const uint32_t* __restrict__ T,
+                                             uint32_t* __restrict__ out) {
+    const int VS = VS_ ? VS_ : vs_rt;
+    constexpr int N = VS_ ? VS_ : MG_MAX_VIEW;
+    const int ax = VS / 2, ay = VS - 1 - off;
+    const uint32_t full = (1u << VS) - 1u;
+    const uint32_t hi = full & ~((1u << ax) - 1u);            // columns ax .. VS-1
+    const uint32_t lo = ((1u << (ax + 2)) - 2u) & full;       // columns 1 .. ax+1
+    const uint32_t pr = hi & ~(1u << (VS - 1));               // right flood sources: ax .. VS-2
+    uint32_t m[N], t[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) { m[j] = 0; t[j] = (j < VS) ? T[j] : 0u; }
+#pragma unroll
+    for (int j = 0; j < N; j++) if (j == ay) m[j] = 1u << ax;
+    // first nest: rows ay+1 .. 1 propagate upwards (row ay+1 is still empty there: a no-op)
+#pragma unroll
+    for (int j = N - 1; j >= 1; j--) {
+        if (j < VS && j <= ay) {
+            uint32_t r = flood_right(m[j], t[j] & pr);
+            uint32_t s = r & t[j] & hi;
+            m[j - 1] |= (s | (s << 1)) & full;
+            r = flood_left(r, t[j] & lo);
+            s = r & t[j] & lo;
+            m[j - 1] |= s | (s >> 1);
+            m[j] = r;
+        }
+    }
+    // second nest: rows ay .. VS-1 propagate downwards
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        if (j < VS && j >= ay) {
+            uint32_t r = flood_right(m[j], t[j] & pr);
+            uint32_t s = r & t[j] & hi;
+            uint32_t down = (s | (s << 1)) & full;
+            r = flood_left(r, t[j] & lo);
+            s = r & t[j] & lo;
+            down |= s | (s >> 1);
+            m[j] = r;
+            if (j + 1 < N && j + 1 < VS) m[j + 1] |= down;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < N; j++) if (j < VS) out[j] = m[j];
+}
+
+// ---- the kernel ----------------------------------------------------------------------------------
+// VS_/TS_ > 0: compile-time view/tile size, dword fast path (requires TS_ % 4 == 0).
+// VS_ == TS_ == 0: any size, byte-granular store loop (correct, slower).
+template <int VS_, int TS_>
+__global__ __launch_bounds__(kBlock) void render_kernel(MgConfig cfg, MgState st, uint8_t* __restrict__ obs,
+                                                        uint8_t* __restrict__ dbg_cells,
+                                                        uint8_t* __restrict__ dbg_agent,
+                                                        uint8_t* __restrict__ dbg_vis) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int VS = VS_ ? VS_ : cfg.view_size;
+    const int TS = TS_ ? TS_ : cfg.tile_size;
+    const int n = cfg.n_agents, W = cfg.W, H = cfg.H;
+    const int tile_bytes = TS * TS * 3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int VV = VS * VS;
+
+    // ---- block-shared: atlas + object flags ----
+    const int atlas_bytes = round_up(4 * cfg.n_tiles * tile_bytes, 16);
+    uint8_t* s_atlas = smem;
+    uint8_t* s_oflags = smem + atlas_bytes;             // [MG_MAX_OBJ]
+    uint8_t* s_oslot = s_oflags + MG_MAX_OBJ;           // [MG_MAX_OBJ]
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(cfg.atlas);
+        uint4* dst = reinterpret_cast<uint4*>(s_atlas);
+        for (int i = tid; i < atlas_bytes / 16; i += kBlock) dst[i] = src[i];
+        if (tid < MG_MAX_OBJ) {
+            uint8_t f = 0, sl = 0xFF;
+            if (tid < cfg.n_obj) { f = cfg.obj[tid].flags; sl = cfg.obj[tid].ovl_slot; }
+            if (tid == 0) { f = MG_OF_SEE_BEHIND | MG_OF_CAN_OVERLAP; sl = 0; }   // empty cell
+            s_oflags[tid] = f;
+            s_oslot[tid] = sl;
+        }
+    }
+    __syncthreads();
+
+    const RenderScratch L = render_scratch_layout(cfg.cells_stride, n, VS);
+    uint8_t* ws = smem + atlas_bytes + 2 * MG_MAX_OBJ + (size_t)wave * L.total;
+    uint8_t* w_grid = ws + L.grid;
+    uint8_t* w_first = ws + L.first;
+    uint64_t* w_rec = reinterpret_cast<uint64_t*>(ws + L.rec);
+    uint8_t* w_vbase = ws + L.vbase;
+    uint8_t* w_vshow = ws + L.vshow;
+    uint32_t* w_trow = reinterpret_cast<uint32_t*>(ws + L.trow);
+    uint32_t* w_vis = reinterpret_cast<uint32_t*>(ws + L.vis);
+    uint16_t* w_tmap = reinterpret_cast<uint16_t*>(ws + L.tmap);
+
+    const int h = VS / 2, off = cfg.view_offset;
+    const size_t img_bytes = (size_t)VS * TS * VS * TS * 3;
+
+    for (int e = blockIdx.x * 4 + wave; e < cfg.B; e += gridDim.x * 4) {
+        // 1. stage the env's grid + agent records
+        {
+            const uint32_t* gsrc = reinterpret_cast<const uint32_t*>(st.grid + (size_t)e * cfg.cells_stride);
+            for (int i = lane; i < cfg.cells_stride / 4; i += kWave) {
+                reinterpret_cast<uint32_t*>(w_grid)[i] = gsrc[i];
+                reinterpret_cast<uint32_t*>(w_first)[i] = 0xFFFFFFFFu;
+            }
+            if (lane < n) w_rec[lane] = st.agents[(size_t)e * n + lane];
+            for (int i = lane; i < n * VS; i += kWave) w_trow[i] = 0;
+        }
+        wave_lds_sync();
+        // 2. first (lowest-rank) agent of every occupied cell: the reference's "cell object" when
+        //    the base is empty, and `obj.agents[0]` when agents stand on an overlappable object
+        if (lane < n) {
+            const uint64_t r = w_rec[lane];
+            if (rec_byte(r, MG_AG_FLAGS) & MG_AF_PLACED) {
+                bool lowest = true;
+                for (int j = 0; j < n; j++) {
+                    const uint64_t rj = w_rec[j];
+                    if (j != lane && (rec_byte(rj, MG_AG_FLAGS) & MG_AF_PLACED) && rec_xy(rj) == rec_xy(r) &&
+                        rec_byte(rj, MG_AG_RANK) < rec_byte(r, MG_AG_RANK))
+                        lowest = false;
+                }
+                if (lowest) w_first[rec_byte(r, MG_AG_X) * H + rec_byte(r, MG_AG_Y)] = (uint8_t)lane;
+            }
+        }
+        wave_lds_sync();
+        // 3. egocentric crop + rotate: view cell (a = column, b = row) -> world cell
+        for (int it = lane; it < n * VV; it += kWave) {
+            const int k = it / VV, c = it - k * VV;
+            const int vb = c / VS, va = c - vb * VS;
+            const uint64_t r = w_rec[k];
+            const int x = (int)rec_byte(r, MG_AG_X), y = (int)rec_byte(r, MG_AG_Y), dir = (int)rec_byte(r, MG_AG_DIR);
+            int wx, wy;
+            if (dir == 3)      { wx = x - h + va;                 wy = y - (VS - 1) + off + vb; }
+            else if (dir == 0) { wx = x - off + (VS - 1 - vb);    wy = y - h + va; }
+            else if (dir == 1) { wx = x - h + (VS - 1 - va);      wy = y - off + (VS - 1 - vb); }
+            else               { wx = x - VS + 1 + off + vb;      wy = y - h + (VS - 1 - va); }
+            const bool inb = wx >= 0 && wx < W && wy >= 0 && wy < H;
+            uint32_t base = 0, show = 0xFF;
+            if (inb) {
+                const int cell = wx * H + wy;
+                base = w_grid[cell];
+                show = w_first[cell];
+                if (show != 0xFF && wx == x && wy == y) show = (uint32_t)k;   // viewer in the stack: base.py:282-291
+            }
+            w_vbase[it] = (uint8_t)base;
+            w_vshow[it] = (uint8_t)show;
+            if (s_oflags[base] & MG_OF_SEE_BEHIND) atomicOr(&w_trow[k * VS + vb], 1u << va);
+        }
+        wave_lds_sync();
+        // 4. visibility per agent (lanes 0..n-1)
+        if (lane < n) {
+            const uint64_t r = w_rec[lane];
+            uint32_t m[VS_ ? VS_ : MG_MAX_VIEW];
+            if (!(rec_byte(r, MG_AG_FLAGS) & MG_AF_ACTIVE)) {           // base.py:420-425
+                for (int j = 0; j < VS; j++) m[j] = 0;
+            } else if (cfg.see_through_walls) {                          // agents.py:294-295
+                for (int j = 0; j < VS; j++) m[j] = (1u << VS) - 1u;
+            } else {
+                occlude_rows<VS_>(VS, off, &w_trow[lane * VS], m);
+            }
+            for (int j = 0; j < VS; j++) w_vis[lane * VS + j] = m[j];
+        }
+        wave_lds_sync();
+        // 5. tile selection (base.py:275-299) -> atlas byte offset / 4 per view cell
+        for (int it = lane; it < n * VV; it += kWave) {
+            const int k = it / VV, c = it - k * VV;
+            const int vb = c / VS, va = c - vb * VS;
+            const uint32_t visible = (w_vis[k * VS + vb] >> va) & 1u;
+            const uint32_t base = w_vbase[it], show = w_vshow[it];
+            uint32_t tile = 0;   // shadow
+            if (visible) {
+                const uint32_t slot = s_oslot[base];
+                if (show == 0xFF || slot == 0xFF) tile = 1 + base;
+                else {
+                    const uint32_t sdir = rec_byte(w_rec[show], MG_AG_DIR);
+                    tile = 1 + cfg.n_obj + (slot * n + show) * 4 + sdir;
+                }
+            }
+            const uint32_t orient = (3u - rec_byte(w_rec[k], MG_AG_DIR)) & 3u;   // -(dir+1) mod 4
+            if constexpr (VS_ > 0 && TS_ > 0 && (TS_ % 4) == 0)
+                w_tmap[it] = (uint16_t)((orient * cfg.n_tiles + tile) * (TS_ * TS_ * 3 / 4));   // dword offset
+            else
+                w_tmap[it] = (uint16_t)(orient * cfg.n_tiles + tile);                            // tile index
+            if (dbg_cells) {
+                const size_t o = ((size_t)e * n + k) * VV + va * VS + vb;         // [i][j] like the reference
+                dbg_cells[o] = (uint8_t)base;
+                dbg_agent[o] = (uint8_t)show;
+                dbg_vis[o] = (uint8_t)visible;
+            }
+        }
+        wave_lds_sync();
+        // 6. raster: stream the env's n images out
+        if constexpr (VS_ > 0 && TS_ > 0 && (TS_ % 4) == 0) {
+            constexpr int TD = TS_ * 3 / 4;         // dwords per tile row
+            constexpr int DR = VS_ * TD;            // dwords per pixel row
+            constexpr int IMG_CHUNKS = VS_ * TS_ * DR / 4;
+            const uint32_t* atlas32 = reinterpret_cast<const uint32_t*>(s_atlas);
+            uint4* out = reinterpret_cast<uint4*>(obs + (size_t)e * n * img_bytes);
+            const int total = n * IMG_CHUNKS;
+            for (int c = lane; c < total; c += kWave) {
+                const int k = c / IMG_CHUNKS;
+                const int q = (c - k * IMG_CHUNKS) * 4;
+                int row = q / DR;
+                int dw = q - row * DR;
+                int va = dw / TD;
+                int kk = dw - va * TD;
+                const uint16_t* tm = w_tmap + k * (VS_ * VS_);
+                uint32_t v[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int vb = row / TS_, rr = row - vb * TS_;
+                    v[i] = atlas32[(uint32_t)tm[vb * VS_ + va] + rr * TD + kk];
+                    if (++kk == TD) { kk = 0; if (++va == VS_) { va = 0; ++row; } }
+                }
+                out[c] = make_uint4(v[0], v[1], v[2], v[3]);
+            }
+        } else {
+            uint8_t* out = obs + (size_t)e * n * img_bytes;
+            const int P = VS * TS;
+            const int total = n * P * P;
+            for (int p = lane; p < total; p += kWave) {
+                const int k = p / (P * P), pp = p - k * (P * P);
+                const int row = pp / P, col = pp - row * P;
+                const int vb = row / TS, rr = row - vb * TS, va = col / TS, cc = col - va * TS;
+                const uint8_t* src = s_atlas + (size_t)w_tmap[k * VV + vb * VS + va] * tile_bytes + (rr * TS + cc) * 3;
+                uint8_t* d = out + (size_t)p * 3;
+                d[0] = src[0]; d[1] = src[1]; d[2] = src[2];
+            }
+        }
+        wave_lds_sync();   // scratch is reused by the next env
+    }
+}
+
+template <int VS_, int TS_>
+static hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_t* obs, uint8_t* c, uint8_t* a,
+                                  uint8_t* v, hipStream_t s) {
+    const int tile_bytes = cfg.tile_size * cfg.tile_size * 3;
+    const RenderScratch L = render_scratch_layout(cfg.cells_stride, cfg.n_agents, cfg.view_size);
+    size_t lds = (size_t)round_up(4 * cfg.n_tiles * tile_bytes, 16) + 2 * MG_MAX_OBJ + 4 * (size_t)L.total;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<VS_, TS_>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    // persistent grid: enough workgroups to fill 256 CUs at the occupancy LDS allows, never more
+    // than one wave per env
+    int per_cu = (int)((160 * 1024) / (lds ? lds : 1));
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 8) per_cu = 8;
+    int blocks = 256 * per_cu;
+    int need = (cfg.B + 3) / 4;
+    if (blocks > need) blocks = need;
+    hipLaunchKernelGGL((render_kernel<VS_, TS_>), dim3(blocks), dim3(kBlock), lds, s, cfg, st, obs, c, a, v);
+    return hipGetLastError();
+}
+
+hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, uint8_t* view_cells,
+                         uint8_t* view_agent, uint8_t* vis_mask, hipStream_t s) {
+    if (cfg.B <= 0) return hipSuccess;
+    if ((view_cells || view_agent || vis_mask) && !(view_cells && view_agent && vis_mask)) return hipErrorInvalidValue;
+    const int vs = cfg.view_size, ts = cfg.tile_size;
+    if (ts == 8 && vs == 7) return launch_render_t<7, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
+    if (ts == 8 && vs == 9) return launch_render_t<9, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
+    if (ts == 8 && vs == 5) return launch_render_t<5, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
+    if (ts == 8 && vs == 3) return launch_render_t<3, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
+    return launch_render_t<0, 0>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
+}
+
+}  // namespace mg

@@ -1,0 +1,187 @@
+// mg_step.hip — batched MultiGridEnv.step action loop (marlgrid/base.py:501-649).
+//
+// Per env the reference is strictly sequential: agents act in a freshly shuffled order
+// (base.py:514-516) and each action sees the grid left by the previous one, so the only parallel
+// axis is the env batch.  One LANE per env (64 envs per wave, 256 per workgroup): a wave-per-env
+// mapping would idle 63 of 64 lanes through ~100 scalar instructions.  The env's agent records are
+// staged in LDS as [agent][lane] (conflict-free 8-byte columns) so they can be indexed dynamically
+// by the shuffled order; the grid is touched in place in HBM (<= 2 cells per agent).
+//
+// Flat state model that reproduces the reference's object graph: a cell holds a
+// base object id (0 = none) and any number of agents; the ordered stack the reference keeps in
+// `obj.agents` lists (append on entry base.py:547-552, remove on exit :555-559, re-seat left-behind
+// agents in order :562-569) is exactly "agents in this cell sorted by arrival", carried as a rank
+// permutation: a successful move gives the mover the highest rank.
+#include "mg_device.h"
+#include "mg_launch.h"
+
+namespace mg {
+
+template <typename ActT>
+__global__ __launch_bounds__(kBlock) void step_kernel(MgConfig cfg, MgState st, const ActT* __restrict__ actions,
+                                                      float* __restrict__ rewards) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t s_rec[];  // [n][kBlock]
+    uint8_t* s_order = reinterpret_cast<uint8_t*>(s_rec + (size_t)cfg.n_agents * kBlock);  // [n][kBlock]
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x * kBlock + tid;
+    if (b >= cfg.B) return;
+    const int n = cfg.n_agents, W = cfg.W, H = cfg.H;
+
+    for (int k = 0; k < n; k++) s_rec[k * kBlock + tid] = st.agents[(size_t)b * n + k];
+    uint8_t* g = st.grid + (size_t)b * cfg.cells_stride;
+    Mt mt{st.mt + (size_t)b * MG_MT_N, st.mt_pos[b]};
+    int err = 0;
+
+    const int step_count = st.step_count[b] + 1;   // base.py:512
+    // reward decay factor, float64 like the reference (base.py:579)
+    const double decay = cfg.reward_decay ? (1.0 - 0.9 * ((double)step_count / (double)cfg.max_steps)) : 1.0;
+
+    // iter_order = arange(n); np_random.shuffle(iter_order)  (base.py:514-516): legacy Fisher-Yates
+    for (int k = 0; k < n; k++) s_order[k * kBlock + tid] = (uint8_t)k;
+    for (int i = n - 1; i >= 1; i--) {
+        int j = (int)mt.bounded((uint32_t)i);
+        uint8_t t = s_order[i * kBlock + tid];
+        s_order[i * kBlock + tid] = s_order[j * kBlock + tid];
+        s_order[j * kBlock + tid] = t;
+    }
+
+    for (int oi = 0; oi < n; oi++) {
+        const int k = s_order[oi * kBlock + tid];
+        float rew = 0.0f;
+        uint64_t r = s_rec[k * kBlock + tid];
+        const uint32_t flags = rec_byte(r, MG_AG_FLAGS);
+        if (flags & MG_AF_ACTIVE) {   // base.py:521
+            const long long action = (long long)actions[(size_t)b * n + k];
+            const int cx = (int)rec_byte(r, MG_AG_X), cy = (int)rec_byte(r, MG_AG_Y);
+            const int dir = (int)rec_byte(r, MG_AG_DIR);
+            const int fx = cx + dir_dx(dir), fy = cy + dir_dy(dir);   // agent.front_pos agents.py:194-198
+            if (fx < 0 || fx >= W || fy < 0 || fy >= H) {
+                err = err ? err : MG_ERR_ASSERT;   // grid.get asserts (base.py:154-156)
+            } else {
+                const int fcell = fx * H + fy;
+                const uint32_t fbase = g[fcell];
+                const uint32_t fxy = (uint32_t)fx | ((uint32_t)fy << 8);
+                const uint32_t fflags = fbase ? cfg.obj[fbase].flags : 0u;
+                if (action == 0) {                                   // left  base.py:530-531
+                    r = rec_set(r, MG_AG_DIR, (uint32_t)((dir + 3) & 3));
+                } else if (action == 1) {                            // right :534-535
+                    r = rec_set(r, MG_AG_DIR, (uint32_t)((dir + 1) & 3));
+                } else if (action == 2 || action == 4) {             // forward :538-585 / drop :600-606
+                    int agents_there = 0;
+                    for (int j = 0; j < n; j++) {
+                        uint64_t rj = s_rec[j * kBlock + tid];
+                        agents_there += ((rec_byte(rj, MG_AG_FLAGS) & MG_AF_PLACED) && rec_xy(rj) == fxy) ? 1 : 0;
+                    }
+                    if (action == 2) {
+                        // fwd_cell is None, or it can_overlap(); the top object is the base object if
+                        // there is one, else the first agent standing there (agents overlap)
+                        bool can_move = fbase ? (fflags & MG_OF_CAN_OVERLAP) != 0 : true;
+                        if (!cfg.ghost_mode && fbase == 0 && agents_there > 0) can_move = false;  // :541-542
+                        if (can_move) {
+                            // arrival: highest rank; everyone above the old rank slides down
+                            const uint32_t old_rank = rec_byte(r, MG_AG_RANK);
+                            for (int j = 0; j < n; j++) {
+                                uint64_t rj = s_rec[j * kBlock + tid];
+                                uint32_t rk = rec_byte(rj, MG_AG_RANK);
+                                if (rk > old_rank) s_rec[j * kBlock + tid] = rec_set(rj, MG_AG_RANK, rk - 1);
+                            }
+                            r = rec_set(r, MG_AG_RANK, (uint32_t)(n - 1));
+                            r = rec_set(r, MG_AG_X, (uint32_t)fx);
+                            r = rec_set(r, MG_AG_Y, (uint32_t)fy);
+                            if (fbase) {
+                                const MgObjDesc od = cfg.obj[fbase];
+                                if (od.reward_kind) {                 // hasattr(fwd_cell,'get_reward') :576-581
+                                    double rwd;
+                                    if (od.reward_kind == 1) {
+                                        rwd = od.reward;              // Goal.get_reward objects.py:219-220
+                                    } else {                          // BonusTile.get_reward objects.py:180-206
+                                        int bs = (int)rec_byte(r, MG_AG_BONUS);
+                                        bool first_bonus = false;
+                                        int nb = od.n_bonus ? od.n_bonus : 1;
+                                        if (bs == 0xFF) { bs = ((int)od.bonus_id - 1 + nb) % nb; first_bonus = true; }
+                                        if (bs == od.bonus_id) rwd = -fabs(od.penalty);
+                                        else if ((bs + 1) % nb == od.bonus_id) { bs = od.bonus_id; rwd = od.reward; }
+                                        else rwd = -fabs(od.penalty);
+                                        if (od.bonus_flags & 2) bs = od.bonus_id;
+                                        if (first_bonus && !(od.bonus_flags & 1)) rwd = 0.0;
+                                        r = rec_set(r, MG_AG_BONUS, (uint32_t)bs);
+                                    }
+                                    rew = (float)(rwd * decay);
+                                }
+                                if (fflags & MG_OF_ENDS_EPISODE) r = rec_set(r, MG_AG_FLAGS, flags | MG_AF_DONE);  // :584-585
+                            }
+                        }
+                    } else {
+                        // drop: `if not fwd_cell and agent.carrying`
+                        const uint32_t carry = rec_byte(r, MG_AG_CARRY);
+                        if (fbase == 0 && agents_there == 0 && carry) {
+                            g[fcell] = (uint8_t)carry;
+                            r = rec_set(r, MG_AG_CARRY, 0);
+                        }
+                    }
+                } else if (action == 3) {                            // pickup :590-597
+                    if (fbase && (fflags & MG_OF_CAN_PICKUP) && rec_byte(r, MG_AG_CARRY) == 0) {
+                        r = rec_set(r, MG_AG_CARRY, fbase);
+                        g[fcell] = 0;
+                    }
+                } else if (action == 5) {                            // toggle :609-613
+                    if (fbase) {
+                        if (fflags & MG_OF_IS_BOX) {
+                            err = err ? err : MG_ERR_TYPE;           // Box.toggle arity objects.py:381-382
+                        } else if (fflags & MG_OF_IS_DOOR) {         // Door.toggle objects.py:333-346
+                            const MgObjDesc od = cfg.obj[fbase];
+                            if (fflags & MG_OF_DOOR_LOCKED) {
+                                const uint32_t carry = rec_byte(r, MG_AG_CARRY);
+                                if (carry) {
+                                    const MgObjDesc cd = cfg.obj[carry];
+                                    if ((cd.flags & MG_OF_IS_KEY) && cd.color_idx == od.color_idx)
+                                        g[fcell] = od.unlock_next;
+                                }
+                            } else {
+                                g[fcell] = od.toggle_next;
+                            }
+                        }
+                    }
+                } else if (action == 6) {                            // done :616-617
+                } else {
+                    err = err ? err : MG_ERR_VALUE;                  // :619-620
+                }
+            }
+            s_rec[k * kBlock + tid] = r;
+        }
+        rewards[(size_t)b * n + k] = rew;
+    }
+
+    // done agents are deactivated but stay where they are (base.py:627-646, respawn=False);
+    // episode done (base.py:649)
+    bool all_done = true;
+    for (int k = 0; k < n; k++) {
+        uint64_t r = s_rec[k * kBlock + tid];
+        uint32_t f = rec_byte(r, MG_AG_FLAGS);
+        if (f & MG_AF_DONE) r = rec_set(r, MG_AG_FLAGS, f & ~MG_AF_ACTIVE);
+        else all_done = false;
+        st.agents[(size_t)b * n + k] = r;
+    }
+    st.step_count[b] = step_count;
+    st.mt_pos[b] = mt.pos;
+    st.done[b] = (uint8_t)((step_count >= cfg.max_steps) || all_done);
+    if (err && st.error[b] == 0) st.error[b] = err;
+}
+
+hipError_t launch_step(const MgConfig& cfg, const MgState& st, const void* actions, int action_bytes,
+                       float* rewards, hipStream_t s) {
+    if (cfg.B <= 0) return hipSuccess;
+    dim3 grid((cfg.B + kBlock - 1) / kBlock), block(kBlock);
+    size_t lds = (size_t)cfg.n_agents * kBlock * (sizeof(uint64_t) + 1);
+    if (action_bytes == 8)
+        hipLaunchKernelGGL(step_kernel<int64_t>, grid, block, lds, s, cfg, st, (const int64_t*)actions, rewards);
+    else if (action_bytes == 4)
+        hipLaunchKernelGGL(step_kernel<int32_t>, grid, block, lds, s, cfg, st, (const int32_t*)actions, rewards);
+    else if (action_bytes == 1)
+        hipLaunchKernelGGL(step_kernel<uint8_t>, grid, block, lds, s, cfg, st, (const uint8_t*)actions, rewards);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+}  // namespace mg

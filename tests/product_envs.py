@@ -1,0 +1,42 @@
+"""Build the PRODUCT env (marlgrid_amd, HIP path) for a named test scenario."""
+import numpy as np
+
+import canon
+
+
+def build(name, **kw):
+    from marlgrid_amd.agents import GridAgentInterface
+    from marlgrid_amd import envs as E
+    import scenarios
+    if name in E._registry:
+        return E.make(name, **kw)
+    spec = scenarios.registered(name)
+    cls_name, kwargs = scenarios.ref_recipe(name)
+    agents = [GridAgentInterface(color=a["color"], view_size=spec["view_size"], view_tile_size=spec["tile_size"],
+                                 view_offset=spec["view_offset"], see_through_walls=spec["see_through_walls"])
+              for a in spec["agents"]]
+    return getattr(E, cls_name)(agents=agents, **{**kwargs, **kw})
+
+
+def canonical(env, b=None):
+    """canonical id-free state of every env (list) or env b (dict)"""
+    import _native_consts as K
+    spec = env.scenario_spec()
+    B, n = env.batch_size, env.num_agents
+    base = env.grid.grid.cpu().numpy()
+    rec = env.agent_state.cpu().numpy().astype(np.uint64)
+    by = lambda i: ((rec >> np.uint64(8 * i)) & np.uint64(0xFF)).astype(np.int64)
+    x, y, d, fl, ca, rk = by(K.AG_X), by(K.AG_Y), by(K.AG_DIR), by(K.AG_FLAGS), by(K.AG_CARRY), by(K.AG_RANK)
+    placed = (fl & K.AF_PLACED) != 0
+    sc = env.step_count.cpu().numpy()
+    out = []
+    for bb in (range(B) if b is None else [b]):
+        pos = np.stack([np.where(placed[bb], x[bb], -1), np.where(placed[bb], y[bb], -1)], axis=1)
+        ordinal = np.full(n, -1)
+        for k in range(n):
+            if placed[bb, k]:
+                same = placed[bb] & (x[bb] == x[bb, k]) & (y[bb] == y[bb, k])
+                ordinal[k] = int((same & (rk[bb] < rk[bb, k])).sum())
+        out.append(canon.from_ids(spec, base[bb], pos, d[bb], (fl[bb] & K.AF_ACTIVE) != 0,
+                                  (fl[bb] & K.AF_DONE) != 0, ca[bb], ordinal, sc[bb]))
+    return out if b is None else out[0]

@@ -1,0 +1,138 @@
+"""CPU (-m "not gpu"): host logic of the product package, C-ABI symbol check, scope guards."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import scenarios
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "marlgrid_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(mg_[a-z_0-9]+)\s*\(", hdr)))
+    assert declared, "no declarations parsed"
+    so = os.path.join(ROOT, "marlgrid_amd", "csrc", "libmarlgrid_hip.so")
+    if not os.path.exists(so):
+        import __graft_entry__ as ge
+        ge.build()
+    L = ctypes.CDLL(so)
+    for name in declared:
+        assert hasattr(L, name), name
+    L.mg_abi_version.restype = ctypes.c_int32
+    assert L.mg_abi_version() == 1
+    from marlgrid_amd import _native
+    assert sorted(_native.SYMBOLS) == declared
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "marlgrid_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".sh")):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"import\s+oracle|from\s+oracle|from\s+\.+oracle|oracle/|oracle\.|libmgoracle|mgo_",
+                                     src), os.path.join(dp, f)
+
+
+@pytest.mark.parametrize("name", ["MarlGrid-1AgentCluttered15x15-v0", "MarlGrid-3AgentCluttered11x11-v0",
+                                  "MarlGrid-3AgentCluttered15x15-v0", "MarlGrid-2AgentEmpty9x9-v0",
+                                  "MarlGrid-3AgentEmpty9x9-v0", "MarlGrid-4AgentEmpty9x9-v0",
+                                  "Goalcycle-demo-solo-v0"])
+def test_scenario_spec_matches_independent_restatement(name):
+    from marlgrid_amd.envs import make
+    env = make(name, _dry=True)
+    a = env.scenario_spec()
+    assert a["gen_ctor"] == scenarios.registered(name)["gen_ctor"]
+    env.reset()
+    a, b = env.scenario_spec(), scenarios.registered(name)
+    for k in b:
+        assert a[k] == b[k], (k, a[k], b[k])
+
+
+@pytest.mark.parametrize("ts", [5, 8, 11, 32])
+def test_atlas_builder_against_reference_tiles(ts):
+    """product atlas (marlgrid_amd/rendering.py) == tiles captured from the reference"""
+    from marlgrid_amd import objects as PO
+    from marlgrid_amd import rendering
+    g = np.load(os.path.join(GOLD, "atlas.npz"))
+    colors = [str(c) for c in g["colors"]]
+    objs = [None, PO.Wall(), PO.Goal(color="green", reward=1), PO.Box("yellow"), PO.Door("yellow", 1),
+            PO.Door("yellow", 3), PO.BonusTile(color="yellow", reward=1)]
+    atlas, slot, n_slots = rendering.build_atlas(objs, colors, ts)
+    n_obj, n_ag = len(objs), len(colors)
+    assert atlas.shape == (4, 1 + n_obj + n_slots * n_ag * 4, ts, ts, 3)
+    assert (atlas[:, 0] == np.array([35, 25, 30])).all()
+    for i, key in enumerate(["empty", "wall", "goal", "box_yellow", "door_yellow_open", "door_yellow_locked", "bonus"]):
+        assert np.array_equal(atlas[0, 1 + i], g["%s_ts%d" % (key, ts)]), key
+    for k in range(n_ag):
+        for d in range(4):
+            assert np.array_equal(atlas[0, 1 + n_obj + (0 * n_ag + k) * 4 + d], g["agent_ts%d" % ts][k, d])
+            assert np.array_equal(atlas[0, 1 + n_obj + (slot[2] * n_ag + k) * 4 + d], g["goal_blend_ts%d" % ts][k, d])
+    # orientations are the reference's rotate_grid of orientation 0
+    t = atlas[0, 1 + n_obj + 3]
+    assert np.array_equal(atlas[3, 1 + n_obj + 3], np.moveaxis(t[:, ::-1], 0, 1))
+    assert np.array_equal(atlas[1, 1 + n_obj + 3], np.moveaxis(t[::-1, :], 0, 1))
+    assert np.array_equal(atlas[2, 1 + n_obj + 3], t[::-1, ::-1])
+
+
+def test_seed_words_match_golden_states():
+    """host hashing (seeding.py) + numpy's own init_by_array == the reference's seeded states"""
+    from marlgrid_amd import seeding
+    g = np.load(os.path.join(GOLD, "rng.npz"))
+    for s, key in list(zip(g["seeds"], g["mt_key"]))[:16] + list(zip(g["special_seeds"], g["special_mt_key"])):
+        rs = np.random.RandomState()
+        rs.seed(seeding.seed_words(int(s)))
+        assert np.array_equal(rs.get_state()[1], key)
+    assert seeding.seed_words(1337) == [1606814319, 1720193504]
+
+
+def test_independent_learners_contract():
+    """README.md:21-63 — per-agent fan-out of observations / actions, episode context manager."""
+    import torch
+    from marlgrid_amd.agents import IndependentLearners, LearningAgent
+    log = []
+
+    class A(LearningAgent):
+        def __init__(self, v, **k):
+            super().__init__(**k)
+            self.v = v
+
+        def action_step(self, obs):
+            return torch.full((obs.shape[0],), self.v)
+
+        def save_step(self, *tr):
+            log.append((self.v, [tuple(x.shape) for x in tr]))
+
+        def start_episode(self):
+            log.append(("start", self.v))
+
+        def end_episode(self):
+            log.append(("end", self.v))
+
+    ag = IndependentLearners(A(0, color="red"), A(2, color="blue"))
+    obs = torch.zeros((5, 2, 35, 35, 3), dtype=torch.uint8)
+    with ag.episode():
+        act = ag.action_step(obs)
+        assert act.shape == (5, 2) and act[:, 1].eq(2).all()
+        ag.save_step(obs, act, obs, torch.zeros(5, 2), torch.zeros(5, dtype=torch.bool))
+    assert log[0] == ("start", 0) and log[-1] == ("end", 2)
+    assert log[2] == (0, [(5, 35, 35, 3), (5,), (5, 35, 35, 3), (5,), (5,)])
+    assert len(list(ag)) == 2
+
+
+def test_constructor_errors():
+    from marlgrid_amd.envs import ClutteredMultiGrid
+    from marlgrid_amd.agents import GridAgentInterface
+    with pytest.raises(ValueError):
+        ClutteredMultiGrid(agents=[GridAgentInterface()], grid_size=9, _dry=True)          # neither
+    with pytest.raises(ValueError):
+        ClutteredMultiGrid(agents=[GridAgentInterface()], grid_size=9, n_clutter=1, clutter_density=.1, _dry=True)
+    with pytest.raises(ValueError):
+        ClutteredMultiGrid(agents=[object()], grid_size=9, n_clutter=1, _dry=True)
+    with pytest.raises(ValueError):
+        GridAgentInterface(observation_style="nope")
