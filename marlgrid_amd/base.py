@@ -289,7 +289,10 @@ class MultiGridEnv(object):
         """Seed every env's RNG (base.py:371-374).  Env b gets `seed + b` unless explicit per-env
         `seeds` were given to the constructor."""
         if self._seeds_arg is not None:
-            seeds = [int(s) for s in np.asarray(self._seeds_arg).reshape(-1)]
+            sa = self._seeds_arg
+            if hasattr(sa, "reshape"):                 # ndarray / tensor
+                sa = sa.reshape(-1).tolist()
+            seeds = [int(s) for s in sa]               # python ints: seeds may exceed int64
             if len(seeds) != self.batch_size:
                 raise ValueError("seeds must have batch_size entries")
         else:
@@ -499,6 +502,7 @@ class MultiGridEnv(object):
         if actions.dtype not in (torch.int64, torch.int32, torch.uint8):
             actions = actions.to(torch.int64)
         actions = actions.to(self.device).contiguous()
+        self._sync_tables()       # no-op unless a new object kind was registered since the last launch
         N.check(self._lib.mg_step(C.byref(self._cfg), C.byref(self._state), actions.data_ptr(),
                                   actions.element_size(), self.rewards.data_ptr(), self._stream()))
         done = self.done_t.to(torch.bool)
@@ -522,6 +526,7 @@ class MultiGridEnv(object):
 
     def _render(self, debug=False):
         import torch
+        self._sync_tables()
         if debug:
             B, n, vs = self.batch_size, self.num_agents, self.view_size
             cells = torch.zeros((B, n, vs, vs), dtype=torch.uint8, device=self.device)
@@ -569,6 +574,7 @@ class MultiGridEnv(object):
 
     def _encode(self, vis_mask=None):
         import torch
+        self._sync_tables()
         out = torch.empty((self.batch_size, self.width, self.height, 3), dtype=torch.uint8, device=self.device)
         vm = None
         if vis_mask is not None:
