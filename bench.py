@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=32768)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default=WORKLOAD, help="exploration only; the contract line uses the default")
     args = ap.parse_args()
 
     import numpy as np
@@ -59,7 +60,16 @@ def main():
     B = args.batch_per_gpu
     # the env batch shards embarrassingly: rank r owns global envs [r*B, (r+1)*B), seeds 1337 + id
     seeds = 1337 + rank * B + np.arange(B)
-    env = make(WORKLOAD, batch_size=B, device=dev, seeds=seeds, auto_reset=True, strict=False)
+    wl = args.workload
+    if wl == "Custom-8AgentCluttered30x30":     # BASELINE.json configs[4]; not a registered id upstream
+        from marlgrid_amd.agents import GridAgentInterface
+        from marlgrid_amd.envs import ClutteredMultiGrid
+        cols = ["red", "blue", "purple", "orange", "olive", "pink", "cyan", "yellow"]
+        env = ClutteredMultiGrid(agents=[GridAgentInterface(color=c, view_size=9, view_tile_size=8) for c in cols],
+                                 grid_size=30, clutter_density=0.15, batch_size=B, device=dev, seeds=seeds,
+                                 auto_reset=True, strict=False)
+    else:
+        env = make(wl, batch_size=B, device=dev, seeds=seeds, auto_reset=True, strict=False)
     env.reset()
     n = env.num_agents
     K, Wm = args.steps, args.warmup
@@ -107,24 +117,24 @@ def main():
             "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": WORKLOAD, "batch_per_gpu": B, "global_batch": B * n_gpus, "n_agents": n,
+            "config": {"workload": wl, "batch_per_gpu": B, "global_batch": B * n_gpus, "n_agents": n,
                        "view_size": vs, "tile_size": ts, "obs_shape": [B * n_gpus, n, P, P, 3],
                        "actions": "uniform over 7 ids, torch.randint seed=rank", "auto_reset": True,
                        "sharding": "env batch split contiguously, no collectives"},
-            "roofline": {"bound": "hbm", "kernel": "mg::render_kernel<7,8>", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "mg::render_kernel<%d,%d>" % (vs, ts), "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "kernel_ms": avg_ms.value, "algorithmic_bytes_per_agent_step": alg_bytes_per_agent_step,
                          "traffic": None},
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, wl)
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(budget_s):
+def cpu_baseline(budget_s, workload=WORKLOAD):
     """The parity-checked CPU oracle (a C port of the reference algorithm, OpenMP over envs) on a
     bounded sample of the same workload, on this box's host cores.  The Python reference cannot
     travel to the GPU box; its own measured speed (2 377 agent-steps/s on one Xeon core) is in
@@ -134,7 +144,7 @@ def cpu_baseline(budget_s):
     from oracle import oracle as O
     Bc = 2048
     seeds = 1337 + np.arange(Bc)
-    orc = O.OracleBatch(scenarios.registered(WORKLOAD), seeds)
+    orc = O.OracleBatch(scenarios.registered(workload), seeds)
     orc.reset()
     threads = orc.max_threads()
     rng = np.random.RandomState(0)
@@ -148,7 +158,7 @@ def cpu_baseline(budget_s):
     dt = time.perf_counter() - t0
     return {"value": Bc * orc.n * steps / dt, "unit": "agent-steps/s", "cores": int(threads), "kind": "port",
             "sample": "%d envs x %d steps of %s (C oracle, OpenMP, obs render included), %.1f s" % (
-                Bc, steps, WORKLOAD, dt),
+                Bc, steps, workload, dt),
             "host_cpus": os.cpu_count()}
 
 
