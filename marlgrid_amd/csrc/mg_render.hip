@@ -18,6 +18,8 @@
 //     dword of the image lies inside exactly one tile row, so there is no byte shuffling at all.
 // No MFMA: there is no contraction anywhere in this path.
 #include "mg_device.h"
+#include <stdlib.h>
+
 #include "mg_launch.h"
 
 namespace mg {
@@ -98,7 +100,10 @@ __device__ __forceinline__ void occlude_rows(int vs_rt, int off, const uint32_t*
 // ---- the kernel ----------------------------------------------------------------------------------
 // VS_/TS_ > 0: compile-time view/tile size, dword fast path (requires TS_ % 4 == 0).
 // VS_ == TS_ == 0: any size, byte-granular store loop (correct, slower).
-template <int VS_, int TS_>
+// V_: 0 = production.  1..5 = measurement variants used by tools/bench_render_variants.py (selected
+// with MG_RENDER_VARIANT, <7,8> only): 1 per-dword index math, 2 nontemporal stores, 3 raster only
+// (phases 2-5 skipped), 4 stores only (no LDS look-ups), 5 no next-env prefetch.
+template <int VS_, int TS_, int V_ = 0>
 __global__ __launch_bounds__(kBlock) void render_kernel(MgConfig cfg, MgState st, uint8_t* __restrict__ obs,
                                                         uint8_t* __restrict__ dbg_cells,
                                                         uint8_t* __restrict__ dbg_agent,
@@ -144,18 +149,51 @@ __global__ __launch_bounds__(kBlock) void render_kernel(MgConfig cfg, MgState st
     const int h = VS / 2, off = cfg.view_offset;
     const size_t img_bytes = (size_t)VS * TS * VS * TS * 3;
 
-    for (int e = blockIdx.x * 4 + wave; e < cfg.B; e += gridDim.x * 4) {
-        // 1. stage the env's grid + agent records
-        {
+    // next-env prefetch registers: the env's grid (<= 1 KiB: one dword per lane per 256 B) and records
+    constexpr int kPF = 4;
+    const int gdw = cfg.cells_stride / 4;
+    const bool use_pf = (V_ != 5) && gdw <= kPF * kWave;
+    uint32_t pf_g[kPF];
+    uint64_t pf_r = 0;
+    const int e_stride = gridDim.x * 4;
+    int e = blockIdx.x * 4 + wave;
+    auto prefetch = [&](int en) {
+        const uint32_t* gsrc = reinterpret_cast<const uint32_t*>(st.grid + (size_t)en * cfg.cells_stride);
+#pragma unroll
+        for (int i = 0; i < kPF; i++) {
+            const int idx = i * kWave + lane;
+            pf_g[i] = (idx < gdw) ? gsrc[idx] : 0u;
+        }
+        pf_r = (lane < n) ? st.agents[(size_t)en * n + lane] : 0ull;
+    };
+    if (use_pf && e < cfg.B) prefetch(e);
+
+    for (; e < cfg.B; e += e_stride) {
+        // 1. stage the env's grid + agent records (from the prefetch registers when they fit)
+        if (use_pf) {
+#pragma unroll
+            for (int i = 0; i < kPF; i++) {
+                const int idx = i * kWave + lane;
+                if (idx < gdw) {
+                    reinterpret_cast<uint32_t*>(w_grid)[idx] = pf_g[i];
+                    reinterpret_cast<uint32_t*>(w_first)[idx] = 0xFFFFFFFFu;
+                }
+            }
+            if (lane < n) w_rec[lane] = pf_r;
+            if (e + e_stride < cfg.B) prefetch(e + e_stride);   // in flight behind this env's raster
+        } else {
             const uint32_t* gsrc = reinterpret_cast<const uint32_t*>(st.grid + (size_t)e * cfg.cells_stride);
-            for (int i = lane; i < cfg.cells_stride / 4; i += kWave) {
+            for (int i = lane; i < gdw; i += kWave) {
                 reinterpret_cast<uint32_t*>(w_grid)[i] = gsrc[i];
                 reinterpret_cast<uint32_t*>(w_first)[i] = 0xFFFFFFFFu;
             }
             if (lane < n) w_rec[lane] = st.agents[(size_t)e * n + lane];
-            for (int i = lane; i < n * VS; i += kWave) w_trow[i] = 0;
         }
+        for (int i = lane; i < n * VS; i += kWave) w_trow[i] = 0;
         wave_lds_sync();
+        if constexpr (V_ == 3 || V_ == 4) {
+            for (int it = lane; it < n * VV; it += kWave) w_tmap[it] = 0;
+        } else {
         // 2. first (lowest-rank) agent of every occupied cell: the reference's "cell object" when
         //    the base is empty, and `obj.agents[0]` when agents stand on an overlappable object
         if (lane < n) {
@@ -237,6 +275,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(MgConfig cfg, MgState st
                 dbg_vis[o] = (uint8_t)visible;
             }
         }
+        }
         wave_lds_sync();
         // 6. raster: stream the env's n images out
         if constexpr (VS_ > 0 && TS_ > 0 && (TS_ % 4) == 0) {
@@ -246,6 +285,44 @@ __global__ __launch_bounds__(kBlock) void render_kernel(MgConfig cfg, MgState st
             const uint32_t* atlas32 = reinterpret_cast<const uint32_t*>(s_atlas);
             uint4* out = reinterpret_cast<uint4*>(obs + (size_t)e * n * img_bytes);
             const int total = n * IMG_CHUNKS;
+            if constexpr ((TD % 2) == 0 && V_ != 1) {
+                // A 16-byte chunk is two 8-byte pairs; TD even => a pair never straddles a tile row, and
+                // every pair is 8-byte aligned in the atlas (ds_read_b64).  The (image, pixel row, dword)
+                // position of a lane's chunk advances by a constant 64 chunks per iteration, so it is
+                // carried incrementally instead of being re-derived by division.
+                constexpr int P = VS_ * TS_;
+                constexpr int STEP_ROWS = (4 * kWave) / DR, STEP_DW = (4 * kWave) % DR;
+                int row = (lane * 4) / DR;
+                int dw = lane * 4 - row * DR;
+                int tbase = 0;                                   // k * VS*VS
+                if (row >= P) { row -= P; tbase += VS_ * VS_; }  // tiny images only
+                for (int c = lane; c < total; c += kWave) {
+                    uint2 p0, p1;
+                    if constexpr (V_ == 4) {
+                        p0 = make_uint2(0x1e19231eu, 0x231e1923u); p1 = p0;
+                    } else {
+                        int row1 = row, dw1 = dw + 2;
+                        if (dw1 >= DR) { dw1 -= DR; row1++; }
+                        const int va0 = dw / TD, kk0 = dw - va0 * TD;
+                        const int va1 = dw1 / TD, kk1 = dw1 - va1 * TD;
+                        const int vb0 = row / TS_, rr0 = row - vb0 * TS_;
+                        const int vb1 = row1 / TS_, rr1 = row1 - vb1 * TS_;
+                        const uint32_t a0 = (uint32_t)w_tmap[tbase + vb0 * VS_ + va0] + rr0 * TD + kk0;
+                        const uint32_t a1 = (uint32_t)w_tmap[tbase + vb1 * VS_ + va1] + rr1 * TD + kk1;
+                        p0 = *reinterpret_cast<const uint2*>(atlas32 + a0);
+                        p1 = *reinterpret_cast<const uint2*>(atlas32 + a1);
+                    }
+                    const uint4 v = make_uint4(p0.x, p0.y, p1.x, p1.y);
+                    if constexpr (V_ == 2) {
+                        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                        u32x4 nv = {v.x, v.y, v.z, v.w};
+                        __builtin_nontemporal_store(nv, reinterpret_cast<u32x4*>(out + c));
+                    } else out[c] = v;
+                    dw += STEP_DW; row += STEP_ROWS;
+                    if (dw >= DR) { dw -= DR; row++; }
+                    if (row >= P) { row -= P; tbase += VS_ * VS_; }
+                }
+            } else {
             for (int c = lane; c < total; c += kWave) {
                 const int k = c / IMG_CHUNKS;
                 const int q = (c - k * IMG_CHUNKS) * 4;
@@ -262,6 +339,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(MgConfig cfg, MgState st
                     if (++kk == TD) { kk = 0; if (++va == VS_) { va = 0; ++row; } }
                 }
                 out[c] = make_uint4(v[0], v[1], v[2], v[3]);
+            }
             }
         } else {
             uint8_t* out = obs + (size_t)e * n * img_bytes;
@@ -280,7 +358,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(MgConfig cfg, MgState st
     }
 }
 
-template <int VS_, int TS_>
+template <int VS_, int TS_, int V_ = 0>
 static hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_t* obs, uint8_t* c, uint8_t* a,
                                   uint8_t* v, hipStream_t s) {
     const int tile_bytes = cfg.tile_size * cfg.tile_size * 3;
@@ -288,19 +366,21 @@ static hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_
     size_t lds = (size_t)round_up(4 * cfg.n_tiles * tile_bytes, 16) + 2 * MG_MAX_OBJ + 4 * (size_t)L.total;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<VS_, TS_>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<VS_, TS_, V_>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    // persistent grid: enough workgroups to fill 256 CUs at the occupancy LDS allows, never more
-    // than one wave per env
+    // Persistent grid: at most the workgroups that are co-resident on 256 CUs at the occupancy the
+    // LDS footprint allows (each stages the atlas once), and sized so that every wave walks the same
+    // number of envs (an uneven tail costs up to one env-time in ~6).
     int per_cu = (int)((160 * 1024) / (lds ? lds : 1));
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
-    int blocks = 256 * per_cu;
-    int need = (cfg.B + 3) / 4;
-    if (blocks > need) blocks = need;
-    hipLaunchKernelGGL((render_kernel<VS_, TS_>), dim3(blocks), dim3(kBlock), lds, s, cfg, st, obs, c, a, v);
+    const int max_blocks = 256 * per_cu;
+    const int need = (cfg.B + 3) / 4;                      // workgroups if every wave took one env
+    const int rounds = (need + max_blocks - 1) / max_blocks;
+    const int blocks = (need + rounds - 1) / rounds;
+    hipLaunchKernelGGL((render_kernel<VS_, TS_, V_>), dim3(blocks), dim3(kBlock), lds, s, cfg, st, obs, c, a, v);
     return hipGetLastError();
 }
 
@@ -309,7 +389,17 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
     if (cfg.B <= 0) return hipSuccess;
     if ((view_cells || view_agent || vis_mask) && !(view_cells && view_agent && vis_mask)) return hipErrorInvalidValue;
     const int vs = cfg.view_size, ts = cfg.tile_size;
-    if (ts == 8 && vs == 7) return launch_render_t<7, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
+    if (ts == 8 && vs == 7) {
+        const int variant = getenv("MG_RENDER_VARIANT") ? atoi(getenv("MG_RENDER_VARIANT")) : 0;
+        switch (variant) {   // measurement variants, see render_kernel
+        case 1: return launch_render_t<7, 8, 1>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
+        case 2: return launch_render_t<7, 8, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
+        case 3: return launch_render_t<7, 8, 3>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
+        case 4: return launch_render_t<7, 8, 4>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
+        case 5: return launch_render_t<7, 8, 5>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
+        default: return launch_render_t<7, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
+        }
+    }
     if (ts == 8 && vs == 9) return launch_render_t<9, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
     if (ts == 8 && vs == 5) return launch_render_t<5, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
     if (ts == 8 && vs == 3) return launch_render_t<3, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s);

