@@ -57,9 +57,11 @@ def main():
 
     from marlgrid_amd.envs import make
     from marlgrid_amd import _native as N
+    from marlgrid_amd import sharding
     B = args.batch_per_gpu
     # the env batch shards embarrassingly: rank r owns global envs [r*B, (r+1)*B), seeds 1337 + id
-    seeds = 1337 + rank * B + np.arange(B)
+    seeds = sharding.shard_seeds(1337, B * n_gpus, rank, n_gpus)
+    assert len(seeds) == B
     wl = args.workload
     if wl == "Custom-8AgentCluttered30x30":     # BASELINE.json configs[4]; not a registered id upstream
         from marlgrid_amd.agents import GridAgentInterface
@@ -90,10 +92,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = sharding.max_over_ranks(elapsed, device=dev)      # the slowest rank defines the step time
     env.check_errors()
 
     # dominant kernel: mg_render_obs, timed live with HIP events on the launch stream
