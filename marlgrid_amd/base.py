@@ -274,6 +274,7 @@ class MultiGridEnv(object):
             self.mt_pos = torch.zeros((B,), dtype=torch.int32, device=dev)
             self.step_count_t = torch.zeros((B,), dtype=torch.int32, device=dev)
             self.done_t = torch.zeros((B,), dtype=torch.uint8, device=dev)
+            self.done_b = self.done_t.view(torch.bool)      # the same bytes, as the bool tensor step() returns
             self.error_t = torch.zeros((B,), dtype=torch.int32, device=dev)
             self.obs = torch.zeros((B, n, P, P, 3), dtype=torch.uint8, device=dev)
             self.rewards = torch.zeros((B, n), dtype=torch.float32, device=dev)
@@ -501,11 +502,15 @@ class MultiGridEnv(object):
             "actions must have shape (batch_size, n_agents)"                            # base.py:508
         if actions.dtype not in (torch.int64, torch.int32, torch.uint8):
             actions = actions.to(torch.int64)
-        actions = actions.to(self.device).contiguous()
+        if actions.device != self.device or not actions.is_contiguous():
+            actions = actions.to(self.device).contiguous()
         self._sync_tables()       # no-op unless a new object kind was registered since the last launch
+        stream = self._stream()
         N.check(self._lib.mg_step(C.byref(self._cfg), C.byref(self._state), actions.data_ptr(),
-                                  actions.element_size(), self.rewards.data_ptr(), self._stream()))
-        done = self.done_t.to(torch.bool)
+                                  actions.element_size(), self.rewards.data_ptr(), stream))
+        # `done` aliases the engine's flag buffer (like obs / rewards it is overwritten by the next
+        # step; clone it to keep it)
+        done = self.done_b
         if self.auto_reset:
             # envs that just finished start their next episode before the obs is rendered (their
             # returned obs is the first obs of the new episode; `done` still reports the end).  The
@@ -518,8 +523,9 @@ class MultiGridEnv(object):
                 self._reset_prog = self._program(template, ops)
                 self._retrace = False
             N.check(self._lib.mg_reset(C.byref(self._cfg), C.byref(self._state), C.byref(self._reset_prog),
-                                       C.c_void_p(self.done_t.data_ptr()), self._stream()))
-        self._render()
+                                       C.c_void_p(self.done_t.data_ptr()), stream))
+        N.check(self._lib.mg_render_obs(C.byref(self._cfg), C.byref(self._state), self.obs.data_ptr(), None, None,
+                                        None, stream))
         if self.strict:
             self.check_errors()
         return self.obs, self.rewards, done, {}

@@ -75,7 +75,6 @@ int32_t mg_step(const MgConfig* cfg, const MgState* st, const void* actions, int
     if (e) return e;
     if (!actions || !rewards) return MG_E_ARG;
     if (action_bytes != 1 && action_bytes != 4 && action_bytes != 8) return MG_E_ARG;
-    if (cfg->respawn) return MG_E_UNSUPPORTED;
     return rc(mg::launch_step(*cfg, *st, actions, action_bytes, rewards, (hipStream_t)stream));
 }
 

@@ -102,9 +102,10 @@ __device__ __forceinline__ void occlude_rows(int vs_rt, int off, const uint32_t*
 // VS_ == TS_ == 0: any size, byte-granular store loop (correct, slower).
 // V_: 0 = production.  1..5 = measurement variants used by tools/bench_render_variants.py (selected
 // with MG_RENDER_VARIANT, <7,8> only): 1 per-dword index math, 2 nontemporal stores, 3 raster only
-// (phases 2-5 skipped), 4 stores only (no LDS look-ups), 5 no next-env prefetch.
-template <int VS_, int TS_, int V_ = 0>
-__global__ __launch_bounds__(kBlock) void render_kernel(MgConfig cfg, MgState st, uint8_t* __restrict__ obs,
+// (phases 2-5 skipped), 4 stores only (no LDS look-ups), 5 no next-env prefetch, 6 no store bursts.
+// WPB = waves per workgroup (4 or 16; MG_RENDER_WPB overrides the launcher's choice).
+template <int VS_, int TS_, int WPB, int V_ = 0>
+__global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState st, uint8_t* __restrict__ obs,
                                                         uint8_t* __restrict__ dbg_cells,
                                                         uint8_t* __restrict__ dbg_agent,
                                                         uint8_t* __restrict__ dbg_vis) {
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(MgConfig cfg, MgState st
     {
         const uint4* src = reinterpret_cast<const uint4*>(cfg.atlas);
         uint4* dst = reinterpret_cast<uint4*>(s_atlas);
-        for (int i = tid; i < atlas_bytes / 16; i += kBlock) dst[i] = src[i];
+        for (int i = tid; i < atlas_bytes / 16; i += WPB * 64) dst[i] = src[i];
         if (tid < MG_MAX_OBJ) {
             uint8_t f = 0, sl = 0xFF;
             if (tid < cfg.n_obj) { f = cfg.obj[tid].flags; sl = cfg.obj[tid].ovl_slot; }
@@ -155,8 +156,9 @@ __global__ __launch_bounds__(kBlock) void render_kernel(MgConfig cfg, MgState st
     const bool use_pf = (V_ != 5) && gdw <= kPF * kWave;
     uint32_t pf_g[kPF];
     uint64_t pf_r = 0;
-    const int e_stride = gridDim.x * 4;
-    int e = blockIdx.x * 4 + wave;
+    const int e_stride = gridDim.x * WPB;
+    int e = blockIdx.x * WPB + wave;
+    const int e_end = cfg.B;
     auto prefetch = [&](int en) {
         const uint32_t* gsrc = reinterpret_cast<const uint32_t*>(st.grid + (size_t)en * cfg.cells_stride);
 #pragma unroll
@@ -166,9 +168,9 @@ __global__ __launch_bounds__(kBlock) void render_kernel(MgConfig cfg, MgState st
         }
         pf_r = (lane < n) ? st.agents[(size_t)en * n + lane] : 0ull;
     };
-    if (use_pf && e < cfg.B) prefetch(e);
+    if (use_pf && e < e_end) prefetch(e);
 
-    for (; e < cfg.B; e += e_stride) {
+    for (; e < e_end; e += e_stride) {
         // 1. stage the env's grid + agent records (from the prefetch registers when they fit)
         if (use_pf) {
 #pragma unroll
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(MgConfig cfg, MgState st
                 }
             }
             if (lane < n) w_rec[lane] = pf_r;
-            if (e + e_stride < cfg.B) prefetch(e + e_stride);   // in flight behind this env's raster
+            if (e + e_stride < e_end) prefetch(e + e_stride);   // in flight behind this env's raster
         } else {
             const uint32_t* gsrc = reinterpret_cast<const uint32_t*>(st.grid + (size_t)e * cfg.cells_stride);
             for (int i = lane; i < gdw; i += kWave) {
@@ -296,10 +298,9 @@ __global__ __launch_bounds__(kBlock) void render_kernel(MgConfig cfg, MgState st
                 int dw = lane * 4 - row * DR;
                 int tbase = 0;                                   // k * VS*VS
                 if (row >= P) { row -= P; tbase += VS_ * VS_; }  // tiny images only
-                for (int c = lane; c < total; c += kWave) {
-                    uint2 p0, p1;
+                auto fetch = [&](uint4& v) {
                     if constexpr (V_ == 4) {
-                        p0 = make_uint2(0x1e19231eu, 0x231e1923u); p1 = p0;
+                        v = make_uint4(0x1e19231eu, 0x231e1923u, 0x1e19231eu, 0x231e1923u);
                     } else {
                         int row1 = row, dw1 = dw + 2;
                         if (dw1 >= DR) { dw1 -= DR; row1++; }
@@ -309,18 +310,36 @@ __global__ __launch_bounds__(kBlock) void render_kernel(MgConfig cfg, MgState st
                         const int vb1 = row1 / TS_, rr1 = row1 - vb1 * TS_;
                         const uint32_t a0 = (uint32_t)w_tmap[tbase + vb0 * VS_ + va0] + rr0 * TD + kk0;
                         const uint32_t a1 = (uint32_t)w_tmap[tbase + vb1 * VS_ + va1] + rr1 * TD + kk1;
-                        p0 = *reinterpret_cast<const uint2*>(atlas32 + a0);
-                        p1 = *reinterpret_cast<const uint2*>(atlas32 + a1);
+                        const uint2 p0 = *reinterpret_cast<const uint2*>(atlas32 + a0);
+                        const uint2 p1 = *reinterpret_cast<const uint2*>(atlas32 + a1);
+                        v = make_uint4(p0.x, p0.y, p1.x, p1.y);
                     }
-                    const uint4 v = make_uint4(p0.x, p0.y, p1.x, p1.y);
+                    dw += STEP_DW; row += STEP_ROWS;
+                    if (dw >= DR) { dw -= DR; row++; }
+                    if (row >= P) { row -= P; tbase += VS_ * VS_; }
+                };
+                auto put = [&](int c, const uint4& v) {
                     if constexpr (V_ == 2) {
                         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                         u32x4 nv = {v.x, v.y, v.z, v.w};
                         __builtin_nontemporal_store(nv, reinterpret_cast<u32x4*>(out + c));
                     } else out[c] = v;
-                    dw += STEP_DW; row += STEP_ROWS;
-                    if (dw >= DR) { dw -= DR; row++; }
-                    if (row >= P) { row -= P; tbase += VS_ * VS_; }
+                };
+                int c = lane;
+                if constexpr (V_ != 6) {
+                    // gather four chunks from LDS, then issue their four 1-KiB stores back to back:
+                    // bursts of stores sustain ~8 % more HBM write bandwidth than evenly spaced ones
+                    // (tools/microbench/store_patterns.hip, patterns B vs E)
+                    for (; c + 3 * kWave < total; c += 4 * kWave) {
+                        uint4 v0, v1, v2, v3;
+                        fetch(v0); fetch(v1); fetch(v2); fetch(v3);
+                        put(c, v0); put(c + kWave, v1); put(c + 2 * kWave, v2); put(c + 3 * kWave, v3);
+                    }
+                }
+                for (; c < total; c += kWave) {
+                    uint4 v;
+                    fetch(v);
+                    put(c, v);
                 }
             } else {
             for (int c = lane; c < total; c += kWave) {
@@ -358,52 +377,70 @@ __global__ __launch_bounds__(kBlock) void render_kernel(MgConfig cfg, MgState st
     }
 }
 
-template <int VS_, int TS_, int V_ = 0>
+template <int VS_, int TS_, int WPB, int V_ = 0>
 static hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_t* obs, uint8_t* c, uint8_t* a,
                                   uint8_t* v, hipStream_t s) {
     const int tile_bytes = cfg.tile_size * cfg.tile_size * 3;
     const RenderScratch L = render_scratch_layout(cfg.cells_stride, cfg.n_agents, cfg.view_size);
-    size_t lds = (size_t)round_up(4 * cfg.n_tiles * tile_bytes, 16) + 2 * MG_MAX_OBJ + 4 * (size_t)L.total;
+    size_t lds = (size_t)round_up(4 * cfg.n_tiles * tile_bytes, 16) + 2 * MG_MAX_OBJ + WPB * (size_t)L.total;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<VS_, TS_, V_>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<VS_, TS_, WPB, V_>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    // Persistent grid: at most the workgroups that are co-resident on 256 CUs at the occupancy the
-    // LDS footprint allows (each stages the atlas once), and sized so that every wave walks the same
-    // number of envs (an uneven tail costs up to one env-time in ~6).
+    // Persistent grid: at most the workgroups that are co-resident on 256 CUs (each stages the atlas
+    // once), sized so that every wave walks the same number of envs (an uneven tail costs up to one
+    // env-time in ~6).  Registers (~87 VGPRs) admit 5 waves per SIMD = 20 per CU.
     int per_cu = (int)((160 * 1024) / (lds ? lds : 1));
+    if (per_cu > 20 / WPB) per_cu = 20 / WPB;
     if (per_cu < 1) per_cu = 1;
-    if (per_cu > 8) per_cu = 8;
     const int max_blocks = 256 * per_cu;
-    const int need = (cfg.B + 3) / 4;                      // workgroups if every wave took one env
+    const int need = (cfg.B + WPB - 1) / WPB;              // workgroups if every wave took one env
     const int rounds = (need + max_blocks - 1) / max_blocks;
     const int blocks = (need + rounds - 1) / rounds;
-    hipLaunchKernelGGL((render_kernel<VS_, TS_, V_>), dim3(blocks), dim3(kBlock), lds, s, cfg, st, obs, c, a, v);
+    hipLaunchKernelGGL((render_kernel<VS_, TS_, WPB, V_>), dim3(blocks), dim3(WPB * 64), lds, s, cfg, st, obs, c, a, v);
     return hipGetLastError();
 }
+
+// Workgroup shape.  16 waves per workgroup walk 16 *adjacent* envs at a time (a 450 KB contiguous
+// output window per workgroup, one atlas copy per 16 waves): measured +7..13 % HBM write throughput
+// over 4-wave workgroups at the bench batch.  Small batches keep 4-wave workgroups so that they
+// still spread over all CUs.
+static int choose_wpb(const MgConfig& cfg) {
+    if (const char* f = getenv("MG_RENDER_WPB")) { int w = atoi(f); if (w == 4 || w == 16) return w; }
+    const int tile_bytes = cfg.tile_size * cfg.tile_size * 3;
+    const RenderScratch L = render_scratch_layout(cfg.cells_stride, cfg.n_agents, cfg.view_size);
+    size_t lds16 = (size_t)round_up(4 * cfg.n_tiles * tile_bytes, 16) + 2 * MG_MAX_OBJ + 16 * (size_t)L.total;
+    return (cfg.B >= 4096 && lds16 <= 160 * 1024) ? 16 : 4;
+}
+
+#define MG_RENDER_DISPATCH(VS, TS, V)                                                                      \
+    (wpb == 16 ? launch_render_t<VS, TS, 16, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s)           \
+               : launch_render_t<VS, TS, 4, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s))
 
 hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, uint8_t* view_cells,
                          uint8_t* view_agent, uint8_t* vis_mask, hipStream_t s) {
     if (cfg.B <= 0) return hipSuccess;
     if ((view_cells || view_agent || vis_mask) && !(view_cells && view_agent && vis_mask)) return hipErrorInvalidValue;
     const int vs = cfg.view_size, ts = cfg.tile_size;
+    const int wpb = choose_wpb(cfg);
     if (ts == 8 && vs == 7) {
         const int variant = getenv("MG_RENDER_VARIANT") ? atoi(getenv("MG_RENDER_VARIANT")) : 0;
-        switch (variant) {   // measurement variants, see render_kernel
-        case 1: return launch_render_t<7, 8, 1>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
-        case 2: return launch_render_t<7, 8, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
-        case 3: return launch_render_t<7, 8, 3>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
-        case 4: return launch_render_t<7, 8, 4>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
-        case 5: return launch_render_t<7, 8, 5>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
-        default: return launch_render_t<7, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
+        switch (variant) {   // measurement variants (tools/ab_render.py), see render_kernel
+        case 1: return MG_RENDER_DISPATCH(7, 8, 1);
+        case 2: return MG_RENDER_DISPATCH(7, 8, 2);
+        case 3: return MG_RENDER_DISPATCH(7, 8, 3);
+        case 4: return MG_RENDER_DISPATCH(7, 8, 4);
+        case 5: return MG_RENDER_DISPATCH(7, 8, 5);
+        case 6: return MG_RENDER_DISPATCH(7, 8, 6);
+        default: return MG_RENDER_DISPATCH(7, 8, 0);
         }
     }
-    if (ts == 8 && vs == 9) return launch_render_t<9, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
-    if (ts == 8 && vs == 5) return launch_render_t<5, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
-    if (ts == 8 && vs == 3) return launch_render_t<3, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
-    return launch_render_t<0, 0>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
+    if (ts == 8 && vs == 9) return MG_RENDER_DISPATCH(9, 8, 0);
+    if (ts == 8 && vs == 5) return MG_RENDER_DISPATCH(5, 8, 0);
+    if (ts == 8 && vs == 3) return MG_RENDER_DISPATCH(3, 8, 0);
+    return MG_RENDER_DISPATCH(0, 0, 0);
 }
 
 }  // namespace mg

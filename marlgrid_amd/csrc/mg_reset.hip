@@ -83,7 +83,9 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(MgConfig cfg, MgState st,
     }
     st.mt_pos[b] = mt.pos;
     st.step_count[b] = 0;
-    st.done[b] = 0;
+    // auto-reset passes the done flags themselves as the mask: they stay readable as step()'s return
+    // value (the next mg_step overwrites them); an explicit reset clears them
+    if (mask != st.done) st.done[b] = 0;
     if (err && st.error[b] == 0) st.error[b] = err;
 }
 

@@ -21,27 +21,58 @@ namespace mg {
 
 template <typename ActT, int BS>
 __global__ __launch_bounds__(BS) void step_kernel(MgConfig cfg, MgState st, const ActT* __restrict__ actions,
-                                                      float* __restrict__ rewards) {
-    extern __shared__ __attribute__((aligned(16))) uint64_t s_rec[];  // [n][BS]
-    uint8_t* s_order = reinterpret_cast<uint8_t*>(s_rec + (size_t)cfg.n_agents * BS);  // [n][BS]
+                                                  float* __restrict__ rewards) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t s_rec[];                      // [n][BS]
+    uint8_t* s_order = reinterpret_cast<uint8_t*>(s_rec + (size_t)cfg.n_agents * BS);      // [n][BS]
+    uint8_t* s_act = s_order + (size_t)cfg.n_agents * BS;                                   // [n][BS] action (0xFF: invalid)
+    uint8_t* s_fb = s_act + (size_t)cfg.n_agents * BS;                                      // [n][BS] front-cell base id
+    uint8_t* s_oflags = s_fb + (size_t)cfg.n_agents * BS;                                   // [MG_MAX_OBJ]
     const int tid = threadIdx.x;
     const int b = blockIdx.x * BS + tid;
-    if (b >= cfg.B) return;
+    const bool live = b < cfg.B;
     const int n = cfg.n_agents, W = cfg.W, H = cfg.H;
 
-    for (int k = 0; k < n; k++) s_rec[k * BS + tid] = st.agents[(size_t)b * n + k];
+    // ---- round trip 1: everything whose address is known up front ----
+    if (tid < MG_MAX_OBJ) s_oflags[tid] = (tid < cfg.n_obj && tid > 0) ? cfg.obj[tid].flags : 0;
+    int pos0 = 0, sc0 = 0;
+    if (live) {
+        for (int k = 0; k < n; k++) s_rec[k * BS + tid] = st.agents[(size_t)b * n + k];
+        for (int k = 0; k < n; k++) {
+            const long long a = (long long)actions[(size_t)b * n + k];
+            s_act[k * BS + tid] = (a >= 0 && a <= 6) ? (uint8_t)a : (uint8_t)0xFF;
+        }
+        pos0 = st.mt_pos[b];
+        sc0 = st.step_count[b];
+    }
+    __syncthreads();
+    if (!live) return;
     uint8_t* g = st.grid + (size_t)b * cfg.cells_stride;
-    Mt mt{st.mt + (size_t)b * MG_MT_N, st.mt_pos[b]};
+    uint32_t* mtw = st.mt + (size_t)b * MG_MT_N;
+
+    // ---- round trip 2: every agent's front cell.  An agent's position
+    // and heading are only ever changed by its own action, so its front cell is known before the
+    // loop; the cell's *content* can only be changed by a pickup / drop / toggle earlier in this
+    // step (grid_dirty), in which case it is re-read. ----
+    for (int k = 0; k < n; k++) {
+        const uint64_t r = s_rec[k * BS + tid];
+        const int dir = (int)rec_byte(r, MG_AG_DIR);
+        const int fx = (int)rec_byte(r, MG_AG_X) + dir_dx(dir), fy = (int)rec_byte(r, MG_AG_Y) + dir_dy(dir);
+        const bool ok = (rec_byte(r, MG_AG_FLAGS) & MG_AF_ACTIVE) && fx >= 0 && fx < W && fy >= 0 && fy < H;
+        s_fb[k * BS + tid] = ok ? g[fx * H + fy] : (uint8_t)0;
+    }
+    bool grid_dirty = false;
     int err = 0;
 
-    const int step_count = st.step_count[b] + 1;   // base.py:512
+    const int step_count = sc0 + 1;   // base.py:512
     // reward decay factor, float64 like the reference (base.py:579)
     const double decay = cfg.reward_decay ? (1.0 - 0.9 * ((double)step_count / (double)cfg.max_steps)) : 1.0;
 
     // iter_order = arange(n); np_random.shuffle(iter_order)  (base.py:514-516): legacy Fisher-Yates
+    // over numpy's masked-rejection bounded draws
+    Mt mt{mtw, pos0};
     for (int k = 0; k < n; k++) s_order[k * BS + tid] = (uint8_t)k;
     for (int i = n - 1; i >= 1; i--) {
-        int j = (int)mt.bounded((uint32_t)i);
+        const int j = (int)mt.bounded((uint32_t)i);
         uint8_t t = s_order[i * BS + tid];
         s_order[i * BS + tid] = s_order[j * BS + tid];
         s_order[j * BS + tid] = t;
@@ -53,7 +84,7 @@ __global__ __launch_bounds__(BS) void step_kernel(MgConfig cfg, MgState st, cons
         uint64_t r = s_rec[k * BS + tid];
         const uint32_t flags = rec_byte(r, MG_AG_FLAGS);
         if (flags & MG_AF_ACTIVE) {   // base.py:521
-            const long long action = (long long)actions[(size_t)b * n + k];
+            const int action = (int)s_act[k * BS + tid];
             const int cx = (int)rec_byte(r, MG_AG_X), cy = (int)rec_byte(r, MG_AG_Y);
             const int dir = (int)rec_byte(r, MG_AG_DIR);
             const int fx = cx + dir_dx(dir), fy = cy + dir_dy(dir);   // agent.front_pos agents.py:194-198
@@ -61,9 +92,9 @@ __global__ __launch_bounds__(BS) void step_kernel(MgConfig cfg, MgState st, cons
                 err = err ? err : MG_ERR_ASSERT;   // grid.get asserts (base.py:154-156)
             } else {
                 const int fcell = fx * H + fy;
-                const uint32_t fbase = g[fcell];
+                const uint32_t fbase = grid_dirty ? (uint32_t)g[fcell] : (uint32_t)s_fb[k * BS + tid];
                 const uint32_t fxy = (uint32_t)fx | ((uint32_t)fy << 8);
-                const uint32_t fflags = fbase ? cfg.obj[fbase].flags : 0u;
+                const uint32_t fflags = s_oflags[fbase];
                 if (action == 0) {                                   // left  base.py:530-531
                     r = rec_set(r, MG_AG_DIR, (uint32_t)((dir + 3) & 3));
                 } else if (action == 1) {                            // right :534-535
@@ -118,6 +149,7 @@ __global__ __launch_bounds__(BS) void step_kernel(MgConfig cfg, MgState st, cons
                         const uint32_t carry = rec_byte(r, MG_AG_CARRY);
                         if (fbase == 0 && agents_there == 0 && carry) {
                             g[fcell] = (uint8_t)carry;
+                            grid_dirty = true;
                             r = rec_set(r, MG_AG_CARRY, 0);
                         }
                     }
@@ -125,6 +157,7 @@ __global__ __launch_bounds__(BS) void step_kernel(MgConfig cfg, MgState st, cons
                     if (fbase && (fflags & MG_OF_CAN_PICKUP) && rec_byte(r, MG_AG_CARRY) == 0) {
                         r = rec_set(r, MG_AG_CARRY, fbase);
                         g[fcell] = 0;
+                        grid_dirty = true;
                     }
                 } else if (action == 5) {                            // toggle :609-613
                     if (fbase) {
@@ -137,10 +170,11 @@ __global__ __launch_bounds__(BS) void step_kernel(MgConfig cfg, MgState st, cons
                                 if (carry) {
                                     const MgObjDesc cd = cfg.obj[carry];
                                     if ((cd.flags & MG_OF_IS_KEY) && cd.color_idx == od.color_idx)
-                                        g[fcell] = od.unlock_next;
+                                        { g[fcell] = od.unlock_next; grid_dirty = true; }
                                 }
                             } else {
                                 g[fcell] = od.toggle_next;
+                                grid_dirty = true;
                             }
                         }
                     }
@@ -154,16 +188,55 @@ __global__ __launch_bounds__(BS) void step_kernel(MgConfig cfg, MgState st, cons
         rewards[(size_t)b * n + k] = rew;
     }
 
-    // done agents are deactivated but stay where they are (base.py:627-646, respawn=False);
-    // episode done (base.py:649)
+    // done agents (base.py:627-646), in index order: without respawn they are deactivated but stay
+    // where they are; with respawn they leave their cell (an agent only ever becomes done on a Goal /
+    // Lava, i.e. inside that object's stack, so nothing is left behind), drop what they carry
+    // (agent.reset(new_episode=False), agents.py:161-166) and are re-placed by rejection sampling
+    // among the agents currently on the grid.  Then episode done (base.py:649).
     bool all_done = true;
     for (int k = 0; k < n; k++) {
         uint64_t r = s_rec[k * BS + tid];
-        uint32_t f = rec_byte(r, MG_AG_FLAGS);
-        if (f & MG_AF_DONE) r = rec_set(r, MG_AG_FLAGS, f & ~MG_AF_ACTIVE);
-        else all_done = false;
-        st.agents[(size_t)b * n + k] = r;
+        const uint32_t f = rec_byte(r, MG_AG_FLAGS);
+        if (f & MG_AF_DONE) {
+            if (cfg.respawn) {
+                r = rec_set(r, MG_AG_FLAGS, 0);
+                r = rec_set(r, MG_AG_CARRY, 0);
+                s_rec[k * BS + tid] = r;                      // off the grid while sampling
+                bool ok = false;
+                for (int t = 0; t < 100000; t++) {            // place_obj default max_tries = 1e5
+                    const int x = (int)mt.bounded((uint32_t)(W - 1));
+                    const int y = (int)mt.bounded((uint32_t)(H - 1));
+                    const uint32_t base = g[x * H + y];
+                    const uint32_t xy = (uint32_t)x | ((uint32_t)y << 8);
+                    int cnt = 0;
+                    for (int j = 0; j < n; j++) {
+                        const uint64_t rj = s_rec[j * BS + tid];
+                        cnt += ((rec_byte(rj, MG_AG_FLAGS) & MG_AF_PLACED) && rec_xy(rj) == xy) ? 1 : 0;
+                    }
+                    if ((s_oflags[base] & MG_OF_CAN_OVERLAP || base == 0) && (cnt == 0 || cfg.ghost_mode)) {
+                        const uint32_t old_rank = rec_byte(r, MG_AG_RANK);
+                        for (int j = 0; j < n; j++) {
+                            const uint64_t rj = s_rec[j * BS + tid];
+                            const uint32_t rk = rec_byte(rj, MG_AG_RANK);
+                            if (rk > old_rank) s_rec[j * BS + tid] = rec_set(rj, MG_AG_RANK, rk - 1);
+                        }
+                        r = rec_set(r, MG_AG_RANK, (uint32_t)(n - 1));
+                        r = rec_set(r, MG_AG_X, (uint32_t)x);
+                        r = rec_set(r, MG_AG_Y, (uint32_t)y);
+                        r = rec_set(r, MG_AG_FLAGS, MG_AF_ACTIVE | MG_AF_PLACED);
+                        ok = true;
+                        break;
+                    }
+                }
+                if (!ok) err = err ? err : MG_ERR_RECURSION;
+                all_done = false;
+            } else {
+                r = rec_set(r, MG_AG_FLAGS, f & ~MG_AF_ACTIVE);
+            }
+            s_rec[k * BS + tid] = r;
+        } else all_done = false;
     }
+    for (int k = 0; k < n; k++) st.agents[(size_t)b * n + k] = s_rec[k * BS + tid];
     st.step_count[b] = step_count;
     st.mt_pos[b] = mt.pos;
     st.done[b] = (uint8_t)((step_count >= cfg.max_steps) || all_done);
@@ -174,7 +247,7 @@ template <int BS>
 static hipError_t launch_step_bs(const MgConfig& cfg, const MgState& st, const void* actions, int action_bytes,
                                  float* rewards, hipStream_t s) {
     dim3 grid((cfg.B + BS - 1) / BS), block(BS);
-    size_t lds = (size_t)cfg.n_agents * BS * (sizeof(uint64_t) + 1);
+    size_t lds = (size_t)cfg.n_agents * BS * (sizeof(uint64_t) + 3) + MG_MAX_OBJ;
     if (action_bytes == 8)
         hipLaunchKernelGGL((step_kernel<int64_t, BS>), grid, block, lds, s, cfg, st, (const int64_t*)actions, rewards);
     else if (action_bytes == 4)
@@ -189,12 +262,11 @@ static hipError_t launch_step_bs(const MgConfig& cfg, const MgState& st, const v
 hipError_t launch_step(const MgConfig& cfg, const MgState& st, const void* actions, int action_bytes,
                        float* rewards, hipStream_t s) {
     if (cfg.B <= 0) return hipSuccess;
-    // One lane per env is latency-bound (a chain of dependent HBM accesses per agent), so spread the
-    // envs over as many CUs as possible: single-wave workgroups until the batch alone fills the chip.
+    // One lane per env: spread the envs over as many CUs as possible with single-wave workgroups
+    // until the batch alone fills the chip several times over.
     const int forced = getenv("MG_STEP_BLOCK") ? atoi(getenv("MG_STEP_BLOCK")) : 0;
-    int bs = forced ? forced : (cfg.B >= 256 * 8 * 256 ? 256 : 64);
+    const int bs = forced ? forced : (cfg.B > 256 * 8 * 64 ? 256 : 64);
     if (bs == 256) return launch_step_bs<256>(cfg, st, actions, action_bytes, rewards, s);
-    if (bs == 128) return launch_step_bs<128>(cfg, st, actions, action_bytes, rewards, s);
     return launch_step_bs<64>(cfg, st, actions, action_bytes, rewards, s);
 }
 

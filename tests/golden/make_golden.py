@@ -40,6 +40,8 @@ TRAJ = {  # scenario -> (n_seeds, n_steps, n_full_obs_seeds)
     "Test-4AgentEmpty5x5-crowded-noghost": (8, 150, 1),
     "Test-2AgentCluttered9x9-offset2-ts5": (6, 120, 2),
     "Test-2AgentEmpty7x7-see-through": (4, 60, 2),
+    "Test-3AgentCluttered9x9-respawn": (8, 200, 1),
+    "Test-4AgentEmpty5x5-respawn-noghost": (8, 200, 1),
 }
 CANON = ("base_enc", "pos", "dir", "active", "done", "carry_enc", "ordinal")
 
@@ -266,6 +268,10 @@ def main():
         gen_rng(os.path.join(HERE, "rng.npz"))
     if "occlusion" in which:
         gen_occlusion(m, os.path.join(HERE, "occlusion.npz"))
+    only = [w for w in which if w in TRAJ]
+    for name in only:
+        gen_traj(name, os.path.join(HERE, "traj_%s.npz" % name))
+        print("traj", name, flush=True)
     if "traj" in which:
         for name in TRAJ:
             gen_traj(name, os.path.join(HERE, "traj_%s.npz" % name))

@@ -106,6 +106,8 @@ def ref_recipe(name):
         "Test-4AgentEmpty5x5-crowded-noghost": ("EmptyMultiGrid", dict(grid_size=5, ghost_mode=False)),
         "Test-2AgentCluttered9x9-offset2-ts5": ("ClutteredMultiGrid", dict(grid_size=9, n_clutter=8, randomize_goal=True)),
         "Test-2AgentEmpty7x7-see-through": ("EmptyMultiGrid", dict(grid_size=7)),
+        "Test-3AgentCluttered9x9-respawn": ("ClutteredMultiGrid", dict(grid_size=9, n_clutter=6, respawn=True)),
+        "Test-4AgentEmpty5x5-respawn-noghost": ("EmptyMultiGrid", dict(grid_size=5, respawn=True, ghost_mode=False)),
     }
     return t[name]
 
@@ -121,6 +123,8 @@ def registered(name):   # noqa: F811  (extends the table above with test-only sc
         "Test-2AgentCluttered9x9-offset2-ts5": lambda: cluttered_spec(2, 9, 5, n_clutter=8, randomize_goal=True,
                                                                         tile_size=5, view_offset=2),
         "Test-2AgentEmpty7x7-see-through": lambda: empty_spec(2, 7, 3, see_through_walls=True, tile_size=11),
+        "Test-3AgentCluttered9x9-respawn": lambda: cluttered_spec(3, 9, 7, n_clutter=6, respawn=True),
+        "Test-4AgentEmpty5x5-respawn-noghost": lambda: empty_spec(4, 5, 5, respawn=True, ghost_mode=False),
     }
     if name in extra:
         return extra[name]()
@@ -133,7 +137,7 @@ ALL_SCENARIOS = [
     "MarlGrid-1AgentCluttered15x15-v0", "MarlGrid-3AgentEmpty9x9-v0", "Goalcycle-demo-solo-v0",
     "Test-3AgentCluttered11x11-noghost", "Test-4AgentEmpty5x5-crowded",
     "Test-4AgentEmpty5x5-crowded-noghost", "Test-2AgentCluttered9x9-offset2-ts5",
-    "Test-2AgentEmpty7x7-see-through",
+    "Test-2AgentEmpty7x7-see-through", "Test-3AgentCluttered9x9-respawn", "Test-4AgentEmpty5x5-respawn-noghost",
 ]
 
 

@@ -1,0 +1,36 @@
+#!/usr/bin/env python
+"""In-process interleaved A/B of obs-render variants (MG_RENDER_VARIANT is read at every launch).
+usage: ab_render.py [variants...]   e.g. ab_render.py 0 1 3 4"""
+import ctypes as C
+import os
+import statistics
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from marlgrid_amd import _native as N  # noqa: E402
+from marlgrid_amd.envs import make  # noqa: E402
+
+variants = sys.argv[1:] or ["0", "1", "2", "3", "4", "5"]      # "V" or "V:waves_per_workgroup"
+B = int(os.environ.get("B", "32768"))
+env = make(os.environ.get("WL", "MarlGrid-3AgentCluttered15x15-v0"), batch_size=B, auto_reset=True, strict=False)
+env.reset()
+g = torch.Generator().manual_seed(0)
+for i in range(30):
+    env.step(torch.randint(0, 7, (B, env.num_agents), generator=g).cuda())
+torch.cuda.synchronize()
+vs, ts, n = env.view_size, env.tile_size, env.num_agents
+alg = B * n * (vs * ts * vs * ts * 3 + vs * vs + 8 * n)
+res = {v: [] for v in variants}
+ms = C.c_float(0)
+for rep in range(7):
+    for v in variants:
+        os.environ["MG_RENDER_VARIANT"] = v.split(":")[0]
+        os.environ["MG_RENDER_WPB"] = v.split(":")[1] if ":" in v else "0"
+        N.check(env._lib.mg_time_render_obs(C.byref(env._cfg), C.byref(env._state), env.obs.data_ptr(), 40,
+                                            C.byref(ms), env._stream()))
+        res[v].append(ms.value)
+for v in variants:
+    m = statistics.median(res[v])
+    print("variant %s: median %.4f ms (min %.4f max %.4f)  %.0f GB/s  %.1f%% of 8 TB/s"
+          % (v, m, min(res[v]), max(res[v]), alg / m / 1e6, alg / m / 1e6 / 80))
