@@ -288,35 +288,39 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             uint4* out = reinterpret_cast<uint4*>(obs + (size_t)e * n * img_bytes);
             const int total = n * IMG_CHUNKS;
             if constexpr ((TD % 2) == 0 && V_ != 1) {
-                // A 16-byte chunk is two 8-byte pairs; TD even => a pair never straddles a tile row, and
-                // every pair is 8-byte aligned in the atlas (ds_read_b64).  The (image, pixel row, dword)
-                // position of a lane's chunk advances by a constant 64 chunks per iteration, so it is
-                // carried incrementally instead of being re-derived by division.
-                constexpr int P = VS_ * TS_;
-                constexpr int STEP_ROWS = (4 * kWave) / DR, STEP_DW = (4 * kWave) % DR;
-                int row = (lane * 4) / DR;
-                int dw = lane * 4 - row * DR;
-                int tbase = 0;                                   // k * VS*VS
-                if (row >= P) { row -= P; tbase += VS_ * VS_; }  // tiny images only
+                // The env's n images are one contiguous run of 8-byte *pairs*: PR pairs per pixel row,
+                // PT per tile row (TD even => a pair never straddles a tile row, and every pair is
+                // 8-byte aligned in the atlas: ds_read_b64).  A 16-byte chunk is pairs (2c, 2c+1).
+                // tmap is laid out [image][band][column], and an image has exactly VS bands, so the
+                // GLOBAL pixel row r (counted across the env's images) indexes it directly:
+                // tile = tmap[(r / TS) * VS + column].  A lane's chunk advances by 64 chunks = 128
+                // pairs per trip, so (r, pair-in-row) is carried incrementally: no per-chunk division
+                // by anything but the compile-time PT.
+                constexpr uint32_t PR = DR / 2, PT = TD / 2;
+                constexpr uint32_t STEP_R = (2 * kWave) / PR, STEP_P = (2 * kWave) % PR;
+                uint32_t r = (2u * lane) / PR;
+                uint32_t pr = 2u * lane - r * PR;
+                // all quantities are < 2^16: 24-bit multiplies (full-rate v_mul/mad_u32_u24) and
+                // multiply-shift division by the compile-time PT / TS
+                constexpr uint32_t M_PT = (65536u + PT - 1) / PT, M_TS = (65536u + TS_ - 1) / TS_;
+                static_assert(PR * M_PT < (1u << 24) && MG_MAX_AGENTS * VS_ * TS_ * M_TS < (1u << 24), "u24 range");
+                auto pair_addr = [&](uint32_t rr_, uint32_t pr_) -> uint32_t {
+                    const uint32_t va = __umul24(pr_, M_PT) >> 16, kp = pr_ - __umul24(va, PT);
+                    const uint32_t vb = __umul24(rr_, M_TS) >> 16, rr = rr_ - __umul24(vb, (uint32_t)TS_);
+                    return (uint32_t)w_tmap[__umul24(vb, (uint32_t)VS_) + va] + __umul24(rr, (uint32_t)TD) + kp * 2u;
+                };
                 auto fetch = [&](uint4& v) {
                     if constexpr (V_ == 4) {
                         v = make_uint4(0x1e19231eu, 0x231e1923u, 0x1e19231eu, 0x231e1923u);
                     } else {
-                        int row1 = row, dw1 = dw + 2;
-                        if (dw1 >= DR) { dw1 -= DR; row1++; }
-                        const int va0 = dw / TD, kk0 = dw - va0 * TD;
-                        const int va1 = dw1 / TD, kk1 = dw1 - va1 * TD;
-                        const int vb0 = row / TS_, rr0 = row - vb0 * TS_;
-                        const int vb1 = row1 / TS_, rr1 = row1 - vb1 * TS_;
-                        const uint32_t a0 = (uint32_t)w_tmap[tbase + vb0 * VS_ + va0] + rr0 * TD + kk0;
-                        const uint32_t a1 = (uint32_t)w_tmap[tbase + vb1 * VS_ + va1] + rr1 * TD + kk1;
-                        const uint2 p0 = *reinterpret_cast<const uint2*>(atlas32 + a0);
-                        const uint2 p1 = *reinterpret_cast<const uint2*>(atlas32 + a1);
+                        uint32_t r1 = r, pr1 = pr + 1;
+                        if (pr1 == PR) { pr1 = 0; r1++; }
+                        const uint2 p0 = *reinterpret_cast<const uint2*>(atlas32 + pair_addr(r, pr));
+                        const uint2 p1 = *reinterpret_cast<const uint2*>(atlas32 + pair_addr(r1, pr1));
                         v = make_uint4(p0.x, p0.y, p1.x, p1.y);
                     }
-                    dw += STEP_DW; row += STEP_ROWS;
-                    if (dw >= DR) { dw -= DR; row++; }
-                    if (row >= P) { row -= P; tbase += VS_ * VS_; }
+                    pr += STEP_P; r += STEP_R;
+                    if (pr >= PR) { pr -= PR; r++; }
                 };
                 auto put = [&](int c, const uint4& v) {
                     if constexpr (V_ == 2) {
@@ -327,9 +331,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 };
                 int c = lane;
                 if constexpr (V_ != 6) {
-                    // gather four chunks from LDS, then issue their four 1-KiB stores back to back:
-                    // bursts of stores sustain ~8 % more HBM write bandwidth than evenly spaced ones
-                    // (tools/microbench/store_patterns.hip, patterns B vs E)
+                    // gather four chunks from LDS, then issue their four 1-KiB stores back to back
                     for (; c + 3 * kWave < total; c += 4 * kWave) {
                         uint4 v0, v1, v2, v3;
                         fetch(v0); fetch(v1); fetch(v2); fetch(v3);

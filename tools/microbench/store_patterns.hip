@@ -131,6 +131,30 @@ __global__ __launch_bounds__(256) void k_wave_region_vmem_nopf(uint4* out, const
     }
 }
 
+// K: 16-wave workgroup per region (all 1024 threads stream one region, then the next)
+__global__ __launch_bounds__(1024) void k_bigblock_region(uint4* out, int nregions) {
+    for (int e = blockIdx.x; e < nregions; e += gridDim.x) {
+        uint4* o = out + (size_t)e * RCH;
+        for (int c = threadIdx.x; c < RCH; c += 1024) o[c] = make_uint4(e, c, 3, 4);
+    }
+}
+// L: 16-wave workgroup, wave per region, 16 adjacent regions per workgroup trip (the render kernel now)
+__global__ __launch_bounds__(1024) void k_wave_region_16(uint4* out, int nregions) {
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int e = blockIdx.x * 16 + wave; e < nregions; e += gridDim.x * 16) {
+        uint4* o = out + (size_t)e * RCH;
+        for (int c = lane; c < RCH; c += 64) o[c] = make_uint4(e, c, 3, 4);
+    }
+}
+// M: 16-wave workgroup walks 16 adjacent regions cooperatively, one after the other
+__global__ __launch_bounds__(1024) void k_bigblock_16seq(uint4* out, int nregions) {
+    for (int e0 = blockIdx.x * 16; e0 < nregions; e0 += gridDim.x * 16) {
+        uint4* o = out + (size_t)e0 * RCH;
+        int tot = RCH * min(16, nregions - e0);
+        for (int c = threadIdx.x; c < tot; c += 1024) o[c] = make_uint4(e0, c, 3, 4);
+    }
+}
+
 template <typename F>
 static float time_it(F launch, int iters) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -170,6 +194,15 @@ int main() {
             report(nm, time_it([&] { hipLaunchKernelGGL(k_wave_region_vmem_nopf, dim3(blocks), dim3(256), 0, 0, out, in, nregions); }, 20));
             snprintf(nm, 96, "G wave/region XCD-contiguous, %d wg/CU", per_cu);
             report(nm, time_it([&] { hipLaunchKernelGGL(k_wave_region_xcd, dim3(blocks), dim3(256), 0, 0, out, nregions); }, 20));
+        }
+        for (int nb : {256, 512}) {
+            char nm[96];
+            snprintf(nm, 96, "K 16-wave wg/region, %d wgs", nb);
+            report(nm, time_it([&] { hipLaunchKernelGGL(k_bigblock_region, dim3(nb), dim3(1024), 0, 0, out, nregions); }, 20));
+            snprintf(nm, 96, "L 16-wave wg, wave/region, %d wgs", nb);
+            report(nm, time_it([&] { hipLaunchKernelGGL(k_wave_region_16, dim3(nb), dim3(1024), 0, 0, out, nregions); }, 20));
+            snprintf(nm, 96, "M 16-wave wg, 16 regions cooperatively, %d wgs", nb);
+            report(nm, time_it([&] { hipLaunchKernelGGL(k_bigblock_16seq, dim3(nb), dim3(1024), 0, 0, out, nregions); }, 20));
         }
         report("F wave/region non-persistent", time_it([&] { hipLaunchKernelGGL(k_wave_region_np, dim3(nregions / 4), dim3(256), 0, 0, out, nregions); }, 20));
     }
