@@ -19,6 +19,8 @@
  *                                        agents.py:233-266, 290-343)
  *   mg_encode       MultiGrid.encode    (base.py:196-214; objects.py:90-99)
  *   mg_put_obj      MultiGridEnv.put_obj (base.py:655-662)
+ *   mg_render_frame MultiGridEnv.render's whole-grid image: MultiGrid.render(top_agent=None) +
+ *                   visibility highlight         (base.py:714-759, 301-331)
  *
  * Conventions: plain pointers and sizes only (no torch types).  Every buffer is owned by the
  * caller and lives in device memory (HBM) unless marked HOST; kernels never allocate.  All calls
@@ -168,6 +170,14 @@ int32_t mg_encode(const MgConfig* cfg, const MgState* st, const uint8_t* vis_mas
 /* env_mask as in mg_reset. Replaces whatever is in the cell (base.py:655-662). */
 int32_t mg_put_obj(const MgConfig* cfg, const MgState* st, int32_t obj, int32_t x, int32_t y,
                    const uint8_t* env_mask, void* stream);
+
+/* Whole-grid human view of selected envs (caller-side format, not on the step path).
+ * env_ids: device int32 [n_envs]; frame_atlas: device uint8 [n_tiles][ts][ts][3] (orientation 0,
+ * same tile numbering as MgConfig.atlas) rendered at frame_tile_size (a multiple of 4, normally
+ * TILE_PIXELS = 32); out: device uint8 [n_envs][H*ts][W*ts][3]. */
+int32_t mg_render_frame(const MgConfig* cfg, const MgState* st, const int32_t* env_ids, int32_t n_envs,
+                        const uint8_t* frame_atlas, int32_t frame_tile_size, int32_t highlight,
+                        uint8_t* out, void* stream);
 
 /* timing helper for bench.py: average duration (ms) of `iters` back-to-back mg_render_obs
  * launches on `stream`, bracketed by HIP events recorded on that same stream. */

@@ -245,6 +245,7 @@ class MultiGridEnv(object):
             raise NotImplementedError("view_size must be odd and <= %d" % N.MAX_VIEW)
         if not (0 <= a0.view_offset < a0.view_size):
             raise ValueError("view_offset out of range")
+        self._all_image = all(a.observation_style == "image" for a in self.agents)
         self.view_size, self.tile_size = a0.view_size, a0.view_tile_size
         self.view_offset, self.see_through_walls = a0.view_offset, a0.see_through_walls
         self.obs_pixels = self.view_size * self.tile_size
@@ -488,7 +489,7 @@ class MultiGridEnv(object):
         self._render()
         if self.strict:
             self.check_errors()
-        return self.obs
+        return self._package_obs()
 
     def step(self, actions):
         """actions: (B, n) integer tensor (device preferred) or array-like -> (obs, rewards, done, {})
@@ -528,7 +529,7 @@ class MultiGridEnv(object):
                                         None, stream))
         if self.strict:
             self.check_errors()
-        return self.obs, self.rewards, done, {}
+        return self._package_obs(), self.rewards, done, {}
 
     def _render(self, debug=False):
         import torch
@@ -546,14 +547,26 @@ class MultiGridEnv(object):
         return None
 
     def gen_obs(self):
-        """(B, n, P, P, 3) uint8 (base.py:473-474)"""
+        """(B, n, P, P, 3) uint8, or the per-agent list for 'rich' agents (base.py:473-474)"""
         self._render()
-        return self.obs
+        return self._package_obs()
+
+    def _package_obs(self):
+        """What reset()/step() hand back: the (B, n, P, P, 3) tensor when every agent uses the 'image'
+        style (the fast path), else — like the reference's list of per-agent observations — a list
+        with one entry per agent: its (B, P, P, 3) view or, for 'rich' agents, a dict of batched
+        fields (base.py:459-471)."""
+        if self._all_image:
+            return self.obs
+        return [self._agent_obs(k) for k in range(self.num_agents)]
 
     def gen_agent_obs(self, agent):
         """agent: a GridAgentInterface of this env or its index -> (B, P, P, 3) (base.py:453-471)"""
         k = agent if isinstance(agent, int) else self.agents.index(agent)
         self._render()
+        return self._agent_obs(k)
+
+    def _agent_obs(self, k):
         a = self.agents[k]
         pov = self.obs[:, k]
         if a.observation_style == "image":
@@ -716,9 +729,54 @@ class MultiGridEnv(object):
                     wall_obj=self.obj_reg.find(Wall()), gen_ctor=prog(self._spec_ctor or self._spec_last),
                     gen_reset=prog(self._spec_last))
 
-    def render(self, *args, **kwargs):
-        raise NotImplementedError("full-frame human rendering is out of scope for the batched engine "
-                                  "(SURVEY.md section 8f, row F2)")
+    def render(self, mode="rgb_array", close=False, highlight=True, tile_size=TILE_PIXELS, show_agent_views=True,
+               max_agents_per_col=3, agent_col_width_frac=0.3, agent_col_padding_px=2, pad_grey=100, env_ids=None):
+        """Whole-grid human view (base.py:714-795): every cell at `tile_size` pixels, cells visible to
+        some active agent highlighted, and (show_agent_views) the agents' own observations stacked in
+        side columns.  Returns a uint8 tensor (H_px, W_px, 3) for env 0, or (K, H_px, W_px, 3) for
+        `env_ids`.  There is no window: mode='human' returns the image as well."""
+        import torch
+        if close:
+            return None
+        if tile_size % 4 != 0 or not (4 <= tile_size <= 64):
+            raise NotImplementedError("render(tile_size=) must be a multiple of 4 in [4, 64]")
+        single = env_ids is None
+        ids = torch.as_tensor([0] if single else env_ids, dtype=torch.int32, device=self.device).reshape(-1)
+        K = int(ids.numel())
+        self._sync_tables()
+        key = (self.obj_reg.version, tile_size)
+        if getattr(self, "_frame_atlas_key", None) != key:
+            fa, _, _ = rendering.build_atlas(self.obj_reg.objs, [a.color for a in self.agents], tile_size)
+            self._frame_atlas = torch.from_numpy(np.ascontiguousarray(fa[0])).to(self.device)
+            self._frame_atlas_key = key
+        Hp, Wp = self.height * tile_size, self.width * tile_size
+        img = torch.empty((K, Hp, Wp, 3), dtype=torch.uint8, device=self.device)
+        N.check(self._lib.mg_render_frame(C.byref(self._cfg), C.byref(self._state), ids.data_ptr(), K,
+                                          self._frame_atlas.data_ptr(), tile_size, int(bool(highlight)),
+                                          img.data_ptr(), self._stream()))
+        if show_agent_views:
+            # side columns (base.py:764-786): views enlarged by an integer factor, max_agents_per_col
+            # per column, centred on a grey background.  (The reference mixes shape[0] / shape[1]
+            # here; kept as written — images are square in every shipped scenario.)
+            tpw = int(Hp * agent_col_width_frac - 2 * agent_col_padding_px)
+            tph = (Wp - 2 * agent_col_padding_px) // max_agents_per_col
+            self._render()
+            P = self.obs_pixels
+            f = int(min(tpw / P, tph / P))
+            views = self.obs[ids.long()]                                    # (K, n, P, P, 3)
+            views = views.repeat_interleave(f, dim=2).repeat_interleave(f, dim=3) if f > 0 else views[:, :, :0, :0]
+            vh = vw = P * f
+            cols = []
+            for c0 in range(0, self.num_agents, max_agents_per_col):
+                col = torch.full((K, Hp, tpw + 2 * agent_col_padding_px, 3), pad_grey, dtype=torch.uint8,
+                                 device=self.device)
+                for j, k in enumerate(range(c0, min(c0 + max_agents_per_col, self.num_agents))):
+                    o0 = (tph - vw) // 2 + agent_col_padding_px + j * tph
+                    o1 = (tpw - vh) // 2 + agent_col_padding_px
+                    col[:, o0:o0 + vh, o1:o1 + vw] = views[:, k]
+                cols.append(col)
+            img = torch.cat([img] + cols, dim=2)
+        return img[0] if single else img
 
     def __str__(self):
         return "<%s B=%d %dx%d n_agents=%d>" % (self.__class__.__name__, self.batch_size, self.width,

@@ -107,6 +107,19 @@ int32_t mg_put_obj(const MgConfig* cfg, const MgState* st, int32_t obj, int32_t 
     return rc(mg::launch_put_obj(*cfg, *st, obj, x, y, env_mask, (hipStream_t)stream));
 }
 
+int32_t mg_render_frame(const MgConfig* cfg, const MgState* st, const int32_t* env_ids, int32_t n_envs,
+                        const uint8_t* frame_atlas, int32_t frame_tile_size, int32_t highlight, uint8_t* out,
+                        void* stream) {
+    int e = check_cfg(cfg);
+    if (e) return e;
+    e = check_state(st);
+    if (e) return e;
+    if (!env_ids || n_envs < 0 || !frame_atlas || !out) return MG_E_ARG;
+    if (frame_tile_size < 4 || frame_tile_size > 64 || (frame_tile_size & 3)) return MG_E_UNSUPPORTED;
+    return rc(mg::launch_frame(*cfg, *st, env_ids, n_envs, frame_atlas, frame_tile_size, highlight, out,
+                               (hipStream_t)stream));
+}
+
 int32_t mg_time_render_obs(const MgConfig* cfg, const MgState* st, uint8_t* obs, int32_t iters, float* avg_ms,
                            void* stream) {
     int e = check_cfg(cfg);

@@ -1,0 +1,141 @@
+// mg_frame.hip — whole-grid human view of selected envs: the grid half of MultiGridEnv.render
+// (marlgrid/base.py:714-759 -> MultiGrid.render with top_agent=None, base.py:301-331), i.e. every
+// cell drawn at `frame_tile_size` pixels in world orientation, plus the "visible to some agent"
+// highlight (base.py:740-753, 326-329).  Caller-side format: used for
+// videos / debugging on a handful of envs, not on the step path.
+//
+// One workgroup per selected env.  Wave 0 re-derives each active agent's visibility exactly like
+// the obs kernel (same crop / rotate / shadow-cast) and scatters it back to world cells; all waves
+// then raster rows of the frame as coalesced dwords straight from the (L2-resident) frame atlas.
+#include "mg_device.h"
+#include "mg_launch.h"
+#include "mg_occlude.h"
+
+namespace mg {
+
+__global__ __launch_bounds__(kBlock) void frame_kernel(MgConfig cfg, MgState st, const int32_t* __restrict__ env_ids,
+                                                       const uint8_t* __restrict__ atlas, int ts, int highlight,
+                                                       uint8_t* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int W = cfg.W, H = cfg.H, n = cfg.n_agents, VS = cfg.view_size;
+    const int cells = W * H;
+    uint8_t* s_grid = smem;                                   // [cells_stride]
+    uint8_t* s_first = s_grid + cfg.cells_stride;             // [cells_stride] lowest-rank agent or 0xFF
+    uint8_t* s_hl = s_first + cfg.cells_stride;               // [cells_stride] highlight flag
+    uint16_t* s_tile = reinterpret_cast<uint16_t*>(s_hl + cfg.cells_stride);   // [cells] tile index
+    uint64_t* s_rec = reinterpret_cast<uint64_t*>(s_tile + round_up(cells, 8));
+    uint32_t* s_trow = reinterpret_cast<uint32_t*>(s_rec + MG_MAX_AGENTS);     // [n][VS]
+    const int tid = threadIdx.x;
+    const int e = env_ids[blockIdx.x];
+    if (e < 0 || e >= cfg.B) return;
+
+    for (int i = tid; i < cfg.cells_stride; i += kBlock) {
+        s_grid[i] = st.grid[(size_t)e * cfg.cells_stride + i];
+        s_first[i] = 0xFF;
+        s_hl[i] = 0;
+    }
+    if (tid < n) s_rec[tid] = st.agents[(size_t)e * n + tid];
+    for (int i = tid; i < n * VS; i += kBlock) s_trow[i] = 0;
+    __syncthreads();
+    if (tid < n) {
+        const uint64_t r = s_rec[tid];
+        if (rec_byte(r, MG_AG_FLAGS) & MG_AF_PLACED) {
+            bool lowest = true;
+            for (int j = 0; j < n; j++) {
+                const uint64_t rj = s_rec[j];
+                if (j != tid && (rec_byte(rj, MG_AG_FLAGS) & MG_AF_PLACED) && rec_xy(rj) == rec_xy(r) &&
+                    rec_byte(rj, MG_AG_RANK) < rec_byte(r, MG_AG_RANK))
+                    lowest = false;
+            }
+            if (lowest) s_first[rec_byte(r, MG_AG_X) * H + rec_byte(r, MG_AG_Y)] = (uint8_t)tid;
+        }
+    }
+    __syncthreads();
+    if (highlight) {
+        // transparency rows of every agent's view (as in the obs kernel, phase 3)
+        const int h = VS / 2, off = cfg.view_offset;
+        auto world = [&](const uint64_t r, int va, int vb, int& wx, int& wy) {
+            const int x = (int)rec_byte(r, MG_AG_X), y = (int)rec_byte(r, MG_AG_Y), dir = (int)rec_byte(r, MG_AG_DIR);
+            if (dir == 3)      { wx = x - h + va;              wy = y - (VS - 1) + off + vb; }
+            else if (dir == 0) { wx = x - off + (VS - 1 - vb); wy = y - h + va; }
+            else if (dir == 1) { wx = x - h + (VS - 1 - va);   wy = y - off + (VS - 1 - vb); }
+            else               { wx = x - VS + 1 + off + vb;   wy = y - h + (VS - 1 - va); }
+        };
+        for (int it = tid; it < n * VS * VS; it += kBlock) {
+            const int k = it / (VS * VS), c = it - k * VS * VS, vb = c / VS, va = c - vb * VS;
+            int wx, wy;
+            world(s_rec[k], va, vb, wx, wy);
+            uint32_t base = 0;
+            if (wx >= 0 && wx < W && wy >= 0 && wy < H) base = s_grid[wx * H + wy];
+            const bool transp = base == 0 || (cfg.obj[base].flags & MG_OF_SEE_BEHIND);
+            if (transp) atomicOr(&s_trow[k * VS + vb], 1u << va);
+        }
+        __syncthreads();
+        if (tid < n) {
+            const uint64_t r = s_rec[tid];
+            if (rec_byte(r, MG_AG_FLAGS) & MG_AF_ACTIVE) {          // base.py:743
+                uint32_t m[MG_MAX_VIEW];
+                if (cfg.see_through_walls) { for (int j = 0; j < VS; j++) m[j] = (1u << VS) - 1u; }
+                else occlude_rows<0>(VS, off, &s_trow[tid * VS], m);
+                for (int vb = 0; vb < VS; vb++)
+                    for (int va = 0; va < VS; va++)
+                        if ((m[vb] >> va) & 1u) {
+                            int wx, wy;
+                            world(r, va, vb, wx, wy);
+                            if (wx >= 0 && wx < W && wy >= 0 && wy < H) s_hl[wx * H + wy] = 1;
+                        }
+            }
+        }
+        __syncthreads();
+    }
+    // tile per world cell: render_tile(obj, top_agent=None) — base.py:275-299
+    for (int c = tid; c < cells; c += kBlock) {
+        const uint32_t base = s_grid[c], show = s_first[c];
+        uint32_t tile;
+        const uint32_t slot = base ? cfg.obj[base].ovl_slot : 0u;
+        if (show == 0xFF || slot == 0xFF) tile = 1 + base;
+        else tile = 1 + cfg.n_obj + (slot * n + show) * 4 + rec_byte(s_rec[show], MG_AG_DIR);
+        s_tile[c] = (uint16_t)tile;
+    }
+    __syncthreads();
+    // raster: image [H*ts][W*ts][3]; row R -> world y = R / ts; dword d of the row -> world x = d / TD
+    const int TD = ts * 3 / 4;                    // dwords per tile row (ts % 4 == 0)
+    const int row_dw = W * TD, tile_dw = ts * TD;
+    const uint32_t* atlas32 = reinterpret_cast<const uint32_t*>(atlas);
+    uint32_t* o32 = reinterpret_cast<uint32_t*>(out + (size_t)blockIdx.x * H * ts * W * ts * 3);
+    const int total = H * ts * row_dw;
+    for (int q = tid; q < total; q += kBlock) {
+        const int R = q / row_dw, d = q - R * row_dw;
+        const int j = R / ts, rr = R - j * ts, i = d / TD, kk = d - i * TD;
+        const int c = i * H + j;
+        uint32_t v = atlas32[(size_t)s_tile[c] * tile_dw + rr * TD + kk];
+        if (s_hl[c]) {
+            // (img*8 + 255*2) >> 3, clipped to 255 (base.py:327-329) == min(255, img + 63) per byte
+            uint32_t o = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                uint32_t x = ((v >> (8 * b)) & 0xFFu) + 63u;
+                o |= (x > 255u ? 255u : x) << (8 * b);
+            }
+            v = o;
+        }
+        o32[q] = v;
+    }
+}
+
+hipError_t launch_frame(const MgConfig& cfg, const MgState& st, const int32_t* env_ids, int K, const uint8_t* atlas,
+                        int ts, int highlight, uint8_t* out, hipStream_t s) {
+    if (K <= 0) return hipSuccess;
+    size_t lds = 3 * (size_t)cfg.cells_stride + 2 * (size_t)round_up(cfg.W * cfg.H, 8) + MG_MAX_AGENTS * 8 +
+                 (size_t)cfg.n_agents * cfg.view_size * 4 + 64;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&frame_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(frame_kernel, dim3(K), dim3(kBlock), lds, s, cfg, st, env_ids, atlas, ts, highlight, out);
+    return hipGetLastError();
+}
+
+}  // namespace mg

@@ -205,6 +205,38 @@ def gen_traj(name, out):
     np.savez_compressed(out, **d)
 
 
+FRAMES = {  # scenario -> (seeds, steps at which env.render() is captured)
+    "MarlGrid-3AgentCluttered15x15-v0": ([1337, 1338], [0, 7, 31]),
+    "Test-4AgentEmpty5x5-crowded": ([1337, 1340], [0, 5, 40]),
+    "Goalcycle-demo-solo-v0": ([1337], [0, 12]),
+    "Test-2AgentEmpty7x7-see-through": ([1337], [0, 9]),
+}
+
+
+def gen_frames(out):
+    """Full-frame `MultiGridEnv.render(mode='rgb_array')` images (base.py:714-795): default arguments
+    (highlight + agent-view side panels) and the bare grid (highlight=False, show_agent_views=False)."""
+    d = {}
+    for name, (seeds, steps) in FRAMES.items():
+        spec = scenarios.registered(name)
+        recipe = scenarios.ref_recipe(name)
+        n = len(spec["agents"])
+        for seed in seeds:
+            env = refstate.make_ref_env(spec, recipe, seed=int(seed))
+            env.reset()
+            arng = np.random.RandomState(seed)
+            acts = arng.choice(3, size=(max(steps) + 1, n)).astype(np.int8)
+            d["%s/%d/actions" % (name, seed)] = acts
+            for t in range(max(steps) + 1):
+                if t in steps:
+                    full = env.render(mode="rgb_array")
+                    bare = env.render(mode="rgb_array", highlight=False, show_agent_views=False)
+                    d["%s/%d/%d/full" % (name, seed, t)] = np.asarray(full).astype(np.uint8)
+                    d["%s/%d/%d/bare" % (name, seed, t)] = np.asarray(bare).astype(np.uint8)
+                env.step(acts[t])
+    np.savez_compressed(out, **d)
+
+
 def gen_interact(m, out):
     """Hand-built pickup/drop/toggle scenes (base.py:587-617 — 'TODO: verify' in the reference).
     Each scene: EmptyMultiGrid 7x7, 2 agents teleported via a fresh grid + put_obj; scripted
@@ -261,7 +293,7 @@ def gen_interact(m, out):
 
 def main():
     m = refload.load()
-    which = sys.argv[1:] or ["atlas", "rng", "occlusion", "traj", "interact"]
+    which = sys.argv[1:] or ["atlas", "rng", "occlusion", "traj", "interact", "frames"]
     if "atlas" in which:
         gen_atlas(m, os.path.join(HERE, "atlas.npz"))
     if "rng" in which:
@@ -276,6 +308,8 @@ def main():
         for name in TRAJ:
             gen_traj(name, os.path.join(HERE, "traj_%s.npz" % name))
             print("traj", name, flush=True)
+    if "frames" in which:
+        gen_frames(os.path.join(HERE, "frames.npz"))
     if "interact" in which:
         gen_interact(m, os.path.join(HERE, "interact.npz"))
     for f in sorted(os.listdir(HERE)):
