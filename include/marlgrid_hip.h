@@ -113,6 +113,12 @@ typedef struct MgConfig {
     int32_t agent_type_idx;                                       /* 13 */
     int32_t auto_reset;                                           /* reserved */
     uint8_t agent_color_idx[MG_MAX_AGENTS];
+    int32_t any_spawn_delay;                                      /* 1 if some spawn_delay != 0 */
+    int32_t spawn_delay[MG_MAX_AGENTS];                           /* agents.py:34; base.py:409-412, 503-506 */
+    int32_t any_hide;                                             /* 1 if any mask below is non-zero */
+    uint32_t hide_agent_mask;                                     /* bit k: agent k hides type 'Agent' */
+    uint64_t hide_obj_mask[MG_MAX_AGENTS];                        /* bit o: agent k hides object id o
+                                                                   * (hide_item_types, base.py:441-449) */
     const MgObjDesc* obj;   /* device, [n_obj] */
     const uint8_t* atlas;   /* device, [4 orientations][n_tiles][tile_size*tile_size*3], pre-rotated.
                              * tile 0 = shadow; 1+o = object o alone (o=0: empty tile);

@@ -40,6 +40,8 @@ class Config(C.Structure):
                 ("cells_stride", C.c_int32), ("n_obj", C.c_int32), ("n_ovl_slots", C.c_int32),
                 ("n_tiles", C.c_int32), ("agent_type_idx", C.c_int32), ("auto_reset", C.c_int32),
                 ("agent_color_idx", C.c_uint8 * MAX_AGENTS),
+                ("any_spawn_delay", C.c_int32), ("spawn_delay", C.c_int32 * MAX_AGENTS),
+                ("any_hide", C.c_int32), ("hide_agent_mask", C.c_uint32), ("hide_obj_mask", C.c_uint64 * MAX_AGENTS),
                 ("obj", C.c_void_p), ("atlas", C.c_void_p)]
 
 

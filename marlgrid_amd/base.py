@@ -235,12 +235,10 @@ class MultiGridEnv(object):
                     a0.view_size, a0.view_tile_size, a0.view_offset, a0.see_through_walls):
                 raise NotImplementedError("all agents must share view_size / view_tile_size / view_offset / "
                                           "see_through_walls (one (B, n, P, P, 3) observation tensor)")
-            if a.spawn_delay != 0:
-                raise NotImplementedError("spawn_delay > 0 is not supported by the batched engine")
+            if a.spawn_delay < 0:
+                raise ValueError("spawn_delay must be >= 0")
             if a.color == "prestige":
                 raise NotImplementedError("the data-dependent 'prestige' colour is not supported")
-            if len(a.hide_item_types) > 0:
-                raise NotImplementedError("hide_item_types is not supported")
         if a0.view_size % 2 == 0 or a0.view_size > N.MAX_VIEW:
             raise NotImplementedError("view_size must be odd and <= %d" % N.MAX_VIEW)
         if not (0 <= a0.view_offset < a0.view_size):
@@ -441,6 +439,18 @@ class MultiGridEnv(object):
         cfg.auto_reset = int(self.auto_reset)
         for k, a in enumerate(self.agents):
             cfg.agent_color_idx[k] = COLOR_TO_IDX[a.color]
+            cfg.spawn_delay[k] = a.spawn_delay
+        cfg.any_spawn_delay = int(any(a.spawn_delay != 0 for a in self.agents))
+        # hide_item_types (base.py:441-449): per viewer, the object ids / 'Agent' whose type is hidden
+        for k, a in enumerate(self.agents):
+            m = 0
+            for i, o in enumerate(objs):
+                if o is not None and o.type in a.hide_item_types:
+                    m |= 1 << i
+            cfg.hide_obj_mask[k] = m
+            if "Agent" in a.hide_item_types:
+                cfg.hide_agent_mask |= 1 << k
+        cfg.any_hide = int(cfg.hide_agent_mask != 0 or any(cfg.hide_obj_mask[k] for k in range(len(self.agents))))
         cfg.obj, cfg.atlas = self._obj_dev.data_ptr(), self._atlas_dev.data_ptr()
         self._cfg = cfg
         self._tables_version = self.obj_reg.version
@@ -721,7 +731,14 @@ class MultiGridEnv(object):
 
         def prog(p):
             return list(p["sym"]) + [("place", k, c, t) for (k, c, t) in p["ops"]]
-        return dict(W=self.width, H=self.height, agents=[dict(color=a.color) for a in self.agents],
+        def aspec(a):
+            d = dict(color=a.color)
+            if a.spawn_delay:
+                d["spawn_delay"] = a.spawn_delay
+            if a.hide_item_types:
+                d["hide_item_types"] = list(a.hide_item_types)
+            return d
+        return dict(W=self.width, H=self.height, agents=[aspec(a) for a in self.agents],
                     view_size=self.view_size, tile_size=self.tile_size, view_offset=self.view_offset,
                     see_through_walls=self.see_through_walls, max_steps=self.max_steps,
                     reward_decay=bool(self.reward_decay), ghost_mode=self.ghost_mode is not False,

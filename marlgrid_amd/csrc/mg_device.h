@@ -69,13 +69,14 @@ __host__ __device__ inline int round_up(int v, int m) { return (v + m - 1) / m *
 
 // per-wave LDS scratch of the obs-render kernel (bytes), shared by host launch code and kernel
 struct RenderScratch {
-    int grid, first, rec, vbase, vshow, trow, vis, tmap, total;
+    int grid, first, second, rec, vbase, vshow, trow, vis, tmap, total;
 };
 __host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride, int n, int vs) {
     RenderScratch s;
     int o = 0;
     s.grid = o;  o += round_up(cells_stride, 16);
     s.first = o; o += round_up(cells_stride, 16);
+    s.second = o; o += round_up(cells_stride, 16);
     s.rec = o;   o += MG_MAX_AGENTS * 8;
     s.vbase = o; o += round_up(n * vs * vs, 16);
     s.vshow = o; o += round_up(n * vs * vs, 16);

@@ -50,6 +50,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     uint8_t* s_atlas = smem;
     uint8_t* s_oflags = smem + atlas_bytes;             // [MG_MAX_OBJ]
     uint8_t* s_oslot = s_oflags + MG_MAX_OBJ;           // [MG_MAX_OBJ]
+    uint64_t* s_hide = reinterpret_cast<uint64_t*>(s_oslot + MG_MAX_OBJ);   // [MG_MAX_AGENTS] hide_obj_mask
     {
         const uint4* src = reinterpret_cast<const uint4*>(cfg.atlas);
         uint4* dst = reinterpret_cast<uint4*>(s_atlas);
@@ -61,13 +62,15 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             s_oflags[tid] = f;
             s_oslot[tid] = sl;
         }
+        if (tid < MG_MAX_AGENTS) s_hide[tid] = cfg.hide_obj_mask[tid];
     }
     __syncthreads();
 
     const RenderScratch L = render_scratch_layout(cfg.cells_stride, n, VS);
-    uint8_t* ws = smem + atlas_bytes + 2 * MG_MAX_OBJ + (size_t)wave * L.total;
+    uint8_t* ws = smem + atlas_bytes + 2 * MG_MAX_OBJ + MG_MAX_AGENTS * 8 + (size_t)wave * L.total;
     uint8_t* w_grid = ws + L.grid;
     uint8_t* w_first = ws + L.first;
+    uint8_t* w_second = ws + L.second;
     uint64_t* w_rec = reinterpret_cast<uint64_t*>(ws + L.rec);
     uint8_t* w_vbase = ws + L.vbase;
     uint8_t* w_vshow = ws + L.vshow;
@@ -110,6 +113,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 if (idx < gdw) {
                     reinterpret_cast<uint32_t*>(w_grid)[idx] = pf_g[i];
                     reinterpret_cast<uint32_t*>(w_first)[idx] = 0xFFFFFFFFu;
+                    reinterpret_cast<uint32_t*>(w_second)[idx] = 0xFFFFFFFFu;
                 }
             }
             if (lane < n) w_rec[lane] = pf_r;
@@ -119,6 +123,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             for (int i = lane; i < gdw; i += kWave) {
                 reinterpret_cast<uint32_t*>(w_grid)[i] = gsrc[i];
                 reinterpret_cast<uint32_t*>(w_first)[i] = 0xFFFFFFFFu;
+                reinterpret_cast<uint32_t*>(w_second)[i] = 0xFFFFFFFFu;
             }
             if (lane < n) w_rec[lane] = st.agents[(size_t)e * n + lane];
         }
@@ -132,14 +137,16 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
         if (lane < n) {
             const uint64_t r = w_rec[lane];
             if (rec_byte(r, MG_AG_FLAGS) & MG_AF_PLACED) {
-                bool lowest = true;
+                int below = 0;   // agents of this cell that arrived earlier
                 for (int j = 0; j < n; j++) {
                     const uint64_t rj = w_rec[j];
                     if (j != lane && (rec_byte(rj, MG_AG_FLAGS) & MG_AF_PLACED) && rec_xy(rj) == rec_xy(r) &&
                         rec_byte(rj, MG_AG_RANK) < rec_byte(r, MG_AG_RANK))
-                        lowest = false;
+                        below++;
                 }
-                if (lowest) w_first[rec_byte(r, MG_AG_X) * H + rec_byte(r, MG_AG_Y)] = (uint8_t)lane;
+                const int cell = rec_byte(r, MG_AG_X) * H + rec_byte(r, MG_AG_Y);
+                if (below == 0) w_first[cell] = (uint8_t)lane;
+                else if (below == 1) w_second[cell] = (uint8_t)lane;   // only hide_item_types looks at it
             }
         }
         wave_lds_sync();
@@ -162,9 +169,19 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 show = w_first[cell];
                 if (show != 0xFF && wx == x && wy == y) show = (uint32_t)k;   // viewer in the stack: base.py:282-291
             }
+            if (s_oflags[base] & MG_OF_SEE_BEHIND) atomicOr(&w_trow[k * VS + vb], 1u << va);   // opacity first
+            if (cfg.any_hide && inb) {
+                // hide_item_types (base.py:441-449), applied after visibility: a hidden cell object is
+                // replaced by the first agent standing on it (or nothing) and that agent is drawn as
+                // a plain cell object — the "viewer is in the stack" rule no longer applies to it
+                const int cell = wx * H + wy;
+                const uint32_t first = w_first[cell];
+                if (base && ((s_hide[k] >> base) & 1ull)) { base = 0; show = first; }
+                else if (base == 0 && first != 0xFF && first != (uint32_t)k && ((cfg.hide_agent_mask >> k) & 1u))
+                    show = w_second[cell];
+            }
             w_vbase[it] = (uint8_t)base;
             w_vshow[it] = (uint8_t)show;
-            if (s_oflags[base] & MG_OF_SEE_BEHIND) atomicOr(&w_trow[k * VS + vb], 1u << va);
         }
         wave_lds_sync();
         // 4. visibility per agent (lanes 0..n-1)
@@ -315,7 +332,7 @@ static hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_
                                   uint8_t* v, hipStream_t s) {
     const int tile_bytes = cfg.tile_size * cfg.tile_size * 3;
     const RenderScratch L = render_scratch_layout(cfg.cells_stride, cfg.n_agents, cfg.view_size);
-    size_t lds = (size_t)round_up(4 * cfg.n_tiles * tile_bytes, 16) + 2 * MG_MAX_OBJ + WPB * (size_t)L.total;
+    size_t lds = (size_t)round_up(4 * cfg.n_tiles * tile_bytes, 16) + 2 * MG_MAX_OBJ + MG_MAX_AGENTS * 8 + WPB * (size_t)L.total;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<VS_, TS_, WPB, V_>),
@@ -344,7 +361,7 @@ static int choose_wpb(const MgConfig& cfg) {
     if (const char* f = getenv("MG_RENDER_WPB")) { int w = atoi(f); if (w == 4 || w == 16) return w; }
     const int tile_bytes = cfg.tile_size * cfg.tile_size * 3;
     const RenderScratch L = render_scratch_layout(cfg.cells_stride, cfg.n_agents, cfg.view_size);
-    size_t lds16 = (size_t)round_up(4 * cfg.n_tiles * tile_bytes, 16) + 2 * MG_MAX_OBJ + 16 * (size_t)L.total;
+    size_t lds16 = (size_t)round_up(4 * cfg.n_tiles * tile_bytes, 16) + 2 * MG_MAX_OBJ + MG_MAX_AGENTS * 8 + 16 * (size_t)L.total;
     return (cfg.B >= 4096 && lds16 <= 160 * 1024) ? 16 : 4;
 }
 

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(MgConfig cfg, MgState st,
         nr = rec_set(nr, MG_AG_DIR, dir);
         nr = rec_set(nr, MG_AG_RANK, (uint32_t)k);
         nr = rec_set(nr, MG_AG_BONUS, 0xFFu);
-        if (!err) {
+        if (!err && cfg.spawn_delay[k] == 0) {   // later spawns happen in mg_step (base.py:503-506)
             bool ok = false;
             for (int t = 0; t < prog.agent_max_tries; t++) {
                 int x = (int)mt.bounded((uint32_t)(W - 1));

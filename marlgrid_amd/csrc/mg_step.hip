@@ -49,6 +49,50 @@ __global__ __launch_bounds__(BS) void step_kernel(MgConfig cfg, MgState st, cons
     uint8_t* g = st.grid + (size_t)b * cfg.cells_stride;
     uint32_t* mtw = st.mt + (size_t)b * MG_MT_N;
 
+    Mt mt{mtw, pos0};
+    int err = 0;
+    // place_obj(agent) (base.py:690-708 over try_place_obj :664-688) for an agent that is off the
+    // grid: rejection-sample a cell whose object can be overlapped (or that is empty) and, without
+    // ghost_mode, holds no agent; arrival gives the highest rank.  Used by late spawns and respawns.
+    auto place_agent = [&](int k) {
+        uint64_t r = s_rec[k * BS + tid];
+        bool ok = false;
+        for (int t = 0; t < 100000; t++) {                    // place_obj default max_tries = 1e5
+            const int x = (int)mt.bounded((uint32_t)(W - 1));
+            const int y = (int)mt.bounded((uint32_t)(H - 1));
+            const uint32_t base = g[x * H + y];
+            const uint32_t xy = (uint32_t)x | ((uint32_t)y << 8);
+            int cnt = 0;
+            for (int j = 0; j < n; j++) {
+                const uint64_t rj = s_rec[j * BS + tid];
+                cnt += ((rec_byte(rj, MG_AG_FLAGS) & MG_AF_PLACED) && rec_xy(rj) == xy) ? 1 : 0;
+            }
+            if ((base == 0 || (s_oflags[base] & MG_OF_CAN_OVERLAP)) && (cnt == 0 || cfg.ghost_mode)) {
+                const uint32_t old_rank = rec_byte(r, MG_AG_RANK);
+                for (int j = 0; j < n; j++) {
+                    const uint64_t rj = s_rec[j * BS + tid];
+                    const uint32_t rk = rec_byte(rj, MG_AG_RANK);
+                    if (rk > old_rank) s_rec[j * BS + tid] = rec_set(rj, MG_AG_RANK, rk - 1);
+                }
+                r = rec_set(r, MG_AG_RANK, (uint32_t)(n - 1));
+                r = rec_set(r, MG_AG_X, (uint32_t)x);
+                r = rec_set(r, MG_AG_Y, (uint32_t)y);
+                r = rec_set(r, MG_AG_FLAGS, MG_AF_ACTIVE | MG_AF_PLACED);
+                ok = true;
+                break;
+            }
+        }
+        if (!ok) err = err ? err : MG_ERR_RECURSION;
+        s_rec[k * BS + tid] = r;
+    };
+
+    // late spawns (base.py:503-506), before step_count is incremented and before the shuffle
+    if (cfg.any_spawn_delay)
+        for (int k = 0; k < n; k++) {
+            const uint32_t f = rec_byte(s_rec[k * BS + tid], MG_AG_FLAGS);
+            if (!(f & (MG_AF_ACTIVE | MG_AF_DONE)) && sc0 >= cfg.spawn_delay[k]) place_agent(k);
+        }
+
     // ---- round trip 2: every agent's front cell.  An agent's position
     // and heading are only ever changed by its own action, so its front cell is known before the
     // loop; the cell's *content* can only be changed by a pickup / drop / toggle earlier in this
@@ -61,7 +105,6 @@ __global__ __launch_bounds__(BS) void step_kernel(MgConfig cfg, MgState st, cons
         s_fb[k * BS + tid] = ok ? g[fx * H + fy] : (uint8_t)0;
     }
     bool grid_dirty = false;
-    int err = 0;
 
     const int step_count = sc0 + 1;   // base.py:512
     // reward decay factor, float64 like the reference (base.py:579)
@@ -69,7 +112,6 @@ __global__ __launch_bounds__(BS) void step_kernel(MgConfig cfg, MgState st, cons
 
     // iter_order = arange(n); np_random.shuffle(iter_order)  (base.py:514-516): legacy Fisher-Yates
     // over numpy's masked-rejection bounded draws
-    Mt mt{mtw, pos0};
     for (int k = 0; k < n; k++) s_order[k * BS + tid] = (uint8_t)k;
     for (int i = n - 1; i >= 1; i--) {
         const int j = (int)mt.bounded((uint32_t)i);
@@ -202,33 +244,8 @@ __global__ __launch_bounds__(BS) void step_kernel(MgConfig cfg, MgState st, cons
                 r = rec_set(r, MG_AG_FLAGS, 0);
                 r = rec_set(r, MG_AG_CARRY, 0);
                 s_rec[k * BS + tid] = r;                      // off the grid while sampling
-                bool ok = false;
-                for (int t = 0; t < 100000; t++) {            // place_obj default max_tries = 1e5
-                    const int x = (int)mt.bounded((uint32_t)(W - 1));
-                    const int y = (int)mt.bounded((uint32_t)(H - 1));
-                    const uint32_t base = g[x * H + y];
-                    const uint32_t xy = (uint32_t)x | ((uint32_t)y << 8);
-                    int cnt = 0;
-                    for (int j = 0; j < n; j++) {
-                        const uint64_t rj = s_rec[j * BS + tid];
-                        cnt += ((rec_byte(rj, MG_AG_FLAGS) & MG_AF_PLACED) && rec_xy(rj) == xy) ? 1 : 0;
-                    }
-                    if ((s_oflags[base] & MG_OF_CAN_OVERLAP || base == 0) && (cnt == 0 || cfg.ghost_mode)) {
-                        const uint32_t old_rank = rec_byte(r, MG_AG_RANK);
-                        for (int j = 0; j < n; j++) {
-                            const uint64_t rj = s_rec[j * BS + tid];
-                            const uint32_t rk = rec_byte(rj, MG_AG_RANK);
-                            if (rk > old_rank) s_rec[j * BS + tid] = rec_set(rj, MG_AG_RANK, rk - 1);
-                        }
-                        r = rec_set(r, MG_AG_RANK, (uint32_t)(n - 1));
-                        r = rec_set(r, MG_AG_X, (uint32_t)x);
-                        r = rec_set(r, MG_AG_Y, (uint32_t)y);
-                        r = rec_set(r, MG_AG_FLAGS, MG_AF_ACTIVE | MG_AF_PLACED);
-                        ok = true;
-                        break;
-                    }
-                }
-                if (!ok) err = err ? err : MG_ERR_RECURSION;
+                place_agent(k);
+                r = s_rec[k * BS + tid];
                 all_done = false;
             } else {
                 r = rec_set(r, MG_AG_FLAGS, f & ~MG_AF_ACTIVE);

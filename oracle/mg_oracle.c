@@ -413,7 +413,8 @@ int32_t mgo_reset(MgoEnv* e, int32_t which_gen) {
     }
     int rc = gen_grid(e, which_gen);
     if (rc != MGO_OK) return rc;
-    for (int k = 0; k < cfg->n_agents; k++) {      /* spawn_delay == 0 for every agent */
+    for (int k = 0; k < cfg->n_agents; k++) {      /* base.py:409-412 */
+        if (cfg->spawn_delay[k] != 0) continue;
         rc = place_obj(e, MGO_AGENT_BASE + k, 1e5);
         if (rc != MGO_OK) return rc;
         e->aactive[k] = 1;                         /* agent.activate() */
@@ -457,6 +458,14 @@ int32_t mgo_step(MgoEnv* e, const int32_t* actions, double* rewards, int32_t* ep
     int n = cfg->n_agents;
     static const int DX[4] = {1, 0, -1, 0}, DY[4] = {0, 1, 0, -1}; /* agents.py:183 */
     int rc = MGO_OK;
+
+    /* spawn agents if it's time — base.py:503-506 (before step_count is incremented) */
+    for (int k = 0; k < n; k++)
+        if (!e->aactive[k] && !e->adone[k] && e->step_count >= cfg->spawn_delay[k]) {
+            int prc = place_obj(e, MGO_AGENT_BASE + k, 1e5);
+            if (prc != MGO_OK) rc = prc;
+            e->aactive[k] = 1;
+        }
 
     for (int k = 0; k < n; k++) rewards[k] = 0.0;     /* base.py:510 */
     e->step_count += 1;                               /* base.py:512 */
@@ -680,13 +689,42 @@ void mgo_view(const MgoEnv* e, int32_t k, uint8_t* vis, int32_t* cells) {
             sub[i * vs + j] = in_grid(e, x, y) ? e->cell[cidx(e, x, y)] : 0; /* zero padding */
         }
     rotate_grid_i32(vs, sub, dir + 1, cells);
-    if (cfg->see_through_walls) { memset(vis, 1, (size_t)vs * vs); return; }
-    uint8_t transp[MGO_MAX_VIEW * MGO_MAX_VIEW];
-    for (int c = 0; c < vs * vs; c++) {
-        int v = cells[c];
-        transp[c] = (v == 0 || is_agent_val(v)) ? 1 : (uint8_t)cfg->obj[v].see_behind;
+    if (cfg->see_through_walls) memset(vis, 1, (size_t)vs * vs);
+    else {
+        uint8_t transp[MGO_MAX_VIEW * MGO_MAX_VIEW];
+        for (int c = 0; c < vs * vs; c++) {
+            int v = cells[c];
+            transp[c] = (v == 0 || is_agent_val(v)) ? 1 : (uint8_t)cfg->obj[v].see_behind;
+        }
+        mgo_occlude(vs, vs / 2, vs - 1 - off, transp, vis);  /* get_view_pos agents.py:233-234 */
     }
-    mgo_occlude(vs, vs / 2, vs - 1 - off, transp, vis);  /* get_view_pos agents.py:233-234 */
+    /* hide_item_types — base.py:441-449: after the visibility pass, a cell object whose type is
+     * hidden (and that is not the viewer itself) is replaced by its first stacked agent, or None */
+    uint32_t hm = cfg->hide_type_mask[k];
+    if (hm) {
+        int rot_k = (dir + 1) % 4;
+        for (int i = 0; i < vs; i++)
+            for (int j = 0; j < vs; j++) {
+                int v = cells[i * vs + j];
+                if (v == 0 || v == MGO_AGENT_BASE + k) continue;
+                int hidden = is_agent_val(v) ? (int)((hm >> 31) & 1u) : (int)((hm >> cfg->obj[v].type_idx) & 1u);
+                if (!hidden) continue;
+                int repl = 0;
+                if (is_agent_val(v)) {
+                    int x = v - MGO_AGENT_BASE;
+                    if (e->ag_nagents[x] > 0) repl = MGO_AGENT_BASE + e->ag_agents[x][0];
+                } else {
+                    int si, sj;   /* the world cell behind this view cell (inverse of rotate_grid) */
+                    if (rot_k == 3) { si = j; sj = vs - 1 - i; }
+                    else if (rot_k == 1) { si = vs - 1 - j; sj = i; }
+                    else if (rot_k == 2) { si = vs - 1 - i; sj = vs - 1 - j; }
+                    else { si = i; sj = j; }
+                    int wc = cidx(e, topX + si, topY + sj);
+                    if (e->cell_nagents[wc] > 0) repl = MGO_AGENT_BASE + e->cell_agents[wc * MGO_MAX_AGENTS];
+                }
+                cells[i * vs + j] = repl;
+            }
+    }
 }
 
 /* rotate_grid on a (ts,ts,3) tile — base.py:67-80 as used at base.py:324 */

@@ -83,6 +83,9 @@ typedef struct {
     int32_t wall_obj;                                             /* id used by wall_rect      */
     int32_t n_gen[2];                                             /* [0] ctor-time, [1] reset  */
     MgoGenOp gen[2][MGO_MAX_GEN];
+    int32_t spawn_delay[MGO_MAX_AGENTS];                          /* agents.py:34, base.py:409-412, 503-506 */
+    uint32_t hide_type_mask[MGO_MAX_AGENTS];                      /* hide_item_types: bit t = type_idx t,
+                                                                   * bit 31 = 'Agent' (base.py:441-449) */
 } MgoConfig;
 
 typedef struct MgoEnv MgoEnv;

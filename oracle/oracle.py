@@ -79,7 +79,8 @@ class Config(C.Structure):
                 ("respawn", C.c_int32),
                 ("agent_color_idx", C.c_int32 * MAX_AGENTS), ("agent_rgb", (C.c_uint8 * 4) * MAX_AGENTS),
                 ("agent_type_idx", C.c_int32), ("n_obj", C.c_int32), ("obj", ObjDesc * MAX_OBJ),
-                ("wall_obj", C.c_int32), ("n_gen", C.c_int32 * 2), ("gen", (GenOp * MAX_GEN) * 2)]
+                ("wall_obj", C.c_int32), ("n_gen", C.c_int32 * 2), ("gen", (GenOp * MAX_GEN) * 2),
+                ("spawn_delay", C.c_int32 * MAX_AGENTS), ("hide_type_mask", C.c_uint32 * MAX_AGENTS)]
 
 
 _lib = None
@@ -226,6 +227,9 @@ def make_config(spec):
     for k, a in enumerate(agents):
         cfg.agent_color_idx[k] = COLOR_TO_IDX[a["color"]]
         cfg.agent_rgb[k][:3] = list(COLORS[a["color"]])
+        cfg.spawn_delay[k] = int(a.get("spawn_delay", 0))
+        for tname in a.get("hide_item_types", []):       # item.type: class name, 'Agent' for agents
+            cfg.hide_type_mask[k] |= (1 << 31) if tname == "Agent" else (1 << TYPE_IDX[tname])
     objs = spec["objects"]
     assert objs[0] is None and len(objs) <= MAX_OBJ
     cfg.n_obj = len(objs)

@@ -42,6 +42,9 @@ TRAJ = {  # scenario -> (n_seeds, n_steps, n_full_obs_seeds)
     "Test-2AgentEmpty7x7-see-through": (4, 60, 2),
     "Test-3AgentCluttered9x9-respawn": (8, 200, 1),
     "Test-4AgentEmpty5x5-respawn-noghost": (8, 200, 1),
+    "Test-3AgentEmpty7x7-spawn-delay": (8, 120, 2),
+    "Test-4AgentEmpty5x5-hide": (8, 150, 2),
+    "Test-3AgentCluttered9x9-hide": (6, 120, 2),
 }
 CANON = ("base_enc", "pos", "dir", "active", "done", "carry_enc", "ordinal")
 

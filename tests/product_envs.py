@@ -13,7 +13,9 @@ def build(name, **kw):
     spec = scenarios.registered(name)
     cls_name, kwargs = scenarios.ref_recipe(name)
     agents = [GridAgentInterface(color=a["color"], view_size=spec["view_size"], view_tile_size=spec["tile_size"],
-                                 view_offset=spec["view_offset"], see_through_walls=spec["see_through_walls"])
+                                 view_offset=spec["view_offset"], see_through_walls=spec["see_through_walls"],
+                                 spawn_delay=a.get("spawn_delay", 0),
+                                 hide_item_types=list(a.get("hide_item_types", [])))
               for a in spec["agents"]]
     return getattr(E, cls_name)(agents=agents, **{**kwargs, **kw})
 

@@ -108,8 +108,25 @@ def ref_recipe(name):
         "Test-2AgentEmpty7x7-see-through": ("EmptyMultiGrid", dict(grid_size=7)),
         "Test-3AgentCluttered9x9-respawn": ("ClutteredMultiGrid", dict(grid_size=9, n_clutter=6, respawn=True)),
         "Test-4AgentEmpty5x5-respawn-noghost": ("EmptyMultiGrid", dict(grid_size=5, respawn=True, ghost_mode=False)),
+        "Test-3AgentEmpty7x7-spawn-delay": ("EmptyMultiGrid", dict(grid_size=7, max_steps=40)),
+        "Test-4AgentEmpty5x5-hide": ("EmptyMultiGrid", dict(grid_size=5)),
+        "Test-3AgentCluttered9x9-hide": ("ClutteredMultiGrid", dict(grid_size=9, n_clutter=8)),
     }
     return t[name]
+
+
+def _with_delays(spec, delays):
+    for a, d in zip(spec["agents"], delays):
+        if d:
+            a["spawn_delay"] = d
+    return spec
+
+
+def _with_hide(spec, hides):
+    for a, h in zip(spec["agents"], hides):
+        if h:
+            a["hide_item_types"] = list(h)
+    return spec
 
 
 _registered_base = registered
@@ -125,6 +142,9 @@ def registered(name):   # noqa: F811  (extends the table above with test-only sc
         "Test-2AgentEmpty7x7-see-through": lambda: empty_spec(2, 7, 3, see_through_walls=True, tile_size=11),
         "Test-3AgentCluttered9x9-respawn": lambda: cluttered_spec(3, 9, 7, n_clutter=6, respawn=True),
         "Test-4AgentEmpty5x5-respawn-noghost": lambda: empty_spec(4, 5, 5, respawn=True, ghost_mode=False),
+        "Test-3AgentEmpty7x7-spawn-delay": lambda: _with_delays(empty_spec(3, 7, 5, max_steps=40), [0, 4, 9]),
+        "Test-4AgentEmpty5x5-hide": lambda: _with_hide(empty_spec(4, 5, 5), [["Agent"], ["Goal"], ["Wall", "Goal", "Agent"], []]),
+        "Test-3AgentCluttered9x9-hide": lambda: _with_hide(cluttered_spec(3, 9, 7, n_clutter=8), [["Wall"], ["Agent", "Goal"], []]),
     }
     if name in extra:
         return extra[name]()
@@ -138,6 +158,7 @@ ALL_SCENARIOS = [
     "Test-3AgentCluttered11x11-noghost", "Test-4AgentEmpty5x5-crowded",
     "Test-4AgentEmpty5x5-crowded-noghost", "Test-2AgentCluttered9x9-offset2-ts5",
     "Test-2AgentEmpty7x7-see-through", "Test-3AgentCluttered9x9-respawn", "Test-4AgentEmpty5x5-respawn-noghost",
+    "Test-3AgentEmpty7x7-spawn-delay", "Test-4AgentEmpty5x5-hide", "Test-3AgentCluttered9x9-hide",
 ]
 
 
