@@ -419,6 +419,17 @@ class MultiGridEnv(object):
         tab = self._obj_table()
         for i in range(len(objs)):
             tab[i].ovl_slot = ovl_slot[i]
+        # the obs kernel keeps the atlas + 4 waves of per-env scratch in one workgroup's LDS (160 KiB)
+        r16 = lambda v: (v + 15) // 16 * 16
+        n, vs = self.num_agents, self.view_size
+        scratch = (3 * r16(self.cells_stride) + N.MAX_AGENTS * 8 + 2 * r16(n * vs * vs) + 2 * r16(n * vs * 4)
+                   + r16(n * vs * vs * 2))
+        need = r16(atlas.size) + 2 * N.MAX_OBJ + N.MAX_AGENTS * 8 + 4 * scratch
+        if need > 160 * 1024:
+            raise NotImplementedError(
+                "this configuration needs %d KiB of LDS per workgroup (atlas %d KiB + 4 x %d B of per-env "
+                "scratch); the obs kernel has 160 KiB — reduce grid size, agent count or tile size"
+                % (need // 1024, atlas.size // 1024, scratch))
         raw = np.frombuffer(bytes(tab), dtype=np.uint8).copy()
         flat = atlas.reshape(-1)
         pad = (-flat.size) % 16

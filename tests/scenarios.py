@@ -111,6 +111,12 @@ def ref_recipe(name):
         "Test-3AgentEmpty7x7-spawn-delay": ("EmptyMultiGrid", dict(grid_size=7, max_steps=40)),
         "Test-4AgentEmpty5x5-hide": ("EmptyMultiGrid", dict(grid_size=5)),
         "Test-3AgentCluttered9x9-hide": ("ClutteredMultiGrid", dict(grid_size=9, n_clutter=8)),
+        # oracle-only edge shapes (no golden file): view sizes / tile sizes / agent counts / big grids
+        "Edge-12AgentCluttered9x9-view3": ("ClutteredMultiGrid", dict(grid_size=9, n_clutter=5)),
+        "Edge-2AgentCluttered40x40-view9-off3": ("ClutteredMultiGrid", dict(grid_size=40, clutter_density=0.2)),
+        "Edge-3AgentCluttered13x13-view11": ("ClutteredMultiGrid", dict(grid_size=13, n_clutter=20)),
+        "Edge-2AgentEmpty8x8-view5-ts4": ("EmptyMultiGrid", dict(grid_size=8)),
+        "Edge-16AgentEmpty6x6-view7": ("EmptyMultiGrid", dict(grid_size=6)),
     }
     return t[name]
 
@@ -120,6 +126,9 @@ def _with_delays(spec, delays):
         if d:
             a["spawn_delay"] = d
     return spec
+
+
+_MANY = ["red", "orange", "green", "blue", "cyan", "purple", "yellow", "olive", "grey", "worst", "pink", "white"]
 
 
 def _with_hide(spec, hides):
@@ -145,6 +154,11 @@ def registered(name):   # noqa: F811  (extends the table above with test-only sc
         "Test-3AgentEmpty7x7-spawn-delay": lambda: _with_delays(empty_spec(3, 7, 5, max_steps=40), [0, 4, 9]),
         "Test-4AgentEmpty5x5-hide": lambda: _with_hide(empty_spec(4, 5, 5), [["Agent"], ["Goal"], ["Wall", "Goal", "Agent"], []]),
         "Test-3AgentCluttered9x9-hide": lambda: _with_hide(cluttered_spec(3, 9, 7, n_clutter=8), [["Wall"], ["Agent", "Goal"], []]),
+        "Edge-12AgentCluttered9x9-view3": lambda: cluttered_spec(12, 9, 3, n_clutter=5, colors=_MANY[:12]),
+        "Edge-2AgentCluttered40x40-view9-off3": lambda: cluttered_spec(2, 40, 9, clutter_density=0.2, view_offset=3),
+        "Edge-3AgentCluttered13x13-view11": lambda: cluttered_spec(3, 13, 11, n_clutter=20),
+        "Edge-2AgentEmpty8x8-view5-ts4": lambda: empty_spec(2, 8, 5, tile_size=4),
+        "Edge-16AgentEmpty6x6-view7": lambda: empty_spec(16, 6, 7, colors=(_MANY + _MANY)[:16]),
     }
     if name in extra:
         return extra[name]()

@@ -90,7 +90,15 @@ def test_rng_seeding_golden():
                                        ("Custom-8AgentCluttered30x30", 256, 60),
                                        ("Test-4AgentEmpty5x5-crowded", 512, 80),
                                        ("Test-2AgentCluttered9x9-offset2-ts5", 256, 60),
-                                       ("Goalcycle-demo-solo-v0", 256, 120)])
+                                       ("Goalcycle-demo-solo-v0", 256, 120),
+                                       ("Test-3AgentCluttered9x9-respawn", 256, 150),
+                                       ("Test-3AgentEmpty7x7-spawn-delay", 128, 60),
+                                       ("Test-4AgentEmpty5x5-hide", 256, 80),
+                                       ("Edge-12AgentCluttered9x9-view3", 64, 60),
+                                       ("Edge-2AgentCluttered40x40-view9-off3", 64, 40),
+                                       ("Edge-3AgentCluttered13x13-view11", 64, 40),
+                                       ("Edge-2AgentEmpty8x8-view5-ts4", 64, 40),
+                                       ("Edge-16AgentEmpty6x6-view7", 64, 40)])
 def test_batch_vs_oracle(name, B, T):
     """same seeds, same actions: HIP batch == B oracle envs, every step, full observations."""
     import torch
@@ -118,6 +126,25 @@ def test_batch_vs_oracle(name, B, T):
             env.reset(env_mask=dn2)
             for b in np.nonzero(dn2)[0]:
                 orc.envs[b].reset()
+
+
+def test_stepping_past_done_like_the_reference():
+    """the reference keeps stepping after `done` (no auto-reset, base.py:649-653): step_count runs
+    past max_steps, done agents stay inactive, the decay factor goes negative."""
+    import torch
+    name, B = "MarlGrid-3AgentEmpty9x9-v0", 128
+    seeds = 300 + np.arange(B)
+    env = product_envs.build(name, batch_size=B, seeds=seeds)
+    orc = O.OracleBatch(scenarios.registered(name), seeds)
+    env.reset(); orc.reset()
+    rng = np.random.RandomState(8)
+    for t in range(140):
+        a = rng.randint(0, 3, size=(B, 3))
+        o, r, dn, _ = env.step(torch.from_numpy(a))
+        o2, r2, dn2, _ = orc.step(a)
+        assert np.array_equal(o.cpu().numpy(), o2) and np.array_equal(dn.cpu().numpy(), dn2)
+        assert np.abs(r.cpu().numpy().astype(np.float64) - r2).max() <= REW_TOL
+    assert dn2.all() and int(env.step_count.min().item()) == 140
 
 
 def test_auto_reset_matches_manual():
