@@ -424,12 +424,11 @@ class MultiGridEnv(object):
         n, vs = self.num_agents, self.view_size
         scratch = (3 * r16(self.cells_stride) + N.MAX_AGENTS * 8 + 2 * r16(n * vs * vs) + 2 * r16(n * vs * 4)
                    + r16(n * vs * vs * 2))
-        need = r16(atlas.size) + 2 * N.MAX_OBJ + N.MAX_AGENTS * 8 + 4 * scratch
+        need = 2 * N.MAX_OBJ + N.MAX_AGENTS * 8 + 4 * scratch      # (an atlas that does not fit stays in HBM/L2)
         if need > 160 * 1024:
             raise NotImplementedError(
-                "this configuration needs %d KiB of LDS per workgroup (atlas %d KiB + 4 x %d B of per-env "
-                "scratch); the obs kernel has 160 KiB — reduce grid size, agent count or tile size"
-                % (need // 1024, atlas.size // 1024, scratch))
+                "this configuration needs %d KiB of LDS per workgroup (4 x %d B of per-env scratch); the "
+                "obs kernel has 160 KiB — reduce the grid size" % (need // 1024, scratch))
         raw = np.frombuffer(bytes(tab), dtype=np.uint8).copy()
         flat = atlas.reshape(-1)
         pad = (-flat.size) % 16

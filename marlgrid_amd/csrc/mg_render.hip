@@ -26,11 +26,13 @@
 namespace mg {
 
 // ---- the kernel ----------------------------------------------------------------------------------
-// VS_/TS_ > 0: compile-time view/tile size, dword fast path (requires TS_ % 4 == 0).
-// VS_ == TS_ == 0: any size, byte-granular store loop (correct, slower).
-// V_: 0 = production.  1..5 = measurement variants used by tools/bench_render_variants.py (selected
-// with MG_RENDER_VARIANT, <7,8> only): 1 per-dword index math, 2 nontemporal stores, 3 raster only
-// (phases 2-5 skipped), 4 stores only (no LDS look-ups), 5 no next-env prefetch, 6 no store bursts, 7 grid-strided env walk.
+// TS_ % 8 == 0: 16-byte-chunk fast raster (tile rows are an even number of dwords); VS_ > 0 also
+//              fixes the view size at compile time (the shipped view sizes), VS_ == 0 reads it from cfg.
+// TS_ == 0:    any view / tile size, byte-granular raster (correct, ~5x slower per byte).
+// V_: 0 = production.  2..7 = measurement variants used by tools/bench_render_variants.py (selected
+// with MG_RENDER_VARIANT, <7,8> only): 2 nontemporal stores, 3 raster only
+// (phases 2-5 skipped), 4 stores only (no LDS look-ups), 5 no next-env prefetch, 6 no store bursts, 7 grid-strided env walk.  8 (production, chosen by the launcher) = atlas read
+// from global memory because it does not fit LDS.
 // WPB = waves per workgroup (4 or 16; MG_RENDER_WPB overrides the launcher's choice).
 template <int VS_, int TS_, int WPB, int V_ = 0>
 __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState st, uint8_t* __restrict__ obs,
@@ -46,7 +48,10 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     const int VV = VS * VS;
 
     // ---- block-shared: atlas + object flags ----
-    const int atlas_bytes = round_up(4 * cfg.n_tiles * tile_bytes, 16);
+    // V_ == 8: the atlas does not fit the 160 KiB of LDS next to the per-env scratch (large tiles);
+    // it is then read in place (global memory, L2-resident: it is a few hundred KB).
+    constexpr bool kGlobalAtlas = (V_ == 8);
+    const int atlas_bytes = kGlobalAtlas ? 0 : round_up(4 * cfg.n_tiles * tile_bytes, 16);
     uint8_t* s_atlas = smem;
     uint8_t* s_oflags = smem + atlas_bytes;             // [MG_MAX_OBJ]
     uint8_t* s_oslot = s_oflags + MG_MAX_OBJ;           // [MG_MAX_OBJ]
@@ -54,7 +59,8 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     {
         const uint4* src = reinterpret_cast<const uint4*>(cfg.atlas);
         uint4* dst = reinterpret_cast<uint4*>(s_atlas);
-        for (int i = tid; i < atlas_bytes / 16; i += WPB * 64) dst[i] = src[i];
+        if constexpr (!kGlobalAtlas)
+            for (int i = tid; i < atlas_bytes / 16; i += WPB * 64) dst[i] = src[i];
         if (tid < MG_MAX_OBJ) {
             uint8_t f = 0, sl = 0xFF;
             if (tid < cfg.n_obj) { f = cfg.obj[tid].flags; sl = cfg.obj[tid].ovl_slot; }
@@ -80,6 +86,12 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
 
     const int h = VS / 2, off = cfg.view_offset;
     const size_t img_bytes = (size_t)VS * TS * VS * TS * 3;
+
+    // raster geometry of the 16-byte-chunk path (see phase 6): pairs per pixel row, a lane's start
+    // position and its per-trip advance — constants of the launch, folded at compile time when VS_ > 0
+    const uint32_t PR = (uint32_t)VS * (uint32_t)(TS * 3 / 8);
+    const uint32_t STEP_R = PR ? (2u * kWave) / PR : 0u, STEP_P = PR ? (2u * kWave) - STEP_R * PR : 0u;
+    const uint32_t rast_r0 = PR ? (2u * lane) / PR : 0u, rast_p0 = PR ? 2u * lane - rast_r0 * PR : 0u;
 
     // next-env prefetch registers: the env's grid (<= 1 KiB: one dword per lane per 256 B) and records
     constexpr int kPF = 4;
@@ -214,7 +226,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 }
             }
             const uint32_t orient = (3u - rec_byte(w_rec[k], MG_AG_DIR)) & 3u;   // -(dir+1) mod 4
-            if constexpr (VS_ > 0 && TS_ > 0 && (TS_ % 4) == 0)
+            if constexpr (TS_ > 0 && (TS_ % 8) == 0 && !kGlobalAtlas)
                 w_tmap[it] = (uint16_t)((orient * cfg.n_tiles + tile) * (TS_ * TS_ * 3 / 4));   // dword offset
             else
                 w_tmap[it] = (uint16_t)(orient * cfg.n_tiles + tile);                            // tile index
@@ -228,87 +240,66 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
         }
         wave_lds_sync();
         // 6. raster: stream the env's n images out
-        if constexpr (VS_ > 0 && TS_ > 0 && (TS_ % 4) == 0) {
-            constexpr int TD = TS_ * 3 / 4;         // dwords per tile row
-            constexpr int DR = VS_ * TD;            // dwords per pixel row
-            constexpr int IMG_CHUNKS = VS_ * TS_ * DR / 4;
+        if constexpr (TS_ > 0 && (TS_ % 8) == 0) {
+            // The env's n images are one contiguous run of 8-byte *pairs*: PR pairs per pixel row,
+            // PT per tile row (TD even => a pair never straddles a tile row, and every pair is
+            // 8-byte aligned in the atlas: ds_read_b64).  A 16-byte chunk is pairs (2c, 2c+1).
+            // tmap is laid out [image][band][column], and an image has exactly VS bands, so the
+            // GLOBAL pixel row r (counted across the env's images) indexes it directly:
+            // tile = tmap[(r / TS) * VS + column].  A lane's chunk advances by 64 chunks = 128
+            // pairs per trip, so (r, pair-in-row) is carried incrementally: no per-chunk division
+            // by anything but the compile-time PT / TS (24-bit multiply-shift, all values < 2^16).
+            constexpr uint32_t TD = TS_ * 3 / 4, PT = TD / 2;     // dwords / pairs per tile row
+            constexpr uint32_t M_PT = (65536u + PT - 1) / PT, M_TS = (65536u + TS_ - 1) / TS_;
             const uint32_t* atlas32 = reinterpret_cast<const uint32_t*>(s_atlas);
+            const uint32_t* gatlas32 = reinterpret_cast<const uint32_t*>(cfg.atlas);
+            auto ld_pair = [&](uint32_t a) -> uint2 {
+                if constexpr (kGlobalAtlas) return *reinterpret_cast<const uint2*>(gatlas32 + a);
+                else return *reinterpret_cast<const uint2*>(atlas32 + a);
+            };
             uint4* out = reinterpret_cast<uint4*>(obs + (size_t)e * n * img_bytes);
-            const int total = n * IMG_CHUNKS;
-            if constexpr ((TD % 2) == 0 && V_ != 1) {
-                // The env's n images are one contiguous run of 8-byte *pairs*: PR pairs per pixel row,
-                // PT per tile row (TD even => a pair never straddles a tile row, and every pair is
-                // 8-byte aligned in the atlas: ds_read_b64).  A 16-byte chunk is pairs (2c, 2c+1).
-                // tmap is laid out [image][band][column], and an image has exactly VS bands, so the
-                // GLOBAL pixel row r (counted across the env's images) indexes it directly:
-                // tile = tmap[(r / TS) * VS + column].  A lane's chunk advances by 64 chunks = 128
-                // pairs per trip, so (r, pair-in-row) is carried incrementally: no per-chunk division
-                // by anything but the compile-time PT.
-                constexpr uint32_t PR = DR / 2, PT = TD / 2;
-                constexpr uint32_t STEP_R = (2 * kWave) / PR, STEP_P = (2 * kWave) % PR;
-                uint32_t r = (2u * lane) / PR;
-                uint32_t pr = 2u * lane - r * PR;
-                // all quantities are < 2^16: 24-bit multiplies (full-rate v_mul/mad_u32_u24) and
-                // multiply-shift division by the compile-time PT / TS
-                constexpr uint32_t M_PT = (65536u + PT - 1) / PT, M_TS = (65536u + TS_ - 1) / TS_;
-                static_assert(PR * M_PT < (1u << 24) && MG_MAX_AGENTS * VS_ * TS_ * M_TS < (1u << 24), "u24 range");
-                auto pair_addr = [&](uint32_t rr_, uint32_t pr_) -> uint32_t {
-                    const uint32_t va = __umul24(pr_, M_PT) >> 16, kp = pr_ - __umul24(va, PT);
-                    const uint32_t vb = __umul24(rr_, M_TS) >> 16, rr = rr_ - __umul24(vb, (uint32_t)TS_);
-                    return (uint32_t)w_tmap[__umul24(vb, (uint32_t)VS_) + va] + __umul24(rr, (uint32_t)TD) + kp * 2u;
-                };
-                auto fetch = [&](uint4& v) {
-                    if constexpr (V_ == 4) {
-                        v = make_uint4(0x1e19231eu, 0x231e1923u, 0x1e19231eu, 0x231e1923u);
-                    } else {
-                        uint32_t r1 = r, pr1 = pr + 1;
-                        if (pr1 == PR) { pr1 = 0; r1++; }
-                        const uint2 p0 = *reinterpret_cast<const uint2*>(atlas32 + pair_addr(r, pr));
-                        const uint2 p1 = *reinterpret_cast<const uint2*>(atlas32 + pair_addr(r1, pr1));
-                        v = make_uint4(p0.x, p0.y, p1.x, p1.y);
-                    }
-                    pr += STEP_P; r += STEP_R;
-                    if (pr >= PR) { pr -= PR; r++; }
-                };
-                auto put = [&](int c, const uint4& v) {
-                    if constexpr (V_ == 2) {
-                        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                        u32x4 nv = {v.x, v.y, v.z, v.w};
-                        __builtin_nontemporal_store(nv, reinterpret_cast<u32x4*>(out + c));
-                    } else out[c] = v;
-                };
-                int c = lane;
-                if constexpr (V_ != 6) {
-                    // gather four chunks from LDS, then issue their four 1-KiB stores back to back
-                    for (; c + 3 * kWave < total; c += 4 * kWave) {
-                        uint4 v0, v1, v2, v3;
-                        fetch(v0); fetch(v1); fetch(v2); fetch(v3);
-                        put(c, v0); put(c + kWave, v1); put(c + 2 * kWave, v2); put(c + 3 * kWave, v3);
-                    }
+            const int total = (int)(n * (img_bytes / 16));
+            uint32_t r = rast_r0, pr = rast_p0;
+            auto pair_addr = [&](uint32_t rr_, uint32_t pr_) -> uint32_t {
+                const uint32_t va = __umul24(pr_, M_PT) >> 16, kp = pr_ - __umul24(va, PT);
+                const uint32_t vb = __umul24(rr_, M_TS) >> 16, rr = rr_ - __umul24(vb, (uint32_t)TS_);
+                uint32_t t = (uint32_t)w_tmap[__umul24(vb, (uint32_t)VS) + va];
+                if constexpr (kGlobalAtlas) t *= (uint32_t)(TS_ * TS_ * 3 / 4);       // tile index -> dword offset
+                return t + __umul24(rr, TD) + kp * 2u;
+            };
+            auto fetch = [&](uint4& v) {
+                if constexpr (V_ == 4) {
+                    v = make_uint4(0x1e19231eu, 0x231e1923u, 0x1e19231eu, 0x231e1923u);
+                } else {
+                    uint32_t r1 = r, pr1 = pr + 1;
+                    if (pr1 == PR) { pr1 = 0; r1++; }
+                    const uint2 p0 = ld_pair(pair_addr(r, pr));
+                    const uint2 p1 = ld_pair(pair_addr(r1, pr1));
+                    v = make_uint4(p0.x, p0.y, p1.x, p1.y);
                 }
-                for (; c < total; c += kWave) {
-                    uint4 v;
-                    fetch(v);
-                    put(c, v);
+                pr += STEP_P; r += STEP_R;
+                if (pr >= PR) { pr -= PR; r++; }
+            };
+            auto put = [&](int c, const uint4& v) {
+                if constexpr (V_ == 2) {
+                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                    u32x4 nv = {v.x, v.y, v.z, v.w};
+                    __builtin_nontemporal_store(nv, reinterpret_cast<u32x4*>(out + c));
+                } else out[c] = v;
+            };
+            int c = lane;
+            if constexpr (V_ != 6) {
+                // gather four chunks from LDS, then issue their four 1-KiB stores back to back
+                for (; c + 3 * kWave < total; c += 4 * kWave) {
+                    uint4 v0, v1, v2, v3;
+                    fetch(v0); fetch(v1); fetch(v2); fetch(v3);
+                    put(c, v0); put(c + kWave, v1); put(c + 2 * kWave, v2); put(c + 3 * kWave, v3);
                 }
-            } else {
-            for (int c = lane; c < total; c += kWave) {
-                const int k = c / IMG_CHUNKS;
-                const int q = (c - k * IMG_CHUNKS) * 4;
-                int row = q / DR;
-                int dw = q - row * DR;
-                int va = dw / TD;
-                int kk = dw - va * TD;
-                const uint16_t* tm = w_tmap + k * (VS_ * VS_);
-                uint32_t v[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const int vb = row / TS_, rr = row - vb * TS_;
-                    v[i] = atlas32[(uint32_t)tm[vb * VS_ + va] + rr * TD + kk];
-                    if (++kk == TD) { kk = 0; if (++va == VS_) { va = 0; ++row; } }
-                }
-                out[c] = make_uint4(v[0], v[1], v[2], v[3]);
             }
+            for (; c < total; c += kWave) {
+                uint4 v;
+                fetch(v);
+                put(c, v);
             }
         } else {
             uint8_t* out = obs + (size_t)e * n * img_bytes;
@@ -318,9 +309,10 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 const int k = p / (P * P), pp = p - k * (P * P);
                 const int row = pp / P, col = pp - row * P;
                 const int vb = row / TS, rr = row - vb * TS, va = col / TS, cc = col - va * TS;
-                const uint8_t* src = s_atlas + (size_t)w_tmap[k * VV + vb * VS + va] * tile_bytes + (rr * TS + cc) * 3;
+                const size_t so = (size_t)w_tmap[k * VV + vb * VS + va] * tile_bytes + (rr * TS + cc) * 3;
                 uint8_t* d = out + (size_t)p * 3;
-                d[0] = src[0]; d[1] = src[1]; d[2] = src[2];
+                if constexpr (kGlobalAtlas) { const uint8_t* src = cfg.atlas + so; d[0] = src[0]; d[1] = src[1]; d[2] = src[2]; }
+                else { const uint8_t* src = s_atlas + so; d[0] = src[0]; d[1] = src[1]; d[2] = src[2]; }
             }
         }
         wave_lds_sync();   // scratch is reused by the next env
@@ -332,7 +324,8 @@ static hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_
                                   uint8_t* v, hipStream_t s) {
     const int tile_bytes = cfg.tile_size * cfg.tile_size * 3;
     const RenderScratch L = render_scratch_layout(cfg.cells_stride, cfg.n_agents, cfg.view_size);
-    size_t lds = (size_t)round_up(4 * cfg.n_tiles * tile_bytes, 16) + 2 * MG_MAX_OBJ + MG_MAX_AGENTS * 8 + WPB * (size_t)L.total;
+    size_t lds = (V_ == 8 ? 0 : (size_t)round_up(4 * cfg.n_tiles * tile_bytes, 16)) + 2 * MG_MAX_OBJ +
+                 MG_MAX_AGENTS * 8 + WPB * (size_t)L.total;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<VS_, TS_, WPB, V_>),
@@ -375,10 +368,20 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
     if ((view_cells || view_agent || vis_mask) && !(view_cells && view_agent && vis_mask)) return hipErrorInvalidValue;
     const int vs = cfg.view_size, ts = cfg.tile_size;
     const int wpb = choose_wpb(cfg);
+    {   // atlas too large for LDS (next to 4 waves of scratch): read it from global memory instead
+        const RenderScratch L = render_scratch_layout(cfg.cells_stride, cfg.n_agents, cfg.view_size);
+        const size_t lds4 = (size_t)round_up(4 * cfg.n_tiles * ts * ts * 3, 16) + 2 * MG_MAX_OBJ + MG_MAX_AGENTS * 8 +
+                            4 * (size_t)L.total;
+        if (lds4 > 160 * 1024) {
+            if (ts == 8) return launch_render_t<0, 8, 4, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
+            if (ts == 16) return launch_render_t<0, 16, 4, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
+            if (ts == 32) return launch_render_t<0, 32, 4, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
+            return launch_render_t<0, 0, 4, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
+        }
+    }
     if (ts == 8 && vs == 7) {
         const int variant = getenv("MG_RENDER_VARIANT") ? atoi(getenv("MG_RENDER_VARIANT")) : 0;
         switch (variant) {   // measurement variants (tools/ab_render.py), see render_kernel
-        case 1: return MG_RENDER_DISPATCH(7, 8, 1);
         case 2: return MG_RENDER_DISPATCH(7, 8, 2);
         case 3: return MG_RENDER_DISPATCH(7, 8, 3);
         case 4: return MG_RENDER_DISPATCH(7, 8, 4);
@@ -391,7 +394,10 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
     if (ts == 8 && vs == 9) return MG_RENDER_DISPATCH(9, 8, 0);
     if (ts == 8 && vs == 5) return MG_RENDER_DISPATCH(5, 8, 0);
     if (ts == 8 && vs == 3) return MG_RENDER_DISPATCH(3, 8, 0);
-    return MG_RENDER_DISPATCH(0, 0, 0);
+    if (ts == 8) return MG_RENDER_DISPATCH(0, 8, 0);      // other view sizes: run-time VS, same raster
+    if (ts == 16) return MG_RENDER_DISPATCH(0, 16, 0);
+    if (ts == 32) return MG_RENDER_DISPATCH(0, 32, 0);
+    return MG_RENDER_DISPATCH(0, 0, 0);                   // any other tile size: byte-granular raster
 }
 
 }  // namespace mg

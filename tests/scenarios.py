@@ -117,6 +117,10 @@ def ref_recipe(name):
         "Edge-3AgentCluttered13x13-view11": ("ClutteredMultiGrid", dict(grid_size=13, n_clutter=20)),
         "Edge-2AgentEmpty8x8-view5-ts4": ("EmptyMultiGrid", dict(grid_size=8)),
         "Edge-16AgentEmpty6x6-view7": ("EmptyMultiGrid", dict(grid_size=6)),
+        "Edge-2AgentCluttered9x9-view5-ts16": ("ClutteredMultiGrid", dict(grid_size=9, n_clutter=6)),
+        "Edge-2AgentCluttered9x9-view3-ts32": ("ClutteredMultiGrid", dict(grid_size=9, n_clutter=6)),
+        "Edge-3AgentCluttered13x13-view13-ts8": ("ClutteredMultiGrid", dict(grid_size=13, n_clutter=20)),
+        "Edge-2AgentEmpty6x6-view3-ts33": ("EmptyMultiGrid", dict(grid_size=6)),
     }
     return t[name]
 
@@ -159,6 +163,10 @@ def registered(name):   # noqa: F811  (extends the table above with test-only sc
         "Edge-3AgentCluttered13x13-view11": lambda: cluttered_spec(3, 13, 11, n_clutter=20),
         "Edge-2AgentEmpty8x8-view5-ts4": lambda: empty_spec(2, 8, 5, tile_size=4),
         "Edge-16AgentEmpty6x6-view7": lambda: empty_spec(16, 6, 7, colors=(_MANY + _MANY)[:16]),
+        "Edge-2AgentCluttered9x9-view5-ts16": lambda: cluttered_spec(2, 9, 5, n_clutter=6, tile_size=16),
+        "Edge-2AgentCluttered9x9-view3-ts32": lambda: cluttered_spec(2, 9, 3, n_clutter=6, tile_size=32, view_offset=1),
+        "Edge-3AgentCluttered13x13-view13-ts8": lambda: cluttered_spec(3, 13, 13, n_clutter=20),
+        "Edge-2AgentEmpty6x6-view3-ts33": lambda: empty_spec(2, 6, 3, tile_size=33),
     }
     if name in extra:
         return extra[name]()

@@ -98,7 +98,11 @@ def test_rng_seeding_golden():
                                        ("Edge-2AgentCluttered40x40-view9-off3", 64, 40),
                                        ("Edge-3AgentCluttered13x13-view11", 64, 40),
                                        ("Edge-2AgentEmpty8x8-view5-ts4", 64, 40),
-                                       ("Edge-16AgentEmpty6x6-view7", 64, 40)])
+                                       ("Edge-16AgentEmpty6x6-view7", 64, 40),
+                                       ("Edge-2AgentCluttered9x9-view5-ts16", 4200, 30),
+                                       ("Edge-2AgentCluttered9x9-view3-ts32", 64, 30),
+                                       ("Edge-3AgentCluttered13x13-view13-ts8", 64, 30),
+                                       ("Edge-2AgentEmpty6x6-view3-ts33", 32, 20)])
 def test_batch_vs_oracle(name, B, T):
     """same seeds, same actions: HIP batch == B oracle envs, every step, full observations."""
     import torch
