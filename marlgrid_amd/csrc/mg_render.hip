@@ -28,7 +28,7 @@ namespace mg {
 // ---- the kernel ----------------------------------------------------------------------------------
 // TS_ % 8 == 0: 16-byte-chunk fast raster (tile rows are an even number of dwords); VS_ > 0 also
 //              fixes the view size at compile time (the shipped view sizes), VS_ == 0 reads it from cfg.
-// TS_ == 0:    any view / tile size, byte-granular raster (correct, ~5x slower per byte).
+// TS_ == 0:    any view / tile size: per-byte look-ups assembled into aligned dword stores.
 // V_: 0 = production.  2..7 = measurement variants used by tools/bench_render_variants.py (selected
 // with MG_RENDER_VARIANT, <7,8> only): 2 nontemporal stores, 3 raster only
 // (phases 2-5 skipped), 4 stores only (no LDS look-ups), 5 no next-env prefetch, 6 no store bursts, 7 grid-strided env walk.  8 (production, chosen by the launcher) = atlas read
@@ -302,17 +302,78 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 put(c, v);
             }
         } else {
-            uint8_t* out = obs + (size_t)e * n * img_bytes;
-            const int P = VS * TS;
-            const int total = n * P * P;
-            for (int p = lane; p < total; p += kWave) {
-                const int k = p / (P * P), pp = p - k * (P * P);
-                const int row = pp / P, col = pp - row * P;
-                const int vb = row / TS, rr = row - vb * TS, va = col / TS, cc = col - va * TS;
-                const size_t so = (size_t)w_tmap[k * VV + vb * VS + va] * tile_bytes + (rr * TS + cc) * 3;
-                uint8_t* d = out + (size_t)p * 3;
-                if constexpr (kGlobalAtlas) { const uint8_t* src = cfg.atlas + so; d[0] = src[0]; d[1] = src[1]; d[2] = src[2]; }
-                else { const uint8_t* src = s_atlas + so; d[0] = src[0]; d[1] = src[1]; d[2] = src[2]; }
+            // Any tile size: the env's n*P*P*3 output bytes are still one contiguous run, written as
+            // whole aligned dwords (plus <= 3 head and <= 3 tail bytes when the run is not 4-byte
+            // aligned in the tensor).  Each byte is looked up on its own — (pixel row, byte in row) ->
+            // (tile, row in tile, pixel, channel) — with multiply-high division by 3 and by TS, and
+            // the lane's position is carried incrementally like in the chunk raster.
+            const uint32_t P = (uint32_t)(VS * TS), RB = P * 3u;           // bytes per pixel row
+            const uint32_t S = (uint32_t)n * P * RB;                       // bytes per env
+            const size_t gb = (size_t)e * S;                               // first byte, relative to obs
+            const size_t d0 = (gb + 3) / 4, d1 = (gb + S) / 4;             // aligned dwords [d0, d1)
+            const uint32_t mTS = TS > 1 ? 0xFFFFFFFFu / (uint32_t)TS + 1u : 0u;
+            auto div_ts = [&](uint32_t v) -> uint32_t { return TS > 1 ? __umulhi(v, mTS) : v; };
+            auto byte_at = [&](uint32_t R, uint32_t cb) -> uint32_t {      // R: global pixel row, cb < RB
+                const uint32_t col = __umulhi(cb, 0x55555556u), ch = cb - col * 3u;
+                const uint32_t va = div_ts(col), cc = col - va * (uint32_t)TS;
+                const uint32_t vb = div_ts(R), rr = R - vb * (uint32_t)TS;
+                const uint32_t so = (uint32_t)w_tmap[vb * (uint32_t)VS + va] * (uint32_t)tile_bytes + (rr * (uint32_t)TS + cc) * 3u + ch;
+                if constexpr (kGlobalAtlas) return cfg.atlas[so];
+                else return s_atlas[so];
+            };
+            if (d1 > d0) {
+                // A pixel row is VS segments of SEG = 3*TS bytes, each a contiguous run of one atlas tile
+                // row.  An output dword is therefore 4 contiguous atlas bytes at an arbitrary byte
+                // offset (two aligned dword reads + v_alignbyte), or — when it straddles a segment
+                // boundary — the low bytes of one such fetch merged with the start of the next segment.
+                const uint32_t SEG = 3u * (uint32_t)TS;
+                const uint32_t mSEG = 0xFFFFFFFFu / SEG + 1u;                // SEG >= 3
+                auto fetch4 = [&](uint32_t so) -> uint32_t {
+                    const uint32_t a = so >> 2, sh = so & 3u;
+                    uint32_t lo, hi;
+                    if constexpr (kGlobalAtlas) {
+                        const uint32_t* g32 = reinterpret_cast<const uint32_t*>(cfg.atlas);
+                        lo = g32[a]; hi = g32[a + 1];
+                    } else {
+                        const uint32_t* l32 = reinterpret_cast<const uint32_t*>(s_atlas);
+                        lo = l32[a]; hi = l32[a + 1];
+                    }
+                    return __builtin_amdgcn_alignbyte(hi, lo, sh);
+                };
+                auto seg_src = [&](uint32_t R, uint32_t seg) -> uint32_t {     // atlas byte offset of a segment start
+                    const uint32_t vb = div_ts(R), rr = R - vb * (uint32_t)TS;
+                    return (uint32_t)w_tmap[vb * (uint32_t)VS + seg] * (uint32_t)tile_bytes + rr * SEG;
+                };
+                const uint32_t STEP_Rb = (4u * kWave) / RB, STEP_B = (4u * kWave) - STEP_Rb * RB;
+                uint32_t o = (uint32_t)(4 * (d0 + lane) - gb);             // this lane's first byte offset
+                uint32_t R = o / RB, cb = o - R * RB;
+                uint32_t* out32 = reinterpret_cast<uint32_t*>(obs) + d0;
+                const uint32_t nd = (uint32_t)(d1 - d0);
+                for (uint32_t d = lane; d < nd; d += kWave) {
+                    const uint32_t seg = __umulhi(cb, mSEG), off = cb - seg * SEG, left = SEG - off;
+                    uint32_t v = fetch4(seg_src(R, seg) + off);
+                    if (left < 4u) {                                         // straddles into the next segment
+                        uint32_t R2 = R, seg2 = seg + 1u;
+                        if (seg2 == (uint32_t)VS) { seg2 = 0; R2++; }
+                        const uint32_t v2 = fetch4(seg_src(R2, seg2));
+                        const uint32_t keep = (1u << (8u * left)) - 1u;
+                        v = (v & keep) | (v2 << (8u * left));
+                    }
+                    out32[d] = v;
+                    R += STEP_Rb; cb += STEP_B;
+                    if (cb >= RB) { cb -= RB; R++; }
+                }
+            }
+            // head / tail bytes (at most 3 each)
+            const uint32_t head = (uint32_t)(4 * d0 - gb) < S ? (uint32_t)(4 * d0 - gb) : S;
+            const uint32_t tail0 = d1 > d0 ? (uint32_t)(4 * d1 - gb) : head;
+            if (lane < 8) {
+                uint32_t o = lane < 4 ? (uint32_t)lane : tail0 + (lane - 4);
+                const bool on = lane < 4 ? (uint32_t)lane < head : o < S;
+                if (on) {
+                    const uint32_t R = o / RB, cb = o - R * RB;
+                    obs[gb + o] = (uint8_t)byte_at(R, cb);
+                }
             }
         }
         wave_lds_sync();   // scratch is reused by the next env
@@ -397,7 +458,8 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
     if (ts == 8) return MG_RENDER_DISPATCH(0, 8, 0);      // other view sizes: run-time VS, same raster
     if (ts == 16) return MG_RENDER_DISPATCH(0, 16, 0);
     if (ts == 32) return MG_RENDER_DISPATCH(0, 32, 0);
-    return MG_RENDER_DISPATCH(0, 0, 0);                   // any other tile size: byte-granular raster
+    if (vs == 7) return MG_RENDER_DISPATCH(7, 0, 0);      // the default view with any tile size (default tile: 5)
+    return MG_RENDER_DISPATCH(0, 0, 0);                   // anything else
 }
 
 }  // namespace mg
