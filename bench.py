@@ -104,6 +104,17 @@ def main():
                                         C.byref(avg_ms), env._stream()))
     render_s = avg_ms.value * 1e-3
     achieved = B * n * alg_bytes_per_agent_step / render_s / 1e9
+    # HBM bytes per launch from the PMC passes (rocprofv3 --pmc WRITE_SIZE / --pmc FETCH_SIZE, collected
+    # separately and corrected as MI355X_MICROARCH.md prescribes; summary under profiles/): only valid
+    # for the exact workload / batch they were collected on
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01", "pmc_hbm_bytes.json")
+    if wl == WORKLOAD and B == 32768 and os.path.exists(pmc):
+        try:
+            t = json.load(open(pmc)).get("render_kernel_hbm_bytes_per_launch")
+            traffic = float(t) if t else None
+        except Exception:
+            traffic = None
 
     out = None
     if rank == 0:
@@ -123,7 +134,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "mg::render_kernel<%d,%d>" % (vs, ts), "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "kernel_ms": avg_ms.value, "algorithmic_bytes_per_agent_step": alg_bytes_per_agent_step,
-                         "traffic": None},
+                         "algorithmic_bytes_per_launch": B * n * alg_bytes_per_agent_step,
+                         "traffic": traffic, "traffic_unit": "bytes per launch (PMC: WRITE_SIZE + 2*FETCH_SIZE)"},
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, wl)
