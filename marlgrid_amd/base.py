@@ -164,7 +164,8 @@ class MultiGridEnv(object):
 
     def __init__(self, agents=[], grid_size=None, width=None, height=None, max_steps=100,
                  reward_decay=True, seed=1337, respawn=False, ghost_mode=True, agent_spawn_kwargs={},
-                 batch_size=1, device=None, seeds=None, auto_reset=False, strict=True, _dry=False):
+                 batch_size=1, device=None, seeds=None, auto_reset=False, strict=True, obs_buffers=2,
+                 _dry=False):
         if grid_size is not None:
             assert width is None and height is None
             width, height = grid_size, grid_size
@@ -178,6 +179,7 @@ class MultiGridEnv(object):
         self.batch_size = int(batch_size)
         self.auto_reset = bool(auto_reset)
         self.strict = bool(strict)
+        self.obs_buffers = max(1, int(obs_buffers))
         self._dry = bool(_dry)
         if self.batch_size < 1:
             raise ValueError("batch_size must be >= 1")
@@ -272,11 +274,17 @@ class MultiGridEnv(object):
             self.mt_state = torch.zeros((B, N.MT_N), dtype=torch.int32, device=dev)
             self.mt_pos = torch.zeros((B,), dtype=torch.int32, device=dev)
             self.step_count_t = torch.zeros((B,), dtype=torch.int32, device=dev)
-            self.done_t = torch.zeros((B,), dtype=torch.uint8, device=dev)
-            self.done_b = self.done_t.view(torch.bool)      # the same bytes, as the bool tensor step() returns
             self.error_t = torch.zeros((B,), dtype=torch.int32, device=dev)
-            self.obs = torch.zeros((B, n, P, P, 3), dtype=torch.uint8, device=dev)
-            self.rewards = torch.zeros((B, n), dtype=torch.float32, device=dev)
+            # step() outputs rotate through `obs_buffers` buffer sets (default 2), so what one step
+            # returned stays intact while the next step is computed — the README loop
+            # `save_step(obs, act, next_obs, rew, done)` sees two different observations.
+            self._ring = [dict(obs=torch.zeros((B, n, P, P, 3), dtype=torch.uint8, device=dev),
+                               rewards=torch.zeros((B, n), dtype=torch.float32, device=dev),
+                               done=torch.zeros((B,), dtype=torch.uint8, device=dev))
+                          for _ in range(self.obs_buffers)]
+            self._ring_i = 0
+            self.obs, self.rewards, self.done_t = (self._ring[0][k] for k in ("obs", "rewards", "done"))
+            self.done_b = self.done_t.view(torch.bool)      # the same bytes, as the bool tensor step() returns
         self._state = N.State(self.grid_state.data_ptr(), self.agent_state.data_ptr(), self.mt_state.data_ptr(),
                               self.mt_pos.data_ptr(), self.step_count_t.data_ptr(), self.done_t.data_ptr(),
                               self.error_t.data_ptr())
@@ -526,11 +534,16 @@ class MultiGridEnv(object):
         if actions.device != self.device or not actions.is_contiguous():
             actions = actions.to(self.device).contiguous()
         self._sync_tables()       # no-op unless a new object kind was registered since the last launch
+        if self.obs_buffers > 1:
+            self._ring_i = (self._ring_i + 1) % self.obs_buffers
+            r = self._ring[self._ring_i]
+            self.obs, self.rewards, self.done_t = r["obs"], r["rewards"], r["done"]
+            self.done_b = self.done_t.view(torch.bool)
+            self._state.done = self.done_t.data_ptr()
         stream = self._stream()
         N.check(self._lib.mg_step(C.byref(self._cfg), C.byref(self._state), actions.data_ptr(),
                                   actions.element_size(), self.rewards.data_ptr(), stream))
-        # `done` aliases the engine's flag buffer (like obs / rewards it is overwritten by the next
-        # step; clone it to keep it)
+        # obs / rewards / done are views of the current buffer set (see `obs_buffers`)
         done = self.done_b
         if self.auto_reset:
             # envs that just finished start their next episode before the obs is rendered (their

@@ -332,3 +332,50 @@ def test_grid_recorder_roundtrip(tmp_path):
     assert rec.ptr == 5 and sorted(os.listdir(path)) == ["frame_%d.png" % i for i in range(5)]
     back = np.asarray(Image.open(os.path.join(path, "frame_4.png")))
     assert np.array_equal(back, last) and np.array_equal(rec.frames[4], last)
+
+
+def test_readme_loop_with_independent_learners():
+    """README.md:39-63 as written (batched): obs from the previous step must survive the next step."""
+    import torch
+    from marlgrid_amd.agents import IndependentLearners, LearningAgent
+    from marlgrid_amd.envs import ClutteredMultiGrid
+    seen = []
+
+    class RandomAgent(LearningAgent):
+        def action_step(self, obs):
+            return torch.randint(0, 3, (obs.shape[0],), device=obs.device)
+
+        def save_step(self, obs, act, next_obs, rew, done):
+            seen.append((obs.clone(), next_obs.clone()))
+
+    agents = IndependentLearners(RandomAgent(color="red", view_tile_size=8), RandomAgent(color="blue", view_tile_size=8))
+    env = ClutteredMultiGrid(agents, grid_size=9, n_clutter=4, batch_size=32, max_steps=20)
+    obs_array = env.reset()
+    with agents.episode():
+        for _ in range(25):
+            prev = obs_array.clone()
+            action_array = agents.action_step(obs_array)
+            next_obs_array, reward_array, done, _ = env.step(action_array)
+            assert torch.equal(obs_array, prev), "the previous observation was overwritten by step()"
+            agents.save_step(obs_array, action_array, next_obs_array, reward_array, done)
+            obs_array = next_obs_array
+            if done.all():
+                obs_array = env.reset()
+    assert any(not torch.equal(a, b) for a, b in seen)
+
+
+def test_state_dict_checkpoint_resume():
+    """state is plain tensors: saving and restoring it replays the same trajectory (incl. the RNG)."""
+    import torch
+    env = product_envs.build("MarlGrid-3AgentCluttered11x11-v0", batch_size=64, auto_reset=True)
+    env.reset()
+    g = torch.Generator().manual_seed(1)
+    acts = [torch.randint(0, 7, (64, 3), generator=g) for _ in range(30)]
+    for a in acts[:10]:
+        env.step(a)
+    sd = env.state_dict()
+    first = [tuple(x.clone() for x in env.step(a)[:3]) for a in acts[10:]]
+    env.load_state_dict(sd)
+    again = [tuple(x.clone() for x in env.step(a)[:3]) for a in acts[10:]]
+    for (o1, r1, d1), (o2, r2, d2) in zip(first, again):
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2)
