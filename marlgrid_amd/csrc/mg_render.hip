@@ -5,17 +5,19 @@
 // producing obs[B][n][P][P][3] uint8.  This is the HBM-write-bound kernel of the engine: 9 408 B
 // (view 7, tile 8) per agent-step out, ~60 B in.
 //
-// Mapping (CDNA4): ONE WAVEFRONT PER ENV, 4 waves per workgroup, persistent grid-stride over envs.
+// Mapping (CDNA4): ONE WAVEFRONT PER ENV, 16 waves per workgroup (4 for small batches), persistent
+// grid; every wave walks its own contiguous run of envs.
 //   * the whole pre-rotated sprite atlas ([4 orientations][n_tiles][ts*ts*3] bytes, ~21 KB for the
-//     3-agent configs) is staged once per workgroup in LDS;
-//   * per env, the wave stages the env's grid (W*H bytes) and agent records in LDS, derives the
-//     n view_size x view_size egocentric neighbourhoods (base object, shown agent, transparency)
-//     cooperatively, lanes 0..n-1 run the shadow-casting pass as row bit-masks (log-step floods),
-//     and the wave writes a per-view-cell atlas offset map (tmap) to LDS;
-//   * the store loop then emits the env's n*P*P*3 contiguous output bytes as 16-byte
+//     3-agent configs) is staged once per workgroup in LDS (read in place from L2 if it cannot fit);
+//   * per env, the wave stages the env's grid (W*H bytes) and agent records in LDS (prefetched into
+//     registers during the previous env's raster), derives the n view_size x view_size egocentric
+//     neighbourhoods (base object, shown agent, transparency) cooperatively, lanes 0..n-1 run the
+//     shadow-casting pass as row bit-masks (log-step floods), and the wave writes a per-view-cell
+//     atlas offset map (tmap) to LDS;
+//   * the raster then emits the env's n*P*P*3 contiguous output bytes as 16-byte
 //     (global_store_dwordx4) chunks, consecutive lanes -> consecutive chunks, each chunk assembled
-//     from 4 LDS dword look-ups atlas[tmap[cell] + row*TD + k].  Because (ts*3) % 4 == 0 every
-//     dword of the image lies inside exactly one tile row, so there is no byte shuffling at all.
+//     from two 8-byte LDS look-ups atlas[tmap[cell] + row*TD + k] (tile sizes that are a multiple of
+//     8), or as aligned dwords cut out of contiguous atlas runs (any other tile size).
 // No MFMA: there is no contraction anywhere in this path.
 #include "mg_device.h"
 #include <stdlib.h>
@@ -29,10 +31,10 @@ namespace mg {
 // TS_ % 8 == 0: 16-byte-chunk fast raster (tile rows are an even number of dwords); VS_ > 0 also
 //              fixes the view size at compile time (the shipped view sizes), VS_ == 0 reads it from cfg.
 // TS_ == 0:    any view / tile size: per-byte look-ups assembled into aligned dword stores.
-// V_: 0 = production.  2..7 = measurement variants used by tools/bench_render_variants.py (selected
-// with MG_RENDER_VARIANT, <7,8> only): 2 nontemporal stores, 3 raster only
-// (phases 2-5 skipped), 4 stores only (no LDS look-ups), 5 no next-env prefetch, 6 no store bursts, 7 grid-strided env walk.  8 (production, chosen by the launcher) = atlas read
-// from global memory because it does not fit LDS.
+// V_: 0 = production; 8 = production with the atlas read from global memory (chosen by the launcher
+//     when it does not fit LDS).  2..7 = measurement variants for tools/ab_render.py (MG_RENDER_VARIANT,
+//     <7,8> only): 2 nontemporal stores, 3 raster only (phases 2-5 skipped), 4 stores only (no LDS
+//     look-ups), 5 no next-env prefetch, 6 no store bursts, 7 grid-strided env walk.
 // WPB = waves per workgroup (4 or 16; MG_RENDER_WPB overrides the launcher's choice).
 template <int VS_, int TS_, int WPB, int V_ = 0>
 __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState st, uint8_t* __restrict__ obs,
