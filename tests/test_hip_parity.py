@@ -379,3 +379,27 @@ def test_state_dict_checkpoint_resume():
     again = [tuple(x.clone() for x in env.step(a)[:3]) for a in acts[10:]]
     for (o1, r1, d1), (o2, r2, d2) in zip(first, again):
         assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2)
+
+
+def test_full_headline_batch_properties():
+    """BASELINE.json's headline batch (262 144 envs of 3AgentCluttered15x15) on ONE GPU: shard
+    invariance against a 7-env instance holding the same global env ids, no runtime errors, and
+    every 8x8 block of the rendered images is an atlas tile."""
+    import torch
+    from marlgrid_amd.envs import make
+    B = 262144
+    env = make("MarlGrid-3AgentCluttered15x15-v0", batch_size=B, strict=False, obs_buffers=1)
+    ids = np.array([0, 1, 65535, 65536, 131071, 200000, B - 1])
+    small = make("MarlGrid-3AgentCluttered15x15-v0", batch_size=len(ids), seeds=1337 + ids)
+    env.reset(); small.reset()
+    g = torch.Generator().manual_seed(0)
+    for t in range(12):
+        a = torch.randint(0, 7, (B, 3), generator=g)
+        o, r, d, _ = env.step(a)
+        o2, r2, d2, _ = small.step(a[ids])
+        assert torch.equal(o[ids].cpu(), o2.cpu()) and torch.equal(r[ids].cpu(), r2.cpu())
+        assert torch.equal(d[ids].cpu(), d2.cpu())
+    env.check_errors()
+    tiles = env.obs[-64:].reshape(64, 3, 7, 8, 7, 8, 3).permute(0, 1, 2, 4, 3, 5, 6).reshape(-1, 192).cpu().numpy()
+    known = {bytes(x) for x in env.atlas.reshape(-1, 192)}
+    assert all(bytes(x) in known for x in np.unique(tiles, axis=0))
