@@ -403,3 +403,35 @@ def test_full_headline_batch_properties():
     tiles = env.obs[-64:].reshape(64, 3, 7, 8, 7, 8, 3).permute(0, 1, 2, 4, 3, 5, 6).reshape(-1, 192).cpu().numpy()
     known = {bytes(x) for x in env.atlas.reshape(-1, 192)}
     assert all(bytes(x) in known for x in np.unique(tiles, axis=0))
+
+
+def test_error_paths_raise_like_the_reference():
+    """RecursionError when rejection sampling runs out of tries (base.py:705-706) and AssertionError
+    when an agent's front cell is outside the grid (MultiGrid.get asserts, base.py:154-156)."""
+    import torch
+    from marlgrid_amd.agents import GridAgentInterface
+    from marlgrid_amd.base import MultiGrid, MultiGridEnv
+    from marlgrid_amd.envs import ClutteredMultiGrid
+    from marlgrid_amd.objects import Wall
+
+    # 3x3 room: one interior cell, two clutter blocks -> the second placement cannot succeed
+    env = ClutteredMultiGrid(agents=[GridAgentInterface(view_tile_size=8)], grid_size=3, n_clutter=0, batch_size=4)
+    env.n_clutter = 2
+    with pytest.raises(RecursionError):
+        env.reset()
+    # the oracle agrees
+    spec = scenarios.cluttered_spec(1, 3, 7, n_clutter=2)
+    orc = O.OracleEnv(spec, seed=1337)
+    with pytest.raises(RecursionError):
+        orc.reset()
+
+    class NoWalls(MultiGridEnv):
+        def _gen_grid(self, width, height):
+            self.grid = MultiGrid((width, height))
+            self.grid.horz_wall(0, 0, width, obj_type=Wall)       # top row only
+
+    env = NoWalls(agents=[GridAgentInterface(view_tile_size=8)], grid_size=4, batch_size=8, max_steps=1000)
+    env.reset()
+    with pytest.raises(AssertionError):
+        for _ in range(200):
+            env.step(torch.randint(0, 3, (8, 1)))
