@@ -75,6 +75,12 @@ def lib():
         return _lib
     import torch  # noqa: F401  — loads libamdhip64 first; our .so resolves against the same runtime
     if not os.path.exists(LIB_PATH):
+        # not a fallback: build the one and only implementation if the toolchain is at hand
+        import shutil
+        import subprocess
+        if shutil.which(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+            subprocess.call(["bash", os.path.join(os.path.dirname(LIB_PATH), "build.sh")])
+    if not os.path.exists(LIB_PATH):
         raise ImportError("marlgrid_amd: %s is missing — build it (marlgrid_amd/csrc/build.sh); there is "
                           "no CPU fallback" % LIB_PATH)
     L = C.CDLL(LIB_PATH)

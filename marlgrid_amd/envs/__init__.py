@@ -11,10 +11,7 @@ import sys
 
 from ..agents import GridAgentInterface
 from ..base import MultiGridEnv
-from .cluttered import ClutteredMultiGrid
-from .empty import EmptyMultiGrid
-from .goalcycle import ClutteredGoalCycleEnv
-from .viz_test import VisibilityTestEnv
+from .scenarios import ClutteredGoalCycleEnv, ClutteredMultiGrid, EmptyMultiGrid, VisibilityTestEnv
 
 this_module = sys.modules[__name__]
 registered_envs = []
@@ -56,14 +53,21 @@ def env_from_config(env_config, randomize_seed=True):
     return env_class(**env_kwargs)
 
 
-register_marl_env("MarlGrid-1AgentCluttered15x15-v0", ClutteredMultiGrid, n_agents=1, grid_size=11, view_size=5,
-                  env_kwargs={"n_clutter": 30})
-register_marl_env("MarlGrid-3AgentCluttered11x11-v0", ClutteredMultiGrid, n_agents=3, grid_size=11, view_size=7,
-                  env_kwargs={"clutter_density": 0.15})
-register_marl_env("MarlGrid-3AgentCluttered15x15-v0", ClutteredMultiGrid, n_agents=3, grid_size=15, view_size=7,
-                  env_kwargs={"clutter_density": 0.15})
-register_marl_env("MarlGrid-2AgentEmpty9x9-v0", EmptyMultiGrid, n_agents=2, grid_size=9, view_size=7)
-register_marl_env("MarlGrid-3AgentEmpty9x9-v0", EmptyMultiGrid, n_agents=3, grid_size=9, view_size=7)
-register_marl_env("MarlGrid-4AgentEmpty9x9-v0", EmptyMultiGrid, n_agents=4, grid_size=9, view_size=7)
-register_marl_env("Goalcycle-demo-solo-v0", ClutteredGoalCycleEnv, n_agents=1, grid_size=13, view_size=7,
-                  view_tile_size=5, view_offset=1, env_kwargs={"clutter_density": 0.1, "n_bonus_tiles": 3})
+# the ids upstream registers (marlgrid/envs/__init__.py:70-121), as data.  Note that upstream's
+# "1AgentCluttered15x15" really is an 11x11 grid with view 5.
+_SHIPPED = [
+    ("MarlGrid-1AgentCluttered15x15-v0", ClutteredMultiGrid, dict(n_agents=1, grid_size=11, view_size=5,
+                                                                  env_kwargs={"n_clutter": 30})),
+    ("MarlGrid-3AgentCluttered11x11-v0", ClutteredMultiGrid, dict(n_agents=3, grid_size=11, view_size=7,
+                                                                  env_kwargs={"clutter_density": 0.15})),
+    ("MarlGrid-3AgentCluttered15x15-v0", ClutteredMultiGrid, dict(n_agents=3, grid_size=15, view_size=7,
+                                                                  env_kwargs={"clutter_density": 0.15})),
+    ("MarlGrid-2AgentEmpty9x9-v0", EmptyMultiGrid, dict(n_agents=2, grid_size=9, view_size=7)),
+    ("MarlGrid-3AgentEmpty9x9-v0", EmptyMultiGrid, dict(n_agents=3, grid_size=9, view_size=7)),
+    ("MarlGrid-4AgentEmpty9x9-v0", EmptyMultiGrid, dict(n_agents=4, grid_size=9, view_size=7)),
+    ("Goalcycle-demo-solo-v0", ClutteredGoalCycleEnv, dict(n_agents=1, grid_size=13, view_size=7, view_tile_size=5,
+                                                            view_offset=1,
+                                                            env_kwargs={"clutter_density": 0.1, "n_bonus_tiles": 3})),
+]
+for _name, _cls, _kw in _SHIPPED:
+    register_marl_env(_name, _cls, **_kw)
