@@ -131,7 +131,7 @@ def main():
                        "view_size": vs, "tile_size": ts, "obs_shape": [B * n_gpus, n, P, P, 3],
                        "actions": "uniform over 7 ids, torch.randint seed=rank", "auto_reset": True,
                        "sharding": "env batch split contiguously, no collectives"},
-            "roofline": {"bound": "hbm", "kernel": "mg::render_kernel<%d,%d>" % (vs, ts), "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "mg::render_kernel<%d, %d, %d, 0>" % (vs, ts, 16 if B >= 4096 else 4), "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "kernel_ms": avg_ms.value, "algorithmic_bytes_per_agent_step": alg_bytes_per_agent_step,
                          "algorithmic_bytes_per_launch": B * n * alg_bytes_per_agent_step,
