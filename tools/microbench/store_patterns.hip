@@ -155,6 +155,92 @@ __global__ __launch_bounds__(1024) void k_bigblock_16seq(uint4* out, int nregion
     }
 }
 
+// N: non-persistent, NS consecutive stores per thread (wave writes NS consecutive KiB): between fill
+// (NS = 1) and "wave per region" (NS = 28)
+template <int NS>
+__global__ __launch_bounds__(256) void k_fill_n(uint4* out, size_t nchunks) {
+    size_t wave = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    int lane = threadIdx.x & 63;
+    size_t base = wave * 64 * NS + lane;
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+        size_t c = base + (size_t)i * 64;
+        if (c < nchunks) out[c] = make_uint4(1, 2, 3, (unsigned)i);
+    }
+}
+// P: persistent workgroups, dense moving front: in round r workgroup w writes the contiguous block
+// (r * gridDim + w) of BLK bytes (= what fill does, but with long-lived waves)
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_front(uint4* out, size_t nchunks) {
+    const size_t per_round = (size_t)gridDim.x * THREADS;
+    for (size_t c = (size_t)blockIdx.x * THREADS + threadIdx.x; c < nchunks; c += per_round) out[c] = make_uint4(1, 2, 3, 4);
+}
+// Q: like P but each workgroup writes RUN consecutive blocks per round (longer runs per workgroup)
+template <int THREADS, int RUN>
+__global__ __launch_bounds__(THREADS) void k_front_run(uint4* out, size_t nchunks) {
+    const size_t per_round = (size_t)gridDim.x * THREADS * RUN;
+    for (size_t c0 = (size_t)blockIdx.x * THREADS * RUN; c0 < nchunks; c0 += per_round)
+#pragma unroll
+        for (int i = 0; i < RUN; i++) {
+            size_t c = c0 + (size_t)i * THREADS + threadIdx.x;
+            if (c < nchunks) out[c] = make_uint4(1, 2, 3, 4);
+        }
+}
+
+// R: P (persistent dense front, 4 KiB blocks) + what a real raster needs per chunk: the block's env
+// tmap fetched from global into LDS (prefetched one round ahead), then per chunk 2 x (u16 tmap read
+// -> 8-byte atlas read) from LDS.  UNR = chunks per thread per round handled with independent chains
+// (UNR blocks of 4 KiB apart by gridDim*4KiB, i.e. still one store per wave per dense front).
+template <int UNR>
+__global__ __launch_bounds__(256) void k_front_lds(uint4* out, const uint16_t* __restrict__ tmaps, size_t nchunks) {
+    __shared__ uint32_t atlas[4 * 28 * 48];
+    __shared__ uint16_t tm[2][UNR][2 * 160];
+    for (int i = threadIdx.x; i < 4 * 28 * 48; i += 256) atlas[i] = i * 2654435761u;
+    const size_t per_round = (size_t)gridDim.x * 256;
+    auto load_tm = [&](int buf, size_t round_c0) {
+        for (int u = 0; u < UNR; u++) {
+            size_t c0 = round_c0 + (size_t)u * per_round;
+            size_t e0 = c0 / 1764;
+            if (threadIdx.x < 160 && c0 < nchunks) {
+                tm[buf][u][threadIdx.x] = tmaps[e0 * 160 + threadIdx.x];
+                tm[buf][u][160 + threadIdx.x] = tmaps[(e0 + 1) * 160 + threadIdx.x];
+            }
+        }
+    };
+    size_t c0 = (size_t)blockIdx.x * 256;
+    load_tm(0, c0);
+    __syncthreads();
+    int buf = 0;
+    for (; c0 < nchunks; c0 += per_round * UNR) {
+        if (c0 + per_round * UNR < nchunks) load_tm(buf ^ 1, c0 + per_round * UNR);
+        uint4 v[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            size_t cb = c0 + (size_t)u * per_round, c = cb + threadIdx.x;
+            size_t e0 = cb / 1764;
+            uint32_t ci = (uint32_t)(c - e0 * 1764);             // may run into env e0+1 (second tmap half)
+            uint32_t sel = ci >= 1764 ? 160u : 0u;
+            if (ci >= 1764) ci -= 1764;
+            uint32_t p0 = 2 * ci, r = p0 / 21, pr = p0 - r * 21, r1 = r, pr1 = pr + 1;
+            if (pr1 == 21) { pr1 = 0; r1++; }
+            uint32_t va = pr / 3, kp = pr - va * 3, vb = r >> 3, rr = r & 7;
+            uint32_t a0 = (tm[buf][u][sel + (vb * 7 + va) % 147] % (4 * 28)) * 48 + rr * 6 + kp * 2;
+            va = pr1 / 3; kp = pr1 - va * 3; vb = r1 >> 3; rr = r1 & 7;
+            uint32_t a1 = (tm[buf][u][sel + (vb * 7 + va) % 147] % (4 * 28)) * 48 + rr * 6 + kp * 2;
+            uint2 q0 = *reinterpret_cast<const uint2*>(&atlas[a0]);
+            uint2 q1 = *reinterpret_cast<const uint2*>(&atlas[a1]);
+            v[u] = make_uint4(q0.x, q0.y, q1.x, q1.y);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            size_t c = c0 + (size_t)u * per_round + threadIdx.x;
+            if (c < nchunks) out[c] = v[u];
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+}
+
 template <typename F>
 static float time_it(F launch, int iters) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -171,11 +257,12 @@ int main() {
     const size_t bytes = (size_t)nregions * REGION;
     uint4* out; CK(hipMalloc(&out, bytes));
     uint32_t* in; CK(hipMalloc(&in, (size_t)nregions * 256 + 4096)); CK(hipMemset(in, 1, (size_t)nregions * 256 + 4096));
+    uint16_t* tmaps; CK(hipMalloc(&tmaps, (size_t)(nregions + 2) * 320)); CK(hipMemset(tmaps, 3, (size_t)(nregions + 2) * 320));
     const size_t nch = bytes / 16;
     auto report = [&](const char* name, float ms) { printf("%-44s %.4f ms  %.0f GB/s\n", name, ms, bytes / ms / 1e6); fflush(stdout); };
     for (int rep = 0; rep < 2; rep++) {
         report("A fill (1 store/thread)", time_it([&] { hipLaunchKernelGGL(k_fill, dim3((nch + 255) / 256), dim3(256), 0, 0, out, nch); }, 20));
-        for (int per_cu : {5, 8}) {
+        for (int per_cu : {5}) {
             char nm[96];
             int blocks = 256 * per_cu;
             snprintf(nm, 96, "B wave/region persistent, %d wg/CU", per_cu);
@@ -195,7 +282,7 @@ int main() {
             snprintf(nm, 96, "G wave/region XCD-contiguous, %d wg/CU", per_cu);
             report(nm, time_it([&] { hipLaunchKernelGGL(k_wave_region_xcd, dim3(blocks), dim3(256), 0, 0, out, nregions); }, 20));
         }
-        for (int nb : {256, 512}) {
+        for (int nb : {256}) {
             char nm[96];
             snprintf(nm, 96, "K 16-wave wg/region, %d wgs", nb);
             report(nm, time_it([&] { hipLaunchKernelGGL(k_bigblock_region, dim3(nb), dim3(1024), 0, 0, out, nregions); }, 20));
@@ -203,6 +290,28 @@ int main() {
             report(nm, time_it([&] { hipLaunchKernelGGL(k_wave_region_16, dim3(nb), dim3(1024), 0, 0, out, nregions); }, 20));
             snprintf(nm, 96, "M 16-wave wg, 16 regions cooperatively, %d wgs", nb);
             report(nm, time_it([&] { hipLaunchKernelGGL(k_bigblock_16seq, dim3(nb), dim3(1024), 0, 0, out, nregions); }, 20));
+        }
+        for (int nb : {256, 384, 512}) {
+            char nm[96];
+            snprintf(nm, 96, "R dense front + tmap/atlas LDS look-ups x1, %d wgs", nb);
+            report(nm, time_it([&] { hipLaunchKernelGGL((k_front_lds<1>), dim3(nb), dim3(256), 0, 0, out, tmaps, nch); }, 20));
+            snprintf(nm, 96, "R dense front + tmap/atlas LDS look-ups x2, %d wgs", nb);
+            report(nm, time_it([&] { hipLaunchKernelGGL((k_front_lds<2>), dim3(nb), dim3(256), 0, 0, out, tmaps, nch); }, 20));
+            snprintf(nm, 96, "R dense front + tmap/atlas LDS look-ups x4, %d wgs", nb);
+            report(nm, time_it([&] { hipLaunchKernelGGL((k_front_lds<4>), dim3(nb), dim3(256), 0, 0, out, tmaps, nch); }, 20));
+        }
+        report("N fill, 2 stores/thread", time_it([&] { hipLaunchKernelGGL((k_fill_n<2>), dim3((nch / 2 + 255) / 256), dim3(256), 0, 0, out, nch); }, 20));
+        report("N fill, 4 stores/thread", time_it([&] { hipLaunchKernelGGL((k_fill_n<4>), dim3((nch / 4 + 255) / 256), dim3(256), 0, 0, out, nch); }, 20));
+        report("N fill, 8 stores/thread", time_it([&] { hipLaunchKernelGGL((k_fill_n<8>), dim3((nch / 8 + 255) / 256), dim3(256), 0, 0, out, nch); }, 20));
+        report("N fill, 28 stores/thread", time_it([&] { hipLaunchKernelGGL((k_fill_n<28>), dim3((nch / 28 + 255) / 256), dim3(256), 0, 0, out, nch); }, 20));
+        for (int nb : {256, 512, 1024, 2048}) {
+            char nm[96];
+            snprintf(nm, 96, "P persistent dense front, 256 thr, %d wgs", nb);
+            report(nm, time_it([&] { hipLaunchKernelGGL((k_front<256>), dim3(nb), dim3(256), 0, 0, out, nch); }, 20));
+            snprintf(nm, 96, "P persistent dense front, 1024 thr, %d wgs", nb / 4);
+            report(nm, time_it([&] { hipLaunchKernelGGL((k_front<1024>), dim3(nb / 4), dim3(1024), 0, 0, out, nch); }, 20));
+            snprintf(nm, 96, "Q dense front, 256 thr x 4-block runs, %d wgs", nb);
+            report(nm, time_it([&] { hipLaunchKernelGGL((k_front_run<256, 4>), dim3(nb), dim3(256), 0, 0, out, nch); }, 20));
         }
         report("F wave/region non-persistent", time_it([&] { hipLaunchKernelGGL(k_wave_region_np, dim3(nregions / 4), dim3(256), 0, 0, out, nregions); }, 20));
     }
