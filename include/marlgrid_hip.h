@@ -138,6 +138,8 @@ typedef struct MgState {
 /* `_gen_grid` as data: a static template (walls / put_obj results) + ordered random placements */
 typedef struct MgGenOp {
     int32_t obj, count, max_tries;
+    int32_t x0, y0, x1, y1;       /* sampling rectangle [x0,x1) x [y0,y1): place_obj(top=, size=) clamped
+                                   * to the grid (base.py:692-695); the whole grid by default */
 } MgGenOp;
 typedef struct MgGenProgram {
     const uint8_t* template_grid; /* device, [cells_stride] */

@@ -51,7 +51,8 @@ class State(C.Structure):
 
 
 class GenOp(C.Structure):
-    _fields_ = [("obj", C.c_int32), ("count", C.c_int32), ("max_tries", C.c_int32)]
+    _fields_ = [("obj", C.c_int32), ("count", C.c_int32), ("max_tries", C.c_int32),
+                ("x0", C.c_int32), ("y0", C.c_int32), ("x1", C.c_int32), ("y1", C.c_int32)]
 
 
 class GenProgram(C.Structure):

@@ -370,14 +370,22 @@ class MultiGridEnv(object):
             raise NotImplementedError("place_obj outside _gen_grid is not supported by the batched engine")
         if isinstance(obj, GridAgentInterface):
             raise NotImplementedError("agents are placed by reset() itself")
-        if reject_fn is not None or (top not in (None, (0, 0))) or size is not None:
-            raise NotImplementedError("place_obj(top=, size=, reject_fn=) is not supported")
+        if reject_fn is not None:
+            raise NotImplementedError("place_obj(reject_fn=) is a Python callback per draw: not supported")
         max_tries = int(max(1, min(max_tries, 1e5)))
+        # sampling rectangle, clamped exactly like base.py:692-695
+        top = (0, 0) if top is None else (max(int(top[0]), 0), max(int(top[1]), 0))
+        if size is None:
+            size = (self.width, self.height)
+        x1, y1 = min(top[0] + int(size[0]), self.width), min(top[1] + int(size[1]), self.height)
+        if x1 <= top[0] or y1 <= top[1]:
+            raise ValueError("place_obj: empty sampling rectangle")
         key = self.obj_reg.get_key(obj)
-        if self._tr_ops and self._tr_ops[-1][0] == key and self._tr_ops[-1][2] == max_tries:
-            self._tr_ops[-1] = (key, self._tr_ops[-1][1] + 1, max_tries)
+        op = (key, 1, max_tries, top[0], top[1], x1, y1)
+        if self._tr_ops and self._tr_ops[-1][0] == key and self._tr_ops[-1][2:] == op[2:]:
+            self._tr_ops[-1] = (key, self._tr_ops[-1][1] + 1) + op[2:]
         else:
-            self._tr_ops.append((key, 1, max_tries))
+            self._tr_ops.append(op)
         return None
 
     def try_place_obj(self, obj, pos):
@@ -486,8 +494,9 @@ class MultiGridEnv(object):
         prog = N.GenProgram()
         prog.template_grid = t_dev.data_ptr()
         prog.n_ops = len(ops)
-        for i, (obj, count, max_tries) in enumerate(ops):
-            prog.ops[i].obj, prog.ops[i].count, prog.ops[i].max_tries = obj, count, max_tries
+        for i, (obj, count, max_tries, x0, y0, x1, y1) in enumerate(ops):
+            o = prog.ops[i]
+            o.obj, o.count, o.max_tries, o.x0, o.y0, o.x1, o.y1 = obj, count, max_tries, x0, y0, x1, y1
         prog.agent_max_tries = 100000
         self._prog_cache[key] = (prog, t_dev)
         return prog
@@ -753,7 +762,11 @@ class MultiGridEnv(object):
             return d
 
         def prog(p):
-            return list(p["sym"]) + [("place", k, c, t) for (k, c, t) in p["ops"]]
+            out = list(p["sym"])
+            for (k, c, t, x0, y0, x1, y1) in p["ops"]:
+                full = (x0, y0, x1, y1) == (0, 0, self.width, self.height)
+                out.append(("place", k, c, t) if full else ("place", k, c, t, x0, y0, x1, y1))
+            return out
         def aspec(a):
             d = dict(color=a.color)
             if a.spawn_delay:

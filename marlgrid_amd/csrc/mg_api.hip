@@ -63,7 +63,11 @@ int32_t mg_reset(const MgConfig* cfg, const MgState* st, const MgGenProgram* pro
     if (e) return e;
     if (!prog || !prog->template_grid || prog->n_ops < 0 || prog->n_ops > MG_MAX_GEN) return MG_E_ARG;
     for (int i = 0; i < prog->n_ops; i++)
-        if (prog->ops[i].obj <= 0 || prog->ops[i].obj >= cfg->n_obj || prog->ops[i].count < 0) return MG_E_ARG;
+    {
+        const MgGenOp& op = prog->ops[i];
+        if (op.obj <= 0 || op.obj >= cfg->n_obj || op.count < 0) return MG_E_ARG;
+        if (op.x0 < 0 || op.y0 < 0 || op.x1 > cfg->W || op.y1 > cfg->H || op.x1 <= op.x0 || op.y1 <= op.y0) return MG_E_ARG;
+    }
     return rc(mg::launch_reset(*cfg, *st, *prog, env_mask, (hipStream_t)stream));
 }
 

@@ -35,8 +35,9 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(MgConfig cfg, MgState st,
         for (int c = 0; c < op.count && !err; c++) {
             bool ok = false;
             for (int t = 0; t < op.max_tries; t++) {
-                int x = (int)mt.bounded((uint32_t)(W - 1));   // np_random.randint((0,0),(W,H))
-                int y = (int)mt.bounded((uint32_t)(H - 1));
+                // np_random.randint(top, bottom): low + bounded(high - low - 1) per coordinate
+                int x = op.x0 + (int)mt.bounded((uint32_t)(op.x1 - op.x0 - 1));
+                int y = op.y0 + (int)mt.bounded((uint32_t)(op.y1 - op.y0 - 1));
                 int cell = x * H + y;
                 if (g[cell] == 0) { g[cell] = (uint8_t)op.obj; ok = true; break; }
             }

@@ -338,15 +338,19 @@ static int try_place(MgoEnv* e, int val, int x, int y) {
 }
 
 /* MultiGridEnv.place_obj — base.py:690-708 (top=(0,0), size=None, reject_fn=None) */
+static int place_obj_in(MgoEnv* e, int val, double max_tries_in, int x0, int y0, int x1, int y1);
 static int place_obj(MgoEnv* e, int val, double max_tries_in) {
-    const MgoConfig* cfg = &e->sh->cfg;
+    return place_obj_in(e, val, max_tries_in, 0, 0, e->sh->cfg.W, e->sh->cfg.H);
+}
+/* top / size already clamped to [x0,x1) x [y0,y1) as base.py:692-695 does */
+static int place_obj_in(MgoEnv* e, int val, double max_tries_in, int x0, int y0, int x1, int y1) {
     double mt = max_tries_in < 1e5 ? max_tries_in : 1e5;
     if (mt < 1) mt = 1;
     long max_tries = (long)mt;
     for (long t = 0; t < max_tries; t++) {
-        /* np_random.randint((0,0), (W,H)): element 0 then element 1 */
-        int x = (int)mgo_bounded(e->mt, &e->mt_pos, (uint32_t)(cfg->W - 1));
-        int y = (int)mgo_bounded(e->mt, &e->mt_pos, (uint32_t)(cfg->H - 1));
+        /* np_random.randint(top, bottom): element 0 then element 1; low + bounded(high-low-1) */
+        int x = x0 + (int)mgo_bounded(e->mt, &e->mt_pos, (uint32_t)(x1 - x0 - 1));
+        int y = y0 + (int)mgo_bounded(e->mt, &e->mt_pos, (uint32_t)(y1 - y0 - 1));
         if (try_place(e, val, x, y)) return MGO_OK;
     }
     return MGO_ERR_RECURSION;
@@ -391,7 +395,8 @@ static int gen_grid(MgoEnv* e, int which) {
             break;
         case MGO_GEN_PLACE:
             for (int n = 0; n < op->count; n++) {
-                int rc = place_obj(e, op->obj, (double)op->max_tries);
+                int rc = (op->w > 0) ? place_obj_in(e, op->obj, (double)op->max_tries, op->x, op->y, op->x + op->w, op->y + op->h)
+                                     : place_obj(e, op->obj, (double)op->max_tries);
                 if (rc != MGO_OK) return rc;
             }
             break;

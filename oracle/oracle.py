@@ -292,6 +292,8 @@ def make_config(spec):
                 op.obj, op.x, op.y = g[1:4]
             elif g[0] == "place":
                 op.obj, op.count, op.max_tries = g[1:4]
+                if len(g) == 8:                      # sampling rectangle [x0,x1) x [y0,y1)
+                    op.x, op.y, op.w, op.h = g[4], g[5], g[6] - g[4], g[7] - g[5]
     return cfg
 
 

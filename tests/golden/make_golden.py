@@ -45,6 +45,7 @@ TRAJ = {  # scenario -> (n_seeds, n_steps, n_full_obs_seeds)
     "Test-3AgentEmpty7x7-spawn-delay": (8, 120, 2),
     "Test-4AgentEmpty5x5-hide": (8, 150, 2),
     "Test-3AgentCluttered9x9-hide": (6, 120, 2),
+    "Test-2AgentRegion9x9": (6, 100, 1),
 }
 CANON = ("base_enc", "pos", "dir", "active", "done", "carry_enc", "ordinal")
 

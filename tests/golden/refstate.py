@@ -21,7 +21,30 @@ def make_ref_env(spec, recipe, seed=1337):
     kw = dict(kwargs)
     kw.setdefault("max_steps", spec["max_steps"])
     kw["seed"] = seed
+    if cls_name == "RegionTestEnv":
+        return _region_env_class()(agents=agents, **kw)
     return getattr(E, cls_name)(agents=agents, **kw)
+
+
+def _region_env_class():
+    """A test-only scenario ON TOP OF the reference's classes exercising place_obj(top=, size=)
+    (base.py:690-708): a room split by a wall, a locked Door sampled in the left half, clutter in the right."""
+    from marlgrid.base import MultiGridEnv, MultiGrid
+    from marlgrid.objects import Goal, Wall, Door
+
+    class RegionTestEnv(MultiGridEnv):
+        mission = ""
+        metadata = {}
+
+        def _gen_grid(self, width, height):
+            self.grid = MultiGrid((width, height))
+            self.grid.wall_rect(0, 0, width, height)
+            self.grid.vert_wall(width // 2, 0, height - 3)
+            self.put_obj(Goal(color="green", reward=1), width - 2, height - 2)
+            self.place_obj(Door(color="yellow", state=3), top=(0, 0), size=(width // 2, height), max_tries=100)
+            for _ in range(3):
+                self.place_obj(Wall(), top=(width // 2 + 1, 2), size=(width, height - 3), max_tries=50)
+    return RegionTestEnv
 
 
 def canonical(env):

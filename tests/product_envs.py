@@ -17,7 +17,26 @@ def build(name, **kw):
                                  spawn_delay=a.get("spawn_delay", 0),
                                  hide_item_types=list(a.get("hide_item_types", [])))
               for a in spec["agents"]]
+    if cls_name == "RegionTestEnv":
+        return _region_env_class()(agents=agents, **{**kwargs, **kw})
     return getattr(E, cls_name)(agents=agents, **{**kwargs, **kw})
+
+
+def _region_env_class():
+    """the product-side twin of tests/golden/refstate.py:_region_env_class (same _gen_grid text)"""
+    from marlgrid_amd.base import MultiGridEnv, MultiGrid
+    from marlgrid_amd.objects import Goal, Wall, Door
+
+    class RegionTestEnv(MultiGridEnv):
+        def _gen_grid(self, width, height):
+            self.grid = MultiGrid((width, height))
+            self.grid.wall_rect(0, 0, width, height)
+            self.grid.vert_wall(width // 2, 0, height - 3)
+            self.put_obj(Goal(color="green", reward=1), width - 2, height - 2)
+            self.place_obj(Door(color="yellow", state=3), top=(0, 0), size=(width // 2, height), max_tries=100)
+            for _ in range(3):
+                self.place_obj(Wall(), top=(width // 2 + 1, 2), size=(width, height - 3), max_tries=50)
+    return RegionTestEnv
 
 
 def canonical(env, b=None):

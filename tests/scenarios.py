@@ -111,6 +111,7 @@ def ref_recipe(name):
         "Test-3AgentEmpty7x7-spawn-delay": ("EmptyMultiGrid", dict(grid_size=7, max_steps=40)),
         "Test-4AgentEmpty5x5-hide": ("EmptyMultiGrid", dict(grid_size=5)),
         "Test-3AgentCluttered9x9-hide": ("ClutteredMultiGrid", dict(grid_size=9, n_clutter=8)),
+        "Test-2AgentRegion9x9": ("RegionTestEnv", dict(grid_size=9)),
         # oracle-only edge shapes (no golden file): view sizes / tile sizes / agent counts / big grids
         "Edge-12AgentCluttered9x9-view3": ("ClutteredMultiGrid", dict(grid_size=9, n_clutter=5)),
         "Edge-2AgentCluttered40x40-view9-off3": ("ClutteredMultiGrid", dict(grid_size=40, clutter_density=0.2)),
@@ -130,6 +131,19 @@ def _with_delays(spec, delays):
         if d:
             a["spawn_delay"] = d
     return spec
+
+
+def region_spec():
+    """test-only scenario with place_obj(top=, size=): see tests/golden/refstate.py:_region_env_class"""
+    s = _base(2, 9, 7)
+    W = H = 9
+    s["objects"] = [None, WALL, GOAL, dict(type="Door", color="yellow", state=3),
+                    dict(type="Door", color="yellow", state=1), dict(type="Door", color="yellow", state=2)]
+    s["wall_obj"] = 1
+    prog = [("wall_rect", 0, 0, W, H), ("vert_wall", W // 2, 0, H - 3), ("put", 2, W - 2, H - 2),
+            ("place", 3, 1, 100, 0, 0, W // 2, H), ("place", 1, 3, 50, W // 2 + 1, 2, W, H - 1)]
+    s["gen_ctor"], s["gen_reset"] = prog, prog
+    return s
 
 
 _MANY = ["red", "orange", "green", "blue", "cyan", "purple", "yellow", "olive", "grey", "worst", "pink", "white"]
@@ -158,6 +172,7 @@ def registered(name):   # noqa: F811  (extends the table above with test-only sc
         "Test-3AgentEmpty7x7-spawn-delay": lambda: _with_delays(empty_spec(3, 7, 5, max_steps=40), [0, 4, 9]),
         "Test-4AgentEmpty5x5-hide": lambda: _with_hide(empty_spec(4, 5, 5), [["Agent"], ["Goal"], ["Wall", "Goal", "Agent"], []]),
         "Test-3AgentCluttered9x9-hide": lambda: _with_hide(cluttered_spec(3, 9, 7, n_clutter=8), [["Wall"], ["Agent", "Goal"], []]),
+        "Test-2AgentRegion9x9": lambda: region_spec(),
         "Edge-12AgentCluttered9x9-view3": lambda: cluttered_spec(12, 9, 3, n_clutter=5, colors=_MANY[:12]),
         "Edge-2AgentCluttered40x40-view9-off3": lambda: cluttered_spec(2, 40, 9, clutter_density=0.2, view_offset=3),
         "Edge-3AgentCluttered13x13-view11": lambda: cluttered_spec(3, 13, 11, n_clutter=20),
@@ -181,6 +196,7 @@ ALL_SCENARIOS = [
     "Test-4AgentEmpty5x5-crowded-noghost", "Test-2AgentCluttered9x9-offset2-ts5",
     "Test-2AgentEmpty7x7-see-through", "Test-3AgentCluttered9x9-respawn", "Test-4AgentEmpty5x5-respawn-noghost",
     "Test-3AgentEmpty7x7-spawn-delay", "Test-4AgentEmpty5x5-hide", "Test-3AgentCluttered9x9-hide",
+    "Test-2AgentRegion9x9",
 ]
 
 
