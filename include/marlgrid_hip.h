@@ -19,6 +19,7 @@
  *                                        agents.py:233-266, 290-343)
  *   mg_encode       MultiGrid.encode    (base.py:196-214; objects.py:90-99)
  *   mg_put_obj      MultiGridEnv.put_obj (base.py:655-662)
+ *   mg_place        MultiGridEnv.place_obj / try_place_obj outside _gen_grid (base.py:664-708)
  *   mg_render_frame MultiGridEnv.render's whole-grid image: MultiGrid.render(top_agent=None) +
  *                   visibility highlight         (base.py:714-759, 301-331)
  *
@@ -178,6 +179,15 @@ int32_t mg_encode(const MgConfig* cfg, const MgState* st, const uint8_t* vis_mas
 /* env_mask as in mg_reset. Replaces whatever is in the cell (base.py:655-662). */
 int32_t mg_put_obj(const MgConfig* cfg, const MgState* st, int32_t obj, int32_t x, int32_t y,
                    const uint8_t* env_mask, void* stream);
+
+/* Live placement (outside the reset program).  what >= 1: object id; what < 0: agent -(what+1), which
+ * is lifted off the grid first and re-seated with the highest arrival rank (as a respawn does).
+ * fixed_pos == NULL: rejection sampling in [x0,x1) x [y0,y1) with at most max_tries draws per env on the
+ * env's RNG (place_obj, RecursionError recorded on failure); fixed_pos: device int32 [B][2], one attempt
+ * at that cell (try_place_obj).  out_pos: device int32 [B][2] or NULL; out_ok: device uint8 [B] or NULL. */
+int32_t mg_place(const MgConfig* cfg, const MgState* st, int32_t what, int32_t x0, int32_t y0, int32_t x1,
+                 int32_t y1, int32_t max_tries, const int32_t* fixed_pos, const uint8_t* env_mask,
+                 int32_t* out_pos, uint8_t* out_ok, void* stream);
 
 /* Whole-grid human view of selected envs (caller-side format, not on the step path).
  * env_ids: device int32 [n_envs]; frame_atlas: device uint8 [n_tiles][ts][ts][3] (orientation 0,

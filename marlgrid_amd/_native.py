@@ -64,7 +64,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "lib
 
 # every symbol include/marlgrid_hip.h declares
 SYMBOLS = ["mg_abi_version", "mg_error_string", "mg_mt_seed", "mg_reset", "mg_step", "mg_render_obs",
-           "mg_encode", "mg_put_obj", "mg_render_frame", "mg_time_render_obs"]
+           "mg_encode", "mg_put_obj", "mg_place", "mg_render_frame", "mg_time_render_obs"]
 
 _lib = None
 
@@ -95,6 +95,7 @@ def lib():
     L.mg_render_obs.argtypes = [C.POINTER(Config), C.POINTER(State), vp, vp, vp, vp, vp]
     L.mg_encode.argtypes = [C.POINTER(Config), C.POINTER(State), vp, vp, vp]
     L.mg_put_obj.argtypes = [C.POINTER(Config), C.POINTER(State), i32, i32, i32, vp, vp]
+    L.mg_place.argtypes = [C.POINTER(Config), C.POINTER(State), i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     L.mg_render_frame.argtypes = [C.POINTER(Config), C.POINTER(State), vp, i32, vp, i32, i32, vp, vp]
     L.mg_time_render_obs.argtypes = [C.POINTER(Config), C.POINTER(State), vp, i32, C.POINTER(C.c_float), vp]
     for f in SYMBOLS:

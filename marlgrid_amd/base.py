@@ -363,16 +363,7 @@ class MultiGridEnv(object):
                                          self._mask_ptr(env_mask), self._stream()))
         return True
 
-    def place_obj(self, obj, top=None, size=None, reject_fn=None, max_tries=1e5):
-        """Rejection-sample a free cell for `obj` (base.py:690-708).  Inside `_gen_grid` this records
-        one placement; the draw happens on the device, per env."""
-        if not self._tracing:
-            raise NotImplementedError("place_obj outside _gen_grid is not supported by the batched engine")
-        if isinstance(obj, GridAgentInterface):
-            raise NotImplementedError("agents are placed by reset() itself")
-        if reject_fn is not None:
-            raise NotImplementedError("place_obj(reject_fn=) is a Python callback per draw: not supported")
-        max_tries = int(max(1, min(max_tries, 1e5)))
+    def _place_region(self, top, size):
         # sampling rectangle, clamped exactly like base.py:692-695
         top = (0, 0) if top is None else (max(int(top[0]), 0), max(int(top[1]), 0))
         if size is None:
@@ -380,16 +371,62 @@ class MultiGridEnv(object):
         x1, y1 = min(top[0] + int(size[0]), self.width), min(top[1] + int(size[1]), self.height)
         if x1 <= top[0] or y1 <= top[1]:
             raise ValueError("place_obj: empty sampling rectangle")
+        return top[0], top[1], x1, y1
+
+    def _what(self, obj):
+        if isinstance(obj, GridAgentInterface):
+            return -(self.agents.index(obj) + 1)
+        return self.obj_reg.get_key(obj)
+
+    def _place_live(self, obj, top, size, max_tries, env_mask):
+        """place_obj on the live grids: per-env rejection sampling on each env's RNG.  Returns the
+        chosen positions (B, 2) int32 (-1, -1 where it failed: RecursionError on check_errors())."""
+        import torch
+        what = self._what(obj)
+        self._sync_tables()
+        x0, y0, x1, y1 = self._place_region(top, size)
+        pos = torch.empty((self.batch_size, 2), dtype=torch.int32, device=self.device)
+        N.check(self._lib.mg_place(C.byref(self._cfg), C.byref(self._state), what, x0, y0, x1, y1,
+                                   int(max(1, min(max_tries, 1e5))), None, self._mask_ptr(env_mask),
+                                   pos.data_ptr(), None, self._stream()))
+        if self.strict:
+            self.check_errors()
+        return pos
+
+    def place_obj(self, obj, top=None, size=None, reject_fn=None, max_tries=1e5, env_mask=None):
+        """Rejection-sample a free cell for `obj` (base.py:690-708).  Inside `_gen_grid` this records
+        one placement; the draw happens on the device, per env."""
+        if reject_fn is not None:
+            raise NotImplementedError("place_obj(reject_fn=) is a Python callback per draw: not supported")
+        if not self._tracing:
+            return self._place_live(obj, top, size, max_tries, env_mask)
+        if isinstance(obj, GridAgentInterface):
+            raise NotImplementedError("inside _gen_grid agents are placed by reset() itself")
+        max_tries = int(max(1, min(max_tries, 1e5)))
         key = self.obj_reg.get_key(obj)
-        op = (key, 1, max_tries, top[0], top[1], x1, y1)
+        op = (key, 1, max_tries) + self._place_region(top, size)
         if self._tr_ops and self._tr_ops[-1][0] == key and self._tr_ops[-1][2:] == op[2:]:
             self._tr_ops[-1] = (key, self._tr_ops[-1][1] + 1) + op[2:]
         else:
             self._tr_ops.append(op)
         return None
 
-    def try_place_obj(self, obj, pos):
-        raise NotImplementedError("try_place_obj is folded into the device reset / place kernels")
+    def try_place_obj(self, obj, pos, env_mask=None):
+        """Try to place `obj` (an object, or one of this env's agents) at `pos` — one (x, y) for every
+        env or a (B, 2) tensor — and return a (B,) bool tensor saying where it worked (base.py:664-688)."""
+        import torch
+        if self._tracing:
+            raise NotImplementedError("inside _gen_grid use put_obj / place_obj")
+        what = self._what(obj)
+        self._sync_tables()
+        p = torch.as_tensor(pos, dtype=torch.int32, device=self.device)
+        if p.dim() == 1:
+            p = p.expand(self.batch_size, 2)
+        p = p.contiguous()
+        ok = torch.zeros((self.batch_size,), dtype=torch.uint8, device=self.device)
+        N.check(self._lib.mg_place(C.byref(self._cfg), C.byref(self._state), what, 0, 0, self.width, self.height, 1,
+                                   p.data_ptr(), self._mask_ptr(env_mask), None, ok.data_ptr(), self._stream()))
+        return ok.bool()
 
     def place_agents(self, top=None, size=None, rand_dir=True, max_tries=1000):
         pass    # deprecated no-op upstream as well (base.py:710-712)

@@ -111,6 +111,20 @@ int32_t mg_put_obj(const MgConfig* cfg, const MgState* st, int32_t obj, int32_t 
     return rc(mg::launch_put_obj(*cfg, *st, obj, x, y, env_mask, (hipStream_t)stream));
 }
 
+int32_t mg_place(const MgConfig* cfg, const MgState* st, int32_t what, int32_t x0, int32_t y0, int32_t x1, int32_t y1,
+                 int32_t max_tries, const int32_t* fixed_pos, const uint8_t* env_mask, int32_t* out_pos,
+                 uint8_t* out_ok, void* stream) {
+    int e = check_cfg(cfg);
+    if (e) return e;
+    e = check_state(st);
+    if (e) return e;
+    if (what == 0 || what >= cfg->n_obj || -(what + 1) >= cfg->n_agents) return MG_E_ARG;
+    if (!fixed_pos && (x0 < 0 || y0 < 0 || x1 > cfg->W || y1 > cfg->H || x1 <= x0 || y1 <= y0 || max_tries < 1))
+        return MG_E_ARG;
+    return rc(mg::launch_place(*cfg, *st, what, x0, y0, x1, y1, max_tries, fixed_pos, env_mask, out_pos, out_ok,
+                               (hipStream_t)stream));
+}
+
 int32_t mg_render_frame(const MgConfig* cfg, const MgState* st, const int32_t* env_ids, int32_t n_envs,
                         const uint8_t* frame_atlas, int32_t frame_tile_size, int32_t highlight, uint8_t* out,
                         void* stream) {

@@ -98,6 +98,74 @@ __global__ __launch_bounds__(kBlock) void put_obj_kernel(MgConfig cfg, MgState s
     st.grid[(size_t)b * cfg.cells_stride + x * cfg.H + y] = (uint8_t)obj;
 }
 
+// MultiGridEnv.place_obj / try_place_obj on a live grid (base.py:664-708): lane per env.
+__global__ __launch_bounds__(kBlock) void place_kernel(MgConfig cfg, MgState st, int what, int x0, int y0, int x1,
+                                                       int y1, int max_tries, const int32_t* __restrict__ fixed_pos,
+                                                       const uint8_t* __restrict__ mask, int32_t* __restrict__ out_pos,
+                                                       uint8_t* __restrict__ out_ok) {
+    const int b = blockIdx.x * kBlock + threadIdx.x;
+    if (b >= cfg.B) return;
+    if (mask && !mask[b]) return;
+    const int n = cfg.n_agents, H = cfg.H;
+    uint8_t* g = st.grid + (size_t)b * cfg.cells_stride;
+    uint64_t* recs = st.agents + (size_t)b * n;
+    const bool is_agent = what < 0;
+    const int k = -(what + 1);
+    if (is_agent) {   // off the grid while a cell is looked for
+        uint64_t r = recs[k];
+        recs[k] = rec_set(r, MG_AG_FLAGS, rec_byte(r, MG_AG_FLAGS) & ~(MG_AF_PLACED | MG_AF_ACTIVE));
+    }
+    Mt mt{st.mt + (size_t)b * MG_MT_N, st.mt_pos[b]};
+    bool ok = false;
+    int x = -1, y = -1;
+    const int tries = fixed_pos ? 1 : max_tries;
+    for (int t = 0; t < tries && !ok; t++) {
+        if (fixed_pos) { x = fixed_pos[2 * b]; y = fixed_pos[2 * b + 1]; if (x < 0 || x >= cfg.W || y < 0 || y >= H) break; }
+        else {
+            x = x0 + (int)mt.bounded((uint32_t)(x1 - x0 - 1));
+            y = y0 + (int)mt.bounded((uint32_t)(y1 - y0 - 1));
+        }
+        const uint32_t base = g[x * H + y];
+        const uint32_t xy = (uint32_t)x | ((uint32_t)y << 8);
+        int cnt = 0;
+        for (int j = 0; j < n; j++) {
+            const uint64_t rj = recs[j];
+            cnt += ((rec_byte(rj, MG_AG_FLAGS) & MG_AF_PLACED) && rec_xy(rj) == xy) ? 1 : 0;
+        }
+        if (!is_agent) {
+            // only an empty cell (no object, no agent) accepts a non-agent object (base.py:672-679)
+            if (base == 0 && cnt == 0) { g[x * H + y] = (uint8_t)what; ok = true; }
+        } else if ((base == 0 || (cfg.obj[base].flags & MG_OF_CAN_OVERLAP)) && (cnt == 0 || cfg.ghost_mode)) {
+            uint64_t r = recs[k];
+            const uint32_t old_rank = rec_byte(r, MG_AG_RANK);
+            for (int j = 0; j < n; j++) {
+                const uint64_t rj = recs[j];
+                const uint32_t rk = rec_byte(rj, MG_AG_RANK);
+                if (rk > old_rank) recs[j] = rec_set(rj, MG_AG_RANK, rk - 1);
+            }
+            r = rec_set(r, MG_AG_RANK, (uint32_t)(n - 1));
+            r = rec_set(r, MG_AG_X, (uint32_t)x);
+            r = rec_set(r, MG_AG_Y, (uint32_t)y);
+            r = rec_set(r, MG_AG_FLAGS, (rec_byte(r, MG_AG_FLAGS) & MG_AF_DONE) | MG_AF_ACTIVE | MG_AF_PLACED);
+            recs[k] = r;
+            ok = true;
+        }
+    }
+    st.mt_pos[b] = mt.pos;
+    if (out_pos) { out_pos[2 * b] = ok ? x : -1; out_pos[2 * b + 1] = ok ? y : -1; }
+    if (out_ok) out_ok[b] = ok ? 1 : 0;
+    if (!ok && !fixed_pos && st.error[b] == 0) st.error[b] = MG_ERR_RECURSION;
+}
+
+hipError_t launch_place(const MgConfig& cfg, const MgState& st, int what, int x0, int y0, int x1, int y1, int max_tries,
+                        const int32_t* fixed_pos, const uint8_t* mask, int32_t* out_pos, uint8_t* out_ok,
+                        hipStream_t s) {
+    if (cfg.B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(place_kernel, dim3((cfg.B + kBlock - 1) / kBlock), dim3(kBlock), 0, s, cfg, st, what, x0, y0, x1,
+                       y1, max_tries, fixed_pos, mask, out_pos, out_ok);
+    return hipGetLastError();
+}
+
 hipError_t launch_reset(const MgConfig& cfg, const MgState& st, const MgGenProgram& prog, const uint8_t* mask,
                         hipStream_t s) {
     if (cfg.B <= 0) return hipSuccess;

@@ -86,12 +86,15 @@ __global__ __launch_bounds__(BS) void step_kernel(MgConfig cfg, MgState st, cons
         s_rec[k * BS + tid] = r;
     };
 
-    // late spawns (base.py:503-506), before step_count is incremented and before the shuffle
-    if (cfg.any_spawn_delay)
+    // late spawns (base.py:503-506), before step_count is incremented and before the shuffle: any agent
+    // that is neither active nor done (spawn_delay not reached at reset, or lifted off the grid by a
+    // failed live placement) is placed as soon as step_count >= its spawn_delay
+    {
         for (int k = 0; k < n; k++) {
             const uint32_t f = rec_byte(s_rec[k * BS + tid], MG_AG_FLAGS);
             if (!(f & (MG_AF_ACTIVE | MG_AF_DONE)) && sc0 >= cfg.spawn_delay[k]) place_agent(k);
         }
+    }
 
     // ---- round trip 2: every agent's front cell.  An agent's position
     // and heading are only ever changed by its own action, so its front cell is known before the

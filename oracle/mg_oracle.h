@@ -124,6 +124,9 @@ void mgo_set_carrying(MgoEnv* e, int32_t k, int32_t obj);
 /* test helper: overwrite a cell with a non-agent object id (env.put_obj, base.py:655-662) */
 int32_t mgo_put_obj(MgoEnv* e, int32_t obj, int32_t x, int32_t y);
 /* test helper: teleport an (already placed) agent; re-seats stacks like a fresh placement */
+int32_t mgo_place_obj(MgoEnv* e, int32_t what, int32_t x0, int32_t y0, int32_t x1, int32_t y1, int32_t max_tries,
+                      int32_t* out_xy);
+int32_t mgo_try_place_obj(MgoEnv* e, int32_t what, int32_t x, int32_t y);
 int32_t mgo_regen_grid(MgoEnv* e, int32_t which_gen);
 int32_t mgo_place_agent_at(MgoEnv* e, int32_t k, int32_t x, int32_t y);
 

@@ -120,6 +120,8 @@ def lib():
         L.mgo_set_agent_dir.argtypes = [vp, C.c_int32, C.c_int32]
         L.mgo_set_carrying.argtypes = [vp, C.c_int32, C.c_int32]
         L.mgo_regen_grid.argtypes = [vp, C.c_int32]
+        L.mgo_place_obj.argtypes = [vp] + [C.c_int32] * 6 + [i32p]
+        L.mgo_try_place_obj.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
         L.mgo_put_obj.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
         L.mgo_place_agent_at.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
         L.mgo_mt_init_by_array.argtypes = [u32p, i32p, u32p, C.c_int32]
@@ -399,6 +401,16 @@ class OracleEnv(object):
 
     def put_obj(self, obj, x, y):
         _raise(self.L.mgo_put_obj(self.h, obj, x, y))
+
+    def place_obj(self, what, region=None, max_tries=100000):
+        """live place_obj: what >= 1 object id, what < 0 agent -(what+1). Returns (x, y)."""
+        x0, y0, x1, y1 = region or (0, 0, self.W, self.H)
+        xy = np.zeros(2, np.int32)
+        _raise(self.L.mgo_place_obj(self.h, what, x0, y0, x1, y1, int(max_tries), _p(xy, C.c_int32)))
+        return int(xy[0]), int(xy[1])
+
+    def try_place_obj(self, what, x, y):
+        return bool(self.L.mgo_try_place_obj(self.h, what, int(x), int(y)))
 
     def place_agent_at(self, k, x, y):
         _raise(self.L.mgo_place_agent_at(self.h, k, x, y))

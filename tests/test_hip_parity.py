@@ -435,3 +435,40 @@ def test_error_paths_raise_like_the_reference():
     with pytest.raises(AssertionError):
         for _ in range(200):
             env.step(torch.randint(0, 3, (8, 1)))
+
+
+def test_live_place_obj_and_try_place_obj_vs_oracle():
+    """env.place_obj / env.try_place_obj outside _gen_grid (mg_place): positions, success flags, state
+    and RNG consumption equal the oracle's, then the envs keep stepping identically."""
+    import torch
+    from marlgrid_amd.objects import Goal, Wall
+    name, B = "MarlGrid-3AgentCluttered11x11-v0", 96
+    seeds = 4000 + np.arange(B)
+    env = product_envs.build(name, batch_size=B, seeds=seeds)
+    orc = O.OracleBatch(scenarios.registered(name), seeds)
+    env.reset(); orc.reset()
+    for i in range(4):
+        pos = env.place_obj(Wall(), max_tries=100).cpu().numpy()
+        want = np.array([e.place_obj(1, max_tries=100) for e in orc.envs])
+        assert np.array_equal(pos, want)
+    pos = env.place_obj(Goal(color="green", reward=1), top=(2, 3), size=(4, 20), max_tries=100).cpu().numpy()
+    assert np.array_equal(pos, np.array([e.place_obj(2, region=(2, 3, 6, 11), max_tries=100) for e in orc.envs]))
+    # re-seat agent 1 at random (lift + place, highest rank), and try fixed cells for objects / agent 0
+    pos = env.place_obj(env.agents[1]).cpu().numpy()
+    assert np.array_equal(pos, np.array([e.place_obj(-2) for e in orc.envs]))
+    rng = np.random.RandomState(0)
+    for i in range(12):
+        xy = rng.randint(0, 11, size=(B, 2))
+        ok = env.try_place_obj(Wall(), torch.from_numpy(xy)).cpu().numpy()
+        assert np.array_equal(ok, np.array([e.try_place_obj(1, *xy[b]) for b, e in enumerate(orc.envs)]))
+        ok = env.try_place_obj(env.agents[0], (int(xy[0, 0]), int(xy[0, 1]))).cpu().numpy()
+        assert np.array_equal(ok, np.array([e.try_place_obj(-1, xy[0, 0], xy[0, 1]) for e in orc.envs])), i
+    st = product_envs.canonical(env)
+    for b in range(B):
+        canon.assert_same(st[b], canon.oracle_canonical(orc.envs[b]), "env %d" % b)
+    assert np.array_equal(env.gen_obs().cpu().numpy(), orc.gen_obs())
+    for t in range(20):
+        a = rng.randint(0, 7, size=(B, 3))
+        o, r, dn, _ = env.step(torch.from_numpy(a))
+        o2, r2, dn2, _ = orc.step(a)
+        assert np.array_equal(o.cpu().numpy(), o2) and np.array_equal(dn.cpu().numpy(), dn2)

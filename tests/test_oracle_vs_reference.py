@@ -57,3 +57,32 @@ def test_occlusion_live_random():
                 T = rng.rand(vs, vs) < rng.choice([0.6, 0.8, 0.95])
                 want = occlude_mask(T.copy(), (vs // 2, vs - 1 - off))
                 assert np.array_equal(O.occlude(T, (vs // 2, vs - 1 - off)), want)
+
+
+def test_live_place_obj_and_try_place_obj():
+    """place_obj / try_place_obj on a live grid (base.py:664-708): positions, success flags and RNG
+    consumption of the oracle against the reference's own methods."""
+    import refstate
+    from marlgrid.objects import Wall, Goal
+    name = "MarlGrid-3AgentCluttered11x11-v0"
+    spec = scenarios.registered(name)
+    for seed in (1, 2, 3, 4):
+        env = refstate.make_ref_env(spec, scenarios.ref_recipe(name), seed=seed)
+        orc = O.OracleEnv(spec, seed=seed)
+        env.reset(); orc.reset()
+        for i in range(6):
+            pos = env.place_obj(Wall(), max_tries=100)
+            assert tuple(pos) == orc.place_obj(1, max_tries=100)
+        pos = env.place_obj(Goal(color="green", reward=1), top=(2, 3), size=(4, 20), max_tries=100)
+        assert tuple(pos) == orc.place_obj(2, region=(2, 3, 6, 11), max_tries=100)
+        rng = np.random.RandomState(seed)
+        for i in range(30):
+            x, y = int(rng.randint(0, 11)), int(rng.randint(0, 11))
+            ok = env.try_place_obj(Wall(), np.array([x, y]))
+            assert bool(ok) == orc.try_place_obj(1, x, y), (seed, i, x, y)
+        a, b = refstate.canonical(env), canon.oracle_canonical(orc)
+        for k in canon.KEYS[:-1]:
+            assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
+        st = env.np_random.get_state()
+        mt, p = orc.mt_state()
+        assert st[2] == p and np.array_equal(st[1], mt)
