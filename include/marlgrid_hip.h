@@ -97,7 +97,8 @@ typedef struct MgObjDesc {
     uint8_t toggle_next;                       /* Door closed<->open successor id */
     uint8_t unlock_next;                       /* Door locked->closed successor id */
     uint8_t ovl_slot;                          /* atlas slot for "object + agent on top", 0xFF none */
-    uint8_t bonus_id, n_bonus, bonus_flags, pad0; /* bonus_flags: 1 initial_reward, 2 reset_on_mistake */
+    uint8_t bonus_id, n_bonus, bonus_flags;    /* bonus_flags: 1 initial_reward, 2 reset_on_mistake */
+    uint8_t flags2;                            /* 1: a corner pixel of the plain tile is black (base.py:297) */
     uint32_t pad1;
     double reward;                             /* Goal.reward / BonusTile.reward */
     double penalty;                            /* BonusTile.penalty */
@@ -110,12 +111,17 @@ typedef struct MgConfig {
     int32_t cells_stride;                                         /* bytes per env in `grid` */
     int32_t n_obj;                                                /* valid object ids: 0..n_obj-1 */
     int32_t n_ovl_slots;                                          /* slot 0 = empty cell */
-    int32_t n_tiles;                                              /* 1 + n_obj + n_ovl_slots*n_agents*4 */
+    int32_t n_tiles;                                              /* >= 1 + n_obj + n_ovl_slots*n_agents*4 */
     int32_t agent_type_idx;                                       /* 13 */
     int32_t auto_reset;                                           /* reserved */
     uint8_t agent_color_idx[MG_MAX_AGENTS];
     int32_t any_spawn_delay;                                      /* 1 if some spawn_delay != 0 */
     int32_t spawn_delay[MG_MAX_AGENTS];                           /* agents.py:34; base.py:409-412, 503-506 */
+    uint32_t prestige_mask;                                       /* bit k: agent k's colour is 'prestige' */
+    uint8_t prestige_amax[4];                                     /* max sprite alpha per dir at tile_size */
+    int32_t prestige_sprite_tile;                                 /* atlas tile index of the 4 un-bordered white
+                                                                   * agent sprites (dir 0..3) appended to the atlas */
+    double prestige_beta[MG_MAX_AGENTS], prestige_scale[MG_MAX_AGENTS];   /* agents.py:31-32, 141-153 */
     int32_t any_hide;                                             /* 1 if any mask below is non-zero */
     uint32_t hide_agent_mask;                                     /* bit k: agent k hides type 'Agent' */
     uint64_t hide_obj_mask[MG_MAX_AGENTS];                        /* bit o: agent k hides object id o
@@ -134,6 +140,7 @@ typedef struct MgState {
     int32_t* step_count;
     uint8_t* done;
     int32_t* error;
+    double* prestige;     /* [B][n_agents] agent.prestige (agents.py:141-153); NULL unless prestige_mask != 0 */
 } MgState;
 
 /* `_gen_grid` as data: a static template (walls / put_obj results) + ordered random placements */
@@ -195,7 +202,9 @@ int32_t mg_place(const MgConfig* cfg, const MgState* st, int32_t what, int32_t x
  * TILE_PIXELS = 32); out: device uint8 [n_envs][H*ts][W*ts][3]. */
 int32_t mg_render_frame(const MgConfig* cfg, const MgState* st, const int32_t* env_ids, int32_t n_envs,
                         const uint8_t* frame_atlas, int32_t frame_tile_size, int32_t highlight,
-                        uint8_t* out, void* stream);
+                        uint32_t frame_amax, uint8_t* out, void* stream);
+/* frame_amax: the four per-dir max sprite alphas at frame_tile_size packed little-endian (only used
+ * when prestige_mask != 0). */
 
 /* timing helper for bench.py: average duration (ms) of `iters` back-to-back mg_render_obs
  * launches on `stream`, bracketed by HIP events recorded on that same stream. */

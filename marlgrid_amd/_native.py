@@ -24,7 +24,7 @@ class ObjDesc(C.Structure):
     _fields_ = [("type_idx", C.c_uint8), ("color_idx", C.c_uint8), ("state", C.c_uint8), ("flags", C.c_uint8),
                 ("reward_kind", C.c_uint8), ("toggle_next", C.c_uint8), ("unlock_next", C.c_uint8),
                 ("ovl_slot", C.c_uint8),
-                ("bonus_id", C.c_uint8), ("n_bonus", C.c_uint8), ("bonus_flags", C.c_uint8), ("pad0", C.c_uint8),
+                ("bonus_id", C.c_uint8), ("n_bonus", C.c_uint8), ("bonus_flags", C.c_uint8), ("flags2", C.c_uint8),
                 ("pad1", C.c_uint32), ("reward", C.c_double), ("penalty", C.c_double)]
 
 
@@ -41,13 +41,15 @@ class Config(C.Structure):
                 ("n_tiles", C.c_int32), ("agent_type_idx", C.c_int32), ("auto_reset", C.c_int32),
                 ("agent_color_idx", C.c_uint8 * MAX_AGENTS),
                 ("any_spawn_delay", C.c_int32), ("spawn_delay", C.c_int32 * MAX_AGENTS),
+                ("prestige_mask", C.c_uint32), ("prestige_amax", C.c_uint8 * 4), ("prestige_sprite_tile", C.c_int32),
+                ("prestige_beta", C.c_double * MAX_AGENTS), ("prestige_scale", C.c_double * MAX_AGENTS),
                 ("any_hide", C.c_int32), ("hide_agent_mask", C.c_uint32), ("hide_obj_mask", C.c_uint64 * MAX_AGENTS),
                 ("obj", C.c_void_p), ("atlas", C.c_void_p)]
 
 
 class State(C.Structure):
     _fields_ = [("grid", C.c_void_p), ("agents", C.c_void_p), ("mt", C.c_void_p), ("mt_pos", C.c_void_p),
-                ("step_count", C.c_void_p), ("done", C.c_void_p), ("error", C.c_void_p)]
+                ("step_count", C.c_void_p), ("done", C.c_void_p), ("error", C.c_void_p), ("prestige", C.c_void_p)]
 
 
 class GenOp(C.Structure):
@@ -96,7 +98,7 @@ def lib():
     L.mg_encode.argtypes = [C.POINTER(Config), C.POINTER(State), vp, vp, vp]
     L.mg_put_obj.argtypes = [C.POINTER(Config), C.POINTER(State), i32, i32, i32, vp, vp]
     L.mg_place.argtypes = [C.POINTER(Config), C.POINTER(State), i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]
-    L.mg_render_frame.argtypes = [C.POINTER(Config), C.POINTER(State), vp, i32, vp, i32, i32, vp, vp]
+    L.mg_render_frame.argtypes = [C.POINTER(Config), C.POINTER(State), vp, i32, vp, i32, i32, C.c_uint32, vp, vp]
     L.mg_time_render_obs.argtypes = [C.POINTER(Config), C.POINTER(State), vp, i32, C.POINTER(C.c_float), vp]
     for f in SYMBOLS:
         getattr(L, f)

@@ -239,12 +239,16 @@ class MultiGridEnv(object):
                                           "see_through_walls (one (B, n, P, P, 3) observation tensor)")
             if a.spawn_delay < 0:
                 raise ValueError("spawn_delay must be >= 0")
-            if a.color == "prestige":
-                raise NotImplementedError("the data-dependent 'prestige' colour is not supported")
+            if a.allow_negative_prestige:
+                raise NotImplementedError("allow_negative_prestige=True raises AttributeError upstream "
+                                          "(agents.py:147-148) and is not supported")
         if a0.view_size % 2 == 0 or a0.view_size > N.MAX_VIEW:
             raise NotImplementedError("view_size must be odd and <= %d" % N.MAX_VIEW)
         if not (0 <= a0.view_offset < a0.view_size):
             raise ValueError("view_offset out of range")
+        self._prestige = [a.color == "prestige" for a in self.agents]
+        if any(self._prestige) and any(len(a.hide_item_types) > 0 for a in self.agents):
+            raise NotImplementedError("'prestige'-coloured agents together with hide_item_types are not supported")
         self._all_image = all(a.observation_style == "image" for a in self.agents)
         self.view_size, self.tile_size = a0.view_size, a0.view_tile_size
         self.view_offset, self.see_through_walls = a0.view_offset, a0.see_through_walls
@@ -275,6 +279,8 @@ class MultiGridEnv(object):
             self.mt_pos = torch.zeros((B,), dtype=torch.int32, device=dev)
             self.step_count_t = torch.zeros((B,), dtype=torch.int32, device=dev)
             self.error_t = torch.zeros((B,), dtype=torch.int32, device=dev)
+            # agent.prestige (agents.py:141-153): only needed when some agent's colour is 'prestige'
+            self.prestige_t = torch.zeros((B, n), dtype=torch.float64, device=dev) if any(self._prestige) else None
             # step() outputs rotate through `obs_buffers` buffer sets (default 2), so what one step
             # returned stays intact while the next step is computed — the README loop
             # `save_step(obs, act, next_obs, rew, done)` sees two different observations.
@@ -287,7 +293,8 @@ class MultiGridEnv(object):
             self.done_b = self.done_t.view(torch.bool)      # the same bytes, as the bool tensor step() returns
         self._state = N.State(self.grid_state.data_ptr(), self.agent_state.data_ptr(), self.mt_state.data_ptr(),
                               self.mt_pos.data_ptr(), self.step_count_t.data_ptr(), self.done_t.data_ptr(),
-                              self.error_t.data_ptr())
+                              self.error_t.data_ptr(),
+                              self.prestige_t.data_ptr() if self.prestige_t is not None else None)
 
     def _stream(self):
         import torch
@@ -455,6 +462,11 @@ class MultiGridEnv(object):
                 d.unlock_next = self.obj_reg.find(Door(o.color, Door.CLOSED))
                 d.toggle_next = self.obj_reg.find(Door(o.color, Door.OPEN if o.state == Door.CLOSED else Door.CLOSED))
             d.flags = f
+            try:    # "a corner of the plain tile is black" (the border rule of render_tile, base.py:296-298)
+                plain = rendering.render_sprite(o.sprite_ops(), self.tile_size)
+            except NotImplementedError:
+                plain = np.zeros((self.tile_size, self.tile_size, 3), np.uint8)
+            d.flags2 = int((plain[[0, 0, -1, -1], [0, -1, 0, -1]] == 0).all(axis=-1).any())
             if isinstance(o, Goal):
                 d.reward_kind, d.reward = 1, float(o.reward)
             elif isinstance(o, BonusTile):
@@ -468,7 +480,8 @@ class MultiGridEnv(object):
             return
         import torch
         objs = self.obj_reg.objs
-        atlas, ovl_slot, n_slots = rendering.build_atlas(objs, [a.color for a in self.agents], self.tile_size)
+        atlas, ovl_slot, n_slots = rendering.build_atlas(objs, [a.color for a in self.agents], self.tile_size,
+                                                         prestige_sprites=any(self._prestige))
         tab = self._obj_table()
         for i in range(len(objs)):
             tab[i].ovl_slot = ovl_slot[i]
@@ -504,6 +517,15 @@ class MultiGridEnv(object):
             cfg.agent_color_idx[k] = COLOR_TO_IDX[a.color]
             cfg.spawn_delay[k] = a.spawn_delay
         cfg.any_spawn_delay = int(any(a.spawn_delay != 0 for a in self.agents))
+        # 'prestige' agents (agents.py:92-119, 141-153): per-env recoloured sprites
+        for k, a in enumerate(self.agents):
+            cfg.prestige_beta[k], cfg.prestige_scale[k] = float(a.prestige_beta), float(a.prestige_scale)
+            if self._prestige[k]:
+                cfg.prestige_mask |= 1 << k
+        if cfg.prestige_mask:
+            cfg.prestige_sprite_tile = atlas.shape[1] - 4
+            for d in range(4):      # max alpha of the (white) sprite per dir = max of blend_tiles' alpha map
+                cfg.prestige_amax[d] = int(atlas[0, atlas.shape[1] - 4 + d][..., 0].max())
         # hide_item_types (base.py:441-449): per viewer, the object ids / 'Agent' whose type is hidden
         for k, a in enumerate(self.agents):
             m = 0
@@ -779,7 +801,10 @@ class MultiGridEnv(object):
 
     def state_dict(self):
         keys = ("grid_state", "agent_state", "mt_state", "mt_pos", "step_count_t", "done_t", "error_t")
-        return {k: getattr(self, k).clone() for k in keys}
+        sd = {k: getattr(self, k).clone() for k in keys}
+        if self.prestige_t is not None:
+            sd["prestige_t"] = self.prestige_t.clone()
+        return sd
 
     def load_state_dict(self, sd):
         for k, v in sd.items():
@@ -810,6 +835,8 @@ class MultiGridEnv(object):
                 d["spawn_delay"] = a.spawn_delay
             if a.hide_item_types:
                 d["hide_item_types"] = list(a.hide_item_types)
+            if a.color == "prestige":
+                d.update(prestige_beta=a.prestige_beta, prestige_scale=a.prestige_scale)
             return d
         return dict(W=self.width, H=self.height, agents=[aspec(a) for a in self.agents],
                     view_size=self.view_size, tile_size=self.tile_size, view_offset=self.view_offset,
@@ -836,14 +863,19 @@ class MultiGridEnv(object):
         self._sync_tables()
         key = (self.obj_reg.version, tile_size)
         if getattr(self, "_frame_atlas_key", None) != key:
-            fa, _, _ = rendering.build_atlas(self.obj_reg.objs, [a.color for a in self.agents], tile_size)
+            fa, _, _ = rendering.build_atlas(self.obj_reg.objs, [a.color for a in self.agents], tile_size,
+                                             prestige_sprites=any(self._prestige))
             self._frame_atlas = torch.from_numpy(np.ascontiguousarray(fa[0])).to(self.device)
             self._frame_atlas_key = key
+            self._frame_amax = 0
+            if any(self._prestige):
+                for d in range(4):
+                    self._frame_amax |= int(fa[0, fa.shape[1] - 4 + d][..., 0].max()) << (8 * d)
         Hp, Wp = self.height * tile_size, self.width * tile_size
         img = torch.empty((K, Hp, Wp, 3), dtype=torch.uint8, device=self.device)
         N.check(self._lib.mg_render_frame(C.byref(self._cfg), C.byref(self._state), ids.data_ptr(), K,
                                           self._frame_atlas.data_ptr(), tile_size, int(bool(highlight)),
-                                          img.data_ptr(), self._stream()))
+                                          self._frame_amax, img.data_ptr(), self._stream()))
         if show_agent_views:
             # side columns (base.py:764-786): views enlarged by an integer factor, max_agents_per_col
             # per column, centred on a grey background.  (The reference mixes shape[0] / shape[1]

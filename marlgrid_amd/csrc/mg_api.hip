@@ -15,7 +15,8 @@ int check_cfg(const MgConfig* c) {
     if (c->view_offset < 0 || c->view_offset >= c->view_size) return MG_E_ARG;
     if (c->cells_stride < c->W * c->H || (c->cells_stride & 15)) return MG_E_ARG;
     if (c->n_obj < 1 || c->n_obj > MG_MAX_OBJ) return MG_E_UNSUPPORTED;
-    if (c->n_tiles != 1 + c->n_obj + c->n_ovl_slots * c->n_agents * 4) return MG_E_ARG;
+    if (c->n_tiles < 1 + c->n_obj + c->n_ovl_slots * c->n_agents * 4) return MG_E_ARG;
+    if (c->prestige_mask && (c->prestige_sprite_tile < 0 || c->prestige_sprite_tile + 4 > c->n_tiles)) return MG_E_ARG;
     if (!c->obj || !c->atlas) return MG_E_ARG;
     if (c->max_steps < 1) return MG_E_ARG;
     return MG_OK;
@@ -24,6 +25,15 @@ int check_cfg(const MgConfig* c) {
 int check_state(const MgState* s) {
     if (!s || !s->grid || !s->agents || !s->mt || !s->mt_pos || !s->step_count || !s->done || !s->error)
         return MG_E_ARG;
+    return MG_OK;
+}
+
+int check_both(const MgConfig* c, const MgState* s) {
+    int e = check_cfg(c);
+    if (e) return e;
+    e = check_state(s);
+    if (e) return e;
+    if (c->prestige_mask && !s->prestige) return MG_E_ARG;
     return MG_OK;
 }
 
@@ -57,9 +67,7 @@ int32_t mg_mt_seed(int32_t B, const uint32_t* keys, const int32_t* key_len, uint
 
 int32_t mg_reset(const MgConfig* cfg, const MgState* st, const MgGenProgram* prog, const uint8_t* env_mask,
                  void* stream) {
-    int e = check_cfg(cfg);
-    if (e) return e;
-    e = check_state(st);
+    int e = check_both(cfg, st);
     if (e) return e;
     if (!prog || !prog->template_grid || prog->n_ops < 0 || prog->n_ops > MG_MAX_GEN) return MG_E_ARG;
     for (int i = 0; i < prog->n_ops; i++)
@@ -73,9 +81,7 @@ int32_t mg_reset(const MgConfig* cfg, const MgState* st, const MgGenProgram* pro
 
 int32_t mg_step(const MgConfig* cfg, const MgState* st, const void* actions, int32_t action_bytes, float* rewards,
                 void* stream) {
-    int e = check_cfg(cfg);
-    if (e) return e;
-    e = check_state(st);
+    int e = check_both(cfg, st);
     if (e) return e;
     if (!actions || !rewards) return MG_E_ARG;
     if (action_bytes != 1 && action_bytes != 4 && action_bytes != 8) return MG_E_ARG;
@@ -84,9 +90,7 @@ int32_t mg_step(const MgConfig* cfg, const MgState* st, const void* actions, int
 
 int32_t mg_render_obs(const MgConfig* cfg, const MgState* st, uint8_t* obs, uint8_t* view_cells,
                       uint8_t* view_agent, uint8_t* vis_mask, void* stream) {
-    int e = check_cfg(cfg);
-    if (e) return e;
-    e = check_state(st);
+    int e = check_both(cfg, st);
     if (e) return e;
     if (!obs) return MG_E_ARG;
     return rc(mg::launch_render(*cfg, *st, obs, view_cells, view_agent, vis_mask, (hipStream_t)stream));
@@ -126,15 +130,16 @@ int32_t mg_place(const MgConfig* cfg, const MgState* st, int32_t what, int32_t x
 }
 
 int32_t mg_render_frame(const MgConfig* cfg, const MgState* st, const int32_t* env_ids, int32_t n_envs,
-                        const uint8_t* frame_atlas, int32_t frame_tile_size, int32_t highlight, uint8_t* out,
-                        void* stream) {
+                        const uint8_t* frame_atlas, int32_t frame_tile_size, int32_t highlight, uint32_t frame_amax,
+                        uint8_t* out, void* stream) {
     int e = check_cfg(cfg);
     if (e) return e;
     e = check_state(st);
     if (e) return e;
     if (!env_ids || n_envs < 0 || !frame_atlas || !out) return MG_E_ARG;
     if (frame_tile_size < 4 || frame_tile_size > 64 || (frame_tile_size & 3)) return MG_E_UNSUPPORTED;
-    return rc(mg::launch_frame(*cfg, *st, env_ids, n_envs, frame_atlas, frame_tile_size, highlight, out,
+    if (cfg->prestige_mask && !st->prestige) return MG_E_ARG;
+    return rc(mg::launch_frame(*cfg, *st, env_ids, n_envs, frame_atlas, frame_tile_size, highlight, frame_amax, out,
                                (hipStream_t)stream));
 }
 

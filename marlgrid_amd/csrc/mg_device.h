@@ -67,11 +67,41 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 __host__ __device__ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+// GridAgentInterface.render_post (marlgrid/agents.py:92-119): the sprite colour of an active
+// 'prestige' agent, between red (prestige 0) and blue: (ps*blue + (1-ps)*red).astype(int)
+struct PrestigeColor { uint32_t r, g, b; };
+__device__ inline PrestigeColor prestige_color(double prestige, double scale) {
+    const double ps = tanh(prestige / scale);
+    PrestigeColor c;
+    c.r = (uint32_t)(long long)(ps * 0.0 + (1. - ps) * 255.0);
+    c.g = (uint32_t)(long long)(ps * 0.0 + (1. - ps) * 0.0);
+    c.b = (uint32_t)(long long)(ps * 255.0 + (1. - ps) * 0.0);
+    return c;
+}
+
+// One pixel of the tile a recoloured agent produces: alpha = the white sprite's coverage value,
+// `base` = the overlappable object's pixel it stands on (blend_tiles, base.py:260-273) or NULL,
+// `border` = the empty tile's pixel when the border rule applies (base.py:296-298) or NULL.
+__device__ inline void prestige_pixel(uint32_t alpha, const PrestigeColor& col, uint32_t M, const uint8_t* base,
+                                      const uint8_t* border, uint8_t* out) {
+    uint32_t v[3] = {(alpha * col.r) >> 8, (alpha * col.g) >> 8, (alpha * col.b) >> 8};
+    if (base) {
+        if (M == 0) { v[0] = base[0]; v[1] = base[1]; v[2] = base[2]; }
+        else {
+            const uint32_t al = v[0] + v[1] + v[2];
+#pragma unroll
+            for (int c = 0; c < 3; c++) v[c] = ((uint32_t)base[c] * (M - al) + v[c] * al) / M;
+        }
+    }
+    if (border) { v[0] += border[0]; v[1] += border[1]; v[2] += border[2]; }     // uint8 wrap-around add
+    out[0] = (uint8_t)v[0]; out[1] = (uint8_t)v[1]; out[2] = (uint8_t)v[2];
+}
+
 // per-wave LDS scratch of the obs-render kernel (bytes), shared by host launch code and kernel
 struct RenderScratch {
-    int grid, first, second, rec, vbase, vshow, trow, vis, tmap, total;
+    int grid, first, second, rec, vbase, vshow, trow, vis, tmap, dyn, total;
 };
-__host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride, int n, int vs) {
+__host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride, int n, int vs, int dyn_bytes = 0) {
     RenderScratch s;
     int o = 0;
     s.grid = o;  o += round_up(cells_stride, 16);
@@ -83,6 +113,7 @@ __host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride,
     s.trow = o;  o += round_up(n * vs * 4, 16);
     s.vis = o;   o += round_up(n * vs * 4, 16);
     s.tmap = o;  o += round_up(n * vs * vs * 2, 16);
+    s.dyn = o;   o += round_up(dyn_bytes, 16);   // per-env recoloured ('prestige') agent tiles
     s.total = o;
     return s;
 }

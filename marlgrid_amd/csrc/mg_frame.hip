@@ -15,7 +15,7 @@ namespace mg {
 
 __global__ __launch_bounds__(kBlock) void frame_kernel(MgConfig cfg, MgState st, const int32_t* __restrict__ env_ids,
                                                        const uint8_t* __restrict__ atlas, int ts, int highlight,
-                                                       uint8_t* __restrict__ out) {
+                                                       uint32_t amax4, uint8_t* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int W = cfg.W, H = cfg.H, n = cfg.n_agents, VS = cfg.view_size;
     const int cells = W * H;
@@ -25,6 +25,7 @@ __global__ __launch_bounds__(kBlock) void frame_kernel(MgConfig cfg, MgState st,
     uint16_t* s_tile = reinterpret_cast<uint16_t*>(s_hl + cfg.cells_stride);   // [cells] tile index
     uint64_t* s_rec = reinterpret_cast<uint64_t*>(s_tile + round_up(cells, 8));
     uint32_t* s_trow = reinterpret_cast<uint32_t*>(s_rec + MG_MAX_AGENTS);     // [n][VS]
+    uint8_t* s_dyn = reinterpret_cast<uint8_t*>(s_trow + round_up(n * VS, 4));   // [n][ts*ts*3] recoloured tiles
     const int tid = threadIdx.x;
     const int e = env_ids[blockIdx.x];
     if (e < 0 || e >= cfg.B) return;
@@ -88,12 +89,36 @@ __global__ __launch_bounds__(kBlock) void frame_kernel(MgConfig cfg, MgState st,
         }
         __syncthreads();
     }
+    const int tile_bytes = ts * ts * 3;
+    // active 'prestige' agents: recoloured (and blended) tile per agent, world orientation (render_post)
+    if (cfg.prestige_mask) {
+        for (int X = 0; X < n; X++) {
+            if (!((cfg.prestige_mask >> X) & 1u)) continue;
+            const uint64_t rx = s_rec[X];
+            if ((rec_byte(rx, MG_AG_FLAGS) & (MG_AF_ACTIVE | MG_AF_PLACED)) != (MG_AF_ACTIVE | MG_AF_PLACED)) continue;
+            const uint32_t base = s_grid[rec_byte(rx, MG_AG_X) * H + rec_byte(rx, MG_AG_Y)];
+            const uint32_t sdir = rec_byte(rx, MG_AG_DIR);
+            const PrestigeColor col = prestige_color(st.prestige[(size_t)e * n + X], cfg.prestige_scale[X]);
+            const uint32_t amax = (amax4 >> (8 * sdir)) & 0xFFu;
+            const uint32_t M = ((amax * col.r) >> 8) + ((amax * col.g) >> 8) + ((amax * col.b) >> 8);
+            const uint8_t* white = atlas + (size_t)(cfg.prestige_sprite_tile + sdir) * tile_bytes;   // no border
+            const uint8_t* btile = base ? atlas + (size_t)(1 + base) * tile_bytes : nullptr;
+            const bool border = base ? (cfg.obj[base].flags2 & 1) != 0 : true;
+            const uint8_t* etile = atlas + (size_t)tile_bytes;
+            for (int p = tid; p < ts * ts; p += kBlock)
+                prestige_pixel(white[p * 3], col, M, btile ? btile + p * 3 : nullptr, border ? etile + p * 3 : nullptr,
+                               s_dyn + (size_t)X * tile_bytes + p * 3);
+        }
+    }
     // tile per world cell: render_tile(obj, top_agent=None) — base.py:275-299
+    const uint32_t n_tiles = (uint32_t)cfg.n_tiles;
     for (int c = tid; c < cells; c += kBlock) {
         const uint32_t base = s_grid[c], show = s_first[c];
         uint32_t tile;
         const uint32_t slot = base ? cfg.obj[base].ovl_slot : 0u;
         if (show == 0xFF || slot == 0xFF) tile = 1 + base;
+        else if (((cfg.prestige_mask >> show) & 1u) && (rec_byte(s_rec[show], MG_AG_FLAGS) & MG_AF_ACTIVE))
+            tile = n_tiles + show;                                   // dynamic tile (LDS)
         else tile = 1 + cfg.n_obj + (slot * n + show) * 4 + rec_byte(s_rec[show], MG_AG_DIR);
         s_tile[c] = (uint16_t)tile;
     }
@@ -108,7 +133,9 @@ __global__ __launch_bounds__(kBlock) void frame_kernel(MgConfig cfg, MgState st,
         const int R = q / row_dw, d = q - R * row_dw;
         const int j = R / ts, rr = R - j * ts, i = d / TD, kk = d - i * TD;
         const int c = i * H + j;
-        uint32_t v = atlas32[(size_t)s_tile[c] * tile_dw + rr * TD + kk];
+        const uint32_t t = s_tile[c];
+        uint32_t v = (t < n_tiles) ? atlas32[(size_t)t * tile_dw + rr * TD + kk]
+                                   : reinterpret_cast<const uint32_t*>(s_dyn)[(size_t)(t - n_tiles) * tile_dw + rr * TD + kk];
         if (s_hl[c]) {
             // (img*8 + 255*2) >> 3, clipped to 255 (base.py:327-329) == min(255, img + 63) per byte
             uint32_t o = 0;
@@ -124,17 +151,18 @@ __global__ __launch_bounds__(kBlock) void frame_kernel(MgConfig cfg, MgState st,
 }
 
 hipError_t launch_frame(const MgConfig& cfg, const MgState& st, const int32_t* env_ids, int K, const uint8_t* atlas,
-                        int ts, int highlight, uint8_t* out, hipStream_t s) {
+                        int ts, int highlight, uint32_t amax, uint8_t* out, hipStream_t s) {
     if (K <= 0) return hipSuccess;
     size_t lds = 3 * (size_t)cfg.cells_stride + 2 * (size_t)round_up(cfg.W * cfg.H, 8) + MG_MAX_AGENTS * 8 +
-                 (size_t)cfg.n_agents * cfg.view_size * 4 + 64;
+                 (size_t)round_up(cfg.n_agents * cfg.view_size, 4) * 4 + 64 +
+                 (cfg.prestige_mask ? (size_t)cfg.n_agents * ts * ts * 3 : 0);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&frame_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(frame_kernel, dim3(K), dim3(kBlock), lds, s, cfg, st, env_ids, atlas, ts, highlight, out);
+    hipLaunchKernelGGL(frame_kernel, dim3(K), dim3(kBlock), lds, s, cfg, st, env_ids, atlas, ts, highlight, amax, out);
     return hipGetLastError();
 }
 

@@ -32,7 +32,7 @@ namespace mg {
 //              fixes the view size at compile time (the shipped view sizes), VS_ == 0 reads it from cfg.
 // TS_ == 0:    any view / tile size: per-byte look-ups assembled into aligned dword stores.
 // V_: 0 = production; 8 = production with the atlas read from global memory (chosen by the launcher
-//     when it does not fit LDS).  2..7 = measurement variants for tools/ab_render.py (MG_RENDER_VARIANT,
+//     when it does not fit LDS); 9 = production with per-env recoloured tiles for 'prestige' agents.  2..7 = measurement variants for tools/ab_render.py (MG_RENDER_VARIANT,
 //     <7,8> only): 2 nontemporal stores, 3 raster only (phases 2-5 skipped), 4 stores only (no LDS
 //     look-ups), 5 no next-env prefetch, 6 no store bursts, 7 grid-strided env walk.
 // WPB = waves per workgroup (4 or 16; MG_RENDER_WPB overrides the launcher's choice).
@@ -53,6 +53,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     // V_ == 8: the atlas does not fit the 160 KiB of LDS next to the per-env scratch (large tiles);
     // it is then read in place (global memory, L2-resident: it is a few hundred KB).
     constexpr bool kGlobalAtlas = (V_ == 8);
+    constexpr bool kPrestige = (V_ == 9);      // some agent is 'prestige'-coloured: per-env recoloured tiles
     const int atlas_bytes = kGlobalAtlas ? 0 : round_up(4 * cfg.n_tiles * tile_bytes, 16);
     uint8_t* s_atlas = smem;
     uint8_t* s_oflags = smem + atlas_bytes;             // [MG_MAX_OBJ]
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     }
     __syncthreads();
 
-    const RenderScratch L = render_scratch_layout(cfg.cells_stride, n, VS);
+    const RenderScratch L = render_scratch_layout(cfg.cells_stride, n, VS, kPrestige ? n * 4 * tile_bytes : 0);
     uint8_t* ws = smem + atlas_bytes + 2 * MG_MAX_OBJ + MG_MAX_AGENTS * 8 + (size_t)wave * L.total;
     uint8_t* w_grid = ws + L.grid;
     uint8_t* w_first = ws + L.first;
@@ -85,6 +86,9 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     uint32_t* w_trow = reinterpret_cast<uint32_t*>(ws + L.trow);
     uint32_t* w_vis = reinterpret_cast<uint32_t*>(ws + L.vis);
     uint16_t* w_tmap = reinterpret_cast<uint16_t*>(ws + L.tmap);
+    uint8_t* w_dyn = ws + L.dyn;                               // [n][4 orientations][tile_bytes]
+    const uint32_t dyn_off = (uint32_t)(w_dyn - smem);         // byte offset from the atlas base
+    const uint32_t NT4 = 4u * (uint32_t)cfg.n_tiles;           // first virtual tile index of the dynamic tiles
 
     const int h = VS / 2, off = cfg.view_offset;
     const size_t img_bytes = (size_t)VS * TS * VS * TS * 3;
@@ -212,6 +216,37 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             for (int j = 0; j < VS; j++) w_vis[lane * VS + j] = m[j];
         }
         wave_lds_sync();
+        if constexpr (kPrestige) {
+            // 4b. tiles of active 'prestige' agents are recoloured per env (render_post) — and blended
+            //     with the object they stand on — before rotation; generate them for all 4 orientations
+            const int npx = TS * TS;
+            for (int X = 0; X < n; X++) {
+                if (!((cfg.prestige_mask >> X) & 1u)) continue;
+                const uint64_t rx = w_rec[X];
+                if ((rec_byte(rx, MG_AG_FLAGS) & (MG_AF_ACTIVE | MG_AF_PLACED)) != (MG_AF_ACTIVE | MG_AF_PLACED)) continue;
+                const uint32_t base = w_grid[rec_byte(rx, MG_AG_X) * H + rec_byte(rx, MG_AG_Y)];
+                const uint32_t sdir = rec_byte(rx, MG_AG_DIR);
+                const PrestigeColor col = prestige_color(st.prestige[(size_t)e * n + X], cfg.prestige_scale[X]);
+                const uint32_t amax = cfg.prestige_amax[sdir];
+                const uint32_t M = ((amax * col.r) >> 8) + ((amax * col.g) >> 8) + ((amax * col.b) >> 8);
+                const uint8_t* white = s_atlas + (size_t)(cfg.prestige_sprite_tile + sdir) * tile_bytes;   // orientation 0, no border
+                const uint8_t* btile = base ? s_atlas + (size_t)(1 + base) * tile_bytes : nullptr;
+                const bool border = base ? (cfg.obj[base].flags2 & 1) != 0 : true;
+                const uint8_t* etile = s_atlas + (size_t)tile_bytes;                                   // empty tile
+                for (int idx = lane; idx < 4 * npx; idx += kWave) {
+                    const int o = idx / npx, p = idx - o * npx, r = p / TS, c = p - r * TS;
+                    int sr, sc;   // source pixel of output pixel (r, c) at orientation o (rotate_grid, base.py:67-80)
+                    if (o == 3) { sr = c; sc = TS - 1 - r; }
+                    else if (o == 1) { sr = TS - 1 - c; sc = r; }
+                    else if (o == 2) { sr = TS - 1 - r; sc = TS - 1 - c; }
+                    else { sr = r; sc = c; }
+                    const int sp = (sr * TS + sc) * 3;
+                    prestige_pixel(white[sp], col, M, btile ? btile + sp : nullptr, border ? etile + sp : nullptr,
+                                   w_dyn + ((size_t)(X * 4 + o) * npx + p) * 3);
+                }
+            }
+            wave_lds_sync();
+        }
         // 5. tile selection (base.py:275-299) -> atlas byte offset / 4 per view cell
         for (int it = lane; it < n * VV; it += kWave) {
             const int k = it / VV, c = it - k * VV;
@@ -228,10 +263,19 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 }
             }
             const uint32_t orient = (3u - rec_byte(w_rec[k], MG_AG_DIR)) & 3u;   // -(dir+1) mod 4
-            if constexpr (TS_ > 0 && (TS_ % 8) == 0 && !kGlobalAtlas)
-                w_tmap[it] = (uint16_t)((orient * cfg.n_tiles + tile) * (TS_ * TS_ * 3 / 4));   // dword offset
+            uint32_t vt = orient * cfg.n_tiles + tile;                            // (virtual) tile index
+            bool dyn = false;
+            if constexpr (kPrestige) {
+                if (visible && show != 0xFF && s_oslot[base] != 0xFF && ((cfg.prestige_mask >> show) & 1u) &&
+                    (rec_byte(w_rec[show], MG_AG_FLAGS) & MG_AF_ACTIVE)) {
+                    vt = NT4 + show * 4 + orient;
+                    dyn = true;
+                }
+            }
+            if constexpr (TS_ > 0 && (TS_ % 8) == 0 && !kGlobalAtlas)             // dword offset from the atlas base
+                w_tmap[it] = (uint16_t)(dyn ? dyn_off / 4 + (vt - NT4) * (TS_ * TS_ * 3 / 4) : vt * (TS_ * TS_ * 3 / 4));
             else
-                w_tmap[it] = (uint16_t)(orient * cfg.n_tiles + tile);                            // tile index
+                w_tmap[it] = (uint16_t)vt;
             if (dbg_cells) {
                 const size_t o = ((size_t)e * n + k) * VV + va * VS + vb;         // [i][j] like the reference
                 dbg_cells[o] = (uint8_t)base;
@@ -315,11 +359,15 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             const size_t d0 = (gb + 3) / 4, d1 = (gb + S) / 4;             // aligned dwords [d0, d1)
             const uint32_t mTS = TS > 1 ? 0xFFFFFFFFu / (uint32_t)TS + 1u : 0u;
             auto div_ts = [&](uint32_t v) -> uint32_t { return TS > 1 ? __umulhi(v, mTS) : v; };
+            auto tile_off = [&](uint32_t vt) -> uint32_t {                 // virtual tile index -> byte offset
+                if constexpr (kPrestige) return vt < NT4 ? vt * (uint32_t)tile_bytes : dyn_off + (vt - NT4) * (uint32_t)tile_bytes;
+                else return vt * (uint32_t)tile_bytes;
+            };
             auto byte_at = [&](uint32_t R, uint32_t cb) -> uint32_t {      // R: global pixel row, cb < RB
                 const uint32_t col = __umulhi(cb, 0x55555556u), ch = cb - col * 3u;
                 const uint32_t va = div_ts(col), cc = col - va * (uint32_t)TS;
                 const uint32_t vb = div_ts(R), rr = R - vb * (uint32_t)TS;
-                const uint32_t so = (uint32_t)w_tmap[vb * (uint32_t)VS + va] * (uint32_t)tile_bytes + (rr * (uint32_t)TS + cc) * 3u + ch;
+                const uint32_t so = tile_off((uint32_t)w_tmap[vb * (uint32_t)VS + va]) + (rr * (uint32_t)TS + cc) * 3u + ch;
                 if constexpr (kGlobalAtlas) return cfg.atlas[so];
                 else return s_atlas[so];
             };
@@ -344,7 +392,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 };
                 auto seg_src = [&](uint32_t R, uint32_t seg) -> uint32_t {     // atlas byte offset of a segment start
                     const uint32_t vb = div_ts(R), rr = R - vb * (uint32_t)TS;
-                    return (uint32_t)w_tmap[vb * (uint32_t)VS + seg] * (uint32_t)tile_bytes + rr * SEG;
+                    return tile_off((uint32_t)w_tmap[vb * (uint32_t)VS + seg]) + rr * SEG;
                 };
                 const uint32_t STEP_Rb = (4u * kWave) / RB, STEP_B = (4u * kWave) - STEP_Rb * RB;
                 uint32_t o = (uint32_t)(4 * (d0 + lane) - gb);             // this lane's first byte offset
@@ -386,7 +434,8 @@ template <int VS_, int TS_, int WPB, int V_ = 0>
 static hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_t* obs, uint8_t* c, uint8_t* a,
                                   uint8_t* v, hipStream_t s) {
     const int tile_bytes = cfg.tile_size * cfg.tile_size * 3;
-    const RenderScratch L = render_scratch_layout(cfg.cells_stride, cfg.n_agents, cfg.view_size);
+    const RenderScratch L = render_scratch_layout(cfg.cells_stride, cfg.n_agents, cfg.view_size,
+                                                  V_ == 9 ? cfg.n_agents * 4 * tile_bytes : 0);
     size_t lds = (V_ == 8 ? 0 : (size_t)round_up(4 * cfg.n_tiles * tile_bytes, 16)) + 2 * MG_MAX_OBJ +
                  MG_MAX_AGENTS * 8 + WPB * (size_t)L.total;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
@@ -431,6 +480,12 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
     if ((view_cells || view_agent || vis_mask) && !(view_cells && view_agent && vis_mask)) return hipErrorInvalidValue;
     const int vs = cfg.view_size, ts = cfg.tile_size;
     const int wpb = choose_wpb(cfg);
+    if (cfg.prestige_mask) {   // per-env recoloured agent tiles: 4-wave workgroups, atlas must be LDS-resident
+        if (ts == 8) return launch_render_t<0, 8, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
+        if (ts == 16) return launch_render_t<0, 16, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
+        if (ts == 32) return launch_render_t<0, 32, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
+        return launch_render_t<0, 0, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
+    }
     {   // atlas too large for LDS (next to 4 waves of scratch): read it from global memory instead
         const RenderScratch L = render_scratch_layout(cfg.cells_stride, cfg.n_agents, cfg.view_size);
         const size_t lds4 = (size_t)round_up(4 * cfg.n_tiles * ts * ts * 3, 16) + 2 * MG_MAX_OBJ + MG_MAX_AGENTS * 8 +

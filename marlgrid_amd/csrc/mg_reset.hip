@@ -81,6 +81,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(MgConfig cfg, MgState st,
         }
         s_rec[k * kBlock + tid] = nr;
         st.agents[(size_t)b * n + k] = nr;
+        if (cfg.prestige_mask) st.prestige[(size_t)b * n + k] = 0.0;   // new_episode=True: agents.py:167-168
     }
     st.mt_pos[b] = mt.pos;
     st.step_count[b] = 0;

@@ -126,6 +126,8 @@ __global__ __launch_bounds__(BS) void step_kernel(MgConfig cfg, MgState st, cons
     for (int oi = 0; oi < n; oi++) {
         const int k = s_order[oi * BS + tid];
         float rew = 0.0f;
+        bool rewarded = false;      // agent.reward(rwd) was called (prestige bookkeeping)
+        double rwd_applied = 0.0;
         uint64_t r = s_rec[k * BS + tid];
         const uint32_t flags = rec_byte(r, MG_AG_FLAGS);
         if (flags & MG_AF_ACTIVE) {   // base.py:521
@@ -184,7 +186,9 @@ __global__ __launch_bounds__(BS) void step_kernel(MgConfig cfg, MgState st, cons
                                         if (first_bonus && !(od.bonus_flags & 1)) rwd = 0.0;
                                         r = rec_set(r, MG_AG_BONUS, (uint32_t)bs);
                                     }
-                                    rew = (float)(rwd * decay);
+                                    rwd_applied = rwd * decay;
+                                    rewarded = true;
+                                    rew = (float)rwd_applied;
                                 }
                                 if (fflags & MG_OF_ENDS_EPISODE) r = rec_set(r, MG_AG_FLAGS, flags | MG_AF_DONE);  // :584-585
                             }
@@ -229,6 +233,13 @@ __global__ __launch_bounds__(BS) void step_kernel(MgConfig cfg, MgState st, cons
                 }
             }
             s_rec[k * BS + tid] = r;
+            if (cfg.prestige_mask) {
+                // agent.reward(rwd) then agent.on_step(): agents.py:141-153 (allow_negative_prestige=False)
+                double* pp = st.prestige + (size_t)b * n + k;
+                double p = *pp;
+                if (rewarded) p = (rwd_applied >= 0) ? p + rwd_applied : 0.0;
+                *pp = p * cfg.prestige_beta[k];
+            }
         }
         rewards[(size_t)b * n + k] = rew;
     }

@@ -117,9 +117,11 @@ def rotate_tile(t, orientation):
     return t
 
 
-def build_atlas(objects, agent_colors, ts):
+def build_atlas(objects, agent_colors, ts, prestige_sprites=False):
     """objects: list indexed by object id (index 0 = None).  Returns
-    (atlas uint8 [4][n_tiles][ts][ts][3], ovl_slot list[int] per object id, n_slots)."""
+    (atlas uint8 [4][n_tiles][ts][ts][3], ovl_slot list[int] per object id, n_slots).
+    prestige_sprites: append the 4 un-bordered white agent sprites (dir 0..3) that the kernels
+    recolour per env for 'prestige' agents (GridAgentInterface.render_post, agents.py:92-119)."""
     n_obj, n_ag = len(objects), len(agent_colors)
     ovl_slot = [0xFF] * n_obj
     ovl_slot[0] = 0
@@ -128,7 +130,7 @@ def build_atlas(objects, agent_colors, ts):
         if o is not None and o.can_overlap():
             ovl_slot[i] = n_slots
             n_slots += 1
-    n_tiles = 1 + n_obj + n_slots * n_ag * 4
+    n_tiles = 1 + n_obj + n_slots * n_ag * 4 + (4 if prestige_sprites else 0)
     tiles = np.zeros((n_tiles, ts, ts, 3), np.uint8)
     tiles[0] = np.asarray(COLORS["shadow"], np.uint8)
     plain = [None] * n_obj
@@ -151,5 +153,8 @@ def build_atlas(objects, agent_colors, ts):
                 t = 1 + n_obj + (s * n_ag + k) * 4 + d
                 img = sprites[k][d] if i == 0 else blend(plain[i], sprites[k][d])
                 tiles[t] = with_border(img, ts)
+    if prestige_sprites:
+        for d in range(4):
+            tiles[n_tiles - 4 + d] = agent_sprite("prestige", d, ts)
     atlas = np.stack([np.stack([rotate_tile(t, o) for t in tiles]) for o in range(4)])
     return np.ascontiguousarray(atlas), ovl_slot, n_slots

@@ -109,6 +109,7 @@ struct MgoEnv {
     int32_t aactive[MGO_MAX_AGENTS], adone[MGO_MAX_AGENTS];
     int32_t acarry[MGO_MAX_AGENTS];                    /* carried object id, 0 = None */
     int32_t abonus[MGO_MAX_AGENTS];                    /* agent.bonus_state, -1 = None */
+    double aprestige[MGO_MAX_AGENTS];                  /* agent.prestige (agents.py:141-153,168) */
     int32_t step_count;
     uint32_t mt[MT_N];
     int32_t mt_pos;
@@ -251,16 +252,34 @@ static void add_border_if_black_corner(const MgoShared* sh, uint8_t* img) {
 }
 
 /* MultiGrid.render_tile (base.py:275-299), expressed on (object id, shown agent) */
+/* GridAgentInterface.render_post — agents.py:92-119: an ACTIVE agent whose colour is 'prestige' is
+ * recoloured between red (prestige 0) and blue by tanh(prestige / prestige_scale) */
+static const uint8_t* agent_sprite(const MgoEnv* e, int k, int dir, uint8_t* scratch) {
+    const MgoShared* sh = e->sh;
+    const uint8_t* tile = sh->agent_tile + ((size_t)k * 4 + dir) * sh->tile_bytes;
+    if (!sh->cfg.is_prestige[k] || !e->aactive[k]) return tile;
+    double ps = tanh(e->aprestige[k] / sh->cfg.prestige_scale[k]);
+    /* (ps*blue + (1.-ps)*red).astype(int) */
+    long col[3] = {(long)(ps * 0.0 + (1. - ps) * 255.0), (long)(ps * 0.0 + (1. - ps) * 0.0), (long)(ps * 255.0 + (1. - ps) * 0.0)};
+    int npx = sh->cfg.tile_size * sh->cfg.tile_size;
+    for (int p = 0; p < npx; p++) {
+        long alpha = tile[p * 3];                       /* tile[...,0].astype(uint16) */
+        for (int ch = 0; ch < 3; ch++) scratch[p * 3 + ch] = (uint8_t)((alpha * col[ch]) >> 8);
+    }
+    return scratch;
+}
+
 void mgo_tile(const MgoEnv* e, int32_t obj, int32_t agent_k, int32_t agent_dir, uint8_t* out) {
     const MgoShared* sh = e->sh;
     int ts = sh->cfg.tile_size;
+    uint8_t recol[64 * 64 * 3];
     if (obj == 0 && agent_k < 0) { memcpy(out, sh->empty_tile, sh->tile_bytes); return; }
     if (obj == 0) {
-        memcpy(out, sh->agent_tile + ((size_t)agent_k * 4 + agent_dir) * sh->tile_bytes, sh->tile_bytes);
+        memcpy(out, agent_sprite(e, agent_k, agent_dir, recol), sh->tile_bytes);
     } else {
         const uint8_t* base = sh->obj_tile + (size_t)obj * sh->tile_bytes;
         if (agent_k >= 0)
-            blend_tiles(ts, base, sh->agent_tile + ((size_t)agent_k * 4 + agent_dir) * sh->tile_bytes, out);
+            blend_tiles(ts, base, agent_sprite(e, agent_k, agent_dir, recol), out);
         else
             memcpy(out, base, sh->tile_bytes);
     }
@@ -415,6 +434,7 @@ int32_t mgo_reset(MgoEnv* e, int32_t which_gen) {
         e->ax[k] = e->ay[k] = -1;
         e->acarry[k] = 0;
         e->abonus[k] = -1;
+        e->aprestige[k] = 0.0;                     /* new_episode=True: agents.py:167-168 */
         /* agent.state (dir) is NOT touched by reset */
     }
     int rc = gen_grid(e, which_gen);
@@ -538,6 +558,8 @@ int32_t mgo_step(MgoEnv* e, const int32_t* actions, double* rewards, int32_t* ep
                     double rwd = (o->reward_kind == 1) ? o->reward : bonus_reward(e, o, k);
                     if (cfg->reward_decay) rwd *= (1.0 - 0.9 * ((double)e->step_count / (double)cfg->max_steps));
                     rewards[k] += rwd;
+                    /* agent.reward(rwd) — agents.py:146-153 (allow_negative_prestige=False) */
+                    if (rwd >= 0) e->aprestige[k] += rwd; else e->aprestige[k] = 0;
                 }
                 if (fwd_cell != 0 && !is_agent_val(fwd_cell) && cfg->obj[fwd_cell].ends_episode)
                     e->adone[k] = 1;                  /* :584-585 */
@@ -571,6 +593,7 @@ int32_t mgo_step(MgoEnv* e, const int32_t* actions, double* rewards, int32_t* ep
         } else {
             rc = MGO_ERR_VALUE;                       /* :619-620 */
         }
+        e->aprestige[k] *= cfg->prestige_beta[k];     /* agent.on_step — base.py:622, agents.py:141-144 */
     }
 
     /* done agents: respawn or deactivate — base.py:627-646 */
@@ -850,6 +873,10 @@ void mgo_get_state(const MgoEnv* e, uint8_t* base, int32_t* agents7, int32_t* st
         a[6] = ord;
     }
     *step_count = e->step_count;
+}
+
+void mgo_get_prestige(const MgoEnv* e, double* out) {
+    for (int k = 0; k < e->sh->cfg.n_agents; k++) out[k] = e->aprestige[k];
 }
 
 void mgo_get_mt(const MgoEnv* e, uint32_t* mt624, int32_t* pos) {

@@ -84,6 +84,8 @@ typedef struct {
     int32_t n_gen[2];                                             /* [0] ctor-time, [1] reset  */
     MgoGenOp gen[2][MGO_MAX_GEN];
     int32_t spawn_delay[MGO_MAX_AGENTS];                          /* agents.py:34, base.py:409-412, 503-506 */
+    int32_t is_prestige[MGO_MAX_AGENTS];                          /* color == 'prestige' (agents.py:99) */
+    double prestige_beta[MGO_MAX_AGENTS], prestige_scale[MGO_MAX_AGENTS]; /* agents.py:31-32,54-56 */
     uint32_t hide_type_mask[MGO_MAX_AGENTS];                      /* hide_item_types: bit t = type_idx t,
                                                                    * bit 31 = 'Agent' (base.py:441-449) */
 } MgoConfig;
@@ -118,6 +120,7 @@ void mgo_occlude(int32_t vs, int32_t ax, int32_t ay, const uint8_t* transp, uint
 /* canonical state dump. base: (W*H) object id of the non-agent object in each cell (0 if none);
  * agents: per agent x,y,dir,active,done,carrying,ordinal (position in its cell's stack) */
 void mgo_get_state(const MgoEnv* e, uint8_t* base, int32_t* agents7, int32_t* step_count);
+void mgo_get_prestige(const MgoEnv* e, double* out);
 void mgo_get_mt(const MgoEnv* e, uint32_t* mt624, int32_t* pos);
 void mgo_set_agent_dir(MgoEnv* e, int32_t k, int32_t dir);
 void mgo_set_carrying(MgoEnv* e, int32_t k, int32_t obj);

@@ -80,7 +80,9 @@ class Config(C.Structure):
                 ("agent_color_idx", C.c_int32 * MAX_AGENTS), ("agent_rgb", (C.c_uint8 * 4) * MAX_AGENTS),
                 ("agent_type_idx", C.c_int32), ("n_obj", C.c_int32), ("obj", ObjDesc * MAX_OBJ),
                 ("wall_obj", C.c_int32), ("n_gen", C.c_int32 * 2), ("gen", (GenOp * MAX_GEN) * 2),
-                ("spawn_delay", C.c_int32 * MAX_AGENTS), ("hide_type_mask", C.c_uint32 * MAX_AGENTS)]
+                ("spawn_delay", C.c_int32 * MAX_AGENTS), ("is_prestige", C.c_int32 * MAX_AGENTS),
+                ("prestige_beta", C.c_double * MAX_AGENTS), ("prestige_scale", C.c_double * MAX_AGENTS),
+                ("hide_type_mask", C.c_uint32 * MAX_AGENTS)]
 
 
 _lib = None
@@ -117,6 +119,7 @@ def lib():
         L.mgo_occlude.argtypes = [C.c_int32, C.c_int32, C.c_int32, u8p, u8p]
         L.mgo_get_state.argtypes = [vp, u8p, i32p, i32p]
         L.mgo_get_mt.argtypes = [vp, u32p, i32p]
+        L.mgo_get_prestige.argtypes = [vp, f64p]
         L.mgo_set_agent_dir.argtypes = [vp, C.c_int32, C.c_int32]
         L.mgo_set_carrying.argtypes = [vp, C.c_int32, C.c_int32]
         L.mgo_regen_grid.argtypes = [vp, C.c_int32]
@@ -230,6 +233,10 @@ def make_config(spec):
         cfg.agent_color_idx[k] = COLOR_TO_IDX[a["color"]]
         cfg.agent_rgb[k][:3] = list(COLORS[a["color"]])
         cfg.spawn_delay[k] = int(a.get("spawn_delay", 0))
+        cfg.is_prestige[k] = int(a["color"] == "prestige")
+        beta = a.get("prestige_beta", 0.95)
+        cfg.prestige_beta[k] = 0.95 if beta > 1 else beta            # agents.py:54-56
+        cfg.prestige_scale[k] = a.get("prestige_scale", 2)
         for tname in a.get("hide_item_types", []):       # item.type: class name, 'Agent' for agents
             cfg.hide_type_mask[k] |= (1 << 31) if tname == "Agent" else (1 << TYPE_IDX[tname])
     objs = spec["objects"]
@@ -381,6 +388,11 @@ class OracleEnv(object):
         return dict(base=base, pos=ag[:, 0:2].copy(), dir=ag[:, 2].copy(), active=ag[:, 3].astype(bool),
                     done=ag[:, 4].astype(bool), carrying=ag[:, 5].copy(), ordinal=ag[:, 6].copy(),
                     step_count=sc.value)
+
+    def prestige(self):
+        out = np.zeros(self.n, np.float64)
+        self.L.mgo_get_prestige(self.h, _p(out, C.c_double))
+        return out
 
     def mt_state(self):
         mt = np.zeros(624, np.uint32)

@@ -46,6 +46,9 @@ TRAJ = {  # scenario -> (n_seeds, n_steps, n_full_obs_seeds)
     "Test-4AgentEmpty5x5-hide": (8, 150, 2),
     "Test-3AgentCluttered9x9-hide": (6, 120, 2),
     "Test-2AgentRegion9x9": (6, 100, 1),
+    "Test-2AgentGoalcycle9x9-prestige": (8, 120, 2),
+    "Test-1AgentGoalcycle11x11-prestige-ts11": (4, 100, 1),
+    "Test-3AgentCluttered9x9-prestige-mixed": (8, 150, 2),
 }
 CANON = ("base_enc", "pos", "dir", "active", "done", "carry_enc", "ordinal")
 
@@ -214,6 +217,7 @@ FRAMES = {  # scenario -> (seeds, steps at which env.render() is captured)
     "Test-4AgentEmpty5x5-crowded": ([1337, 1340], [0, 5, 40]),
     "Goalcycle-demo-solo-v0": ([1337], [0, 12]),
     "Test-2AgentEmpty7x7-see-through": ([1337], [0, 9]),
+    "Test-2AgentGoalcycle9x9-prestige": ([1337, 1339], [0, 25, 50]),
 }
 
 

@@ -16,7 +16,8 @@ def make_ref_env(spec, recipe, seed=1337):
     agents = [GridAgentInterface(color=a["color"], view_size=spec["view_size"],
                                  view_tile_size=spec["tile_size"], view_offset=spec["view_offset"],
                                  see_through_walls=spec["see_through_walls"], spawn_delay=a.get("spawn_delay", 0),
-                                 hide_item_types=list(a.get("hide_item_types", [])))
+                                 hide_item_types=list(a.get("hide_item_types", [])),
+                                 prestige_beta=a.get("prestige_beta", 0.95), prestige_scale=a.get("prestige_scale", 2))
               for a in spec["agents"]]
     kw = dict(kwargs)
     kw.setdefault("max_steps", spec["max_steps"])

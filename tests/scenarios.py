@@ -10,7 +10,9 @@ GOAL = dict(type="Goal", color="green", state=0, reward=1)          # cluttered.
 
 def _base(n_agents, grid_size, view_size, tile_size=8, view_offset=0, colors=None, **kw):
     colors = colors or REG_COLORS[:n_agents]
-    spec = dict(W=grid_size, H=grid_size, agents=[dict(color=c) for c in colors],
+    spec = dict(W=grid_size, H=grid_size,
+                agents=[dict(color=c, prestige_beta=0.95, prestige_scale=2) if c == "prestige" else dict(color=c)
+                        for c in colors],
                 view_size=view_size, tile_size=tile_size, view_offset=view_offset,
                 see_through_walls=False, max_steps=100, reward_decay=True, ghost_mode=True,
                 respawn=False)
@@ -112,6 +114,11 @@ def ref_recipe(name):
         "Test-4AgentEmpty5x5-hide": ("EmptyMultiGrid", dict(grid_size=5)),
         "Test-3AgentCluttered9x9-hide": ("ClutteredMultiGrid", dict(grid_size=9, n_clutter=8)),
         "Test-2AgentRegion9x9": ("RegionTestEnv", dict(grid_size=9)),
+        "Test-2AgentGoalcycle9x9-prestige": ("ClutteredGoalCycleEnv", dict(grid_size=9, n_clutter=4, n_bonus_tiles=3,
+                                                                           penalty=-1.5, max_steps=60)),
+        "Test-1AgentGoalcycle11x11-prestige-ts11": ("ClutteredGoalCycleEnv", dict(grid_size=11, clutter_density=0.1,
+                                                                                  n_bonus_tiles=3, max_steps=80)),
+        "Test-3AgentCluttered9x9-prestige-mixed": ("ClutteredMultiGrid", dict(grid_size=9, n_clutter=5, respawn=True)),
         # oracle-only edge shapes (no golden file): view sizes / tile sizes / agent counts / big grids
         "Edge-12AgentCluttered9x9-view3": ("ClutteredMultiGrid", dict(grid_size=9, n_clutter=5)),
         "Edge-2AgentCluttered40x40-view9-off3": ("ClutteredMultiGrid", dict(grid_size=40, clutter_density=0.2)),
@@ -173,6 +180,13 @@ def registered(name):   # noqa: F811  (extends the table above with test-only sc
         "Test-4AgentEmpty5x5-hide": lambda: _with_hide(empty_spec(4, 5, 5), [["Agent"], ["Goal"], ["Wall", "Goal", "Agent"], []]),
         "Test-3AgentCluttered9x9-hide": lambda: _with_hide(cluttered_spec(3, 9, 7, n_clutter=8), [["Wall"], ["Agent", "Goal"], []]),
         "Test-2AgentRegion9x9": lambda: region_spec(),
+        "Test-2AgentGoalcycle9x9-prestige": lambda: goalcycle_spec(2, 9, 7, n_clutter=4, n_bonus_tiles=3, penalty=-1.5,
+                                                                   max_steps=60, colors=["prestige", "prestige"]),
+        "Test-1AgentGoalcycle11x11-prestige-ts11": lambda: goalcycle_spec(1, 11, 7, clutter_density=0.1, n_bonus_tiles=3,
+                                                                          max_steps=80, colors=["prestige"], tile_size=11,
+                                                                          view_offset=1),
+        "Test-3AgentCluttered9x9-prestige-mixed": lambda: cluttered_spec(3, 9, 7, n_clutter=5, respawn=True,
+                                                                         colors=["prestige", "blue", "prestige"]),
         "Edge-12AgentCluttered9x9-view3": lambda: cluttered_spec(12, 9, 3, n_clutter=5, colors=_MANY[:12]),
         "Edge-2AgentCluttered40x40-view9-off3": lambda: cluttered_spec(2, 40, 9, clutter_density=0.2, view_offset=3),
         "Edge-3AgentCluttered13x13-view11": lambda: cluttered_spec(3, 13, 11, n_clutter=20),
@@ -196,7 +210,8 @@ ALL_SCENARIOS = [
     "Test-4AgentEmpty5x5-crowded-noghost", "Test-2AgentCluttered9x9-offset2-ts5",
     "Test-2AgentEmpty7x7-see-through", "Test-3AgentCluttered9x9-respawn", "Test-4AgentEmpty5x5-respawn-noghost",
     "Test-3AgentEmpty7x7-spawn-delay", "Test-4AgentEmpty5x5-hide", "Test-3AgentCluttered9x9-hide",
-    "Test-2AgentRegion9x9",
+    "Test-2AgentRegion9x9", "Test-2AgentGoalcycle9x9-prestige", "Test-1AgentGoalcycle11x11-prestige-ts11",
+    "Test-3AgentCluttered9x9-prestige-mixed",
 ]
 
 

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     if not os.path.exists(so):
         import __graft_entry__ as ge
         ge.build()
-    L = ctypes.CDLL(so)
+    L = ctypes.CDLL(so, mode=os.RTLD_NOW)        # RTLD_NOW: also catches undefined internal symbols
     for name in declared:
         assert hasattr(L, name), name
     L.mg_abi_version.restype = ctypes.c_int32
