@@ -107,7 +107,10 @@ typedef struct MgObjDesc {
 typedef struct MgConfig {
     int32_t B, W, H, n_agents;
     int32_t view_size, tile_size, view_offset, see_through_walls; /* agents.py:19-35 (uniform) */
-    int32_t max_steps, reward_decay, ghost_mode, respawn;         /* base.py:341-346 */
+    int32_t max_steps, reward_decay, ghost_mode, respawn;         /* base.py:341-346.  ghost_mode bits:
+                                                                   * 1 = moves may enter occupied cells (`ghost_mode is
+                                                                   * not False`, base.py:541), 2 = placements may land on
+                                                                   * occupied cells (`bool(ghost_mode)`, base.py:683) */
     int32_t cells_stride;                                         /* bytes per env in `grid` */
     int32_t n_obj;                                                /* valid object ids: 0..n_obj-1 */
     int32_t n_ovl_slots;                                          /* slot 0 = empty cell */

@@ -507,7 +507,9 @@ class MultiGridEnv(object):
         cfg.view_size, cfg.tile_size = self.view_size, self.tile_size
         cfg.view_offset, cfg.see_through_walls = self.view_offset, int(self.see_through_walls)
         cfg.max_steps, cfg.reward_decay = self.max_steps, int(bool(self.reward_decay))
-        cfg.ghost_mode = int(self.ghost_mode is not False)        # base.py:541 `is False`
+        # upstream tests `ghost_mode is False` when moving (base.py:541) but `not ghost_mode` when placing
+        # (base.py:683): they differ for falsy non-False values such as 0 or None
+        cfg.ghost_mode = (1 if self.ghost_mode is not False else 0) | (2 if self.ghost_mode else 0)
         cfg.respawn = int(bool(self.respawn))
         cfg.cells_stride = self.cells_stride
         cfg.n_obj, cfg.n_ovl_slots, cfg.n_tiles = len(objs), n_slots, atlas.shape[1]
@@ -841,7 +843,7 @@ class MultiGridEnv(object):
         return dict(W=self.width, H=self.height, agents=[aspec(a) for a in self.agents],
                     view_size=self.view_size, tile_size=self.tile_size, view_offset=self.view_offset,
                     see_through_walls=self.see_through_walls, max_steps=self.max_steps,
-                    reward_decay=bool(self.reward_decay), ghost_mode=self.ghost_mode is not False,
+                    reward_decay=bool(self.reward_decay), ghost_mode=self.ghost_mode,
                     respawn=bool(self.respawn), objects=[ospec(o) for o in self.obj_reg.objs],
                     wall_obj=self.obj_reg.find(Wall()), gen_ctor=prog(self._spec_ctor or self._spec_last),
                     gen_reset=prog(self._spec_last))

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(MgConfig cfg, MgState st,
                 // try_place_obj (base.py:664-688): the cell's object must can_overlap (agents do);
                 // without ghost_mode an occupied cell rejects
                 bool overlap_ok = (base == 0) || (cfg.obj[base].flags & MG_OF_CAN_OVERLAP);
-                if (overlap_ok && (cnt == 0 || cfg.ghost_mode)) {
+                if (overlap_ok && (cnt == 0 || (cfg.ghost_mode & 2))) {
                     nr = rec_set(nr, MG_AG_X, (uint32_t)x);
                     nr = rec_set(nr, MG_AG_Y, (uint32_t)y);
                     nr = rec_set(nr, MG_AG_FLAGS, MG_AF_ACTIVE | MG_AF_PLACED);
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(kBlock) void place_kernel(MgConfig cfg, MgState st,
         if (!is_agent) {
             // only an empty cell (no object, no agent) accepts a non-agent object (base.py:672-679)
             if (base == 0 && cnt == 0) { g[x * H + y] = (uint8_t)what; ok = true; }
-        } else if ((base == 0 || (cfg.obj[base].flags & MG_OF_CAN_OVERLAP)) && (cnt == 0 || cfg.ghost_mode)) {
+        } else if ((base == 0 || (cfg.obj[base].flags & MG_OF_CAN_OVERLAP)) && (cnt == 0 || (cfg.ghost_mode & 2))) {
             uint64_t r = recs[k];
             const uint32_t old_rank = rec_byte(r, MG_AG_RANK);
             for (int j = 0; j < n; j++) {

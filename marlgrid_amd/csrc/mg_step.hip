@@ -67,7 +67,7 @@ __global__ __launch_bounds__(BS) void step_kernel(MgConfig cfg, MgState st, cons
                 const uint64_t rj = s_rec[j * BS + tid];
                 cnt += ((rec_byte(rj, MG_AG_FLAGS) & MG_AF_PLACED) && rec_xy(rj) == xy) ? 1 : 0;
             }
-            if ((base == 0 || (s_oflags[base] & MG_OF_CAN_OVERLAP)) && (cnt == 0 || cfg.ghost_mode)) {
+            if ((base == 0 || (s_oflags[base] & MG_OF_CAN_OVERLAP)) && (cnt == 0 || (cfg.ghost_mode & 2))) {
                 const uint32_t old_rank = rec_byte(r, MG_AG_RANK);
                 for (int j = 0; j < n; j++) {
                     const uint64_t rj = s_rec[j * BS + tid];
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(BS) void step_kernel(MgConfig cfg, MgState st, cons
                         // fwd_cell is None, or it can_overlap(); the top object is the base object if
                         // there is one, else the first agent standing there (agents overlap)
                         bool can_move = fbase ? (fflags & MG_OF_CAN_OVERLAP) != 0 : true;
-                        if (!cfg.ghost_mode && fbase == 0 && agents_there > 0) can_move = false;  // :541-542
+                        if (!(cfg.ghost_mode & 1) && fbase == 0 && agents_there > 0) can_move = false;  // :541-542
                         if (can_move) {
                             // arrival: highest rank; everyone above the old rank slides down
                             const uint32_t old_rank = rec_byte(r, MG_AG_RANK);

@@ -348,7 +348,7 @@ static int try_place(MgoEnv* e, int val, int x, int y) {
     if (!(val_can_overlap(e, g) && obj_is_agent)) return 0;
     int g_is_agent = is_agent_val(g);
     int g_n = g_is_agent ? e->ag_nagents[g - MGO_AGENT_BASE] : e->cell_nagents[c];
-    if (!e->sh->cfg.ghost_mode && (g_is_agent || g_n > 0)) return 0;
+    if (!(e->sh->cfg.ghost_mode & 2) && (g_is_agent || g_n > 0)) return 0;   /* `not self.ghost_mode` */
     int k = val - MGO_AGENT_BASE;
     if (g_is_agent) e->ag_agents[g - MGO_AGENT_BASE][e->ag_nagents[g - MGO_AGENT_BASE]++] = k;
     else e->cell_agents[c * MGO_MAX_AGENTS + e->cell_nagents[c]++] = k;
@@ -524,7 +524,7 @@ int32_t mgo_step(MgoEnv* e, const int32_t* actions, double* rewards, int32_t* ep
             e->adir[k] = (e->adir[k] + 1) % 4;
         } else if (action == 2) {                     /* forward — :538-585 */
             int can_move = (fwd_cell == 0) || val_can_overlap(e, fwd_cell);
-            if (!cfg->ghost_mode && is_agent_val(fwd_cell)) can_move = 0;
+            if (!(cfg->ghost_mode & 1) && is_agent_val(fwd_cell)) can_move = 0;   /* `self.ghost_mode is False` */
             if (can_move) {
                 /* add agent to new cell — :547-552 */
                 if (fwd_cell == 0) e->cell[fc] = me;

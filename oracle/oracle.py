@@ -226,7 +226,8 @@ def make_config(spec):
     cfg.see_through_walls = int(spec.get("see_through_walls", False))
     cfg.max_steps = spec.get("max_steps", 100)
     cfg.reward_decay = int(bool(spec.get("reward_decay", True)))
-    cfg.ghost_mode = int(spec.get("ghost_mode", True) is not False)   # base.py:541 `is False`
+    gm = spec.get("ghost_mode", True)      # bit 1: `is not False` (base.py:541), bit 2: truthy (base.py:683)
+    cfg.ghost_mode = (1 if gm is not False else 0) | (2 if gm else 0)
     cfg.respawn = int(bool(spec.get("respawn", False)))
     cfg.agent_type_idx = TYPE_IDX["GridAgentInterface"]
     for k, a in enumerate(agents):

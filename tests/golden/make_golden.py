@@ -49,6 +49,7 @@ TRAJ = {  # scenario -> (n_seeds, n_steps, n_full_obs_seeds)
     "Test-2AgentGoalcycle9x9-prestige": (8, 120, 2),
     "Test-1AgentGoalcycle11x11-prestige-ts11": (4, 100, 1),
     "Test-3AgentCluttered9x9-prestige-mixed": (8, 150, 2),
+    "Test-4AgentEmpty5x5-ghost0": (6, 120, 1),
 }
 CANON = ("base_enc", "pos", "dir", "active", "done", "carry_enc", "ordinal")
 

@@ -106,6 +106,7 @@ def ref_recipe(name):
         "Test-3AgentCluttered11x11-noghost": ("ClutteredMultiGrid", dict(grid_size=11, clutter_density=0.15, ghost_mode=False)),
         "Test-4AgentEmpty5x5-crowded": ("EmptyMultiGrid", dict(grid_size=5)),
         "Test-4AgentEmpty5x5-crowded-noghost": ("EmptyMultiGrid", dict(grid_size=5, ghost_mode=False)),
+        "Test-4AgentEmpty5x5-ghost0": ("EmptyMultiGrid", dict(grid_size=5, ghost_mode=0)),
         "Test-2AgentCluttered9x9-offset2-ts5": ("ClutteredMultiGrid", dict(grid_size=9, n_clutter=8, randomize_goal=True)),
         "Test-2AgentEmpty7x7-see-through": ("EmptyMultiGrid", dict(grid_size=7)),
         "Test-3AgentCluttered9x9-respawn": ("ClutteredMultiGrid", dict(grid_size=9, n_clutter=6, respawn=True)),
@@ -175,6 +176,7 @@ def registered(name):   # noqa: F811  (extends the table above with test-only sc
         "Test-3AgentCluttered11x11-noghost": lambda: cluttered_spec(3, 11, 7, clutter_density=0.15, ghost_mode=False),
         "Test-4AgentEmpty5x5-crowded": lambda: empty_spec(4, 5, 5),
         "Test-4AgentEmpty5x5-crowded-noghost": lambda: empty_spec(4, 5, 5, ghost_mode=False),
+        "Test-4AgentEmpty5x5-ghost0": lambda: empty_spec(4, 5, 5, ghost_mode=0),
         "Test-2AgentCluttered9x9-offset2-ts5": lambda: cluttered_spec(2, 9, 5, n_clutter=8, randomize_goal=True,
                                                                         tile_size=5, view_offset=2),
         "Test-2AgentEmpty7x7-see-through": lambda: empty_spec(2, 7, 3, see_through_walls=True, tile_size=11),
@@ -219,7 +221,7 @@ ALL_SCENARIOS = [
     "Test-2AgentEmpty7x7-see-through", "Test-3AgentCluttered9x9-respawn", "Test-4AgentEmpty5x5-respawn-noghost",
     "Test-3AgentEmpty7x7-spawn-delay", "Test-4AgentEmpty5x5-hide", "Test-3AgentCluttered9x9-hide",
     "Test-2AgentRegion9x9", "Test-2AgentGoalcycle9x9-prestige", "Test-1AgentGoalcycle11x11-prestige-ts11",
-    "Test-3AgentCluttered9x9-prestige-mixed",
+    "Test-3AgentCluttered9x9-prestige-mixed", "Test-4AgentEmpty5x5-ghost0",
 ]
 
 

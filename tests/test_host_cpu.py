@@ -150,3 +150,24 @@ def test_oversized_configuration_is_rejected_on_the_host():
     env.device = None
     with pytest.raises(NotImplementedError, match="LDS"):
         env._sync_tables()
+
+
+def test_env_from_config_and_make():
+    """env_from_config (envs/__init__.py:58-67) builds the class named in the dict; make() knows the
+    registered ids and rejects unknown ones."""
+    from marlgrid_amd import envs as E
+    cfg = {"env_class": "ClutteredGoalCycleEnv", "grid_size": 13, "max_steps": 250, "clutter_density": 0.15,
+           "respawn": True, "ghost_mode": True, "reward_decay": False, "n_bonus_tiles": 3, "initial_reward": True,
+           "penalty": -1.5,
+           "agents": [{"view_size": 7, "view_offset": 1, "view_tile_size": 11, "observation_style": "rich",
+                       "see_through_walls": False, "color": "prestige"}], "_dry": True}
+    env = E.env_from_config(cfg, randomize_seed=False)
+    assert isinstance(env, E.ClutteredGoalCycleEnv) and env.num_agents == 1 and env.agents[0].color == "prestige"
+    assert env.view_offset == 1 and env.tile_size == 11 and env.respawn is True
+    env2 = E.env_from_config(cfg)          # randomize_seed=True adds random.randint(0, 1337**2) to the seed
+    assert env2.seeds[0] >= 0
+    assert len(E.registered_envs) == 7
+    with pytest.raises(KeyError):
+        E.make("MarlGrid-NoSuchEnv-v0")
+    e3 = E.make("MarlGrid-4AgentEmpty9x9-v0", _dry=True, batch_size=5)
+    assert e3.num_agents == 4 and e3.batch_size == 5 and len(e3.seeds) == 5 and e3.seeds[0] == 1337
