@@ -160,11 +160,11 @@ def cpu_baseline(budget_s, workload=WORKLOAD):
     threads = orc.max_threads()
     rng = np.random.RandomState(0)
     acts = [rng.randint(0, 7, size=(Bc, orc.n)) for _ in range(16)]
-    orc.step(acts[0], auto_reset=True)
+    orc.step(acts[0], auto_reset=True, reuse_obs=True)
     t0 = time.perf_counter()
     steps = 0
     while time.perf_counter() - t0 < budget_s:
-        orc.step(acts[steps % 16], auto_reset=True)
+        orc.step(acts[steps % 16], auto_reset=True, reuse_obs=True)
         steps += 1
     dt = time.perf_counter() - t0
     return {"value": Bc * orc.n * steps / dt, "unit": "agent-steps/s", "cores": int(threads), "kind": "port",

@@ -449,11 +449,18 @@ class OracleBatch(object):
     def gen_obs(self):
         return np.stack([e.gen_obs() for e in self.envs])
 
-    def step(self, actions, render=True, auto_reset=False, threads=0):
+    def step(self, actions, render=True, auto_reset=False, threads=0, reuse_obs=False):
         a = np.ascontiguousarray(actions, dtype=np.int32).reshape(self.B, self.n)
         rew = np.zeros((self.B, self.n), np.float64)
         done = np.zeros(self.B, np.uint8)
-        obs = np.zeros((self.B, self.n, self.P, self.P, 3), np.uint8) if render else None
+        obs = None
+        if render:
+            if reuse_obs:      # benchmark leg: no 50 MB allocation + page faults per step
+                if getattr(self, "_obs_buf", None) is None:
+                    self._obs_buf = np.zeros((self.B, self.n, self.P, self.P, 3), np.uint8)
+                obs = self._obs_buf
+            else:
+                obs = np.zeros((self.B, self.n, self.P, self.P, 3), np.uint8)
         rc = self.L.mgo_batch_step(self._h, self.B, _p(a, C.c_int32), _p(rew, C.c_double), _p(done, C.c_uint8),
                                    None if obs is None else _p(obs, C.c_uint8), int(auto_reset), threads)
         _raise(rc)
