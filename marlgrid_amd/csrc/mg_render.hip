@@ -463,7 +463,7 @@ static hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_
 // over 4-wave workgroups at the bench batch.  Small batches keep 4-wave workgroups so that they
 // still spread over all CUs.
 static int choose_wpb(const MgConfig& cfg) {
-    if (const char* f = getenv("MG_RENDER_WPB")) { int w = atoi(f); if (w == 4 || w == 16) return w; }
+    if (const char* f = getenv("MG_RENDER_WPB")) { int w = atoi(f); if (w == 4 || w == 8 || w == 16) return w; }
     const int tile_bytes = cfg.tile_size * cfg.tile_size * 3;
     const RenderScratch L = render_scratch_layout(cfg.cells_stride, cfg.n_agents, cfg.view_size);
     size_t lds16 = (size_t)round_up(4 * cfg.n_tiles * tile_bytes, 16) + 2 * MG_MAX_OBJ + MG_MAX_AGENTS * 8 + 16 * (size_t)L.total;
@@ -473,6 +473,8 @@ static int choose_wpb(const MgConfig& cfg) {
 #define MG_RENDER_DISPATCH(VS, TS, V)                                                                      \
     (wpb == 16 ? launch_render_t<VS, TS, 16, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s)           \
                : launch_render_t<VS, TS, 4, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s))
+#define MG_RENDER_DISPATCH8(VS, TS, V)                                                                     \
+    (wpb == 8 ? launch_render_t<VS, TS, 8, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s) : MG_RENDER_DISPATCH(VS, TS, V))
 
 hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, uint8_t* view_cells,
                          uint8_t* view_agent, uint8_t* vis_mask, hipStream_t s) {
@@ -506,7 +508,7 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
         case 5: return MG_RENDER_DISPATCH(7, 8, 5);
         case 6: return MG_RENDER_DISPATCH(7, 8, 6);
         case 7: return MG_RENDER_DISPATCH(7, 8, 7);
-        default: return MG_RENDER_DISPATCH(7, 8, 0);
+        default: return MG_RENDER_DISPATCH8(7, 8, 0);
         }
     }
     if (ts == 8 && vs == 9) return MG_RENDER_DISPATCH(9, 8, 0);
