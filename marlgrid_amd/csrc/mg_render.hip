@@ -517,7 +517,8 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
     if (ts == 8) return MG_RENDER_DISPATCH(0, 8, 0);      // other view sizes: run-time VS, same raster
     if (ts == 16) return MG_RENDER_DISPATCH(0, 16, 0);
     if (ts == 32) return MG_RENDER_DISPATCH(0, 32, 0);
-    if (vs == 7) return MG_RENDER_DISPATCH(7, 0, 0);      // the default view with any tile size (default tile: 5)
+    if (vs == 7 && ts == 5) return MG_RENDER_DISPATCH(7, 5, 0);   // GridAgentInterface's defaults (agents.py:21-22)
+    if (vs == 7) return MG_RENDER_DISPATCH(7, 0, 0);      // the default view with any other tile size
     return MG_RENDER_DISPATCH(0, 0, 0);                   // anything else
 }
 

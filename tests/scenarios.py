@@ -130,6 +130,7 @@ def ref_recipe(name):
         "Edge-2AgentCluttered9x9-view3-ts32": ("ClutteredMultiGrid", dict(grid_size=9, n_clutter=6)),
         "Edge-3AgentCluttered13x13-view13-ts8": ("ClutteredMultiGrid", dict(grid_size=13, n_clutter=20)),
         "Edge-2AgentEmpty6x6-view3-ts33": ("EmptyMultiGrid", dict(grid_size=6)),
+        "Edge-3AgentCluttered15x15-default-tiles": ("ClutteredMultiGrid", dict(grid_size=15, n_clutter=10)),
         # the reference's examples/human_player.py configuration (examples/human_player.py:35-55)
         "Edge-HumanPlayerConfig": ("ClutteredGoalCycleEnv", dict(grid_size=13, max_steps=250, clutter_density=0.15,
                                                                  respawn=True, ghost_mode=True, reward_decay=False,
@@ -202,6 +203,9 @@ def registered(name):   # noqa: F811  (extends the table above with test-only sc
         "Edge-2AgentCluttered9x9-view3-ts32": lambda: cluttered_spec(2, 9, 3, n_clutter=6, tile_size=32, view_offset=1),
         "Edge-3AgentCluttered13x13-view13-ts8": lambda: cluttered_spec(3, 13, 13, n_clutter=20),
         "Edge-2AgentEmpty6x6-view3-ts33": lambda: empty_spec(2, 6, 3, tile_size=33),
+        # README.md:36 `ClutteredMultiGrid(agents, grid_size=15, n_clutter=10)` with default agents (view 7, tile 5)
+        "Edge-3AgentCluttered15x15-default-tiles": lambda: cluttered_spec(3, 15, 7, n_clutter=10, tile_size=5,
+                                                                          colors=["red", "red", "red"]),
         "Edge-HumanPlayerConfig": lambda: goalcycle_spec(1, 13, 7, clutter_density=0.15, n_bonus_tiles=3, penalty=-1.5,
                                                          initial_reward=True, max_steps=250, respawn=True,
                                                          reward_decay=False, colors=["prestige"], tile_size=11,

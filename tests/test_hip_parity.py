@@ -104,6 +104,7 @@ def test_rng_seeding_golden():
                                        ("Edge-3AgentCluttered13x13-view13-ts8", 64, 30),
                                        ("Edge-2AgentEmpty6x6-view3-ts33", 32, 20),
                                        ("Edge-HumanPlayerConfig", 128, 260),
+                                       ("Edge-3AgentCluttered15x15-default-tiles", 4100, 40),
                                        ("Test-3AgentCluttered9x9-prestige-mixed", 256, 160)])
 def test_batch_vs_oracle(name, B, T):
     """same seeds, same actions: HIP batch == B oracle envs, every step, full observations."""
