@@ -34,7 +34,7 @@ namespace mg {
 // V_: 0 = production; 8 = production with the atlas read from global memory (chosen by the launcher
 //     when it does not fit LDS); 9 = production with per-env recoloured tiles for 'prestige' agents.  2..7 = measurement variants for tools/ab_render.py (MG_RENDER_VARIANT,
 //     <7,8> only): 2 nontemporal stores, 3 raster only (phases 2-5 skipped), 4 stores only (no LDS
-//     look-ups), 5 no next-env prefetch, 6 no store bursts, 7 grid-strided env walk.
+//     look-ups), 5 no next-env prefetch, 6 no store bursts, 7 grid-strided env walk, 10 two waves per env.
 // WPB = waves per workgroup (4 or 16; MG_RENDER_WPB overrides the launcher's choice).
 template <int VS_, int TS_, int WPB, int V_ = 0>
 __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState st, uint8_t* __restrict__ obs,
@@ -96,8 +96,14 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     // raster geometry of the 16-byte-chunk path (see phase 6): pairs per pixel row, a lane's start
     // position and its per-trip advance — constants of the launch, folded at compile time when VS_ > 0
     const uint32_t PR = (uint32_t)VS * (uint32_t)(TS * 3 / 8);
-    const uint32_t STEP_R = PR ? (2u * kWave) / PR : 0u, STEP_P = PR ? (2u * kWave) - STEP_R * PR : 0u;
-    const uint32_t rast_r0 = PR ? (2u * lane) / PR : 0u, rast_p0 = PR ? 2u * lane - rast_r0 * PR : 0u;
+    // V_ == 10 (measurement): TWO waves per env — both derive the env's tmap on their own (no cross-wave
+    // hand-off) and each rasters every other 1 KiB chunk, which halves the number of concurrent streams
+    constexpr int kPair = (V_ == 10) ? 2 : 1;
+    const int parity = (kPair == 2) ? (wave & 1) : 0;
+    constexpr uint32_t CH_STRIDE = kWave * kPair;                     // chunks a wave advances per trip
+    const uint32_t c_first = (uint32_t)lane + (uint32_t)(kWave * parity);
+    const uint32_t STEP_R = PR ? (2u * CH_STRIDE) / PR : 0u, STEP_P = PR ? (2u * CH_STRIDE) - STEP_R * PR : 0u;
+    const uint32_t rast_r0 = PR ? (2u * c_first) / PR : 0u, rast_p0 = PR ? 2u * c_first - rast_r0 * PR : 0u;
 
     // next-env prefetch registers: the env's grid (<= 1 KiB: one dword per lane per 256 B) and records
     constexpr int kPF = 4;
@@ -107,9 +113,9 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     uint64_t pf_r = 0;
     // Each wave walks its own CONTIGUOUS run of envs, i.e. one long sequential output stream per wave
     // (measured +5 % HBM write throughput over a grid-strided walk, which is variant 7).
-    const int per_wave = (cfg.B + gridDim.x * WPB - 1) / (gridDim.x * WPB);
+    const int per_wave = (cfg.B * kPair + gridDim.x * WPB - 1) / (gridDim.x * WPB);
     const int e_stride = (V_ != 7) ? 1 : gridDim.x * WPB;
-    int e = (V_ != 7) ? (blockIdx.x * WPB + wave) * per_wave : blockIdx.x * WPB + wave;
+    int e = (V_ != 7) ? ((blockIdx.x * WPB + wave) / kPair) * per_wave : blockIdx.x * WPB + wave;
     const int e_end = (V_ != 7) ? min(cfg.B, e + per_wave) : cfg.B;
     auto prefetch = [&](int en) {
         const uint32_t* gsrc = reinterpret_cast<const uint32_t*>(st.grid + (size_t)en * cfg.cells_stride);
@@ -333,16 +339,17 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                     __builtin_nontemporal_store(nv, reinterpret_cast<u32x4*>(out + c));
                 } else out[c] = v;
             };
-            int c = lane;
+            int c = (int)c_first;
+            constexpr int CS = (int)CH_STRIDE;
             if constexpr (V_ != 6) {
                 // gather four chunks from LDS, then issue their four 1-KiB stores back to back
-                for (; c + 3 * kWave < total; c += 4 * kWave) {
+                for (; c + 3 * CS < total; c += 4 * CS) {
                     uint4 v0, v1, v2, v3;
                     fetch(v0); fetch(v1); fetch(v2); fetch(v3);
-                    put(c, v0); put(c + kWave, v1); put(c + 2 * kWave, v2); put(c + 3 * kWave, v3);
+                    put(c, v0); put(c + CS, v1); put(c + 2 * CS, v2); put(c + 3 * CS, v3);
                 }
             }
-            for (; c < total; c += kWave) {
+            for (; c < total; c += CS) {
                 uint4 v;
                 fetch(v);
                 put(c, v);
@@ -451,7 +458,7 @@ static hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_
     if (per_cu > 20 / WPB) per_cu = 20 / WPB;
     if (per_cu < 1) per_cu = 1;
     const int max_blocks = 256 * per_cu;
-    const int need = (cfg.B + WPB - 1) / WPB;              // workgroups if every wave took one env
+    const int need = (cfg.B * (V_ == 10 ? 2 : 1) + WPB - 1) / WPB;   // workgroups if every wave took one env
     const int rounds = (need + max_blocks - 1) / max_blocks;
     const int blocks = (need + rounds - 1) / rounds;
     hipLaunchKernelGGL((render_kernel<VS_, TS_, WPB, V_>), dim3(blocks), dim3(WPB * 64), lds, s, cfg, st, obs, c, a, v);
@@ -508,6 +515,7 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
         case 5: return MG_RENDER_DISPATCH(7, 8, 5);
         case 6: return MG_RENDER_DISPATCH(7, 8, 6);
         case 7: return MG_RENDER_DISPATCH(7, 8, 7);
+        case 10: return MG_RENDER_DISPATCH(7, 8, 10);
         default: return MG_RENDER_DISPATCH8(7, 8, 0);
         }
     }
