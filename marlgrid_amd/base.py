@@ -24,6 +24,7 @@ Differences from the reference that the batch forces (documented in DESIGN.md):
     matching Python exception after the step (strict=True) or on `check_errors()`.
 """
 import ctypes as C
+import functools
 import threading
 
 import numpy as np
@@ -36,6 +37,21 @@ from .objects import COLOR_TO_IDX, OBJECT_TYPES, BonusTile, Box, Door, Goal, Key
 TILE_PIXELS = 32
 
 _trace = threading.local()
+
+
+def _on_device(fn):
+    """Run a method with the env's GPU as the current HIP device (kernels are launched on a stream of
+    that device; a mismatch only happens when one process drives several GPUs)."""
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        if self._dry:
+            return fn(self, *args, **kwargs)
+        import torch
+        if torch.cuda.current_device() == self.device.index:
+            return fn(self, *args, **kwargs)
+        with torch.cuda.device(self.device):
+            return fn(self, *args, **kwargs)
+    return wrapper
 
 
 class ObjectRegistry(object):
@@ -300,6 +316,7 @@ class MultiGridEnv(object):
         import torch
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    @_on_device
     def seed(self, seed=1337):
         """Seed every env's RNG (base.py:371-374).  Env b gets `seed + b` unless explicit per-env
         `seeds` were given to the constructor."""
@@ -357,6 +374,7 @@ class MultiGridEnv(object):
         self._spec_last = dict(sym=list(self._tr_sym), ops=list(self._tr_ops))
         return g._template, list(self._tr_ops)
 
+    @_on_device
     def put_obj(self, obj, i, j, env_mask=None):
         """Put an object at a specific position, replacing what is there (base.py:655-662)."""
         if self._tracing:
@@ -385,6 +403,7 @@ class MultiGridEnv(object):
             return -(self.agents.index(obj) + 1)
         return self.obj_reg.get_key(obj)
 
+    @_on_device
     def _place_live(self, obj, top, size, max_tries, env_mask):
         """place_obj on the live grids: per-env rejection sampling on each env's RNG.  Returns the
         chosen positions (B, 2) int32 (-1, -1 where it failed: RecursionError on check_errors())."""
@@ -418,6 +437,7 @@ class MultiGridEnv(object):
             self._tr_ops.append(op)
         return None
 
+    @_on_device
     def try_place_obj(self, obj, pos, env_mask=None):
         """Try to place `obj` (an object, or one of this env's agents) at `pos` — one (x, y) for every
         env or a (B, 2) tensor — and return a (B,) bool tensor saying where it worked (base.py:664-688)."""
@@ -573,6 +593,7 @@ class MultiGridEnv(object):
         return C.c_void_p(self._mask_keep.data_ptr())
 
     # ---- the gym surface -----------------------------------------------------------------------------
+    @_on_device
     def reset(self, env_mask=None, **kwargs):
         """Start a new episode in every env (or those selected by `env_mask`) and return the
         observation tensor (B, n, P, P, 3) — base.py:402-416."""
@@ -589,6 +610,7 @@ class MultiGridEnv(object):
             self.check_errors()
         return self._package_obs()
 
+    @_on_device
     def step(self, actions):
         """actions: (B, n) integer tensor (device preferred) or array-like -> (obs, rewards, done, {})
         with obs (B, n, P, P, 3) uint8, rewards (B, n) float32, done (B,) bool — base.py:501-653."""
@@ -649,6 +671,7 @@ class MultiGridEnv(object):
                                         None, self._stream()))
         return None
 
+    @_on_device
     def gen_obs(self):
         """(B, n, P, P, 3) uint8, or the per-agent list for 'rich' agents (base.py:473-474)"""
         self._render()
@@ -663,6 +686,7 @@ class MultiGridEnv(object):
             return self.obs
         return [self._agent_obs(k) for k in range(self.num_agents)]
 
+    @_on_device
     def gen_agent_obs(self, agent):
         """agent: a GridAgentInterface of this env or its index -> (B, P, P, 3) (base.py:453-471)"""
         k = agent if isinstance(agent, int) else self.agents.index(agent)
@@ -687,6 +711,7 @@ class MultiGridEnv(object):
             ret["orientation"] = self.agent_dir[:, k]
         return ret
 
+    @_on_device
     def gen_obs_grid(self, agent):
         """(view cells (B, vs, vs) object ids indexed [i, j], visibility mask (B, vs, vs) bool) for one
         agent — base.py:418-451"""
@@ -694,6 +719,7 @@ class MultiGridEnv(object):
         cells, _shown, vis = self._render(debug=True)
         return cells[:, k], vis[:, k].bool()
 
+    @_on_device
     def _encode(self, vis_mask=None):
         import torch
         self._sync_tables()
@@ -706,6 +732,7 @@ class MultiGridEnv(object):
                                     None if vm is None else C.c_void_p(vm.data_ptr()), out.data_ptr(), self._stream()))
         return out
 
+    @_on_device
     def check_errors(self):
         """Raise the reference's exception for the first env that hit one (host sync)."""
         import torch
@@ -848,6 +875,7 @@ class MultiGridEnv(object):
                     wall_obj=self.obj_reg.find(Wall()), gen_ctor=prog(self._spec_ctor or self._spec_last),
                     gen_reset=prog(self._spec_last))
 
+    @_on_device
     def render(self, mode="rgb_array", close=False, highlight=True, tile_size=TILE_PIXELS, show_agent_views=True,
                max_agents_per_col=3, agent_col_width_frac=0.3, agent_col_padding_px=2, pad_grey=100, env_ids=None):
         """Whole-grid human view (base.py:714-795): every cell at `tile_size` pixels, cells visible to
