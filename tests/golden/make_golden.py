@@ -50,6 +50,8 @@ TRAJ = {  # scenario -> (n_seeds, n_steps, n_full_obs_seeds)
     "Test-1AgentGoalcycle11x11-prestige-ts11": (4, 100, 1),
     "Test-3AgentCluttered9x9-prestige-mixed": (8, 150, 2),
     "Test-4AgentEmpty5x5-ghost0": (6, 120, 1),
+    "Test-3AgentEmpty7x11-nonsquare": (6, 120, 2),
+    "Test-3AgentCluttered12x6-nonsquare": (6, 120, 2),
 }
 CANON = ("base_enc", "pos", "dir", "active", "done", "carry_enc", "ordinal")
 
@@ -219,6 +221,8 @@ FRAMES = {  # scenario -> (seeds, steps at which env.render() is captured)
     "Goalcycle-demo-solo-v0": ([1337], [0, 12]),
     "Test-2AgentEmpty7x7-see-through": ([1337], [0, 9]),
     "Test-2AgentGoalcycle9x9-prestige": ([1337, 1339], [0, 25, 50]),
+    "Test-3AgentEmpty7x11-nonsquare": ([1337], [0, 6]),
+    "Test-3AgentCluttered12x6-nonsquare": ([1338], [3]),
 }
 
 
@@ -238,7 +242,13 @@ def gen_frames(out):
             d["%s/%d/actions" % (name, seed)] = acts
             for t in range(max(steps) + 1):
                 if t in steps:
-                    full = env.render(mode="rgb_array")
+                    try:
+                        full = env.render(mode="rgb_array")
+                    except ValueError:
+                        # upstream's side-panel arithmetic (base.py:766-783 mixes shape[0] / shape[1])
+                        # breaks on non-square grids: capture the highlighted grid alone instead
+                        full = env.render(mode="rgb_array", show_agent_views=False)
+                        d["%s/%d/%d/nopanels" % (name, seed, t)] = np.array(1)
                     bare = env.render(mode="rgb_array", highlight=False, show_agent_views=False)
                     d["%s/%d/%d/full" % (name, seed, t)] = np.asarray(full).astype(np.uint8)
                     d["%s/%d/%d/bare" % (name, seed, t)] = np.asarray(bare).astype(np.uint8)

@@ -23,7 +23,7 @@ def _base(n_agents, grid_size, view_size, tile_size=8, view_offset=0, colors=Non
 def empty_spec(n_agents, grid_size, view_size=7, **kw):
     """EmptyMultiGrid — envs/empty.py:9-16"""
     s = _base(n_agents, grid_size, view_size, **kw)
-    W = H = grid_size
+    W, H = s["W"], s["H"]
     s["objects"] = [None, WALL, GOAL]
     s["wall_obj"] = 1
     prog = [("wall_rect", 0, 0, W, H), ("put", 2, W - 2, H - 2)]
@@ -36,7 +36,7 @@ def cluttered_spec(n_agents, grid_size, view_size=7, clutter_density=None, n_clu
     """ClutteredMultiGrid — envs/cluttered.py:9-36, including the constructor-time reset that runs
     before n_clutter / randomize_goal exist (random goal, zero clutter)."""
     s = _base(n_agents, grid_size, view_size, **kw)
-    W = H = grid_size
+    W, H = s["W"], s["H"]
     if clutter_density is not None:
         n_clutter = int(clutter_density * (W - 2) * (H - 2))
     s["objects"] = [None, WALL, GOAL]
@@ -131,6 +131,8 @@ def ref_recipe(name):
         "Edge-3AgentCluttered13x13-view13-ts8": ("ClutteredMultiGrid", dict(grid_size=13, n_clutter=20)),
         "Edge-2AgentEmpty6x6-view3-ts33": ("EmptyMultiGrid", dict(grid_size=6)),
         "Edge-3AgentCluttered15x15-default-tiles": ("ClutteredMultiGrid", dict(grid_size=15, n_clutter=10)),
+        "Test-3AgentEmpty7x11-nonsquare": ("EmptyMultiGrid", dict(width=7, height=11)),
+        "Test-3AgentCluttered12x6-nonsquare": ("ClutteredMultiGrid", dict(width=12, height=6, n_clutter=7)),
         # the reference's examples/human_player.py configuration (examples/human_player.py:35-55)
         "Edge-HumanPlayerConfig": ("ClutteredGoalCycleEnv", dict(grid_size=13, max_steps=250, clutter_density=0.15,
                                                                  respawn=True, ghost_mode=True, reward_decay=False,
@@ -204,6 +206,8 @@ def registered(name):   # noqa: F811  (extends the table above with test-only sc
         "Edge-3AgentCluttered13x13-view13-ts8": lambda: cluttered_spec(3, 13, 13, n_clutter=20),
         "Edge-2AgentEmpty6x6-view3-ts33": lambda: empty_spec(2, 6, 3, tile_size=33),
         # README.md:36 `ClutteredMultiGrid(agents, grid_size=15, n_clutter=10)` with default agents (view 7, tile 5)
+        "Test-3AgentEmpty7x11-nonsquare": lambda: empty_spec(3, 7, 7, H=11),
+        "Test-3AgentCluttered12x6-nonsquare": lambda: cluttered_spec(3, 12, 5, n_clutter=7, H=6),
         "Edge-3AgentCluttered15x15-default-tiles": lambda: cluttered_spec(3, 15, 7, n_clutter=10, tile_size=5,
                                                                           colors=["red", "red", "red"]),
         "Edge-HumanPlayerConfig": lambda: goalcycle_spec(1, 13, 7, clutter_density=0.15, n_bonus_tiles=3, penalty=-1.5,
@@ -225,7 +229,8 @@ ALL_SCENARIOS = [
     "Test-2AgentEmpty7x7-see-through", "Test-3AgentCluttered9x9-respawn", "Test-4AgentEmpty5x5-respawn-noghost",
     "Test-3AgentEmpty7x7-spawn-delay", "Test-4AgentEmpty5x5-hide", "Test-3AgentCluttered9x9-hide",
     "Test-2AgentRegion9x9", "Test-2AgentGoalcycle9x9-prestige", "Test-1AgentGoalcycle11x11-prestige-ts11",
-    "Test-3AgentCluttered9x9-prestige-mixed", "Test-4AgentEmpty5x5-ghost0",
+    "Test-3AgentCluttered9x9-prestige-mixed", "Test-4AgentEmpty5x5-ghost0", "Test-3AgentEmpty7x11-nonsquare",
+    "Test-3AgentCluttered12x6-nonsquare",
 ]
 
 

@@ -290,12 +290,13 @@ def test_full_frame_render_golden():
         acts = np.stack([g["%s/%d/actions" % (name, s)] for s in seeds])      # (S, T, n)
         for t in range(max(steps) + 1):
             if t in steps:
-                full = env.render(env_ids=list(range(len(seeds)))).cpu().numpy()
+                panels = ("%s/%d/%d/nopanels" % (name, seeds[0], t)) not in g.files
+                full = env.render(env_ids=list(range(len(seeds))), show_agent_views=panels).cpu().numpy()
                 bare = env.render(highlight=False, show_agent_views=False, env_ids=list(range(len(seeds)))).cpu().numpy()
                 for si, s in enumerate(seeds):
                     assert np.array_equal(bare[si], g["%s/%d/%d/bare" % (name, s, t)]), (name, s, t, "bare")
                     assert np.array_equal(full[si], g["%s/%d/%d/full" % (name, s, t)]), (name, s, t, "full")
-                one = env.render().cpu().numpy()
+                one = env.render(show_agent_views=panels).cpu().numpy()
                 assert np.array_equal(one, full[0])
             env.step(torch.from_numpy(acts[:, t].astype(np.int64)))
 
