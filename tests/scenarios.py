@@ -250,6 +250,21 @@ def interact_spec():
     return s
 
 
+def objects_zoo_spec(tile_size=8):
+    """every object class on one 9x9 board (sprites the reference cannot draw are defined by the
+    drawing its code spells out — see oracle/oracle.py:_sprite)"""
+    s = empty_spec(2, 9, 7, tile_size=tile_size, colors=["red", "cyan"])
+    s["objects"] = [None, WALL, GOAL,
+                    dict(type="Door", color="blue", state=1), dict(type="Door", color="blue", state=2),
+                    dict(type="Door", color="blue", state=3), dict(type="Key", color="blue", state=0),
+                    dict(type="Ball", color="purple", state=0), dict(type="Lava", color="worst", state=0),
+                    dict(type="Floor", color="grey", state=0),
+                    dict(type="BonusTile", color="yellow", state=0, reward=1, penalty=-0.1, bonus_id=0, n_bonus=1,
+                         initial_reward=True, reset_on_mistake=False),
+                    dict(type="Box", color="olive", state=0)]
+    return s
+
+
 def interact_scenes():
     """name -> dict(agents=[(x, y, dir)], objects=[(obj_id, x, y)], carrying={agent: obj_id},
     actions=[[a0, a1], ...]).  Keys / closed doors are kept out of sight where the reference's

@@ -476,3 +476,49 @@ def test_live_place_obj_and_try_place_obj_vs_oracle():
         o, r, dn, _ = env.step(torch.from_numpy(a))
         o2, r2, dn2, _ = orc.step(a)
         assert np.array_equal(o.cpu().numpy(), o2) and np.array_equal(dn.cpu().numpy(), dn2)
+
+
+def test_objects_zoo_vs_oracle():
+    """every object class on one board (Lava ends the episode, Floor / open Door / BonusTile are
+    walked over, Ball / Key are carried, Doors toggled and unlocked): HIP == oracle step by step."""
+    import torch
+    from marlgrid_amd import objects as PO
+    from marlgrid_amd.agents import GridAgentInterface
+    from marlgrid_amd.envs import EmptyMultiGrid
+    spec = scenarios.objects_zoo_spec(8)
+    B = 96
+    seeds = 700 + np.arange(B)
+    env = EmptyMultiGrid(agents=[GridAgentInterface(color=a["color"], view_size=7, view_tile_size=8) for a in spec["agents"]],
+                         grid_size=9, batch_size=B, seeds=seeds, max_steps=400)
+    spec["max_steps"] = 400
+    orc = O.OracleBatch(spec, seeds)
+    env.reset(); orc.reset()
+    objs = [None, PO.Wall(), PO.Goal(color="green", reward=1), PO.Door("blue", 1), PO.Door("blue", 2),
+            PO.Door("blue", 3), PO.Key("blue"), PO.Ball("purple"), PO.Lava(), PO.Floor("grey"),
+            PO.BonusTile(color="yellow", reward=1), PO.Box("olive")]
+    board = [(5, 2, 2), (3, 4, 2), (4, 6, 2), (6, 2, 5), (7, 5, 2), (8, 3, 3), (9, 4, 4), (10, 5, 5), (4, 1, 6), (8, 6, 6)]
+    for o in objs[3:]:
+        env.obj_reg.get_key(o)
+    # agents to fixed free cells first: put_obj on an occupied cell evicts the agent upstream (the cell's
+    # object is replaced, base.py:655-662) while the engine keeps it — a documented difference
+    for k, (x, y, d) in enumerate([(1, 1, 0), (7, 1, 2)]):
+        env.set_agent(k, x=x, y=y, dir=d)
+        for e in orc.envs:
+            e.place_agent_at(k, x, y)
+            e.set_dir(k, d)
+    for (oid, x, y) in board:                 # (object id, x, y)
+        env.put_obj(objs[oid], x, y)
+        for e in orc.envs:
+            e.put_obj(oid, x, y)
+    assert env.scenario_spec()["objects"] == spec["objects"]
+    assert np.array_equal(env.gen_obs().cpu().numpy(), orc.gen_obs())
+    rng = np.random.RandomState(21)
+    for t in range(150):
+        a = rng.choice(6, size=(B, 2), p=[.15, .15, .4, .1, .1, .1])       # no Box in front => toggle is safe...
+        o, r, dn, _ = env.step(torch.from_numpy(a))
+        o2, r2, dn2, _ = orc.step(a)
+        assert np.array_equal(o.cpu().numpy(), o2), t
+        assert np.abs(r.cpu().numpy().astype(np.float64) - r2).max() <= REW_TOL and np.array_equal(dn.cpu().numpy(), dn2)
+    st = product_envs.canonical(env)
+    for b in range(0, B, 5):
+        canon.assert_same(st[b], canon.oracle_canonical(orc.envs[b]), "env %d" % b)

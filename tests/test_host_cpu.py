@@ -171,3 +171,32 @@ def test_env_from_config_and_make():
         E.make("MarlGrid-NoSuchEnv-v0")
     e3 = E.make("MarlGrid-4AgentEmpty9x9-v0", _dry=True, batch_size=5)
     assert e3.num_agents == 4 and e3.batch_size == 5 and len(e3.seeds) == 5 and e3.seeds[0] == 1337
+
+
+@pytest.mark.parametrize("ts", [8, 11])
+def test_atlas_of_every_object_kind_matches_the_oracle(ts):
+    """product atlas (numpy, marlgrid_amd/rendering.py) == oracle tiles (C) for every object class,
+    including the ones whose upstream sprite code cannot run (Key / Ball / closed Door: NameError;
+    Lava / Floor: no usable sprite) — two independent implementations of the same drawing."""
+    from marlgrid_amd import objects as PO
+    from marlgrid_amd import rendering
+    from oracle import oracle as O
+    spec = scenarios.objects_zoo_spec(ts)
+    objs = [None, PO.Wall(), PO.Goal(color="green", reward=1), PO.Door("blue", 1), PO.Door("blue", 2),
+            PO.Door("blue", 3), PO.Key("blue"), PO.Ball("purple"), PO.Lava(), PO.Floor("grey"),
+            PO.BonusTile(color="yellow", reward=1), PO.Box("olive")]
+    mine = [None if o is None else (o.type, o.color, o.state) for o in objs]
+    theirs = [None if o is None else (o["type"], o["color"], o.get("state", 0)) for o in spec["objects"]]
+    assert mine == theirs
+    colors = [a["color"] for a in spec["agents"]]
+    atlas, slot, n_slots = rendering.build_atlas(objs, colors, ts)
+    orc = O.OracleEnv(spec, construct=False)
+    n_obj, n_ag = len(objs), len(colors)
+    for i in range(n_obj):
+        assert np.array_equal(atlas[0, 1 + i], orc.tile(i)), (i, objs[i])
+        if slot[i] != 0xFF:
+            for k in range(n_ag):
+                for d in range(4):
+                    assert np.array_equal(atlas[0, 1 + n_obj + (slot[i] * n_ag + k) * 4 + d], orc.tile(i, k, d)), (i, k, d)
+    # overlappable kinds: empty, Goal, open Door, Lava, Floor, BonusTile
+    assert n_slots == 6
