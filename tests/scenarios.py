@@ -134,6 +134,7 @@ def ref_recipe(name):
         "Test-3AgentEmpty7x11-nonsquare": ("EmptyMultiGrid", dict(width=7, height=11)),
         "Test-3AgentCluttered12x6-nonsquare": ("ClutteredMultiGrid", dict(width=12, height=6, n_clutter=7)),
         # the reference's examples/human_player.py configuration (examples/human_player.py:35-55)
+        "Edge-3AgentCluttered11x11-offset6": ("ClutteredMultiGrid", dict(grid_size=11, n_clutter=12)),
         "Edge-HumanPlayerConfig": ("ClutteredGoalCycleEnv", dict(grid_size=13, max_steps=250, clutter_density=0.15,
                                                                  respawn=True, ghost_mode=True, reward_decay=False,
                                                                  n_bonus_tiles=3, initial_reward=True, penalty=-1.5)),
@@ -210,6 +211,7 @@ def registered(name):   # noqa: F811  (extends the table above with test-only sc
         "Test-3AgentCluttered12x6-nonsquare": lambda: cluttered_spec(3, 12, 5, n_clutter=7, H=6),
         "Edge-3AgentCluttered15x15-default-tiles": lambda: cluttered_spec(3, 15, 7, n_clutter=10, tile_size=5,
                                                                           colors=["red", "red", "red"]),
+        "Edge-3AgentCluttered11x11-offset6": lambda: cluttered_spec(3, 11, 7, n_clutter=12, view_offset=6),
         "Edge-HumanPlayerConfig": lambda: goalcycle_spec(1, 13, 7, clutter_density=0.15, n_bonus_tiles=3, penalty=-1.5,
                                                          initial_reward=True, max_steps=250, respawn=True,
                                                          reward_decay=False, colors=["prestige"], tile_size=11,

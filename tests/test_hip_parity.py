@@ -104,6 +104,11 @@ def test_rng_seeding_golden():
                                        ("Edge-3AgentCluttered13x13-view13-ts8", 64, 30),
                                        ("Edge-2AgentEmpty6x6-view3-ts33", 32, 20),
                                        ("Edge-HumanPlayerConfig", 128, 260),
+                                       ("Edge-3AgentCluttered11x11-offset6", 64, 40),
+                                       ("MarlGrid-3AgentCluttered11x11-v0", 1, 30),
+                                       ("MarlGrid-3AgentCluttered11x11-v0", 3, 30),
+                                       ("MarlGrid-3AgentCluttered11x11-v0", 65, 30),
+                                       ("MarlGrid-4AgentEmpty9x9-v0", 4097, 20),
                                        ("Edge-3AgentCluttered15x15-default-tiles", 4100, 40),
                                        ("Test-3AgentCluttered9x9-prestige-mixed", 256, 160)])
 def test_batch_vs_oracle(name, B, T):
