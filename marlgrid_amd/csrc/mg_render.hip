@@ -34,7 +34,7 @@ namespace mg {
 // V_: 0 = production; 8 = production with the atlas read from global memory (chosen by the launcher
 //     when it does not fit LDS); 9 = production with per-env recoloured tiles for 'prestige' agents.  2..7 = measurement variants for tools/ab_render.py (MG_RENDER_VARIANT,
 //     <7,8> only): 2 nontemporal stores, 3 raster only (phases 2-5 skipped), 4 stores only (no LDS
-//     look-ups), 5 no next-env prefetch, 6 no store bursts, 7 grid-strided env walk, 10 two waves per env.
+//     look-ups), 5 no next-env prefetch, 6 no store bursts, 7 grid-strided env walk, 10 two waves per env, 11 phases 2-5 executed twice.
 // WPB = waves per workgroup (4 or 16; MG_RENDER_WPB overrides the launcher's choice).
 template <int VS_, int TS_, int WPB, int V_ = 0>
 __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState st, uint8_t* __restrict__ obs,
@@ -156,6 +156,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
         if constexpr (V_ == 3 || V_ == 4) {
             for (int it = lane; it < n * VV; it += kWave) w_tmap[it] = 0;
         } else {
+        for (int rep = 0; rep < (V_ == 11 ? 2 : 1); rep++) {   // V_ == 11 (measurement): phases 2-5 twice
         // 2. first (lowest-rank) agent of every occupied cell: the reference's "cell object" when
         //    the base is empty, and `obj.agents[0]` when agents stand on an overlappable object
         if (lane < n) {
@@ -288,6 +289,8 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 dbg_agent[o] = (uint8_t)show;
                 dbg_vis[o] = (uint8_t)visible;
             }
+        }
+        wave_lds_sync();
         }
         }
         wave_lds_sync();
@@ -516,6 +519,7 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
         case 6: return MG_RENDER_DISPATCH(7, 8, 6);
         case 7: return MG_RENDER_DISPATCH(7, 8, 7);
         case 10: return MG_RENDER_DISPATCH(7, 8, 10);
+        case 11: return MG_RENDER_DISPATCH(7, 8, 11);
         default: return MG_RENDER_DISPATCH8(7, 8, 0);
         }
     }
