@@ -263,8 +263,6 @@ class MultiGridEnv(object):
         if not (0 <= a0.view_offset < a0.view_size):
             raise ValueError("view_offset out of range")
         self._prestige = [a.color == "prestige" for a in self.agents]
-        if any(self._prestige) and any(len(a.hide_item_types) > 0 for a in self.agents):
-            raise NotImplementedError("'prestige'-coloured agents together with hide_item_types are not supported")
         self._all_image = all(a.observation_style == "image" for a in self.agents)
         self.view_size, self.tile_size = a0.view_size, a0.view_tile_size
         self.view_offset, self.see_through_walls = a0.view_offset, a0.see_through_walls
@@ -510,11 +508,15 @@ class MultiGridEnv(object):
         n, vs = self.num_agents, self.view_size
         scratch = (3 * r16(self.cells_stride) + N.MAX_AGENTS * 8 + 2 * r16(n * vs * vs) + 2 * r16(n * vs * 4)
                    + r16(n * vs * vs * 2))
+        if any(self._prestige):     # per-env recoloured agent tiles, twice with hide_item_types
+            hide = any(len(a.hide_item_types) > 0 for a in self.agents)
+            scratch += r16((2 if hide else 1) * n * 4 * self.tile_size ** 2 * 3)
         need = 2 * N.MAX_OBJ + N.MAX_AGENTS * 8 + 4 * scratch      # (an atlas that does not fit stays in HBM/L2)
         if need > 160 * 1024:
             raise NotImplementedError(
                 "this configuration needs %d KiB of LDS per workgroup (4 x %d B of per-env scratch); the "
-                "obs kernel has 160 KiB — reduce the grid size" % (need // 1024, scratch))
+                "obs kernel has 160 KiB — reduce the grid size (or the tile size of 'prestige' agents)"
+                % (need // 1024, scratch))
         raw = np.frombuffer(bytes(tab), dtype=np.uint8).copy()
         flat = atlas.reshape(-1)
         pad = (-flat.size) % 16

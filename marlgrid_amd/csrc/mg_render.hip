@@ -32,7 +32,8 @@ namespace mg {
 //              fixes the view size at compile time (the shipped view sizes), VS_ == 0 reads it from cfg.
 // TS_ == 0:    any view / tile size: per-byte look-ups assembled into aligned dword stores.
 // V_: 0 = production; 8 = production with the atlas read from global memory (chosen by the launcher
-//     when it does not fit LDS); 9 = production with per-env recoloured tiles for 'prestige' agents.  2..7 = measurement variants for tools/ab_render.py (MG_RENDER_VARIANT,
+//     when it does not fit LDS); 9 = production with per-env recoloured tiles for 'prestige' agents;
+//     12 = both (recoloured tiles in LDS, the static atlas in global memory).  2..7 = measurement variants for tools/ab_render.py (MG_RENDER_VARIANT,
 //     <7,8> only): 2 nontemporal stores, 3 raster only (phases 2-5 skipped), 4 stores only (no LDS
 //     look-ups), 5 no next-env prefetch, 6 no store bursts, 7 grid-strided env walk, 10 two waves per env, 11 phases 2-5 executed twice.
 // WPB = waves per workgroup (4 or 16; MG_RENDER_WPB overrides the launcher's choice).
@@ -52,8 +53,10 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     // ---- block-shared: atlas + object flags ----
     // V_ == 8: the atlas does not fit the 160 KiB of LDS next to the per-env scratch (large tiles);
     // it is then read in place (global memory, L2-resident: it is a few hundred KB).
-    constexpr bool kGlobalAtlas = (V_ == 8);
-    constexpr bool kPrestige = (V_ == 9);      // some agent is 'prestige'-coloured: per-env recoloured tiles
+    constexpr bool kGlobalAtlas = (V_ == 8 || V_ == 12);
+    constexpr bool kPrestige = (V_ == 9 || V_ == 12);   // some agent is 'prestige'-coloured: per-env recoloured tiles
+    constexpr bool kSplit = (V_ == 12);        // static tiles in global memory, recoloured ones in LDS
+    constexpr uint32_t kInLds = 0x80000000u;   // kSplit: marks a source offset as relative to the LDS base
     const int atlas_bytes = kGlobalAtlas ? 0 : round_up(4 * cfg.n_tiles * tile_bytes, 16);
     uint8_t* s_atlas = smem;
     uint8_t* s_oflags = smem + atlas_bytes;             // [MG_MAX_OBJ]
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     }
     __syncthreads();
 
-    const RenderScratch L = render_scratch_layout(cfg.cells_stride, n, VS, kPrestige ? n * 4 * tile_bytes : 0);
+    const RenderScratch L = render_scratch_layout(cfg.cells_stride, n, VS, kPrestige ? (cfg.any_hide ? 2 : 1) * n * 4 * tile_bytes : 0);
     uint8_t* ws = smem + atlas_bytes + 2 * MG_MAX_OBJ + MG_MAX_AGENTS * 8 + (size_t)wave * L.total;
     uint8_t* w_grid = ws + L.grid;
     uint8_t* w_first = ws + L.first;
@@ -225,21 +228,26 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
         wave_lds_sync();
         if constexpr (kPrestige) {
             // 4b. tiles of active 'prestige' agents are recoloured per env (render_post) — and blended
-            //     with the object they stand on — before rotation; generate them for all 4 orientations
+            //     with the object they stand on — before rotation; generate them for all 4 orientations.
+            //     With hide_item_types a viewer may hide that object and see the agent as a plain cell
+            //     object instead: a second set (hv = 1) on the empty tile.
             const int npx = TS * TS;
-            for (int X = 0; X < n; X++) {
+            const uint8_t* abase = kGlobalAtlas ? cfg.atlas : s_atlas;
+            for (int Xh = 0; Xh < (cfg.any_hide ? 2 * n : n); Xh++) {
+                const int hv = Xh >= n, X = Xh - hv * n;
                 if (!((cfg.prestige_mask >> X) & 1u)) continue;
                 const uint64_t rx = w_rec[X];
                 if ((rec_byte(rx, MG_AG_FLAGS) & (MG_AF_ACTIVE | MG_AF_PLACED)) != (MG_AF_ACTIVE | MG_AF_PLACED)) continue;
-                const uint32_t base = w_grid[rec_byte(rx, MG_AG_X) * H + rec_byte(rx, MG_AG_Y)];
+                uint32_t base = w_grid[rec_byte(rx, MG_AG_X) * H + rec_byte(rx, MG_AG_Y)];
+                if (hv) { if (!base) continue; base = 0; }
                 const uint32_t sdir = rec_byte(rx, MG_AG_DIR);
                 const PrestigeColor col = prestige_color(st.prestige[(size_t)e * n + X], cfg.prestige_scale[X]);
                 const uint32_t amax = cfg.prestige_amax[sdir];
                 const uint32_t M = ((amax * col.r) >> 8) + ((amax * col.g) >> 8) + ((amax * col.b) >> 8);
-                const uint8_t* white = s_atlas + (size_t)(cfg.prestige_sprite_tile + sdir) * tile_bytes;   // orientation 0, no border
-                const uint8_t* btile = base ? s_atlas + (size_t)(1 + base) * tile_bytes : nullptr;
+                const uint8_t* white = abase + (size_t)(cfg.prestige_sprite_tile + sdir) * tile_bytes;   // orientation 0, no border
+                const uint8_t* btile = base ? abase + (size_t)(1 + base) * tile_bytes : nullptr;
                 const bool border = base ? (cfg.obj[base].flags2 & 1) != 0 : true;
-                const uint8_t* etile = s_atlas + (size_t)tile_bytes;                                   // empty tile
+                const uint8_t* etile = abase + (size_t)tile_bytes;                                   // empty tile
                 for (int idx = lane; idx < 4 * npx; idx += kWave) {
                     const int o = idx / npx, p = idx - o * npx, r = p / TS, c = p - r * TS;
                     int sr, sc;   // source pixel of output pixel (r, c) at orientation o (rotate_grid, base.py:67-80)
@@ -249,7 +257,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                     else { sr = r; sc = c; }
                     const int sp = (sr * TS + sc) * 3;
                     prestige_pixel(white[sp], col, M, btile ? btile + sp : nullptr, border ? etile + sp : nullptr,
-                                   w_dyn + ((size_t)(X * 4 + o) * npx + p) * 3);
+                                   w_dyn + ((size_t)(Xh * 4 + o) * npx + p) * 3);
                 }
             }
             wave_lds_sync();
@@ -275,7 +283,10 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             if constexpr (kPrestige) {
                 if (visible && show != 0xFF && s_oslot[base] != 0xFF && ((cfg.prestige_mask >> show) & 1u) &&
                     (rec_byte(w_rec[show], MG_AG_FLAGS) & MG_AF_ACTIVE)) {
-                    vt = NT4 + show * 4 + orient;
+                    const uint64_t rs = w_rec[show];   // hidden object under it: the plain-cell-object set
+                    const uint32_t hv = (cfg.any_hide && base == 0 &&
+                                         w_grid[rec_byte(rs, MG_AG_X) * H + rec_byte(rs, MG_AG_Y)] != 0) ? (uint32_t)n : 0u;
+                    vt = NT4 + (hv + show) * 4 + orient;
                     dyn = true;
                 }
             }
@@ -309,7 +320,10 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             const uint32_t* atlas32 = reinterpret_cast<const uint32_t*>(s_atlas);
             const uint32_t* gatlas32 = reinterpret_cast<const uint32_t*>(cfg.atlas);
             auto ld_pair = [&](uint32_t a) -> uint2 {
-                if constexpr (kGlobalAtlas) return *reinterpret_cast<const uint2*>(gatlas32 + a);
+                if constexpr (kSplit) {
+                    if (a & kInLds) return *reinterpret_cast<const uint2*>(atlas32 + (a & ~kInLds));
+                    return *reinterpret_cast<const uint2*>(gatlas32 + a);
+                } else if constexpr (kGlobalAtlas) return *reinterpret_cast<const uint2*>(gatlas32 + a);
                 else return *reinterpret_cast<const uint2*>(atlas32 + a);
             };
             uint4* out = reinterpret_cast<uint4*>(obs + (size_t)e * n * img_bytes);
@@ -319,7 +333,10 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 const uint32_t va = __umul24(pr_, M_PT) >> 16, kp = pr_ - __umul24(va, PT);
                 const uint32_t vb = __umul24(rr_, M_TS) >> 16, rr = rr_ - __umul24(vb, (uint32_t)TS_);
                 uint32_t t = (uint32_t)w_tmap[__umul24(vb, (uint32_t)VS) + va];
-                if constexpr (kGlobalAtlas) t *= (uint32_t)(TS_ * TS_ * 3 / 4);       // tile index -> dword offset
+                if constexpr (kSplit)
+                    t = t < NT4 ? t * (uint32_t)(TS_ * TS_ * 3 / 4)
+                                : (kInLds | (dyn_off / 4 + (t - NT4) * (uint32_t)(TS_ * TS_ * 3 / 4)));
+                else if constexpr (kGlobalAtlas) t *= (uint32_t)(TS_ * TS_ * 3 / 4);   // tile index -> dword offset
                 return t + __umul24(rr, TD) + kp * 2u;
             };
             auto fetch = [&](uint4& v) {
@@ -370,7 +387,8 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             const uint32_t mTS = TS > 1 ? 0xFFFFFFFFu / (uint32_t)TS + 1u : 0u;
             auto div_ts = [&](uint32_t v) -> uint32_t { return TS > 1 ? __umulhi(v, mTS) : v; };
             auto tile_off = [&](uint32_t vt) -> uint32_t {                 // virtual tile index -> byte offset
-                if constexpr (kPrestige) return vt < NT4 ? vt * (uint32_t)tile_bytes : dyn_off + (vt - NT4) * (uint32_t)tile_bytes;
+                if constexpr (kSplit) return vt < NT4 ? vt * (uint32_t)tile_bytes : (kInLds | (dyn_off + (vt - NT4) * (uint32_t)tile_bytes));
+                else if constexpr (kPrestige) return vt < NT4 ? vt * (uint32_t)tile_bytes : dyn_off + (vt - NT4) * (uint32_t)tile_bytes;
                 else return vt * (uint32_t)tile_bytes;
             };
             auto byte_at = [&](uint32_t R, uint32_t cb) -> uint32_t {      // R: global pixel row, cb < RB
@@ -378,7 +396,8 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 const uint32_t va = div_ts(col), cc = col - va * (uint32_t)TS;
                 const uint32_t vb = div_ts(R), rr = R - vb * (uint32_t)TS;
                 const uint32_t so = tile_off((uint32_t)w_tmap[vb * (uint32_t)VS + va]) + (rr * (uint32_t)TS + cc) * 3u + ch;
-                if constexpr (kGlobalAtlas) return cfg.atlas[so];
+                if constexpr (kSplit) return (so & kInLds) ? s_atlas[so & ~kInLds] : cfg.atlas[so];
+                else if constexpr (kGlobalAtlas) return cfg.atlas[so];
                 else return s_atlas[so];
             };
             if (d1 > d0) {
@@ -389,9 +408,12 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 const uint32_t SEG = 3u * (uint32_t)TS;
                 const uint32_t mSEG = 0xFFFFFFFFu / SEG + 1u;                // SEG >= 3
                 auto fetch4 = [&](uint32_t so) -> uint32_t {
-                    const uint32_t a = so >> 2, sh = so & 3u;
+                    const uint32_t a = (so & ~kInLds) >> 2, sh = so & 3u;
                     uint32_t lo, hi;
-                    if constexpr (kGlobalAtlas) {
+                    if (kSplit && (so & kInLds)) {
+                        const uint32_t* l32 = reinterpret_cast<const uint32_t*>(s_atlas);
+                        lo = l32[a]; hi = l32[a + 1];
+                    } else if constexpr (kGlobalAtlas) {
                         const uint32_t* g32 = reinterpret_cast<const uint32_t*>(cfg.atlas);
                         lo = g32[a]; hi = g32[a + 1];
                     } else {
@@ -445,8 +467,8 @@ static hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_
                                   uint8_t* v, hipStream_t s) {
     const int tile_bytes = cfg.tile_size * cfg.tile_size * 3;
     const RenderScratch L = render_scratch_layout(cfg.cells_stride, cfg.n_agents, cfg.view_size,
-                                                  V_ == 9 ? cfg.n_agents * 4 * tile_bytes : 0);
-    size_t lds = (V_ == 8 ? 0 : (size_t)round_up(4 * cfg.n_tiles * tile_bytes, 16)) + 2 * MG_MAX_OBJ +
+                                                  (V_ == 9 || V_ == 12) ? (cfg.any_hide ? 2 : 1) * cfg.n_agents * 4 * tile_bytes : 0);
+    size_t lds = ((V_ == 8 || V_ == 12) ? 0 : (size_t)round_up(4 * cfg.n_tiles * tile_bytes, 16)) + 2 * MG_MAX_OBJ +
                  MG_MAX_AGENTS * 8 + WPB * (size_t)L.total;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {
@@ -492,7 +514,17 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
     if ((view_cells || view_agent || vis_mask) && !(view_cells && view_agent && vis_mask)) return hipErrorInvalidValue;
     const int vs = cfg.view_size, ts = cfg.tile_size;
     const int wpb = choose_wpb(cfg);
-    if (cfg.prestige_mask) {   // per-env recoloured agent tiles: 4-wave workgroups, atlas must be LDS-resident
+    if (cfg.prestige_mask) {   // per-env recoloured agent tiles (LDS), 4-wave workgroups
+        const RenderScratch L = render_scratch_layout(cfg.cells_stride, cfg.n_agents, cfg.view_size,
+                                                      (cfg.any_hide ? 2 : 1) * cfg.n_agents * 4 * ts * ts * 3);
+        const size_t lds4 = (size_t)round_up(4 * cfg.n_tiles * ts * ts * 3, 16) + 2 * MG_MAX_OBJ + MG_MAX_AGENTS * 8 +
+                            4 * (size_t)L.total;
+        if (lds4 > 160 * 1024) {   // the static atlas stays in global memory
+            if (ts == 8) return launch_render_t<0, 8, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
+            if (ts == 16) return launch_render_t<0, 16, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
+            if (ts == 32) return launch_render_t<0, 32, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
+            return launch_render_t<0, 0, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
+        }
         if (ts == 8) return launch_render_t<0, 8, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
         if (ts == 16) return launch_render_t<0, 16, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
         if (ts == 32) return launch_render_t<0, 32, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s);

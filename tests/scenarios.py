@@ -43,7 +43,7 @@ def cluttered_spec(n_agents, grid_size, view_size=7, clutter_density=None, n_clu
     s["wall_obj"] = 1
     s["gen_ctor"] = [("wall_rect", 0, 0, W, H), ("place", 2, 1, 100)]
     goal = ("place", 2, 1, 100) if randomize_goal else ("put", 2, W - 2, H - 2)
-    s["gen_reset"] = [("wall_rect", 0, 0, W, H), goal, ("place", 1, n_clutter, 100)]
+    s["gen_reset"] = [("wall_rect", 0, 0, W, H), goal] + ([("place", 1, n_clutter, 100)] if n_clutter else [])
     return s
 
 
@@ -64,7 +64,7 @@ def goalcycle_spec(n_agents, grid_size, view_size=7, clutter_density=None, n_clu
     s["wall_obj"] = 1
     s["gen_ctor"] = [("wall_rect", 0, 0, W, H)]
     s["gen_reset"] = ([("wall_rect", 0, 0, W, H)] + [("place", 2 + b, 1, 100) for b in range(n_bonus_tiles)]
-                      + [("place", 1, n_clutter, 100)])
+                      + ([("place", 1, n_clutter, 100)] if n_clutter else []))
     return s
 
 
@@ -139,6 +139,8 @@ def ref_recipe(name):
                                                                  respawn=True, ghost_mode=True, reward_decay=False,
                                                                  n_bonus_tiles=3, initial_reward=True, penalty=-1.5)),
     }
+    if name.startswith("Fuzz-"):
+        return fuzz_case(int(name[5:]))[1]
     return t[name]
 
 
@@ -219,7 +221,50 @@ def registered(name):   # noqa: F811  (extends the table above with test-only sc
     }
     if name in extra:
         return extra[name]()
+    if name.startswith("Fuzz-"):
+        return fuzz_case(int(name[5:]))[0]
     return _registered_base(name)
+
+
+def fuzz_case(i):
+    """(spec, reference recipe) of pseudo-random scenario `i`: every constructor knob of
+    MultiGridEnv / GridAgentInterface / the three scenario classes drawn at random (base.py:335-347,
+    agents.py:24-60, envs/*.py), kept inside what the reference can construct and draw."""
+    import random
+    r = random.Random(7700 + i)
+    kind = r.choice(["empty", "cluttered", "cluttered", "goalcycle"])
+    W = r.randint(5, 14)
+    H = W if (kind == "goalcycle" or r.random() < 0.5) else r.randint(5, 14)
+    free = (W - 2) * (H - 2)
+    n = r.randint(1, max(1, min(8, free // 4)))
+    vs = r.choice([3, 5, 7, 7, 9])
+    common = dict(ghost_mode=r.random() < 0.6, respawn=r.random() < 0.35, max_steps=r.randint(12, 45))
+    if r.random() < 0.5:
+        common["reward_decay"] = r.random() < 0.5
+    p_prestige = r.choice([0, 0, 0.5])
+    colors = [("prestige" if r.random() < p_prestige else r.choice(_MANY)) for _ in range(n)]
+    akw = dict(view_size=vs, tile_size=r.choice([3, 4, 5, 6, 7, 8, 8, 9, 11, 12]), view_offset=r.randint(0, vs - 1),
+               see_through_walls=r.random() < 0.25, colors=colors)
+    size = dict(grid_size=W) if W == H and r.random() < 0.5 else dict(width=W, height=H)
+    if kind == "empty":
+        spec = empty_spec(n, W, H=H, **akw, **common)
+        recipe = ("EmptyMultiGrid", dict(size, **common))
+    elif kind == "cluttered":
+        extra = dict(n_clutter=r.randint(0, free // 5), randomize_goal=r.random() < 0.4)
+        spec = cluttered_spec(n, W, H=H, **extra, **akw, **common)
+        recipe = ("ClutteredMultiGrid", dict(size, **extra, **common))
+    else:
+        extra = dict(n_clutter=r.randint(0, free // 6), n_bonus_tiles=r.randint(1, 4),
+                     reward=r.choice([1, 1, 2, 0.5]), penalty=r.choice([0.0, -0.5, -1.5]),
+                     initial_reward=r.random() < 0.6, reset_on_mistake=r.random() < 0.4)
+        spec = goalcycle_spec(n, W, **extra, **akw, **common)
+        recipe = ("ClutteredGoalCycleEnv", dict(grid_size=W, **extra, **common))
+    if r.random() < 0.3:
+        _with_delays(spec, [r.choice([0, 0, 1, 3, 7]) for _ in range(n)])
+    if r.random() < 0.3:
+        types = ["Agent", "Wall", "Goal", "BonusTile"]
+        _with_hide(spec, [[t for t in types if r.random() < 0.35] for _ in range(n)])
+    return spec, recipe
 
 
 ALL_SCENARIOS = [

@@ -140,6 +140,15 @@ def test_batch_vs_oracle(name, B, T):
                 orc.envs[b].reset()
 
 
+# 0..39 + picked cases: prestige with hide_item_types (115, 124, 167, 202), atlas in global memory
+# (371, 399), prestige with the atlas in global memory (102, 181, 380) and with hide (349, 572)
+@pytest.mark.parametrize("i", list(range(40)) + [102, 115, 124, 167, 181, 202, 349, 371, 380, 399, 572])
+def test_fuzz_vs_oracle(i):
+    """random constructor knobs (scenarios.fuzz_case; the oracle is checked against the reference on
+    the same cases in test_oracle_vs_reference.py::test_live_fuzz): HIP batch == oracle, every step"""
+    test_batch_vs_oracle("Fuzz-%d" % i, 40 + (i % 3) * 33, 70)
+
+
 def test_stepping_past_done_like_the_reference():
     """the reference keeps stepping after `done` (no auto-reset, base.py:649-653): step_count runs
     past max_steps, done agents stay inactive, the decay factor goes negative."""

@@ -54,6 +54,19 @@ def test_scenario_spec_matches_independent_restatement(name):
         assert a[k] == b[k], (k, a[k], b[k])
 
 
+def test_fuzz_specs_product_equals_restatement():
+    """random constructor knobs (scenarios.fuzz_case): the product's host side derives the same
+    plain-data spec (object table, generator program, agent options) as the independent restatement"""
+    import product_envs
+    for i in range(120):
+        name = "Fuzz-%d" % i
+        env = product_envs.build(name, _dry=True)
+        env.reset()
+        a, b = env.scenario_spec(), scenarios.registered(name)
+        for k in b:
+            assert a[k] == b[k], (name, k, a[k], b[k])
+
+
 @pytest.mark.parametrize("ts", [5, 8, 11, 32])
 def test_atlas_builder_against_reference_tiles(ts):
     """product atlas (marlgrid_amd/rendering.py) == tiles captured from the reference"""

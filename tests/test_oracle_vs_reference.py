@@ -47,6 +47,12 @@ def test_live_side_by_side(name, seed, T):
     assert st[2] == pos and np.array_equal(st[1], mt)
 
 
+@pytest.mark.parametrize("i", list(range(40)) + [102, 115, 124, 167, 181, 202, 349, 371, 380, 399, 572])
+def test_live_fuzz(i):
+    """random constructor knobs (scenarios.fuzz_case): reference == oracle, every step"""
+    test_live_side_by_side("Fuzz-%d" % i, 31000 + i, 90)
+
+
 def test_occlusion_live_random():
     m = refload.load()
     from marlgrid.agents import occlude_mask
