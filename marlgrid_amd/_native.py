@@ -86,7 +86,7 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError("marlgrid_amd: %s is missing — build it (marlgrid_amd/csrc/build.sh); there is "
                           "no CPU fallback" % LIB_PATH)
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(os.environ.get("MARLGRID_HIP_LIB") or LIB_PATH)
     vp, i32 = C.c_void_p, C.c_int32
     L.mg_abi_version.restype = i32
     L.mg_error_string.restype = C.c_char_p

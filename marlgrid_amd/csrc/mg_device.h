@@ -99,9 +99,11 @@ __device__ inline void prestige_pixel(uint32_t alpha, const PrestigeColor& col, 
 
 // per-wave LDS scratch of the obs-render kernel (bytes), shared by host launch code and kernel
 struct RenderScratch {
-    int grid, first, second, rec, vbase, vshow, trow, vis, tmap, dyn, total;
+    int grid, first, second, rec, vbase, vshow, trow, vis, tmap, dyn, seg, total;
+    int seg_entries;   // 0: no segment table (tile size on the 16-byte-chunk path, or it would not fit)
 };
-__host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride, int n, int vs, int dyn_bytes = 0) {
+__host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride, int n, int vs, int dyn_bytes = 0,
+                                                               int seg_entries = 0) {
     RenderScratch s;
     int o = 0;
     s.grid = o;  o += round_up(cells_stride, 16);
@@ -114,8 +116,27 @@ __host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride,
     s.vis = o;   o += round_up(n * vs * 4, 16);
     s.tmap = o;  o += round_up(n * vs * vs * 2, 16);
     s.dyn = o;   o += round_up(dyn_bytes, 16);   // per-env recoloured ('prestige') agent tiles
+    s.seg = o;   o += round_up(seg_entries * 4, 16);   // per-env segment source table (size-generic raster)
+    s.seg_entries = seg_entries;
     s.total = o;
     return s;
+}
+// The layout a launch of the obs kernel uses, from the config alone (kernel and launcher agree):
+// recoloured-tile space when some agent is 'prestige'; for tile sizes off the 16-byte-chunk path
+// a table with the atlas source of every (pixel row, view column) segment of the env's images —
+// n*P*VS entries — when it is small enough to sit next to the atlas and 4 waves of scratch.
+__host__ __device__ inline RenderScratch render_scratch_for(const MgConfig& cfg) {
+    const int n = cfg.n_agents, vs = cfg.view_size, ts = cfg.tile_size;
+    const int dyn = cfg.prestige_mask ? (cfg.any_hide ? 2 : 1) * n * 4 * ts * ts * 3 : 0;
+    int seg = 0;
+    if (ts % 8 != 0) {
+        const int entries = n * vs * ts * vs + 2, bytes = round_up(entries * 4, 16);
+        const RenderScratch b = render_scratch_layout(cfg.cells_stride, n, vs, dyn, 0);
+        const int atlas_b = round_up(4 * cfg.n_tiles * ts * ts * 3, 16), fixed = 4 * b.total + 1024;
+        const int resident = (atlas_b + fixed <= 160 * 1024) ? atlas_b : 0;   // else the atlas is read in place
+        if (bytes <= 16 * 1024 && resident + fixed + 4 * bytes <= 160 * 1024) seg = entries;
+    }
+    return render_scratch_layout(cfg.cells_stride, n, vs, dyn, seg);
 }
 
 }  // namespace mg

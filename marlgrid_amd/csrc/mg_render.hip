@@ -78,7 +78,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     }
     __syncthreads();
 
-    const RenderScratch L = render_scratch_layout(cfg.cells_stride, n, VS, kPrestige ? (cfg.any_hide ? 2 : 1) * n * 4 * tile_bytes : 0);
+    const RenderScratch L = render_scratch_for(cfg);
     uint8_t* ws = smem + atlas_bytes + 2 * MG_MAX_OBJ + MG_MAX_AGENTS * 8 + (size_t)wave * L.total;
     uint8_t* w_grid = ws + L.grid;
     uint8_t* w_first = ws + L.first;
@@ -90,6 +90,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     uint32_t* w_vis = reinterpret_cast<uint32_t*>(ws + L.vis);
     uint16_t* w_tmap = reinterpret_cast<uint16_t*>(ws + L.tmap);
     uint8_t* w_dyn = ws + L.dyn;                               // [n][4 orientations][tile_bytes]
+    uint32_t* w_seg = reinterpret_cast<uint32_t*>(ws + L.seg); // [n*P*VS + 2] segment sources (size-generic raster)
     const uint32_t dyn_off = (uint32_t)(w_dyn - smem);         // byte offset from the atlas base
     const uint32_t NT4 = 4u * (uint32_t)cfg.n_tiles;           // first virtual tile index of the dynamic tiles
 
@@ -376,14 +377,21 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             }
         } else {
             // Any tile size: the env's n*P*P*3 output bytes are still one contiguous run, written as
-            // whole aligned dwords (plus <= 3 head and <= 3 tail bytes when the run is not 4-byte
-            // aligned in the tensor).  Each byte is looked up on its own — (pixel row, byte in row) ->
-            // (tile, row in tile, pixel, channel) — with multiply-high division by 3 and by TS, and
-            // the lane's position is carried incrementally like in the chunk raster.
+            // whole 16-byte chunks at 16-byte-aligned ADDRESSES (plus <= 15 head and <= 15 tail bytes:
+            // an env's run starts wherever e*S falls).  A pixel row is VS segments of SEG = 3*TS bytes,
+            // each a contiguous run of one atlas tile row, so an output dword is 4 contiguous atlas
+            // bytes at an arbitrary byte offset (two aligned dword reads + v_alignbyte) merged — when
+            // it straddles a segment boundary — with the start of the next segment.  Branch-free, so
+            // that the four dwords of a chunk overlap their LDS look-ups; the lane's (row, byte in
+            // row) position is carried incrementally like in the chunk raster.
             const uint32_t P = (uint32_t)(VS * TS), RB = P * 3u;           // bytes per pixel row
             const uint32_t S = (uint32_t)n * P * RB;                       // bytes per env
+            const uint32_t NR = (uint32_t)n * P;                           // pixel rows per env
             const size_t gb = (size_t)e * S;                               // first byte, relative to obs
-            const size_t d0 = (gb + 3) / 4, d1 = (gb + S) / 4;             // aligned dwords [d0, d1)
+            const uintptr_t A = reinterpret_cast<uintptr_t>(obs) + gb;
+            const uint32_t head = (uint32_t)min((uintptr_t)S, ((A + 15) & ~(uintptr_t)15) - A);
+            const uint32_t nq = (S - head) / 16u;                          // whole aligned chunks
+            const uint32_t tail0 = head + nq * 16u;
             const uint32_t mTS = TS > 1 ? 0xFFFFFFFFu / (uint32_t)TS + 1u : 0u;
             auto div_ts = [&](uint32_t v) -> uint32_t { return TS > 1 ? __umulhi(v, mTS) : v; };
             auto tile_off = [&](uint32_t vt) -> uint32_t {                 // virtual tile index -> byte offset
@@ -400,62 +408,153 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 else if constexpr (kGlobalAtlas) return cfg.atlas[so];
                 else return s_atlas[so];
             };
-            if (d1 > d0) {
-                // A pixel row is VS segments of SEG = 3*TS bytes, each a contiguous run of one atlas tile
-                // row.  An output dword is therefore 4 contiguous atlas bytes at an arbitrary byte
-                // offset (two aligned dword reads + v_alignbyte), or — when it straddles a segment
-                // boundary — the low bytes of one such fetch merged with the start of the next segment.
-                const uint32_t SEG = 3u * (uint32_t)TS;
-                const uint32_t mSEG = 0xFFFFFFFFu / SEG + 1u;                // SEG >= 3
-                auto fetch4 = [&](uint32_t so) -> uint32_t {
-                    const uint32_t a = (so & ~kInLds) >> 2, sh = so & 3u;
-                    uint32_t lo, hi;
-                    if (kSplit && (so & kInLds)) {
-                        const uint32_t* l32 = reinterpret_cast<const uint32_t*>(s_atlas);
-                        lo = l32[a]; hi = l32[a + 1];
-                    } else if constexpr (kGlobalAtlas) {
-                        const uint32_t* g32 = reinterpret_cast<const uint32_t*>(cfg.atlas);
-                        lo = g32[a]; hi = g32[a + 1];
-                    } else {
-                        const uint32_t* l32 = reinterpret_cast<const uint32_t*>(s_atlas);
-                        lo = l32[a]; hi = l32[a + 1];
+            const uint32_t SEG = 3u * (uint32_t)TS;
+            const uint32_t mSEG = 0xFFFFFFFFu / SEG + 1u;                    // SEG >= 3
+            auto fetch4 = [&](uint32_t so) -> uint32_t {
+                const uint32_t a = (so & ~kInLds) >> 2, sh = so & 3u;
+                uint32_t lo, hi;
+                if (kSplit && (so & kInLds)) {
+                    const uint32_t* l32 = reinterpret_cast<const uint32_t*>(s_atlas);
+                    lo = l32[a]; hi = l32[a + 1];
+                } else if constexpr (kGlobalAtlas) {
+                    const uint32_t* g32 = reinterpret_cast<const uint32_t*>(cfg.atlas);
+                    lo = g32[a]; hi = g32[a + 1];
+                } else {
+                    const uint32_t* l32 = reinterpret_cast<const uint32_t*>(s_atlas);
+                    lo = l32[a]; hi = l32[a + 1];
+                }
+                return __builtin_amdgcn_alignbyte(hi, lo, sh);
+            };
+            auto fetch8 = [&](uint32_t so) -> uint2 {                      // the two aligned dwords around `so`
+                const uint32_t a = (so & ~kInLds) >> 2;
+                if (kSplit && (so & kInLds)) {
+                    const uint32_t* l32 = reinterpret_cast<const uint32_t*>(s_atlas);
+                    return make_uint2(l32[a], l32[a + 1]);
+                } else if constexpr (kGlobalAtlas) {
+                    const uint32_t* g32 = reinterpret_cast<const uint32_t*>(cfg.atlas);
+                    return make_uint2(g32[a], g32[a + 1]);
+                } else {
+                    const uint32_t* l32 = reinterpret_cast<const uint32_t*>(s_atlas);
+                    return make_uint2(l32[a], l32[a + 1]);
+                }
+            };
+            auto seg_src = [&](uint32_t R, uint32_t seg) -> uint32_t {     // atlas byte offset of a segment start
+                const uint32_t vb = div_ts(R), rr = R - vb * (uint32_t)TS;
+                return tile_off((uint32_t)w_tmap[vb * (uint32_t)VS + seg]) + rr * SEG;
+            };
+            auto dword_at = [&](uint32_t R, uint32_t cb) -> uint32_t {     // 4 output bytes from (R, cb), cb < RB
+                const uint32_t seg = __umulhi(cb, mSEG), off = cb - seg * SEG, left = SEG - off;
+                uint32_t R2 = R, seg2 = seg + 1u;
+                if (seg2 == (uint32_t)VS) { seg2 = 0; R2++; }
+                if (R2 >= NR) R2 = R;                                        // (never used then: left >= 4)
+                const uint32_t v = fetch4(seg_src(R, seg) + off);
+                const uint32_t v2 = fetch4(seg_src(R2, seg2));
+                const uint32_t sh = left < 4u ? 8u * left : 0u;
+                const uint32_t keep = left < 4u ? (1u << sh) - 1u : 0xFFFFFFFFu;
+                return (v & keep) | ((v2 << sh) & ~keep);
+            };
+            if (L.seg_entries) {
+                // Segment-table raster.  The env's output is a linear stream of SEG-byte segments
+                // (segment g = pixel row g / VS, view column g % VS), so one table of their atlas
+                // sources absorbs the row / band / tile structure; a dword then needs only its
+                // (segment, offset) — carried incrementally — and the sources of segments g, g + 1.
+                // Built per (band, column) pair: its TS rows are TS entries VS apart, SEG bytes apart
+                // in the atlas tile (p is the tmap index of the pair).
+                const uint32_t NG = NR * (uint32_t)VS;
+                const uint32_t mVS = 0xFFFFFFFFu / (uint32_t)VS + 1u;
+                for (uint32_t p = lane; p < (uint32_t)(n * VV); p += kWave) {
+                    const uint32_t vb = __umulhi(p, mVS);
+                    uint32_t gg = p + vb * (uint32_t)(VS * (TS - 1));            // (vb*TS)*VS + seg
+                    uint32_t src = tile_off((uint32_t)w_tmap[p]);
+                    for (int rr = 0; rr < TS; rr++) { w_seg[gg] = src; gg += (uint32_t)VS; src += SEG; }
+                }
+                if (lane < 2) w_seg[NG + (uint32_t)lane] = 0u;                  // read (not used) past the last segment
+                wave_lds_sync();
+                const uint32_t nd = (S - head) / 4u;                           // whole dwords after the head
+                const uint32_t tail4 = head + nd * 4u;
+                const uint32_t STEP_G = (4u * kWave) / SEG, STEP_O = (4u * kWave) - STEP_G * SEG;
+                uint32_t o = head + 4u * (uint32_t)lane;
+                uint32_t g = o / SEG, off = o - g * SEG;
+                uint32_t* out32 = reinterpret_cast<uint32_t*>(obs + gb + head);
+                // One trip = kU dwords per lane, staged so that the LDS round trips of the kU dwords
+                // overlap: positions (VALU only) -> kU table look-ups -> 2*kU atlas fetches -> merge.
+                constexpr int kU = 4;
+                auto seg_trip = [&](uint32_t (&v)[kU]) {
+                    uint32_t go[kU], oo[kU], s0[kU], s1[kU];
+#pragma unroll
+                    for (int i = 0; i < kU; i++) {
+                        go[i] = kGlobalAtlas ? min(g, NG) : g;   // lanes past the end (last trip) must stay in the table
+                        oo[i] = off;                             // when its values address global memory
+                        off += STEP_O; g += STEP_G;
+                        if (off >= SEG) { off -= SEG; g++; }
                     }
-                    return __builtin_amdgcn_alignbyte(hi, lo, sh);
+#pragma unroll
+                    for (int i = 0; i < kU; i++) { s0[i] = w_seg[go[i]]; s1[i] = w_seg[go[i] + 1u]; }
+                    __builtin_amdgcn_sched_barrier(0);
+                    uint2 pa[kU], pb[kU];
+#pragma unroll
+                    for (int i = 0; i < kU; i++) { s0[i] += oo[i]; pa[i] = fetch8(s0[i]); pb[i] = fetch8(s1[i]); }
+                    __builtin_amdgcn_sched_barrier(0);   // all 2*kU fetches in flight before the first use
+#pragma unroll
+                    for (int i = 0; i < kU; i++) {
+                        const uint32_t a = __builtin_amdgcn_alignbyte(pa[i].y, pa[i].x, s0[i]);   // (shift = low 2 bits)
+                        const uint32_t b = __builtin_amdgcn_alignbyte(pb[i].y, pb[i].x, s1[i]);
+                        // nl = bytes that come from the next segment (0 unless the dword straddles):
+                        // {b, a << 8 nl} >> 8 nl = a's valid low bytes, then b's first nl bytes
+                        const uint32_t nl = (uint32_t)max((int)oo[i] + 4 - (int)SEG, 0);
+                        v[i] = __builtin_amdgcn_alignbyte(b, a << (8u * nl), nl);
+                    }
                 };
-                auto seg_src = [&](uint32_t R, uint32_t seg) -> uint32_t {     // atlas byte offset of a segment start
-                    const uint32_t vb = div_ts(R), rr = R - vb * (uint32_t)TS;
-                    return tile_off((uint32_t)w_tmap[vb * (uint32_t)VS + seg]) + rr * SEG;
-                };
-                const uint32_t STEP_Rb = (4u * kWave) / RB, STEP_B = (4u * kWave) - STEP_Rb * RB;
-                uint32_t o = (uint32_t)(4 * (d0 + lane) - gb);             // this lane's first byte offset
+                uint32_t d = lane;
+                for (; d + (kU - 1) * kWave < nd; d += kU * kWave) {
+                    uint32_t v[kU];
+                    seg_trip(v);
+#pragma unroll
+                    for (int i = 0; i < kU; i++) out32[d + i * kWave] = v[i];
+                }
+                if (d < nd) {                                                  // last, partial trip
+                    uint32_t v[kU];
+                    seg_trip(v);
+#pragma unroll
+                    for (int i = 0; i < kU; i++) if (d + i * kWave < nd) out32[d + i * kWave] = v[i];
+                }
+                if (lane < 32) {                                               // head / tail bytes
+                    const uint32_t ob = lane < 16 ? (uint32_t)lane : tail4 + (uint32_t)(lane - 16);
+                    const bool on = lane < 16 ? (uint32_t)lane < head : ob < S;
+                    if (on) {
+                        const uint32_t R = ob / RB, cb = ob - R * RB;
+                        obs[gb + ob] = (uint8_t)byte_at(R, cb);
+                    }
+                }
+            } else {
+            if (nq) {
+                const uint32_t STEP_Rb = (16u * kWave) / RB, STEP_B = (16u * kWave) - STEP_Rb * RB;
+                uint32_t o = head + 16u * (uint32_t)lane;                    // this lane's first byte offset
                 uint32_t R = o / RB, cb = o - R * RB;
-                uint32_t* out32 = reinterpret_cast<uint32_t*>(obs) + d0;
-                const uint32_t nd = (uint32_t)(d1 - d0);
-                for (uint32_t d = lane; d < nd; d += kWave) {
-                    const uint32_t seg = __umulhi(cb, mSEG), off = cb - seg * SEG, left = SEG - off;
-                    uint32_t v = fetch4(seg_src(R, seg) + off);
-                    if (left < 4u) {                                         // straddles into the next segment
-                        uint32_t R2 = R, seg2 = seg + 1u;
-                        if (seg2 == (uint32_t)VS) { seg2 = 0; R2++; }
-                        const uint32_t v2 = fetch4(seg_src(R2, seg2));
-                        const uint32_t keep = (1u << (8u * left)) - 1u;
-                        v = (v & keep) | (v2 << (8u * left));
+                uint4* out16 = reinterpret_cast<uint4*>(obs + gb + head);
+                for (uint32_t q = lane; q < nq; q += kWave) {
+                    uint32_t v[4];
+                    uint32_t Ri = R, ci = cb;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        v[i] = dword_at(Ri, ci);
+                        ci += 4u;
+                        if (ci >= RB) { ci -= RB; Ri++; }
                     }
-                    out32[d] = v;
+                    out16[q] = make_uint4(v[0], v[1], v[2], v[3]);
                     R += STEP_Rb; cb += STEP_B;
                     if (cb >= RB) { cb -= RB; R++; }
                 }
             }
-            // head / tail bytes (at most 3 each)
-            const uint32_t head = (uint32_t)(4 * d0 - gb) < S ? (uint32_t)(4 * d0 - gb) : S;
-            const uint32_t tail0 = d1 > d0 ? (uint32_t)(4 * d1 - gb) : head;
-            if (lane < 8) {
-                uint32_t o = lane < 4 ? (uint32_t)lane : tail0 + (lane - 4);
-                const bool on = lane < 4 ? (uint32_t)lane < head : o < S;
+            // head / tail bytes (at most 15 each)
+            if (lane < 32) {
+                const uint32_t o = lane < 16 ? (uint32_t)lane : tail0 + (uint32_t)(lane - 16);
+                const bool on = lane < 16 ? (uint32_t)lane < head : o < S;
                 if (on) {
                     const uint32_t R = o / RB, cb = o - R * RB;
                     obs[gb + o] = (uint8_t)byte_at(R, cb);
                 }
+            }
             }
         }
         wave_lds_sync();   // scratch is reused by the next env
@@ -466,8 +565,7 @@ template <int VS_, int TS_, int WPB, int V_ = 0>
 static hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_t* obs, uint8_t* c, uint8_t* a,
                                   uint8_t* v, hipStream_t s) {
     const int tile_bytes = cfg.tile_size * cfg.tile_size * 3;
-    const RenderScratch L = render_scratch_layout(cfg.cells_stride, cfg.n_agents, cfg.view_size,
-                                                  (V_ == 9 || V_ == 12) ? (cfg.any_hide ? 2 : 1) * cfg.n_agents * 4 * tile_bytes : 0);
+    const RenderScratch L = render_scratch_for(cfg);
     size_t lds = ((V_ == 8 || V_ == 12) ? 0 : (size_t)round_up(4 * cfg.n_tiles * tile_bytes, 16)) + 2 * MG_MAX_OBJ +
                  MG_MAX_AGENTS * 8 + WPB * (size_t)L.total;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
@@ -497,7 +595,7 @@ static hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_
 static int choose_wpb(const MgConfig& cfg) {
     if (const char* f = getenv("MG_RENDER_WPB")) { int w = atoi(f); if (w == 4 || w == 8 || w == 16) return w; }
     const int tile_bytes = cfg.tile_size * cfg.tile_size * 3;
-    const RenderScratch L = render_scratch_layout(cfg.cells_stride, cfg.n_agents, cfg.view_size);
+    const RenderScratch L = render_scratch_for(cfg);
     size_t lds16 = (size_t)round_up(4 * cfg.n_tiles * tile_bytes, 16) + 2 * MG_MAX_OBJ + MG_MAX_AGENTS * 8 + 16 * (size_t)L.total;
     return (cfg.B >= 4096 && lds16 <= 160 * 1024) ? 16 : 4;
 }
@@ -515,8 +613,7 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
     const int vs = cfg.view_size, ts = cfg.tile_size;
     const int wpb = choose_wpb(cfg);
     if (cfg.prestige_mask) {   // per-env recoloured agent tiles (LDS), 4-wave workgroups
-        const RenderScratch L = render_scratch_layout(cfg.cells_stride, cfg.n_agents, cfg.view_size,
-                                                      (cfg.any_hide ? 2 : 1) * cfg.n_agents * 4 * ts * ts * 3);
+        const RenderScratch L = render_scratch_for(cfg);
         const size_t lds4 = (size_t)round_up(4 * cfg.n_tiles * ts * ts * 3, 16) + 2 * MG_MAX_OBJ + MG_MAX_AGENTS * 8 +
                             4 * (size_t)L.total;
         if (lds4 > 160 * 1024) {   // the static atlas stays in global memory
@@ -531,7 +628,7 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
         return launch_render_t<0, 0, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
     }
     {   // atlas too large for LDS (next to 4 waves of scratch): read it from global memory instead
-        const RenderScratch L = render_scratch_layout(cfg.cells_stride, cfg.n_agents, cfg.view_size);
+        const RenderScratch L = render_scratch_for(cfg);
         const size_t lds4 = (size_t)round_up(4 * cfg.n_tiles * ts * ts * 3, 16) + 2 * MG_MAX_OBJ + MG_MAX_AGENTS * 8 +
                             4 * (size_t)L.total;
         if (lds4 > 160 * 1024) {
