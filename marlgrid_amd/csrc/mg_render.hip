@@ -579,6 +579,7 @@ static hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_
     // env-time in ~6).  Registers (~87 VGPRs) admit 5 waves per SIMD = 20 per CU.
     int per_cu = (int)((160 * 1024) / (lds ? lds : 1));
     if (per_cu > 20 / WPB) per_cu = 20 / WPB;
+    if (const char* f = getenv("MG_RENDER_PER_CU")) { const int v = atoi(f); if (v >= 1 && v < per_cu) per_cu = v; }   // (measurement)
     if (per_cu < 1) per_cu = 1;
     const int max_blocks = 256 * per_cu;
     const int need = (cfg.B * (V_ == 10 ? 2 : 1) + WPB - 1) / WPB;   // workgroups if every wave took one env

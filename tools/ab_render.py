@@ -27,6 +27,7 @@ for rep in range(7):
     for v in variants:
         os.environ["MG_RENDER_VARIANT"] = v.split(":")[0]
         os.environ["MG_RENDER_WPB"] = v.split(":")[1] if ":" in v else "0"
+        os.environ["MG_RENDER_PER_CU"] = v.split(":")[2] if v.count(":") > 1 else "0"   # "V:wpb:workgroups per CU"
         N.check(env._lib.mg_time_render_obs(C.byref(env._cfg), C.byref(env._state), env.obs.data_ptr(), 40,
                                             C.byref(ms), env._stream()))
         res[v].append(ms.value)
