@@ -376,14 +376,14 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 put(c, v);
             }
         } else {
-            // Any tile size: the env's n*P*P*3 output bytes are still one contiguous run, written as
-            // whole 16-byte chunks at 16-byte-aligned ADDRESSES (plus <= 15 head and <= 15 tail bytes:
-            // an env's run starts wherever e*S falls).  A pixel row is VS segments of SEG = 3*TS bytes,
-            // each a contiguous run of one atlas tile row, so an output dword is 4 contiguous atlas
-            // bytes at an arbitrary byte offset (two aligned dword reads + v_alignbyte) merged — when
-            // it straddles a segment boundary — with the start of the next segment.  Branch-free, so
-            // that the four dwords of a chunk overlap their LDS look-ups; the lane's (row, byte in
-            // row) position is carried incrementally like in the chunk raster.
+            // Any tile size: the env's n*P*P*3 output bytes are still one contiguous run, but it starts
+            // wherever e*S falls, and tile rows are not whole dwords.  A pixel row is VS segments of
+            // SEG = 3*TS bytes, each a contiguous run of one atlas tile row, so an output dword is 4
+            // contiguous atlas bytes at an arbitrary byte offset (two aligned dword reads +
+            // v_alignbyte) merged — when it straddles a segment boundary — with the start of the next
+            // segment.  Two implementations: the segment-table raster (normal case) and, when that
+            // table does not fit in LDS, per-dword (row, column) arithmetic on 16-byte chunks.  Bytes
+            // before the first aligned address / after the last whole unit are stored singly.
             const uint32_t P = (uint32_t)(VS * TS), RB = P * 3u;           // bytes per pixel row
             const uint32_t S = (uint32_t)n * P * RB;                       // bytes per env
             const uint32_t NR = (uint32_t)n * P;                           // pixel rows per env
