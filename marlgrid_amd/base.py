@@ -90,6 +90,33 @@ class ObjectRegistry(object):
     def find(self, obj):
         return self.key_to_id.get(obj.key(), 0)
 
+    # the rest of the reference's registry interface (base.py:32-53)
+    def get_next_key(self):
+        if len(self.objs) >= self.max_num_objects:
+            raise ValueError("Object registry full.")
+        return len(self.objs)
+
+    def add_object(self, obj):
+        return self.get_key(obj)
+
+    def contains_object(self, obj):
+        return obj is None or (isinstance(obj, WorldObj) and obj.key() in self.key_to_id)
+
+    def contains_key(self, key):
+        return 0 <= int(key) < len(self.objs)
+
+
+def rotate_grid(grid, rot_k):
+    """base.py:67-80 on tensors whose last two dims are (x, y): np.rot90 with the args used for images"""
+    rot_k = rot_k % 4
+    if rot_k == 3:
+        return grid.flip(-1).transpose(-1, -2)
+    if rot_k == 1:
+        return grid.flip(-2).transpose(-1, -2)
+    if rot_k == 2:
+        return grid.flip(-1).flip(-2)
+    return grid
+
 
 class MultiGrid(object):
     """The grid container (base.py:83-331).  Constructed inside `_gen_grid`, where it records the
@@ -167,6 +194,36 @@ class MultiGrid(object):
         """(B, W, H, 3) uint8 — batched MultiGrid.encode (base.py:196-214)"""
         return self._env._encode(vis_mask)
 
+    # host-side (torch) counterparts of the array helpers gen_obs_grid is written with upstream; the
+    # obs kernel does its own crop / rotate / shadow cast, these are for callers and for tests
+    @property
+    def opacity(self):
+        """(B, W, H) bool: cells one cannot see through (base.py:103-106; empty cells and agents are transparent)"""
+        import torch
+        e = self._env
+        opaque = torch.tensor([False] + [not o.see_behind() for o in self.obj_reg.objs[1:]], device=e.device)
+        return opaque[self.grid.long()]
+
+    def rotate_left(self, k=1):
+        """(B, W', H') object ids of the whole grid rotated like base.py:115-120"""
+        return rotate_grid(self.grid, k)
+
+    def slice(self, topX, topY, width, height, rot_k=0):
+        """(B, w, h) object ids of a window of every env, zero-padded outside the grid and rotated
+        (base.py:123-147).  topX / topY: ints or (B,) tensors (e.g. columns of `agent.get_view_exts()`)."""
+        import torch
+        e = self._env
+        g = self.grid
+        B = g.shape[0]
+        tx = torch.as_tensor(topX, device=e.device).long().expand(B)
+        ty = torch.as_tensor(topY, device=e.device).long().expand(B)
+        xs = tx[:, None] + torch.arange(width, device=e.device)[None, :]          # (B, w)
+        ys = ty[:, None] + torch.arange(height, device=e.device)[None, :]         # (B, h)
+        ok = ((xs >= 0) & (xs < self.width))[:, :, None] & ((ys >= 0) & (ys < self.height))[:, None, :]
+        flat = xs.clamp(0, self.width - 1)[:, :, None] * self.height + ys.clamp(0, self.height - 1)[:, None, :]
+        sub = torch.gather(g.reshape(B, -1), 1, flat.reshape(B, -1)).view(B, width, height)
+        return rotate_grid(torch.where(ok, sub, torch.zeros_like(sub)), rot_k)
+
     @classmethod
     def decode(cls, array):
         raise NotImplementedError      # as upstream (base.py:216-218)
@@ -206,6 +263,8 @@ class MultiGridEnv(object):
         for agent in agents:
             self.add_agent(agent)
         self._check_agents()
+        for k, agent in enumerate(self.agents):
+            agent._bind(self, k)         # agent.pos / .dir / .done / ... become batched views of this env
 
         self.obj_reg = ObjectRegistry()
         self._tables_version = -1
@@ -748,6 +807,26 @@ class MultiGridEnv(object):
                     N.ERR_TYPE: "toggle() takes 1 positional argument but 3 were given (Box, env %d)" % b,
                     N.ERR_ASSERT: "grid access out of bounds (env %d)" % b}
             raise N.ERR_EXC[code](msgs[code])
+
+    def check_agent_position_integrity(self, title=""):
+        """base.py:479-499 checks that every agent is in the grid exactly once (stack handling is
+        error-prone there).  The packed records cannot express an agent in two places; what can be
+        checked is that they are consistent: placed agents are inside the grid on a cell an agent
+        can stand on, stack ranks are a permutation, active implies placed.  Raises AssertionError
+        (the reference drops into pdb)."""
+        import torch
+        pos, fl, rk = self.agent_pos, self.agent_flags, self.agent_rank
+        placed = (fl & N.AF_PLACED) != 0
+        ok = ~placed | ((pos[..., 0] < self.width) & (pos[..., 1] < self.height))
+        cell = (pos[..., 0] * self.height + pos[..., 1]).clamp(max=self.width * self.height - 1)
+        base = torch.gather(self.grid_state[:, :self.width * self.height].long(), 1, cell)
+        overlap = torch.tensor([True] + [bool(o.can_overlap()) for o in self.obj_reg.objs[1:]], device=self.device)
+        ok &= ~placed | overlap[base]
+        ok &= ((fl & N.AF_ACTIVE) == 0) | placed
+        ok &= (rk.sort(dim=1).values == torch.arange(self.num_agents, device=self.device)).all(dim=1, keepdim=True)
+        if not bool(ok.all()):
+            bad = torch.nonzero(~ok.all(dim=1))[:8, 0].tolist()
+            raise AssertionError("%s > Failed integrity test! envs %s" % (title, bad))
 
     # ---- agent state views (per-env state lives in HBM, not on the agent objects) -------------------------
     def _rec_byte(self, i):

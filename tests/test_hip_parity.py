@@ -149,6 +149,63 @@ def test_fuzz_vs_oracle(i):
     test_batch_vs_oracle("Fuzz-%d" % i, 40 + (i % 3) * 33, 70)
 
 
+def test_agent_objects_expose_batched_state_and_geometry():
+    """env.agents[k].pos / .dir / .done / .active / .carrying and the view-geometry helpers
+    (agents.py:141-288) are batched views of the device state: checked against the oracle's agents"""
+    import torch
+    name, B = "MarlGrid-3AgentCluttered11x11-v0", 64
+    seeds = 900 + np.arange(B)
+    env = product_envs.build(name, batch_size=B, seeds=seeds)
+    orc = O.OracleBatch(scenarios.registered(name), seeds)
+    env.reset(); orc.reset()
+    rng = np.random.RandomState(3)
+    for t in range(25):
+        a = rng.randint(0, 7, size=(B, 3))
+        env.step(torch.from_numpy(a)); orc.step(a)
+    vs, off = env.view_size, env.view_offset
+    for k, ag in enumerate(env.agents):
+        pos, d = ag.pos.cpu().numpy(), ag.dir.cpu().numpy()
+        exts, front = ag.get_view_exts().cpu().numpy(), ag.front_pos.cpu().numpy()
+        rel, inv = ag.relative_coords(5, 4).cpu().numpy(), ag.in_view(5, 4).cpu().numpy()
+        for b in range(B):
+            st = canon.oracle_canonical(orc.envs[b])
+            assert tuple(pos[b]) == tuple(st["pos"][k]) and d[b] == st["dir"][k]
+            assert bool(ag.done[b]) == bool(st["done"][k]) and bool(ag.active[b]) == bool(st["active"][k])
+            if pos[b][0] < 0:
+                continue
+            x, y = pos[b]
+            fx, fy = [(1, 0), (0, 1), (-1, 0), (0, -1)][d[b]]
+            assert tuple(front[b]) == (x + fx, y + fy)
+            # the view square contains the agent at get_view_pos() after rotation: its own cell is in view
+            tx, ty, bx, by = exts[b]
+            assert tx <= x < bx and ty <= y < by and bx - tx == vs and by - ty == vs
+            own = ag.relative_coords(int(x), int(y))[b].cpu().numpy()
+            assert tuple(own) == ag.get_view_pos()
+            assert inv[b] == (tx <= 5 < bx and ty <= 4 < by) and (rel[b][0] >= 0) == inv[b]
+    env.check_agent_position_integrity("after 25 steps")
+    # MultiGrid.slice / rotate_grid / opacity in torch == what the obs kernel cropped and rotated itself
+    cells, shown, vis = env._render(debug=True)
+    for k, ag in enumerate(env.agents):
+        ex = ag.get_view_exts()
+        for dd in range(4):
+            m = (ag.dir == dd) & ag.active
+            if not bool(m.any()):
+                continue
+            sub = env.grid.slice(ex[:, 0], ex[:, 1], vs, vs, rot_k=dd + 1)
+            assert torch.equal(sub[m], cells[:, k][m]), (k, dd)
+    b0 = env.grid.grid[0].cpu().numpy()
+    wall = env.obj_reg.find(__import__("marlgrid_amd").objects.Wall())
+    assert np.array_equal(env.grid.opacity[0].cpu().numpy(), b0 == wall)
+    assert torch.equal(env.grid.rotate_left(4), env.grid.grid) and env.grid.rotate_left(1).shape[1:] == (env.height, env.width)
+    env.agent_state[3, 1] |= 0xFF                      # x = 255: off the grid
+    with pytest.raises(AssertionError, match="integrity"):
+        env.check_agent_position_integrity("corrupted")
+    with pytest.raises(AttributeError):
+        env.agents[0].prestige
+    with pytest.raises(NotImplementedError):
+        env.agents[0].sees(1, 1)
+
+
 def test_stepping_past_done_like_the_reference():
     """the reference keeps stepping after `done` (no auto-reset, base.py:649-653): step_count runs
     past max_steps, done agents stay inactive, the decay factor goes negative."""

@@ -213,3 +213,16 @@ def test_atlas_of_every_object_kind_matches_the_oracle(ts):
                     assert np.array_equal(atlas[0, 1 + n_obj + (slot[i] * n_ag + k) * 4 + d], orc.tile(i, k, d)), (i, k, d)
     # overlappable kinds: empty, Goal, open Door, Lava, Floor, BonusTile
     assert n_slots == 6
+
+
+def test_object_registry_interface():
+    """ObjectRegistry (base.py:19-64): ids are per object *kind* (hash-by-value), key 0 is None"""
+    from marlgrid_amd.base import ObjectRegistry
+    from marlgrid_amd import objects as PO
+    r = ObjectRegistry()
+    assert len(r) == 1 and r.contains_key(0) and not r.contains_key(1) and r.get_next_key() == 1
+    k = r.add_object(PO.Wall())
+    assert k == 1 and r.get_key(PO.Wall()) == 1 and r.contains_object(PO.Wall()) and not r.contains_object(PO.Goal(color="green", reward=1))
+    assert isinstance(r.obj_of_key(1), PO.Wall) and r.get_key(None) == 0 and r.get_next_key() == 2
+    with pytest.raises(ValueError):
+        r.get_key(PO.GridAgent())

@@ -92,3 +92,41 @@ def test_live_place_obj_and_try_place_obj():
         st = env.np_random.get_state()
         mt, p = orc.mt_state()
         assert st[2] == p and np.array_equal(st[1], mt)
+
+
+def test_agent_geometry_helpers_match_the_reference():
+    """GridAgentInterface.get_view_exts / get_view_coords / relative_coords / in_view (agents.py:200-285):
+    the product's batched tensor versions == the reference's per-agent methods on random poses"""
+    import torch
+    refload.load()
+    from marlgrid.agents import GridAgentInterface as RefAgent
+    from marlgrid_amd.agents import GridAgentInterface as Agent
+    rng = np.random.RandomState(5)
+    for vs, off in ((7, 0), (7, 1), (5, 2), (9, 3), (3, 0), (7, 6)):
+        ref = RefAgent(view_size=vs, view_offset=off)
+        N = 200
+        pos = rng.randint(0, 20, size=(N, 2))
+        d = rng.randint(0, 4, size=N)
+        ij = rng.randint(-3, 24, size=(N, 2))
+        tp, td = torch.from_numpy(pos), torch.from_numpy(d)
+        exts = Agent._view_exts(tp, td, vs, off).numpy()
+        vx, vy = Agent._view_coords(tp, td, torch.from_numpy(ij[:, 0]), torch.from_numpy(ij[:, 1]), vs, off)
+        for b in range(N):
+            ref.pos, ref.dir = tuple(pos[b]), int(d[b])
+            assert tuple(exts[b]) == tuple(ref.get_view_exts())
+            assert (int(vx[b]), int(vy[b])) == tuple(int(v) for v in ref.get_view_coords(*ij[b]))
+            assert np.array_equal(Agent._dir_vec(td[b:b + 1])[0].numpy(), ref.dir_vec)
+
+
+def test_rotate_grid_matches_the_reference():
+    """marlgrid_amd.base.rotate_grid (torch, trailing (x, y) dims) == base.py:67-80 (numpy)"""
+    import torch
+    refload.load()
+    from marlgrid.base import rotate_grid as ref_rot
+    from marlgrid_amd.base import rotate_grid
+    a = np.arange(3 * 5).reshape(3, 5)
+    b = np.arange(2 * 3 * 5).reshape(2, 3, 5)
+    for k in range(-1, 6):
+        assert np.array_equal(rotate_grid(torch.from_numpy(a.copy()), k).numpy(), ref_rot(a, k))
+        r = rotate_grid(torch.from_numpy(b.copy()), k).numpy()
+        assert all(np.array_equal(r[i], ref_rot(b[i], k)) for i in range(2))
