@@ -229,11 +229,20 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
         wave_lds_sync();
         if constexpr (kPrestige) {
             // 4b. tiles of active 'prestige' agents are recoloured per env (render_post) — and blended
-            //     with the object they stand on — before rotation; generate them for all 4 orientations.
-            //     With hide_item_types a viewer may hide that object and see the agent as a plain cell
+            //     with the object they stand on — before rotation, for all 4 orientations.  With
+            //     hide_item_types a viewer may hide that object and see the agent as a plain cell
             //     object instead: a second set (hv = 1) on the empty tile.
+            //     Colours first, one lane per agent (the float64 tanh runs once per env, not once per
+            //     agent); w_trow is free after the shadow cast.  Then per agent the tile in orientation
+            //     0 (the only pass with per-pixel arithmetic) and three rotated byte copies of it.
             const int npx = TS * TS;
             const uint8_t* abase = kGlobalAtlas ? cfg.atlas : s_atlas;
+            uint32_t* w_col = w_trow;
+            if (lane < n && ((cfg.prestige_mask >> lane) & 1u)) {
+                const PrestigeColor c = prestige_color(st.prestige[(size_t)e * n + lane], cfg.prestige_scale[lane]);
+                w_col[lane] = c.r | (c.g << 8) | (c.b << 16);
+            }
+            wave_lds_sync();
             for (int Xh = 0; Xh < (cfg.any_hide ? 2 * n : n); Xh++) {
                 const int hv = Xh >= n, X = Xh - hv * n;
                 if (!((cfg.prestige_mask >> X) & 1u)) continue;
@@ -242,23 +251,29 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 uint32_t base = w_grid[rec_byte(rx, MG_AG_X) * H + rec_byte(rx, MG_AG_Y)];
                 if (hv) { if (!base) continue; base = 0; }
                 const uint32_t sdir = rec_byte(rx, MG_AG_DIR);
-                const PrestigeColor col = prestige_color(st.prestige[(size_t)e * n + X], cfg.prestige_scale[X]);
+                const uint32_t pc = w_col[X];
+                const PrestigeColor col = {pc & 0xFFu, (pc >> 8) & 0xFFu, (pc >> 16) & 0xFFu};
                 const uint32_t amax = cfg.prestige_amax[sdir];
                 const uint32_t M = ((amax * col.r) >> 8) + ((amax * col.g) >> 8) + ((amax * col.b) >> 8);
                 const uint8_t* white = abase + (size_t)(cfg.prestige_sprite_tile + sdir) * tile_bytes;   // orientation 0, no border
                 const uint8_t* btile = base ? abase + (size_t)(1 + base) * tile_bytes : nullptr;
                 const bool border = base ? (cfg.obj[base].flags2 & 1) != 0 : true;
                 const uint8_t* etile = abase + (size_t)tile_bytes;                                   // empty tile
-                for (int idx = lane; idx < 4 * npx; idx += kWave) {
-                    const int o = idx / npx, p = idx - o * npx, r = p / TS, c = p - r * TS;
+                uint8_t* t0 = w_dyn + (size_t)(Xh * 4) * npx * 3;
+                for (int p = lane; p < npx; p += kWave) {
+                    const int sp = p * 3;
+                    prestige_pixel(white[sp], col, M, btile ? btile + sp : nullptr, border ? etile + sp : nullptr, t0 + sp);
+                }
+                wave_lds_sync();
+                for (int idx = lane; idx < 3 * npx; idx += kWave) {
+                    const int o = 1 + idx / npx, p = idx - (o - 1) * npx, r = p / TS, c = p - r * TS;
                     int sr, sc;   // source pixel of output pixel (r, c) at orientation o (rotate_grid, base.py:67-80)
                     if (o == 3) { sr = c; sc = TS - 1 - r; }
                     else if (o == 1) { sr = TS - 1 - c; sc = r; }
-                    else if (o == 2) { sr = TS - 1 - r; sc = TS - 1 - c; }
-                    else { sr = r; sc = c; }
-                    const int sp = (sr * TS + sc) * 3;
-                    prestige_pixel(white[sp], col, M, btile ? btile + sp : nullptr, border ? etile + sp : nullptr,
-                                   w_dyn + ((size_t)(Xh * 4 + o) * npx + p) * 3);
+                    else { sr = TS - 1 - r; sc = TS - 1 - c; }
+                    const uint8_t* src = t0 + (sr * TS + sc) * 3;
+                    uint8_t* dst = t0 + ((size_t)o * npx + p) * 3;
+                    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
                 }
             }
             wave_lds_sync();
@@ -623,6 +638,8 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
             if (ts == 32) return launch_render_t<0, 32, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
             return launch_render_t<0, 0, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
         }
+        if (vs == 7 && ts == 8) return MG_RENDER_DISPATCH(7, 8, 9);     // the shipped view: compile-time size,
+        if (vs == 7 && (ts % 8) != 0) return MG_RENDER_DISPATCH(7, 0, 9);   // 16-wave workgroups when they fit
         if (ts == 8) return launch_render_t<0, 8, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
         if (ts == 16) return launch_render_t<0, 16, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
         if (ts == 32) return launch_render_t<0, 32, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
