@@ -22,17 +22,18 @@ env = make(args.env, batch_size=args.batch, auto_reset=True, strict=False)
 obs = env.reset()                                             # (B, n, P, P, 3) uint8 on the GPU
 n = env.num_agents
 returns = torch.zeros(args.batch, n, device=obs.device)
-episodes = 0
+episodes = torch.zeros((), dtype=torch.int64, device=obs.device)    # counted on the device: no host sync per step
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for t in range(args.steps):
     actions = torch.randint(0, 3, (args.batch, n), device=obs.device)     # left / right / forward
     obs, rew, done, _ = env.step(actions)
     returns += rew
-    episodes += int(done.sum())
+    episodes += done.sum()
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 env.check_errors()
+episodes = int(episodes)
 print("%s: %d envs x %d steps in %.3f s = %.1f M agent-steps/s; %d episodes finished; mean return %.4f"
       % (args.env, args.batch, args.steps, dt, args.batch * n * args.steps / dt / 1e6, episodes,
          float(returns.sum() / max(episodes, 1) / n)))
