@@ -549,6 +549,67 @@ def test_live_place_obj_and_try_place_obj_vs_oracle():
         assert np.array_equal(o.cpu().numpy(), o2) and np.array_equal(dn.cpu().numpy(), dn2)
 
 
+@pytest.mark.parametrize("i", [3, 4, 8, 10, 21, 24, 27, 31, 33, 36])
+def test_operation_fuzz_vs_oracle(i):
+    """random interleaving of step / masked reset / live place_obj / try_place_obj (objects and agents)
+    on randomly configured envs (scenarios.fuzz_case): state, observations and RNG stay equal to the
+    oracle's after every operation"""
+    import torch
+    from marlgrid_amd.objects import Wall
+    name, B = "Fuzz-%d" % i, 24
+    spec = scenarios.registered(name)
+    W, H, n = spec["W"], spec["H"], len(spec["agents"])
+    seeds = 8800 + 100 * i + np.arange(B)
+    env = product_envs.build(name, batch_size=B, seeds=seeds)
+    orc = O.OracleBatch(spec, seeds)
+    env.reset(); orc.reset()
+    rng = np.random.RandomState(77 + i)
+    walls = 0
+
+    def same(what):
+        st = product_envs.canonical(env)
+        for b in range(B):
+            canon.assert_same(st[b], canon.oracle_canonical(orc.envs[b]), "%s env %d" % (what, b))
+        assert np.array_equal(env.gen_obs().cpu().numpy(), orc.gen_obs()), what
+        for b in (0, B - 1):
+            mt, pos = env.numpy_rng_state(b)
+            mt2, pos2 = orc.envs[b].mt_state()
+            assert pos == pos2 and np.array_equal(mt, mt2), what
+
+    for t in range(36):
+        op = rng.choice(["step", "step", "step", "reset", "place_wall", "try_wall", "try_agent", "reseat"])
+        if op == "step":
+            a = rng.randint(0, 7, size=(B, n))
+            o, r, dn, _ = env.step(torch.from_numpy(a))
+            o2, r2, dn2, _ = orc.step(a)
+            assert np.array_equal(o.cpu().numpy(), o2) and np.array_equal(dn.cpu().numpy(), dn2), t
+            assert np.abs(r.cpu().numpy().astype(np.float64) - r2).max() <= REW_TOL
+        elif op == "reset":
+            m = rng.rand(B) < 0.4
+            env.reset(env_mask=m)
+            for b in np.nonzero(m)[0]:
+                orc.envs[b].reset()
+            walls = 0 if m.all() else walls
+        elif op == "place_wall" and walls < 3:       # (kept sparse: rejection sampling must not run dry)
+            walls += 1
+            pos = env.place_obj(Wall(), max_tries=100).cpu().numpy()
+            assert np.array_equal(pos, np.array([e.place_obj(1, max_tries=100) for e in orc.envs])), t
+        elif op == "try_wall":
+            xy = np.stack([rng.randint(0, W, size=B), rng.randint(0, H, size=B)], axis=1)
+            ok = env.try_place_obj(Wall(), torch.from_numpy(xy)).cpu().numpy()
+            assert np.array_equal(ok, np.array([e.try_place_obj(1, *xy[b]) for b, e in enumerate(orc.envs)])), t
+        elif op == "try_agent":
+            k = int(rng.randint(n))
+            x, y = int(rng.randint(W)), int(rng.randint(H))
+            ok = env.try_place_obj(env.agents[k], (x, y)).cpu().numpy()
+            assert np.array_equal(ok, np.array([e.try_place_obj(-(k + 1), x, y) for e in orc.envs])), t
+        elif op == "reseat":
+            k = int(rng.randint(n))
+            pos = env.place_obj(env.agents[k]).cpu().numpy()
+            assert np.array_equal(pos, np.array([e.place_obj(-(k + 1)) for e in orc.envs])), t
+        same("%s @%d" % (op, t))
+
+
 def test_objects_zoo_vs_oracle():
     """every object class on one board (Lava ends the episode, Floor / open Door / BonusTile are
     walked over, Ball / Key are carried, Doors toggled and unlocked): HIP == oracle step by step."""
