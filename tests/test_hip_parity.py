@@ -610,6 +610,33 @@ def test_operation_fuzz_vs_oracle(i):
         same("%s @%d" % (op, t))
 
 
+def test_step_is_stream_capturable():
+    """env.step() makes no allocation, host sync or stream switch: it can be captured into a HIP graph
+    (torch.cuda.graph) and replayed — every replay equals the oracle stepping the same actions"""
+    import torch
+    name, B = "MarlGrid-3AgentCluttered11x11-v0", 48
+    seeds = 600 + np.arange(B)
+    env = product_envs.build(name, batch_size=B, seeds=seeds, obs_buffers=1, strict=False)
+    orc = O.OracleBatch(scenarios.registered(name), seeds)
+    env.reset(); orc.reset()
+    rng = np.random.RandomState(2)
+    a = rng.randint(0, 7, size=(B, 3))
+    static = torch.from_numpy(a).to(env.device)
+    env.step(static); orc.step(a)                  # eager once
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):                      # recorded, not executed
+        obs, rew, done, _ = env.step(static)
+    for t in range(12):
+        a = rng.randint(0, 7, size=(B, 3))
+        static.copy_(torch.from_numpy(a))
+        g.replay()
+        o2, r2, d2, _ = orc.step(a)
+        assert np.array_equal(obs.cpu().numpy(), o2), t
+        assert np.abs(rew.cpu().numpy().astype(np.float64) - r2).max() <= REW_TOL
+        assert np.array_equal(done.cpu().numpy(), d2)
+    env.check_errors()
+
+
 def test_objects_zoo_vs_oracle():
     """every object class on one board (Lava ends the episode, Floor / open Door / BonusTile are
     walked over, Ball / Key are carried, Doors toggled and unlocked): HIP == oracle step by step."""
