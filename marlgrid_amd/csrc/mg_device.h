@@ -99,17 +99,21 @@ __device__ inline void prestige_pixel(uint32_t alpha, const PrestigeColor& col, 
 
 // per-wave LDS scratch of the obs-render kernel (bytes), shared by host launch code and kernel
 struct RenderScratch {
-    int grid, first, second, rec, vbase, vshow, trow, vis, tmap, dyn, seg, total;
+    int grid, rec, first, second, vbase, vshow, trow, vis, tmap, dyn, seg, total;
+    int stage_envs;    // envs whose inputs (grid + agent records) are staged per batch: 1..8
+    int rec_stride;    // u64 records per staged env
     int seg_entries;   // 0: no segment table (tile size on the 16-byte-chunk path, or it would not fit)
 };
-__host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride, int n, int vs, int dyn_bytes = 0,
-                                                               int seg_entries = 0) {
+__host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride, int n, int vs, int stage_envs = 1,
+                                                               int dyn_bytes = 0, int seg_entries = 0) {
     RenderScratch s;
     int o = 0;
-    s.grid = o;  o += round_up(cells_stride, 16);
+    s.stage_envs = stage_envs;
+    s.rec_stride = round_up(n * 8, 16) / 8;
+    s.grid = o;  o += stage_envs * round_up(cells_stride, 16);
+    s.rec = o;   o += stage_envs * s.rec_stride * 8;
     s.first = o; o += round_up(cells_stride, 16);
     s.second = o; o += round_up(cells_stride, 16);
-    s.rec = o;   o += MG_MAX_AGENTS * 8;
     s.vbase = o; o += round_up(n * vs * vs, 16);
     s.vshow = o; o += round_up(n * vs * vs, 16);
     s.trow = o;  o += round_up(n * vs * 4, 16);
@@ -121,22 +125,25 @@ __host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride,
     s.total = o;
     return s;
 }
-// The layout a launch of the obs kernel uses, from the config alone (kernel and launcher agree):
-// recoloured-tile space when some agent is 'prestige'; for tile sizes off the 16-byte-chunk path
-// a table with the atlas source of every (pixel row, view column) segment of the env's images —
-// n*P*VS entries — when it is small enough to sit next to the atlas and 4 waves of scratch.
-__host__ __device__ inline RenderScratch render_scratch_for(const MgConfig& cfg) {
+// The layout a launch of the obs kernel uses, from the config and the workgroup size alone (kernel and
+// launcher agree): recoloured-tile space when some agent is 'prestige'; for tile sizes off the
+// 16-byte-chunk path a table with the atlas source of every (pixel row, view column) segment of the
+// env's images — n*P*VS entries — when it is small enough to sit next to the atlas and 4 waves of
+// scratch; and as many staged envs per batch (8, 4, 2 or 1) as `wpb` waves of scratch leave room for.
+__host__ __device__ inline RenderScratch render_scratch_for(const MgConfig& cfg, int wpb) {
     const int n = cfg.n_agents, vs = cfg.view_size, ts = cfg.tile_size;
     const int dyn = cfg.prestige_mask ? (cfg.any_hide ? 2 : 1) * n * 4 * ts * ts * 3 : 0;
+    const int atlas_b = round_up(4 * cfg.n_tiles * ts * ts * 3, 16), misc = 1024;
+    const RenderScratch b = render_scratch_layout(cfg.cells_stride, n, vs, 1, dyn, 0);
+    const int resident = (atlas_b + 4 * b.total + misc <= 160 * 1024) ? atlas_b : 0;   // else the atlas is read in place
     int seg = 0;
     if (ts % 8 != 0) {
         const int entries = n * vs * ts * vs + 2, bytes = round_up(entries * 4, 16);
-        const RenderScratch b = render_scratch_layout(cfg.cells_stride, n, vs, dyn, 0);
-        const int atlas_b = round_up(4 * cfg.n_tiles * ts * ts * 3, 16), fixed = 4 * b.total + 1024;
-        const int resident = (atlas_b + fixed <= 160 * 1024) ? atlas_b : 0;   // else the atlas is read in place
-        if (bytes <= 16 * 1024 && resident + fixed + 4 * bytes <= 160 * 1024) seg = entries;
+        if (bytes <= 16 * 1024 && resident + 4 * (b.total + bytes) + misc <= 160 * 1024) seg = entries;
     }
-    return render_scratch_layout(cfg.cells_stride, n, vs, dyn, seg);
+    int k = 8;
+    while (k > 1 && resident + wpb * render_scratch_layout(cfg.cells_stride, n, vs, k, dyn, seg).total + misc > 160 * 1024) k >>= 1;
+    return render_scratch_layout(cfg.cells_stride, n, vs, k, dyn, seg);
 }
 
 }  // namespace mg

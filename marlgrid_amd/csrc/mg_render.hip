@@ -35,7 +35,7 @@ namespace mg {
 //     when it does not fit LDS); 9 = production with per-env recoloured tiles for 'prestige' agents;
 //     12 = both (recoloured tiles in LDS, the static atlas in global memory).  2..7 = measurement variants for tools/ab_render.py (MG_RENDER_VARIANT,
 //     <7,8> only): 2 nontemporal stores, 3 raster only (phases 2-5 skipped), 4 stores only (no LDS
-//     look-ups), 5 no next-env prefetch, 6 no store bursts, 7 grid-strided env walk, 10 two waves per env, 11 phases 2-5 executed twice.
+//     look-ups), 6 no store bursts, 11 phases 2-5 executed twice.
 // WPB = waves per workgroup (4 or 16; MG_RENDER_WPB overrides the launcher's choice).
 template <int VS_, int TS_, int WPB, int V_ = 0>
 __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState st, uint8_t* __restrict__ obs,
@@ -78,12 +78,12 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     }
     __syncthreads();
 
-    const RenderScratch L = render_scratch_for(cfg);
+    const RenderScratch L = render_scratch_for(cfg, WPB);
     uint8_t* ws = smem + atlas_bytes + 2 * MG_MAX_OBJ + MG_MAX_AGENTS * 8 + (size_t)wave * L.total;
-    uint8_t* w_grid = ws + L.grid;
+    uint8_t* w_stage_g = ws + L.grid;                                      // [stage_envs][cells_stride] grids of a batch of envs
+    uint64_t* w_stage_r = reinterpret_cast<uint64_t*>(ws + L.rec);        // [stage_envs][rec_stride] their agent records
     uint8_t* w_first = ws + L.first;
     uint8_t* w_second = ws + L.second;
-    uint64_t* w_rec = reinterpret_cast<uint64_t*>(ws + L.rec);
     uint8_t* w_vbase = ws + L.vbase;
     uint8_t* w_vshow = ws + L.vshow;
     uint32_t* w_trow = reinterpret_cast<uint32_t*>(ws + L.trow);
@@ -100,60 +100,56 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     // raster geometry of the 16-byte-chunk path (see phase 6): pairs per pixel row, a lane's start
     // position and its per-trip advance — constants of the launch, folded at compile time when VS_ > 0
     const uint32_t PR = (uint32_t)VS * (uint32_t)(TS * 3 / 8);
-    // V_ == 10 (measurement): TWO waves per env — both derive the env's tmap on their own (no cross-wave
-    // hand-off) and each rasters every other 1 KiB chunk, which halves the number of concurrent streams
-    constexpr int kPair = (V_ == 10) ? 2 : 1;
-    const int parity = (kPair == 2) ? (wave & 1) : 0;
-    constexpr uint32_t CH_STRIDE = kWave * kPair;                     // chunks a wave advances per trip
-    const uint32_t c_first = (uint32_t)lane + (uint32_t)(kWave * parity);
+    constexpr uint32_t CH_STRIDE = kWave;                             // chunks a wave advances per trip
+    const uint32_t c_first = (uint32_t)lane;
     const uint32_t STEP_R = PR ? (2u * CH_STRIDE) / PR : 0u, STEP_P = PR ? (2u * CH_STRIDE) - STEP_R * PR : 0u;
     const uint32_t rast_r0 = PR ? (2u * c_first) / PR : 0u, rast_p0 = PR ? 2u * c_first - rast_r0 * PR : 0u;
 
-    // next-env prefetch registers: the env's grid (<= 1 KiB: one dword per lane per 256 B) and records
-    constexpr int kPF = 4;
-    const int gdw = cfg.cells_stride / 4;
-    const bool use_pf = (V_ != 5) && gdw <= kPF * kWave;
-    uint32_t pf_g[kPF];
-    uint64_t pf_r = 0;
     // Each wave walks its own CONTIGUOUS run of envs, i.e. one long sequential output stream per wave
-    // (measured +5 % HBM write throughput over a grid-strided walk, which is variant 7).
-    const int per_wave = (cfg.B * kPair + gridDim.x * WPB - 1) / (gridDim.x * WPB);
-    const int e_stride = (V_ != 7) ? 1 : gridDim.x * WPB;
-    int e = (V_ != 7) ? ((blockIdx.x * WPB + wave) / kPair) * per_wave : blockIdx.x * WPB + wave;
-    const int e_end = (V_ != 7) ? min(cfg.B, e + per_wave) : cfg.B;
-    auto prefetch = [&](int en) {
-        const uint32_t* gsrc = reinterpret_cast<const uint32_t*>(st.grid + (size_t)en * cfg.cells_stride);
-#pragma unroll
-        for (int i = 0; i < kPF; i++) {
-            const int idx = i * kWave + lane;
-            pf_g[i] = (idx < gdw) ? gsrc[idx] : 0u;
-        }
-        pf_r = (lane < n) ? st.agents[(size_t)en * n + lane] : 0ull;
-    };
-    if (use_pf && e < e_end) prefetch(e);
+    // (measured +5 % HBM write throughput over a grid-strided walk).  The inputs of the run — 240 B of
+    // grid and a few agent records per env — are staged in LDS a BATCH of envs at a time: on gfx950 the
+    // wait for a load's data is a vmcnt wait, vmcnt is in-order and also counts this wave's stores, so
+    // every load consumed in the middle of the run drains the wave's whole store queue first (the
+    // pure-store microbenchmark loses 25 % of its throughput to one such load per env).  At the bench
+    // batch a wave's run is one batch: it reads before its first store and never again.
+    const int gdw = cfg.cells_stride / 4;
+    const int K = L.stage_envs, rec_stride = L.rec_stride;
+    const int per_wave = (cfg.B + gridDim.x * WPB - 1) / (gridDim.x * WPB);
+    const int e0 = (blockIdx.x * WPB + wave) * per_wave;
+    const int e_end = min(cfg.B, e0 + per_wave);
 
-    for (; e < e_end; e += e_stride) {
-        // 1. stage the env's grid + agent records (from the prefetch registers when they fit)
-        if (use_pf) {
+    for (int eb = e0; eb < e_end; eb += K) {
+        const int kb = min(K, e_end - eb);
+        {   // 0. stage the batch (contiguous in HBM): loads first, all in flight, then one wait
+            const uint32_t* gsrc = reinterpret_cast<const uint32_t*>(st.grid + (size_t)eb * cfg.cells_stride);
+            const uint64_t* rsrc = st.agents + (size_t)eb * n;
+            const int nd = kb * gdw, nr = kb * n;
+            constexpr int kSR = 8;
+            const int r0i = lane, r1i = lane + kWave;                       // kb * n <= 8 * 16 = 2 * kWave records
+            const uint64_t rv0 = r0i < nr ? rsrc[r0i] : 0ull, rv1 = r1i < nr ? rsrc[r1i] : 0ull;
+            for (int i0 = 0; i0 < nd; i0 += kSR * kWave) {
+                uint32_t v[kSR];
 #pragma unroll
-            for (int i = 0; i < kPF; i++) {
-                const int idx = i * kWave + lane;
-                if (idx < gdw) {
-                    reinterpret_cast<uint32_t*>(w_grid)[idx] = pf_g[i];
-                    reinterpret_cast<uint32_t*>(w_first)[idx] = 0xFFFFFFFFu;
-                    reinterpret_cast<uint32_t*>(w_second)[idx] = 0xFFFFFFFFu;
+                for (int q = 0; q < kSR; q++) { const int i = i0 + q * kWave + lane; v[q] = i < nd ? gsrc[i] : 0u; }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < kSR; q++) {
+                    const int i = i0 + q * kWave + lane;
+                    if (i < nd) reinterpret_cast<uint32_t*>(w_stage_g)[i] = v[q];
                 }
             }
-            if (lane < n) w_rec[lane] = pf_r;
-            if (e + e_stride < e_end) prefetch(e + e_stride);   // in flight behind this env's raster
-        } else {
-            const uint32_t* gsrc = reinterpret_cast<const uint32_t*>(st.grid + (size_t)e * cfg.cells_stride);
-            for (int i = lane; i < gdw; i += kWave) {
-                reinterpret_cast<uint32_t*>(w_grid)[i] = gsrc[i];
-                reinterpret_cast<uint32_t*>(w_first)[i] = 0xFFFFFFFFu;
-                reinterpret_cast<uint32_t*>(w_second)[i] = 0xFFFFFFFFu;
-            }
-            if (lane < n) w_rec[lane] = st.agents[(size_t)e * n + lane];
+            if (r0i < nr) { const int j = r0i / n; w_stage_r[j * rec_stride + (r0i - j * n)] = rv0; }
+            if (r1i < nr) { const int j = r1i / n; w_stage_r[j * rec_stride + (r1i - j * n)] = rv1; }
+        }
+        wave_lds_sync();
+    for (int ej = 0; ej < kb; ej++) {
+        const int e = eb + ej;
+        const uint8_t* w_grid = w_stage_g + (size_t)ej * cfg.cells_stride;
+        const uint64_t* w_rec = w_stage_r + (size_t)ej * rec_stride;
+        // 1. per-env scratch
+        for (int i = lane; i < gdw; i += kWave) {
+            reinterpret_cast<uint32_t*>(w_first)[i] = 0xFFFFFFFFu;
+            reinterpret_cast<uint32_t*>(w_second)[i] = 0xFFFFFFFFu;
         }
         for (int i = lane; i < n * VS; i += kWave) w_trow[i] = 0;
         wave_lds_sync();
@@ -574,13 +570,14 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
         }
         wave_lds_sync();   // scratch is reused by the next env
     }
+    }
 }
 
 template <int VS_, int TS_, int WPB, int V_ = 0>
 static hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_t* obs, uint8_t* c, uint8_t* a,
                                   uint8_t* v, hipStream_t s) {
     const int tile_bytes = cfg.tile_size * cfg.tile_size * 3;
-    const RenderScratch L = render_scratch_for(cfg);
+    const RenderScratch L = render_scratch_for(cfg, WPB);
     size_t lds = ((V_ == 8 || V_ == 12) ? 0 : (size_t)round_up(4 * cfg.n_tiles * tile_bytes, 16)) + 2 * MG_MAX_OBJ +
                  MG_MAX_AGENTS * 8 + WPB * (size_t)L.total;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
@@ -597,7 +594,7 @@ static hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_
     if (const char* f = getenv("MG_RENDER_PER_CU")) { const int v = atoi(f); if (v >= 1 && v < per_cu) per_cu = v; }   // (measurement)
     if (per_cu < 1) per_cu = 1;
     const int max_blocks = 256 * per_cu;
-    const int need = (cfg.B * (V_ == 10 ? 2 : 1) + WPB - 1) / WPB;   // workgroups if every wave took one env
+    const int need = (cfg.B + WPB - 1) / WPB;   // workgroups if every wave took one env
     const int rounds = (need + max_blocks - 1) / max_blocks;
     const int blocks = (need + rounds - 1) / rounds;
     hipLaunchKernelGGL((render_kernel<VS_, TS_, WPB, V_>), dim3(blocks), dim3(WPB * 64), lds, s, cfg, st, obs, c, a, v);
@@ -611,7 +608,7 @@ static hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_
 static int choose_wpb(const MgConfig& cfg) {
     if (const char* f = getenv("MG_RENDER_WPB")) { int w = atoi(f); if (w == 4 || w == 8 || w == 16) return w; }
     const int tile_bytes = cfg.tile_size * cfg.tile_size * 3;
-    const RenderScratch L = render_scratch_for(cfg);
+    const RenderScratch L = render_scratch_for(cfg, 16);
     size_t lds16 = (size_t)round_up(4 * cfg.n_tiles * tile_bytes, 16) + 2 * MG_MAX_OBJ + MG_MAX_AGENTS * 8 + 16 * (size_t)L.total;
     return (cfg.B >= 4096 && lds16 <= 160 * 1024) ? 16 : 4;
 }
@@ -629,7 +626,7 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
     const int vs = cfg.view_size, ts = cfg.tile_size;
     const int wpb = choose_wpb(cfg);
     if (cfg.prestige_mask) {   // per-env recoloured agent tiles (LDS), 4-wave workgroups
-        const RenderScratch L = render_scratch_for(cfg);
+        const RenderScratch L = render_scratch_for(cfg, 4);
         const size_t lds4 = (size_t)round_up(4 * cfg.n_tiles * ts * ts * 3, 16) + 2 * MG_MAX_OBJ + MG_MAX_AGENTS * 8 +
                             4 * (size_t)L.total;
         if (lds4 > 160 * 1024) {   // the static atlas stays in global memory
@@ -646,7 +643,7 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
         return launch_render_t<0, 0, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
     }
     {   // atlas too large for LDS (next to 4 waves of scratch): read it from global memory instead
-        const RenderScratch L = render_scratch_for(cfg);
+        const RenderScratch L = render_scratch_for(cfg, 4);
         const size_t lds4 = (size_t)round_up(4 * cfg.n_tiles * ts * ts * 3, 16) + 2 * MG_MAX_OBJ + MG_MAX_AGENTS * 8 +
                             4 * (size_t)L.total;
         if (lds4 > 160 * 1024) {
@@ -662,10 +659,7 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
         case 2: return MG_RENDER_DISPATCH(7, 8, 2);
         case 3: return MG_RENDER_DISPATCH(7, 8, 3);
         case 4: return MG_RENDER_DISPATCH(7, 8, 4);
-        case 5: return MG_RENDER_DISPATCH(7, 8, 5);
         case 6: return MG_RENDER_DISPATCH(7, 8, 6);
-        case 7: return MG_RENDER_DISPATCH(7, 8, 7);
-        case 10: return MG_RENDER_DISPATCH(7, 8, 10);
         case 11: return MG_RENDER_DISPATCH(7, 8, 11);
         default: return MG_RENDER_DISPATCH8(7, 8, 0);
         }
