@@ -11,7 +11,7 @@ import torch  # noqa: E402
 from marlgrid_amd import _native as N  # noqa: E402
 from marlgrid_amd.envs import make  # noqa: E402
 
-variants = sys.argv[1:] or ["0", "1", "2", "3", "4", "5"]      # "V" or "V:waves_per_workgroup"
+variants = sys.argv[1:] or ["0", "2", "3", "4", "6", "11"]      # "V" or "V:waves_per_workgroup"
 B = int(os.environ.get("B", "32768"))
 env = make(os.environ.get("WL", "MarlGrid-3AgentCluttered15x15-v0"), batch_size=B, auto_reset=True, strict=False)
 env.reset()
