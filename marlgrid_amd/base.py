@@ -569,8 +569,8 @@ class MultiGridEnv(object):
                    + r16(n * vs * vs * 2))
         if any(self._prestige):     # per-env recoloured agent tiles, twice with hide_item_types
             hide = any(len(a.hide_item_types) > 0 for a in self.agents)
-            scratch += r16((2 if hide else 1) * n * 4 * self.tile_size ** 2 * 3)
-        need = 2 * N.MAX_OBJ + N.MAX_AGENTS * 8 + 4 * scratch      # (an atlas that does not fit stays in HBM/L2)
+            scratch += r16((2 if hide else 1) * n * 4 * self.tile_size ** 2 * 3) + r16(n * 8)
+        need = 3 * N.MAX_OBJ + 2 * N.MAX_AGENTS * 8 + 4 * scratch      # (an atlas that does not fit stays in HBM/L2)
         if need > 160 * 1024:
             raise NotImplementedError(
                 "this configuration needs %d KiB of LDS per workgroup (4 x %d B of per-env scratch); the "

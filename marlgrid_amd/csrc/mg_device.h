@@ -97,9 +97,12 @@ __device__ inline void prestige_pixel(uint32_t alpha, const PrestigeColor& col, 
     out[0] = (uint8_t)v[0]; out[1] = (uint8_t)v[1]; out[2] = (uint8_t)v[2];
 }
 
+// block-shared LDS of the obs-render kernel after the atlas: object flags, overlap slots, hide masks, prestige scales, flags2
+constexpr int kRenderShared = 3 * MG_MAX_OBJ + 2 * MG_MAX_AGENTS * 8;
+
 // per-wave LDS scratch of the obs-render kernel (bytes), shared by host launch code and kernel
 struct RenderScratch {
-    int grid, rec, first, second, vbase, vshow, trow, vis, tmap, dyn, seg, total;
+    int grid, rec, pres, first, second, vbase, vshow, trow, vis, tmap, dyn, seg, total;
     int stage_envs;    // envs whose inputs (grid + agent records) are staged per batch: 1..8
     int rec_stride;    // u64 records per staged env
     int seg_entries;   // 0: no segment table (tile size on the 16-byte-chunk path, or it would not fit)
@@ -112,6 +115,7 @@ __host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride,
     s.rec_stride = round_up(n * 8, 16) / 8;
     s.grid = o;  o += stage_envs * round_up(cells_stride, 16);
     s.rec = o;   o += stage_envs * s.rec_stride * 8;
+    s.pres = o;  o += dyn_bytes ? stage_envs * s.rec_stride * 8 : 0;   // agent.prestige of the staged envs
     s.first = o; o += round_up(cells_stride, 16);
     s.second = o; o += round_up(cells_stride, 16);
     s.vbase = o; o += round_up(n * vs * vs, 16);

@@ -62,26 +62,30 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     uint8_t* s_oflags = smem + atlas_bytes;             // [MG_MAX_OBJ]
     uint8_t* s_oslot = s_oflags + MG_MAX_OBJ;           // [MG_MAX_OBJ]
     uint64_t* s_hide = reinterpret_cast<uint64_t*>(s_oslot + MG_MAX_OBJ);   // [MG_MAX_AGENTS] hide_obj_mask
+    double* s_pscale = reinterpret_cast<double*>(s_hide + MG_MAX_AGENTS);     // [MG_MAX_AGENTS] prestige_scale
+    uint8_t* s_oflags2 = reinterpret_cast<uint8_t*>(s_pscale + MG_MAX_AGENTS); // [MG_MAX_OBJ]
     {
         const uint4* src = reinterpret_cast<const uint4*>(cfg.atlas);
         uint4* dst = reinterpret_cast<uint4*>(s_atlas);
         if constexpr (!kGlobalAtlas)
             for (int i = tid; i < atlas_bytes / 16; i += WPB * 64) dst[i] = src[i];
         if (tid < MG_MAX_OBJ) {
-            uint8_t f = 0, sl = 0xFF;
-            if (tid < cfg.n_obj) { f = cfg.obj[tid].flags; sl = cfg.obj[tid].ovl_slot; }
-            if (tid == 0) { f = MG_OF_SEE_BEHIND | MG_OF_CAN_OVERLAP; sl = 0; }   // empty cell
+            uint8_t f = 0, sl = 0xFF, f2 = 0;
+            if (tid < cfg.n_obj) { f = cfg.obj[tid].flags; sl = cfg.obj[tid].ovl_slot; f2 = cfg.obj[tid].flags2; }
+            if (tid == 0) { f = MG_OF_SEE_BEHIND | MG_OF_CAN_OVERLAP; sl = 0; f2 = 1; }   // empty cell
             s_oflags[tid] = f;
             s_oslot[tid] = sl;
+            s_oflags2[tid] = f2;
         }
-        if (tid < MG_MAX_AGENTS) s_hide[tid] = cfg.hide_obj_mask[tid];
+        if (tid < MG_MAX_AGENTS) { s_hide[tid] = cfg.hide_obj_mask[tid]; s_pscale[tid] = cfg.prestige_scale[tid]; }
     }
     __syncthreads();
 
     const RenderScratch L = render_scratch_for(cfg, WPB);
-    uint8_t* ws = smem + atlas_bytes + 2 * MG_MAX_OBJ + MG_MAX_AGENTS * 8 + (size_t)wave * L.total;
+    uint8_t* ws = smem + atlas_bytes + kRenderShared + (size_t)wave * L.total;
     uint8_t* w_stage_g = ws + L.grid;                                      // [stage_envs][cells_stride] grids of a batch of envs
     uint64_t* w_stage_r = reinterpret_cast<uint64_t*>(ws + L.rec);        // [stage_envs][rec_stride] their agent records
+    double* w_stage_p = reinterpret_cast<double*>(ws + L.pres);          // [stage_envs][rec_stride] agent.prestige ('prestige' agents only)
     uint8_t* w_first = ws + L.first;
     uint8_t* w_second = ws + L.second;
     uint8_t* w_vbase = ws + L.vbase;
@@ -138,8 +142,14 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                     if (i < nd) reinterpret_cast<uint32_t*>(w_stage_g)[i] = v[q];
                 }
             }
-            if (r0i < nr) { const int j = r0i / n; w_stage_r[j * rec_stride + (r0i - j * n)] = rv0; }
-            if (r1i < nr) { const int j = r1i / n; w_stage_r[j * rec_stride + (r1i - j * n)] = rv1; }
+            double pv0 = 0., pv1 = 0.;
+            if constexpr (kPrestige) {
+                const double* psrc = st.prestige + (size_t)eb * n;
+                if (r0i < nr) pv0 = psrc[r0i];
+                if (r1i < nr) pv1 = psrc[r1i];
+            }
+            if (r0i < nr) { const int j = r0i / n; w_stage_r[j * rec_stride + (r0i - j * n)] = rv0; if constexpr (kPrestige) w_stage_p[j * rec_stride + (r0i - j * n)] = pv0; }
+            if (r1i < nr) { const int j = r1i / n; w_stage_r[j * rec_stride + (r1i - j * n)] = rv1; if constexpr (kPrestige) w_stage_p[j * rec_stride + (r1i - j * n)] = pv1; }
         }
         wave_lds_sync();
     for (int ej = 0; ej < kb; ej++) {
@@ -235,7 +245,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             const uint8_t* abase = kGlobalAtlas ? cfg.atlas : s_atlas;
             uint32_t* w_col = w_trow;
             if (lane < n && ((cfg.prestige_mask >> lane) & 1u)) {
-                const PrestigeColor c = prestige_color(st.prestige[(size_t)e * n + lane], cfg.prestige_scale[lane]);
+                const PrestigeColor c = prestige_color(w_stage_p[(size_t)ej * rec_stride + lane], s_pscale[lane]);
                 w_col[lane] = c.r | (c.g << 8) | (c.b << 16);
             }
             wave_lds_sync();
@@ -249,11 +259,13 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 const uint32_t sdir = rec_byte(rx, MG_AG_DIR);
                 const uint32_t pc = w_col[X];
                 const PrestigeColor col = {pc & 0xFFu, (pc >> 8) & 0xFFu, (pc >> 16) & 0xFFu};
-                const uint32_t amax = cfg.prestige_amax[sdir];
+                const uint32_t amax4 = (uint32_t)cfg.prestige_amax[0] | ((uint32_t)cfg.prestige_amax[1] << 8) |
+                                       ((uint32_t)cfg.prestige_amax[2] << 16) | ((uint32_t)cfg.prestige_amax[3] << 24);
+                const uint32_t amax = (amax4 >> (8u * sdir)) & 0xFFu;   // (no indexed kernarg load: that is a VMEM load)
                 const uint32_t M = ((amax * col.r) >> 8) + ((amax * col.g) >> 8) + ((amax * col.b) >> 8);
                 const uint8_t* white = abase + (size_t)(cfg.prestige_sprite_tile + sdir) * tile_bytes;   // orientation 0, no border
                 const uint8_t* btile = base ? abase + (size_t)(1 + base) * tile_bytes : nullptr;
-                const bool border = base ? (cfg.obj[base].flags2 & 1) != 0 : true;
+                const bool border = (s_oflags2[base] & 1) != 0;
                 const uint8_t* etile = abase + (size_t)tile_bytes;                                   // empty tile
                 uint8_t* t0 = w_dyn + (size_t)(Xh * 4) * npx * 3;
                 for (int p = lane; p < npx; p += kWave) {
@@ -578,8 +590,8 @@ static hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_
                                   uint8_t* v, hipStream_t s) {
     const int tile_bytes = cfg.tile_size * cfg.tile_size * 3;
     const RenderScratch L = render_scratch_for(cfg, WPB);
-    size_t lds = ((V_ == 8 || V_ == 12) ? 0 : (size_t)round_up(4 * cfg.n_tiles * tile_bytes, 16)) + 2 * MG_MAX_OBJ +
-                 MG_MAX_AGENTS * 8 + WPB * (size_t)L.total;
+    size_t lds = ((V_ == 8 || V_ == 12) ? 0 : (size_t)round_up(4 * cfg.n_tiles * tile_bytes, 16)) + kRenderShared +
+                 WPB * (size_t)L.total;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<VS_, TS_, WPB, V_>),
@@ -609,13 +621,18 @@ static int choose_wpb(const MgConfig& cfg) {
     if (const char* f = getenv("MG_RENDER_WPB")) { int w = atoi(f); if (w == 4 || w == 8 || w == 16) return w; }
     const int tile_bytes = cfg.tile_size * cfg.tile_size * 3;
     const RenderScratch L = render_scratch_for(cfg, 16);
-    size_t lds16 = (size_t)round_up(4 * cfg.n_tiles * tile_bytes, 16) + 2 * MG_MAX_OBJ + MG_MAX_AGENTS * 8 + 16 * (size_t)L.total;
+    size_t lds16 = (size_t)round_up(4 * cfg.n_tiles * tile_bytes, 16) + kRenderShared + 16 * (size_t)L.total;
     return (cfg.B >= 4096 && lds16 <= 160 * 1024) ? 16 : 4;
 }
 
 #define MG_RENDER_DISPATCH(VS, TS, V)                                                                      \
     (wpb == 16 ? launch_render_t<VS, TS, 16, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s)           \
                : launch_render_t<VS, TS, 4, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s))
+// run-time view size: its MG_MAX_VIEW-entry shadow-cast arrays need more than the 128 VGPRs a 16-wave
+// workgroup leaves per lane (spills would be VMEM traffic in the middle of the run): 8-wave workgroups
+#define MG_RENDER_DISPATCH_RT(TS, V)                                                                       \
+    (wpb == 16 ? launch_render_t<0, TS, 8, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s)             \
+               : launch_render_t<0, TS, 4, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s))
 #define MG_RENDER_DISPATCH8(VS, TS, V)                                                                     \
     (wpb == 8 ? launch_render_t<VS, TS, 8, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s) : MG_RENDER_DISPATCH(VS, TS, V))
 
@@ -627,7 +644,7 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
     const int wpb = choose_wpb(cfg);
     if (cfg.prestige_mask) {   // per-env recoloured agent tiles (LDS), 4-wave workgroups
         const RenderScratch L = render_scratch_for(cfg, 4);
-        const size_t lds4 = (size_t)round_up(4 * cfg.n_tiles * ts * ts * 3, 16) + 2 * MG_MAX_OBJ + MG_MAX_AGENTS * 8 +
+        const size_t lds4 = (size_t)round_up(4 * cfg.n_tiles * ts * ts * 3, 16) + kRenderShared +
                             4 * (size_t)L.total;
         if (lds4 > 160 * 1024) {   // the static atlas stays in global memory
             if (ts == 8) return launch_render_t<0, 8, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
@@ -644,7 +661,7 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
     }
     {   // atlas too large for LDS (next to 4 waves of scratch): read it from global memory instead
         const RenderScratch L = render_scratch_for(cfg, 4);
-        const size_t lds4 = (size_t)round_up(4 * cfg.n_tiles * ts * ts * 3, 16) + 2 * MG_MAX_OBJ + MG_MAX_AGENTS * 8 +
+        const size_t lds4 = (size_t)round_up(4 * cfg.n_tiles * ts * ts * 3, 16) + kRenderShared +
                             4 * (size_t)L.total;
         if (lds4 > 160 * 1024) {
             if (ts == 8) return launch_render_t<0, 8, 4, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
@@ -667,12 +684,14 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
     if (ts == 8 && vs == 9) return MG_RENDER_DISPATCH(9, 8, 0);
     if (ts == 8 && vs == 5) return MG_RENDER_DISPATCH(5, 8, 0);
     if (ts == 8 && vs == 3) return MG_RENDER_DISPATCH(3, 8, 0);
-    if (ts == 8) return MG_RENDER_DISPATCH(0, 8, 0);      // other view sizes: run-time VS, same raster
-    if (ts == 16) return MG_RENDER_DISPATCH(0, 16, 0);
-    if (ts == 32) return MG_RENDER_DISPATCH(0, 32, 0);
+    if (ts == 8) return MG_RENDER_DISPATCH_RT(8, 0);      // other view sizes: run-time VS, same raster
+    if (ts == 16 && vs == 7) return MG_RENDER_DISPATCH(7, 16, 0);
+    if (ts == 32 && vs == 7) return MG_RENDER_DISPATCH(7, 32, 0);
+    if (ts == 16) return MG_RENDER_DISPATCH_RT(16, 0);
+    if (ts == 32) return MG_RENDER_DISPATCH_RT(32, 0);
     if (vs == 7 && ts == 5) return MG_RENDER_DISPATCH(7, 5, 0);   // GridAgentInterface's defaults (agents.py:21-22)
     if (vs == 7) return MG_RENDER_DISPATCH(7, 0, 0);      // the default view with any other tile size
-    return MG_RENDER_DISPATCH(0, 0, 0);                   // anything else
+    return MG_RENDER_DISPATCH_RT(0, 0);                   // anything else
 }
 
 }  // namespace mg
