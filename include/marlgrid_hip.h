@@ -209,6 +209,12 @@ int32_t mg_render_frame(const MgConfig* cfg, const MgState* st, const int32_t* e
 /* frame_amax: the four per-dir max sprite alphas at frame_tile_size packed little-endian (only used
  * when prestige_mask != 0). */
 
+/* LDS bytes per workgroup mg_render_obs needs for `cfg` in its smallest shape (4-wave workgroups, the
+ * atlas read in place when it does not fit next to the per-env scratch).  More than 163840 (160 KiB,
+ * gfx950): the launch would fail with MG_E_LAUNCH — hosts check this when they build the config
+ * (no device access; obj / atlas may still be NULL). */
+int32_t mg_render_obs_lds_bytes(const MgConfig* cfg);
+
 /* timing helper for bench.py: average duration (ms) of `iters` back-to-back mg_render_obs
  * launches on `stream`, bracketed by HIP events recorded on that same stream. */
 int32_t mg_time_render_obs(const MgConfig* cfg, const MgState* st, uint8_t* obs, int32_t iters,

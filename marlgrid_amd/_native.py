@@ -66,7 +66,8 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "lib
 
 # every symbol include/marlgrid_hip.h declares
 SYMBOLS = ["mg_abi_version", "mg_error_string", "mg_mt_seed", "mg_reset", "mg_step", "mg_render_obs",
-           "mg_encode", "mg_put_obj", "mg_place", "mg_render_frame", "mg_time_render_obs"]
+           "mg_encode", "mg_put_obj", "mg_place", "mg_render_frame", "mg_time_render_obs",
+           "mg_render_obs_lds_bytes"]
 
 _lib = None
 

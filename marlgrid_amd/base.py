@@ -562,20 +562,18 @@ class MultiGridEnv(object):
         tab = self._obj_table()
         for i in range(len(objs)):
             tab[i].ovl_slot = ovl_slot[i]
-        # the obs kernel keeps the atlas + 4 waves of per-env scratch in one workgroup's LDS (160 KiB)
-        r16 = lambda v: (v + 15) // 16 * 16
-        n, vs = self.num_agents, self.view_size
-        scratch = (3 * r16(self.cells_stride) + N.MAX_AGENTS * 8 + 2 * r16(n * vs * vs) + 2 * r16(n * vs * 4)
-                   + r16(n * vs * vs * 2))
-        if any(self._prestige):     # per-env recoloured agent tiles, twice with hide_item_types
-            hide = any(len(a.hide_item_types) > 0 for a in self.agents)
-            scratch += r16((2 if hide else 1) * n * 4 * self.tile_size ** 2 * 3) + r16(n * 8)
-        need = 3 * N.MAX_OBJ + 2 * N.MAX_AGENTS * 8 + 4 * scratch      # (an atlas that does not fit stays in HBM/L2)
-        if need > 160 * 1024:
+        # the obs kernel keeps 4 waves of per-env scratch (and the atlas, when it fits) in one workgroup's
+        # LDS: ask the library, which owns that layout, before anything is uploaded
+        probe = N.Config()
+        probe.n_agents, probe.view_size, probe.tile_size = self.num_agents, self.view_size, self.tile_size
+        probe.cells_stride, probe.n_tiles = self.cells_stride, atlas.shape[1]
+        probe.prestige_mask = sum(1 << k for k, p in enumerate(self._prestige) if p)
+        probe.any_hide = int(any(len(a.hide_item_types) > 0 for a in self.agents))
+        need = N.lib().mg_render_obs_lds_bytes(C.byref(probe))
+        if need < 0 or need > 160 * 1024:
             raise NotImplementedError(
-                "this configuration needs %d KiB of LDS per workgroup (4 x %d B of per-env scratch); the "
-                "obs kernel has 160 KiB — reduce the grid size (or the tile size of 'prestige' agents)"
-                % (need // 1024, scratch))
+                "this configuration needs %d KiB of LDS per workgroup for 4 waves of per-env scratch; the obs "
+                "kernel has 160 KiB — reduce the grid size (or the tile size of 'prestige' agents)" % (need // 1024))
         raw = np.frombuffer(bytes(tab), dtype=np.uint8).copy()
         flat = atlas.reshape(-1)
         pad = (-flat.size) % 16

@@ -143,6 +143,13 @@ int32_t mg_render_frame(const MgConfig* cfg, const MgState* st, const int32_t* e
                                (hipStream_t)stream));
 }
 
+int32_t mg_render_obs_lds_bytes(const MgConfig* cfg) {
+    if (!cfg || cfg->n_agents < 1 || cfg->n_agents > MG_MAX_AGENTS || cfg->view_size < 1 || cfg->view_size > MG_MAX_VIEW ||
+        cfg->tile_size < 1 || cfg->tile_size > 64 || cfg->cells_stride < 0 || cfg->n_tiles < 0)
+        return MG_E_ARG;
+    return mg::render_min_lds_bytes(*cfg);
+}
+
 int32_t mg_time_render_obs(const MgConfig* cfg, const MgState* st, uint8_t* obs, int32_t iters, float* avg_ms,
                            void* stream) {
     int e = check_cfg(cfg);

@@ -13,6 +13,7 @@ hipError_t launch_step(const MgConfig& cfg, const MgState& st, const void* actio
                        float* rewards, hipStream_t s);
 hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, uint8_t* view_cells,
                          uint8_t* view_agent, uint8_t* vis_mask, hipStream_t s);
+int render_min_lds_bytes(const MgConfig& cfg);
 hipError_t launch_encode(const MgConfig& cfg, const MgState& st, const uint8_t* vis_mask, uint8_t* out,
                          hipStream_t s);
 hipError_t launch_put_obj(const MgConfig& cfg, const MgState& st, int obj, int x, int y, const uint8_t* mask,

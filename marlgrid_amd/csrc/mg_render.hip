@@ -613,6 +613,13 @@ static hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_
     return hipGetLastError();
 }
 
+int render_min_lds_bytes(const MgConfig& cfg) {
+    const RenderScratch L = render_scratch_for(cfg, 4);
+    const int atlas_b = round_up(4 * cfg.n_tiles * cfg.tile_size * cfg.tile_size * 3, 16);
+    const int rest = kRenderShared + 4 * L.total;
+    return atlas_b + rest <= 160 * 1024 ? atlas_b + rest : rest;   // else the atlas is read in place
+}
+
 // Workgroup shape.  16 waves per workgroup walk 16 *adjacent* envs at a time (a 450 KB contiguous
 // output window per workgroup, one atlas copy per 16 waves): measured +7..13 % HBM write throughput
 // over 4-wave workgroups at the bench batch.  Small batches keep 4-wave workgroups so that they

@@ -226,3 +226,23 @@ def test_object_registry_interface():
     assert isinstance(r.obj_of_key(1), PO.Wall) and r.get_key(None) == 0 and r.get_next_key() == 2
     with pytest.raises(ValueError):
         r.get_key(PO.GridAgent())
+
+
+def test_render_lds_query():
+    """mg_render_obs_lds_bytes: the library reports what its obs kernel needs (the host never re-derives
+    the layout): small for the bench config, atlas dropped from LDS for 32-px tiles, > 160 KiB for a huge grid"""
+    from marlgrid_amd import _native as N
+    L = N.lib()
+
+    def need(n, vs, ts, cells, n_tiles, prestige=0, hide=0):
+        c = N.Config()
+        c.n_agents, c.view_size, c.tile_size, c.cells_stride, c.n_tiles = n, vs, ts, cells, n_tiles
+        c.prestige_mask, c.any_hide = prestige, hide
+        return L.mg_render_obs_lds_bytes(ctypes.byref(c))
+    bench = need(3, 7, 8, 240, 28)
+    assert 20 * 1024 < bench < 64 * 1024
+    assert need(3, 7, 8, 240, 28, prestige=0b111) > bench                 # recoloured-tile space
+    assert need(3, 7, 8, 240, 28, prestige=0b111, hide=1) > need(3, 7, 8, 240, 28, prestige=0b111)
+    assert need(2, 3, 32, 96, 24) < 4 * 24 * 32 * 32 * 3                  # atlas (288 KiB) stays in HBM / L2
+    assert need(1, 7, 8, 200 * 200, 12) > 160 * 1024                      # rejected by MultiGridEnv
+    assert need(0, 7, 8, 240, 28) < 0 and L.mg_render_obs_lds_bytes(None) < 0
