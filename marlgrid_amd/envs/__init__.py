@@ -1,73 +1,77 @@
-"""Scenario classes + the registered ids (marlgrid/envs/__init__.py).
+"""Scenario classes and the ids the reference registers with gym (marlgrid/envs/__init__.py:20-121).
 
-`gym` is not a dependency here: `register_marl_env` fills a module-level registry and
-`make(id, batch_size=..., device=...)` plays the role of `gym.make`.
-`DoorKeyEnv` is not provided: upstream's cannot be constructed (`self._rand_int` is undefined,
-doorkey.py:26,34).
+gym is not a dependency: ids live in a module-level table and `make(id, batch_size=..., device=...)`
+stands in for `gym.make`.  `DoorKeyEnv` is absent on purpose — upstream's cannot be constructed
+(`self._rand_int` is undefined, doorkey.py:26,34).
 """
-import inspect
+import functools
 import random
-import sys
 
 from ..agents import GridAgentInterface
 from ..base import MultiGridEnv
 from .scenarios import ClutteredGoalCycleEnv, ClutteredMultiGrid, EmptyMultiGrid, VisibilityTestEnv
 
-this_module = sys.modules[__name__]
-registered_envs = []
-_registry = {}
+_PALETTE = ("red", "blue", "purple", "orange", "olive", "pink")     # per-slot agent colours of a registered id
+_registry = {}            # id -> factory(**constructor kwargs)
+registered_envs = []      # ids, in registration order (upstream's list of the same name)
+
+
+def _construct(env_class, n_agents, geometry, agent_color, fixed, **extra):
+    view_size, view_offset = geometry
+    team = [GridAgentInterface(color=agent_color or _PALETTE[i], view_size=view_size, view_offset=view_offset,
+                               view_tile_size=8)           # upstream hard-codes 8 here whatever it was given (:42)
+            for i in range(n_agents)]
+    return env_class(agents=team, **dict(fixed, **extra))
 
 
 def register_marl_env(env_name, env_class, n_agents, grid_size, view_size, view_tile_size=8, view_offset=0,
                       agent_color=None, env_kwargs={}):
-    colors = ["red", "blue", "purple", "orange", "olive", "pink"]
-    assert n_agents <= len(colors)
-
-    def build(**extra):
-        agents = [GridAgentInterface(color=c if agent_color is None else agent_color, view_size=view_size,
-                                     view_tile_size=8,        # upstream passes the literal 8 (__init__.py:42)
-                                     view_offset=view_offset)
-                  for c in colors[:n_agents]]
-        return env_class(agents=agents, grid_size=grid_size, **{**env_kwargs, **extra})
-
-    build.__name__ = "env_%d" % len(registered_envs)
-    setattr(this_module, build.__name__, build)
+    """Same signature as upstream (:20-55).  `view_tile_size` is accepted and — as upstream — ignored."""
+    if n_agents > len(_PALETTE):
+        raise AssertionError("a registered id has at most %d agents" % len(_PALETTE))
+    _registry[env_name] = functools.partial(_construct, env_class, n_agents, (view_size, view_offset), agent_color,
+                                            dict(env_kwargs, grid_size=grid_size))
     registered_envs.append(env_name)
-    _registry[env_name] = build
 
 
 def make(env_name, **kwargs):
-    """gym.make stand-in; extra kwargs (batch_size, device, seed, seeds, auto_reset, strict, ...) go to
-    the env constructor."""
-    if env_name not in _registry:
-        raise KeyError("unknown env id %r; registered: %s" % (env_name, ", ".join(registered_envs)))
-    return _registry[env_name](**kwargs)
+    """`gym.make` stand-in; kwargs (batch_size, device, seed, seeds, auto_reset, strict, ...) reach the env."""
+    try:
+        factory = _registry[env_name]
+    except KeyError:
+        raise KeyError("unknown env id %r; registered: %s" % (env_name, ", ".join(registered_envs))) from None
+    return factory(**kwargs)
+
+
+def _scenario_classes():
+    found, todo = {}, [MultiGridEnv]
+    while todo:
+        cls = todo.pop()
+        found[cls.__name__] = cls
+        todo.extend(cls.__subclasses__())
+    return found
 
 
 def env_from_config(env_config, randomize_seed=True):
-    possible_envs = {k: v for k, v in globals().items() if inspect.isclass(v) and issubclass(v, MultiGridEnv)}
-    env_class = possible_envs[env_config["env_class"]]
-    env_kwargs = {k: v for k, v in env_config.items() if k != "env_class"}
+    """Build the scenario class named by `env_config["env_class"]` from the rest of the dict (:58-67)."""
+    spec = dict(env_config)
+    env_class = _scenario_classes()[spec.pop("env_class")]
     if randomize_seed:
-        env_kwargs["seed"] = env_kwargs.get("seed", 0) + random.randint(0, 1337 * 1337)
-    return env_class(**env_kwargs)
+        spec["seed"] = spec.get("seed", 0) + random.randint(0, 1337 * 1337)
+    return env_class(**spec)
 
 
-# the ids upstream registers (marlgrid/envs/__init__.py:70-121), as data.  Note that upstream's
-# "1AgentCluttered15x15" really is an 11x11 grid with view 5.
-_SHIPPED = [
-    ("MarlGrid-1AgentCluttered15x15-v0", ClutteredMultiGrid, dict(n_agents=1, grid_size=11, view_size=5,
-                                                                  env_kwargs={"n_clutter": 30})),
-    ("MarlGrid-3AgentCluttered11x11-v0", ClutteredMultiGrid, dict(n_agents=3, grid_size=11, view_size=7,
-                                                                  env_kwargs={"clutter_density": 0.15})),
-    ("MarlGrid-3AgentCluttered15x15-v0", ClutteredMultiGrid, dict(n_agents=3, grid_size=15, view_size=7,
-                                                                  env_kwargs={"clutter_density": 0.15})),
-    ("MarlGrid-2AgentEmpty9x9-v0", EmptyMultiGrid, dict(n_agents=2, grid_size=9, view_size=7)),
-    ("MarlGrid-3AgentEmpty9x9-v0", EmptyMultiGrid, dict(n_agents=3, grid_size=9, view_size=7)),
-    ("MarlGrid-4AgentEmpty9x9-v0", EmptyMultiGrid, dict(n_agents=4, grid_size=9, view_size=7)),
-    ("Goalcycle-demo-solo-v0", ClutteredGoalCycleEnv, dict(n_agents=1, grid_size=13, view_size=7, view_tile_size=5,
-                                                            view_offset=1,
-                                                            env_kwargs={"clutter_density": 0.1, "n_bonus_tiles": 3})),
-]
-for _name, _cls, _kw in _SHIPPED:
-    register_marl_env(_name, _cls, **_kw)
+# (id, class, agents, grid, view, view_offset, scenario kwargs) — upstream :70-121.  Its
+# "1AgentCluttered15x15" really is an 11x11 room seen through a 5x5 view.
+for _row in (
+        ("MarlGrid-1AgentCluttered15x15-v0", ClutteredMultiGrid, 1, 11, 5, 0, dict(n_clutter=30)),
+        ("MarlGrid-3AgentCluttered11x11-v0", ClutteredMultiGrid, 3, 11, 7, 0, dict(clutter_density=0.15)),
+        ("MarlGrid-3AgentCluttered15x15-v0", ClutteredMultiGrid, 3, 15, 7, 0, dict(clutter_density=0.15)),
+        ("MarlGrid-2AgentEmpty9x9-v0", EmptyMultiGrid, 2, 9, 7, 0, {}),
+        ("MarlGrid-3AgentEmpty9x9-v0", EmptyMultiGrid, 3, 9, 7, 0, {}),
+        ("MarlGrid-4AgentEmpty9x9-v0", EmptyMultiGrid, 4, 9, 7, 0, {}),
+        ("Goalcycle-demo-solo-v0", ClutteredGoalCycleEnv, 1, 13, 7, 1, dict(clutter_density=0.1, n_bonus_tiles=3)),
+):
+    register_marl_env(_row[0], _row[1], n_agents=_row[2], grid_size=_row[3], view_size=_row[4], view_offset=_row[5],
+                      env_kwargs=_row[6])
+del _row
