@@ -11,7 +11,8 @@
  *   mg_reset        MultiGridEnv.reset + _gen_grid + place_obj/try_place_obj
  *                                       (base.py:402-416, 664-708; envs/empty.py:9-16,
  *                                        envs/cluttered.py:25-36, envs/goalcycle.py:30-51)
- *   mg_step         MultiGridEnv.step action loop, rewards, done  (base.py:501-649)
+ *   mg_step         MultiGridEnv.step action loop, rewards, done  (base.py:501-649); with a reset
+ *                   program also the reset() of every env whose episode just ended (auto-reset)
  *   mg_render_obs   MultiGridEnv.gen_obs / gen_agent_obs / gen_obs_grid, MultiGrid.slice,
  *                   MultiGrid.opacity, GridAgentInterface.process_vis / occlude_mask,
  *                   MultiGrid.render / render_tile / blend_tiles
@@ -36,6 +37,8 @@
  *   agents      uint64 [B][n_agents]          packed record, see MG_AG_* below
  *   mt          uint32 [B][624] + mt_pos[B]   per-env MT19937 (numpy RandomState stream), *lazy*
  *                                            form: word mt_pos is the next one to regenerate
+ *   mt_head     uint32 [B][16]                the 16 outputs generated last and not consumed yet
+ *                                            (tempered), contiguous per env: what a step draws from
  *   step_count  int32  [B];  done uint8 [B];  error int32 [B]
  *   obs         uint8  [B][n_agents][P][P][3] with P = view_size*tile_size
  */
@@ -48,13 +51,14 @@
 extern "C" {
 #endif
 
-#define MG_ABI_VERSION 1
+#define MG_ABI_VERSION 2
 #define MG_MAX_AGENTS 16
 #define MG_MAX_OBJ 64
 #define MG_MAX_GEN 16
 #define MG_MAX_VIEW 15
 #define MG_KEY_WORDS 2
 #define MG_MT_N 624
+#define MG_MT_HEAD 16
 
 /* host-side argument errors (return values) */
 #define MG_OK 0
@@ -117,6 +121,10 @@ typedef struct MgConfig {
     int32_t n_tiles;                                              /* >= 1 + n_obj + n_ovl_slots*n_agents*4 */
     int32_t agent_type_idx;                                       /* 13 */
     int32_t auto_reset;                                           /* reserved */
+    int32_t spawn_x0, spawn_y0, spawn_x1, spawn_y1;               /* agent_spawn_kwargs top / size clamped to the
+                                                                   * grid like base.py:692-695: agents are placed
+                                                                   * in [x0,x1) x [y0,y1) (base.py:411, 505, 643) */
+    int32_t spawn_max_tries;                                      /* agent_spawn_kwargs max_tries, 1..100000 */
     uint8_t agent_color_idx[MG_MAX_AGENTS];
     int32_t any_spawn_delay;                                      /* 1 if some spawn_delay != 0 */
     int32_t spawn_delay[MG_MAX_AGENTS];                           /* agents.py:34; base.py:409-412, 503-506 */
@@ -144,6 +152,7 @@ typedef struct MgState {
     uint8_t* done;
     int32_t* error;
     double* prestige;     /* [B][n_agents] agent.prestige (agents.py:141-153); NULL unless prestige_mask != 0 */
+    uint32_t* mt_head;    /* [B][MG_MT_HEAD] */
 } MgState;
 
 /* `_gen_grid` as data: a static template (walls / put_obj results) + ordered random placements */
@@ -156,25 +165,30 @@ typedef struct MgGenProgram {
     const uint8_t* template_grid; /* device, [cells_stride] */
     int32_t n_ops;
     MgGenOp ops[MG_MAX_GEN];      /* place_obj(obj, max_tries) x count, in order */
-    int32_t agent_max_tries;      /* 100000 (place_obj default 1e5, base.py:690-691) */
 } MgGenProgram;
 
 int32_t mg_abi_version(void);
+/* "<library> gfx950 abi<N> <source id>": which build answered (bench.py echoes it) */
+const char* mg_build_info(void);
 const char* mg_error_string(int32_t code);
 
 /* keys: device uint32 [B][MG_KEY_WORDS] (sha512-derived words, host computed), key_len: device
- * int32 [B] (1 or 2).  Writes mt [B][624] and mt_pos [B] (= 0: first draw regenerates word 0). */
+ * int32 [B] (1 or 2).  Writes mt [B][624], mt_head [B][16] (the stream's first 16 outputs) and
+ * mt_pos [B] (= 16: the next word to regenerate). */
 int32_t mg_mt_seed(int32_t B, const uint32_t* keys, const int32_t* key_len, uint32_t* mt,
-                   int32_t* mt_pos, void* stream);
+                   int32_t* mt_pos, uint32_t* mt_head, void* stream);
 
 /* env_mask: device uint8 [B] or NULL (= all); only envs with mask != 0 are reset. */
 int32_t mg_reset(const MgConfig* cfg, const MgState* st, const MgGenProgram* prog,
                  const uint8_t* env_mask, void* stream);
 
 /* actions: device [B][n_agents], element size `action_bytes` in {1,4,8} (little-endian ints).
- * rewards: device float32 [B][n_agents].  Sets st->done[b]. */
+ * rewards: device float32 [B][n_agents].  Sets st->done[b].
+ * auto_reset: NULL, or the reset program: an env whose episode ends in this step (done[b] = 1) starts
+ * its next episode inside the same launch, exactly as mg_reset masked by the done flags would
+ * (done[b] keeps reporting the end; step_count[b] = 0 afterwards). */
 int32_t mg_step(const MgConfig* cfg, const MgState* st, const void* actions, int32_t action_bytes,
-                float* rewards, void* stream);
+                float* rewards, const MgGenProgram* auto_reset, void* stream);
 
 /* obs: device uint8 [B][n][P][P][3].  Optional debug outputs (NULL to skip):
  * view_cells uint8 [B][n][vs][vs] (object id of the rotated sub-grid, index [i][j]),

@@ -7,7 +7,8 @@ this module raises.  Build it with `python -c "import __graft_entry__ as g; g.bu
 import ctypes as C
 import os
 
-MAX_AGENTS, MAX_OBJ, MAX_GEN, MAX_VIEW, KEY_WORDS, MT_N = 16, 64, 16, 15, 2, 624
+MAX_AGENTS, MAX_OBJ, MAX_GEN, MAX_VIEW, KEY_WORDS, MT_N, MT_HEAD = 16, 64, 16, 15, 2, 624, 16
+ABI_VERSION = 2
 
 OK = 0
 ERR_VALUE, ERR_RECURSION, ERR_TYPE, ERR_ASSERT = 1, 2, 3, 4
@@ -39,6 +40,8 @@ class Config(C.Structure):
                 ("respawn", C.c_int32),
                 ("cells_stride", C.c_int32), ("n_obj", C.c_int32), ("n_ovl_slots", C.c_int32),
                 ("n_tiles", C.c_int32), ("agent_type_idx", C.c_int32), ("auto_reset", C.c_int32),
+                ("spawn_x0", C.c_int32), ("spawn_y0", C.c_int32), ("spawn_x1", C.c_int32), ("spawn_y1", C.c_int32),
+                ("spawn_max_tries", C.c_int32),
                 ("agent_color_idx", C.c_uint8 * MAX_AGENTS),
                 ("any_spawn_delay", C.c_int32), ("spawn_delay", C.c_int32 * MAX_AGENTS),
                 ("prestige_mask", C.c_uint32), ("prestige_amax", C.c_uint8 * 4), ("prestige_sprite_tile", C.c_int32),
@@ -49,7 +52,8 @@ class Config(C.Structure):
 
 class State(C.Structure):
     _fields_ = [("grid", C.c_void_p), ("agents", C.c_void_p), ("mt", C.c_void_p), ("mt_pos", C.c_void_p),
-                ("step_count", C.c_void_p), ("done", C.c_void_p), ("error", C.c_void_p), ("prestige", C.c_void_p)]
+                ("step_count", C.c_void_p), ("done", C.c_void_p), ("error", C.c_void_p), ("prestige", C.c_void_p),
+                ("mt_head", C.c_void_p)]
 
 
 class GenOp(C.Structure):
@@ -58,14 +62,13 @@ class GenOp(C.Structure):
 
 
 class GenProgram(C.Structure):
-    _fields_ = [("template_grid", C.c_void_p), ("n_ops", C.c_int32), ("ops", GenOp * MAX_GEN),
-                ("agent_max_tries", C.c_int32)]
+    _fields_ = [("template_grid", C.c_void_p), ("n_ops", C.c_int32), ("ops", GenOp * MAX_GEN)]
 
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmarlgrid_hip.so")
 
 # every symbol include/marlgrid_hip.h declares
-SYMBOLS = ["mg_abi_version", "mg_error_string", "mg_mt_seed", "mg_reset", "mg_step", "mg_render_obs",
+SYMBOLS = ["mg_abi_version", "mg_build_info", "mg_error_string", "mg_mt_seed", "mg_reset", "mg_step", "mg_render_obs",
            "mg_encode", "mg_put_obj", "mg_place", "mg_render_frame", "mg_time_render_obs",
            "mg_render_obs_lds_bytes"]
 
@@ -73,28 +76,36 @@ _lib = None
 
 
 def lib():
-    """Load the HIP library (after torch, so that the HIP runtime torch ships is the one bound)."""
+    """Load the HIP library (after torch, so that the HIP runtime torch ships is the one bound).
+    MARLGRID_HIP_LIB names another build of the same ABI (tools/ use it for the measurement build)."""
     global _lib
     if _lib is not None:
         return _lib
     import torch  # noqa: F401  — loads libamdhip64 first; our .so resolves against the same runtime
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("MARLGRID_HIP_LIB") or LIB_PATH
+    if path == LIB_PATH and not os.path.exists(LIB_PATH):
         # not a fallback: build the one and only implementation if the toolchain is at hand
         import shutil
         import subprocess
         if shutil.which(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
-            subprocess.call(["bash", os.path.join(os.path.dirname(LIB_PATH), "build.sh")])
-    if not os.path.exists(LIB_PATH):
+            rc = subprocess.call(["bash", os.path.join(os.path.dirname(LIB_PATH), "build.sh")])
+            if rc != 0:
+                raise ImportError("marlgrid_amd: building %s failed (build.sh exit code %d)" % (LIB_PATH, rc))
+    if not os.path.exists(path):
         raise ImportError("marlgrid_amd: %s is missing — build it (marlgrid_amd/csrc/build.sh); there is "
-                          "no CPU fallback" % LIB_PATH)
-    L = C.CDLL(os.environ.get("MARLGRID_HIP_LIB") or LIB_PATH)
+                          "no CPU fallback" % path)
+    L = C.CDLL(path)
     vp, i32 = C.c_void_p, C.c_int32
     L.mg_abi_version.restype = i32
+    if L.mg_abi_version() != ABI_VERSION:
+        raise ImportError("marlgrid_amd: %s has ABI version %d, this package needs %d — rebuild it"
+                          % (path, L.mg_abi_version(), ABI_VERSION))
     L.mg_error_string.restype = C.c_char_p
     L.mg_error_string.argtypes = [i32]
-    L.mg_mt_seed.argtypes = [i32, vp, vp, vp, vp, vp]
+    L.mg_build_info.restype = C.c_char_p
+    L.mg_mt_seed.argtypes = [i32, vp, vp, vp, vp, vp, vp]
     L.mg_reset.argtypes = [C.POINTER(Config), C.POINTER(State), C.POINTER(GenProgram), vp, vp]
-    L.mg_step.argtypes = [C.POINTER(Config), C.POINTER(State), vp, i32, vp, vp]
+    L.mg_step.argtypes = [C.POINTER(Config), C.POINTER(State), vp, i32, vp, C.POINTER(GenProgram), vp]
     L.mg_render_obs.argtypes = [C.POINTER(Config), C.POINTER(State), vp, vp, vp, vp, vp]
     L.mg_encode.argtypes = [C.POINTER(Config), C.POINTER(State), vp, vp, vp]
     L.mg_put_obj.argtypes = [C.POINTER(Config), C.POINTER(State), i32, i32, i32, vp, vp]
@@ -103,10 +114,8 @@ def lib():
     L.mg_time_render_obs.argtypes = [C.POINTER(Config), C.POINTER(State), vp, i32, C.POINTER(C.c_float), vp]
     for f in SYMBOLS:
         getattr(L, f)
-        if f not in ("mg_error_string",):
+        if f not in ("mg_error_string", "mg_build_info"):
             getattr(L, f).restype = i32
-    if L.mg_abi_version() != 1:
-        raise ImportError("marlgrid_amd: ABI version mismatch")
     _lib = L
     return L
 

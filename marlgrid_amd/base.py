@@ -8,7 +8,8 @@ no CPU fallback.
 State layout (all torch tensors on one MI355X; struct-of-arrays over B):
     grid_state   uint8  (B, cells_stride)   object id per cell, index x*H + y  (MultiGrid.grid[i, j])
     agent_state  int64  (B, n)              packed 8-byte agent records (MG_AG_* in the C header)
-    mt_state     int32  (B, 624) + mt_pos   per-env MT19937, numpy RandomState stream
+    mt_state     int32  (B, 624) + mt_pos   per-env MT19937, numpy RandomState stream (lazy form)
+    mt_head      int32  (B, 16)             the next 16 outputs of that stream (what a step draws from)
     step_count   int32  (B,), done uint8 (B,), error int32 (B,)
     obs          uint8  (B, n, P, P, 3),   rewards float32 (B, n)
 
@@ -258,6 +259,7 @@ class MultiGridEnv(object):
             raise ValueError("batch_size must be >= 1")
         if self.width > 255 or self.height > 255:
             raise ValueError("grid dimensions are limited to 255")
+        self.cells_stride = (self.width * self.height + 15) // 16 * 16
 
         self.agents = []
         for agent in agents:
@@ -312,8 +314,6 @@ class MultiGridEnv(object):
                     a0.view_size, a0.view_tile_size, a0.view_offset, a0.see_through_walls):
                 raise NotImplementedError("all agents must share view_size / view_tile_size / view_offset / "
                                           "see_through_walls (one (B, n, P, P, 3) observation tensor)")
-            if a.spawn_delay < 0:
-                raise ValueError("spawn_delay must be >= 0")
             if a.allow_negative_prestige:
                 raise NotImplementedError("allow_negative_prestige=True raises AttributeError upstream "
                                           "(agents.py:147-148) and is not supported")
@@ -343,13 +343,13 @@ class MultiGridEnv(object):
     def _alloc_state(self):
         import torch
         B, n, dev = self.batch_size, self.num_agents, self.device
-        self.cells_stride = (self.width * self.height + 15) // 16 * 16
         P = self.obs_pixels
         with torch.cuda.device(dev):
             self.grid_state = torch.zeros((B, self.cells_stride), dtype=torch.uint8, device=dev)
             self.agent_state = torch.zeros((B, n), dtype=torch.int64, device=dev)
             self.mt_state = torch.zeros((B, N.MT_N), dtype=torch.int32, device=dev)
             self.mt_pos = torch.zeros((B,), dtype=torch.int32, device=dev)
+            self.mt_head = torch.zeros((B, N.MT_HEAD), dtype=torch.int32, device=dev)
             self.step_count_t = torch.zeros((B,), dtype=torch.int32, device=dev)
             self.error_t = torch.zeros((B,), dtype=torch.int32, device=dev)
             # agent.prestige (agents.py:141-153): only needed when some agent's colour is 'prestige'
@@ -367,7 +367,8 @@ class MultiGridEnv(object):
         self._state = N.State(self.grid_state.data_ptr(), self.agent_state.data_ptr(), self.mt_state.data_ptr(),
                               self.mt_pos.data_ptr(), self.step_count_t.data_ptr(), self.done_t.data_ptr(),
                               self.error_t.data_ptr(),
-                              self.prestige_t.data_ptr() if self.prestige_t is not None else None)
+                              self.prestige_t.data_ptr() if self.prestige_t is not None else None,
+                              self.mt_head.data_ptr())
 
     def _stream(self):
         import torch
@@ -393,7 +394,7 @@ class MultiGridEnv(object):
             k = torch.from_numpy(keys.view(np.int32)).to(self.device)
             kl = torch.from_numpy(lens).to(self.device)
             N.check(self._lib.mg_mt_seed(self.batch_size, k.data_ptr(), kl.data_ptr(), self.mt_state.data_ptr(),
-                                         self.mt_pos.data_ptr(), self._stream()))
+                                         self.mt_pos.data_ptr(), self.mt_head.data_ptr(), self._stream()))
             torch.cuda.current_stream(self.device).synchronize()    # k / kl die here
         return [seed]
 
@@ -552,55 +553,31 @@ class MultiGridEnv(object):
                 d.bonus_flags = (1 if o.initial_reward else 0) | (2 if o.reset_on_mistake else 0)
         return tab
 
-    def _sync_tables(self):
-        if self._dry or self._tables_version == self.obj_reg.version:
-            return
-        import torch
+    def _host_tables(self):
+        """Everything the kernels need that is derived on the host from the object registry and the agent
+        interfaces: (cfg without device pointers, object table bytes, atlas bytes, atlas array).  Pure
+        host work (no device access) — the upload is `_sync_tables`."""
         objs = self.obj_reg.objs
         atlas, ovl_slot, n_slots = rendering.build_atlas(objs, [a.color for a in self.agents], self.tile_size,
                                                          prestige_sprites=any(self._prestige))
         tab = self._obj_table()
         for i in range(len(objs)):
             tab[i].ovl_slot = ovl_slot[i]
-        # the obs kernel keeps 4 waves of per-env scratch (and the atlas, when it fits) in one workgroup's
-        # LDS: ask the library, which owns that layout, before anything is uploaded
-        probe = N.Config()
-        probe.n_agents, probe.view_size, probe.tile_size = self.num_agents, self.view_size, self.tile_size
-        probe.cells_stride, probe.n_tiles = self.cells_stride, atlas.shape[1]
-        probe.prestige_mask = sum(1 << k for k, p in enumerate(self._prestige) if p)
-        probe.any_hide = int(any(len(a.hide_item_types) > 0 for a in self.agents))
-        need = N.lib().mg_render_obs_lds_bytes(C.byref(probe))
-        if need < 0 or need > 160 * 1024:
-            raise NotImplementedError(
-                "this configuration needs %d KiB of LDS per workgroup for 4 waves of per-env scratch; the obs "
-                "kernel has 160 KiB — reduce the grid size (or the tile size of 'prestige' agents)" % (need // 1024))
         raw = np.frombuffer(bytes(tab), dtype=np.uint8).copy()
         flat = atlas.reshape(-1)
         pad = (-flat.size) % 16
         flat = np.concatenate([flat, np.zeros(pad + 16, np.uint8)])
-        self._obj_dev = torch.from_numpy(raw).to(self.device)
-        self._atlas_dev = torch.from_numpy(flat).to(self.device)
-        self.atlas = atlas
         cfg = N.Config()
         cfg.B, cfg.W, cfg.H, cfg.n_agents = self.batch_size, self.width, self.height, self.num_agents
         cfg.view_size, cfg.tile_size = self.view_size, self.tile_size
         cfg.view_offset, cfg.see_through_walls = self.view_offset, int(self.see_through_walls)
-        cfg.max_steps, cfg.reward_decay = self.max_steps, int(bool(self.reward_decay))
-        # upstream tests `ghost_mode is False` when moving (base.py:541) but `not ghost_mode` when placing
-        # (base.py:683): they differ for falsy non-False values such as 0 or None
-        cfg.ghost_mode = (1 if self.ghost_mode is not False else 0) | (2 if self.ghost_mode else 0)
-        cfg.respawn = int(bool(self.respawn))
         cfg.cells_stride = self.cells_stride
         cfg.n_obj, cfg.n_ovl_slots, cfg.n_tiles = len(objs), n_slots, atlas.shape[1]
         cfg.agent_type_idx = OBJECT_TYPES.index(GridAgentInterface)
-        cfg.auto_reset = int(self.auto_reset)
         for k, a in enumerate(self.agents):
             cfg.agent_color_idx[k] = COLOR_TO_IDX[a.color]
-            cfg.spawn_delay[k] = a.spawn_delay
-        cfg.any_spawn_delay = int(any(a.spawn_delay != 0 for a in self.agents))
         # 'prestige' agents (agents.py:92-119, 141-153): per-env recoloured sprites
         for k, a in enumerate(self.agents):
-            cfg.prestige_beta[k], cfg.prestige_scale[k] = float(a.prestige_beta), float(a.prestige_scale)
             if self._prestige[k]:
                 cfg.prestige_mask |= 1 << k
         if cfg.prestige_mask:
@@ -617,28 +594,78 @@ class MultiGridEnv(object):
             if "Agent" in a.hide_item_types:
                 cfg.hide_agent_mask |= 1 << k
         cfg.any_hide = int(cfg.hide_agent_mask != 0 or any(cfg.hide_obj_mask[k] for k in range(len(self.agents))))
+        self._refresh_cfg(cfg)
+        return cfg, raw, flat, atlas
+
+    def _refresh_cfg(self, cfg):
+        """The scalar settings the reference reads on every step (max_steps, reward_decay, ghost_mode,
+        respawn, agent_spawn_kwargs, the agents' spawn_delay / prestige parameters): copied into the
+        launch config before every launch, so changing the attribute between steps takes effect on the
+        next step, as upstream."""
+        cfg.max_steps, cfg.reward_decay = int(self.max_steps), int(bool(self.reward_decay))
+        # upstream tests `ghost_mode is False` when moving (base.py:541) but `not ghost_mode` when placing
+        # (base.py:683): they differ for falsy non-False values such as 0 or None
+        cfg.ghost_mode = (1 if self.ghost_mode is not False else 0) | (2 if self.ghost_mode else 0)
+        cfg.respawn = int(bool(self.respawn))
+        cfg.auto_reset = int(self.auto_reset)
+        # place_obj(agent, **agent_spawn_kwargs) (base.py:411, 505, 643)
+        kw = dict(self.agent_spawn_kwargs or {})
+        if kw.pop("reject_fn", None) is not None:
+            raise NotImplementedError("agent_spawn_kwargs['reject_fn'] is a Python callback per draw: not supported")
+        top, size, max_tries = kw.pop("top", None), kw.pop("size", None), kw.pop("max_tries", 1e5)
+        if kw:
+            raise TypeError("place_obj() got an unexpected keyword argument %r" % sorted(kw)[0])
+        cfg.spawn_x0, cfg.spawn_y0, cfg.spawn_x1, cfg.spawn_y1 = self._place_region(top, size)
+        cfg.spawn_max_tries = int(max(1, min(max_tries, 1e5)))
+        for k, a in enumerate(self.agents):
+            if a.spawn_delay < 0:
+                raise ValueError("spawn_delay must be >= 0")
+            cfg.spawn_delay[k] = int(a.spawn_delay)
+            cfg.prestige_beta[k], cfg.prestige_scale[k] = float(a.prestige_beta), float(a.prestige_scale)
+        cfg.any_spawn_delay = int(any(a.spawn_delay != 0 for a in self.agents))
+
+    def _sync_tables(self):
+        """Make the launch config current: rebuild and upload the object table / atlas when a new object
+        kind was registered since the last launch, refresh the scalar settings always."""
+        if self._dry:
+            return
+        if self._tables_version == self.obj_reg.version:
+            self._refresh_cfg(self._cfg)
+            return
+        import torch
+        cfg, raw, flat, atlas = self._host_tables()
+        # the obs kernel keeps 4 waves of per-env scratch (and the atlas, when it fits) in one workgroup's
+        # LDS: ask the library, which owns that layout, before anything is uploaded
+        need = N.lib().mg_render_obs_lds_bytes(C.byref(cfg))
+        if need < 0 or need > 160 * 1024:
+            raise NotImplementedError(
+                "this configuration needs %d KiB of LDS per workgroup for 4 waves of per-env scratch; the obs "
+                "kernel has 160 KiB — reduce the grid size (or the tile size of 'prestige' agents)" % (need // 1024))
+        self._obj_dev = torch.from_numpy(raw).to(self.device)
+        self._atlas_dev = torch.from_numpy(flat).to(self.device)
+        self.atlas = atlas
         cfg.obj, cfg.atlas = self._obj_dev.data_ptr(), self._atlas_dev.data_ptr()
         self._cfg = cfg
         self._tables_version = self.obj_reg.version
-        self._prog_cache = {}
 
     def _program(self, template, ops):
         import torch
         key = (template.tobytes(), tuple(ops))
-        hit = self._prog_cache.get(key)
-        if hit is not None:
-            return hit[0]
+        prog = self._prog_cache.get(key)
+        if prog is not None:
+            return prog
         t = np.zeros(self.cells_stride, np.uint8)
         t[:self.width * self.height] = template.reshape(-1)
-        t_dev = torch.from_numpy(t).to(self.device)
         prog = N.GenProgram()
-        prog.template_grid = t_dev.data_ptr()
+        # the struct carries a raw device pointer: the tensor it points at is kept on the struct
+        # itself, so it lives exactly as long as any holder of the program (cache, `_reset_prog`)
+        prog._template_dev = torch.from_numpy(t).to(self.device)
+        prog.template_grid = prog._template_dev.data_ptr()
         prog.n_ops = len(ops)
         for i, (obj, count, max_tries, x0, y0, x1, y1) in enumerate(ops):
             o = prog.ops[i]
             o.obj, o.count, o.max_tries, o.x0, o.y0, o.x1, o.y1 = obj, count, max_tries, x0, y0, x1, y1
-        prog.agent_max_tries = 100000
-        self._prog_cache[key] = (prog, t_dev)
+        self._prog_cache[key] = prog
         return prog
 
     def _mask_ptr(self, env_mask):
@@ -658,6 +685,7 @@ class MultiGridEnv(object):
         observation tensor (B, n, P, P, 3) — base.py:402-416."""
         template, ops = self._trace_gen_grid()
         if self._dry:
+            self._dry_trace = (template, ops)     # host-only instance: the recorded layout, nothing runs
             return None
         self._sync_tables()
         prog = self._program(template, ops)
@@ -692,14 +720,12 @@ class MultiGridEnv(object):
             self.done_b = self.done_t.view(torch.bool)
             self._state.done = self.done_t.data_ptr()
         stream = self._stream()
-        N.check(self._lib.mg_step(C.byref(self._cfg), C.byref(self._state), actions.data_ptr(),
-                                  actions.element_size(), self.rewards.data_ptr(), stream))
-        # obs / rewards / done are views of the current buffer set (see `obs_buffers`)
-        done = self.done_b
+        prog = None
         if self.auto_reset:
-            # envs that just finished start their next episode before the obs is rendered (their
-            # returned obs is the first obs of the new episode; `done` still reports the end).  The
-            # done flags themselves are the device-side reset mask: no host sync.
+            # envs that finish in this step start their next episode inside the same launch, before the
+            # obs is rendered (their returned obs is the first obs of the new episode; `done` still
+            # reports the end): the lane that computes an env's done flag runs its reset — no host sync,
+            # no second launch.
             if self._retrace:
                 # first step after construction: subclass constructors finish configuring the
                 # scenario after the base constructor's reset (cluttered.py:13-20)
@@ -707,8 +733,11 @@ class MultiGridEnv(object):
                 self._sync_tables()
                 self._reset_prog = self._program(template, ops)
                 self._retrace = False
-            N.check(self._lib.mg_reset(C.byref(self._cfg), C.byref(self._state), C.byref(self._reset_prog),
-                                       C.c_void_p(self.done_t.data_ptr()), stream))
+            prog = C.byref(self._reset_prog)
+        N.check(self._lib.mg_step(C.byref(self._cfg), C.byref(self._state), actions.data_ptr(),
+                                  actions.element_size(), self.rewards.data_ptr(), prog, stream))
+        # obs / rewards / done are views of the current buffer set (see `obs_buffers`)
+        done = self.done_b
         N.check(self._lib.mg_render_obs(C.byref(self._cfg), C.byref(self._state), self.obs.data_ptr(), None, None,
                                         None, stream))
         if self.strict:
@@ -895,20 +924,18 @@ class MultiGridEnv(object):
 
     # ---- RNG state exchange with numpy (tests / checkpoints) -------------------------------------------
     def numpy_rng_state(self, b=0):
-        """env b's generator as `np.random.RandomState.get_state()` would report it.  The device
-        keeps the *lazy* form (word mt_pos is regenerated when consumed); numpy regenerates whole
-        blocks, so the not-yet-consumed tail is advanced here."""
-        mt = self.mt_state[b].cpu().numpy().view(np.uint32).copy()
-        pos = int(self.mt_pos[b].item())
-        if pos == 0:
-            return mt, 624
-        for kk in range(pos, 624):
-            y = (int(mt[kk]) & 0x80000000) | (int(mt[(kk + 1) % 624]) & 0x7fffffff)
-            mt[kk] = int(mt[(kk + 397) % 624]) ^ (y >> 1) ^ (0x9908b0df if y & 1 else 0)
-        return mt, pos
+        """env b's generator as `np.random.RandomState.get_state()` would report it: (key[624], pos).
+        The device keeps the *lazy* form plus a look-ahead head (see mg_core.h): words below `mt_pos`
+        are already regenerated, the head holds the 16 outputs before it.  numpy regenerates whole
+        blocks, so the not-yet-regenerated tail is advanced here; when the head reaches across a block
+        boundary the words regenerated ahead of numpy's position are wound back (the twist is
+        invertible except for the low 31 bits of word 0, which MT19937 never reads: reported as 0)."""
+        mt = [int(v) for v in self.mt_state[b].cpu().numpy().view(np.uint32)]
+        G = int(self.mt_pos[b].item())
+        return seeding.numpy_form(mt, G, N.MT_HEAD)
 
     def state_dict(self):
-        keys = ("grid_state", "agent_state", "mt_state", "mt_pos", "step_count_t", "done_t", "error_t")
+        keys = ("grid_state", "agent_state", "mt_state", "mt_pos", "mt_head", "step_count_t", "done_t", "error_t")
         sd = {k: getattr(self, k).clone() for k in keys}
         if self.prestige_t is not None:
             sd["prestige_t"] = self.prestige_t.clone()
@@ -967,8 +994,11 @@ class MultiGridEnv(object):
         if tile_size % 4 != 0 or not (4 <= tile_size <= 64):
             raise NotImplementedError("render(tile_size=) must be a multiple of 4 in [4, 64]")
         single = env_ids is None
-        ids = torch.as_tensor([0] if single else env_ids, dtype=torch.int32, device=self.device).reshape(-1)
+        ids = torch.as_tensor([0] if single else env_ids, dtype=torch.int32).reshape(-1)
         K = int(ids.numel())
+        if K and (int(ids.min()) < 0 or int(ids.max()) >= self.batch_size):
+            raise IndexError("render(env_ids=): env index out of range [0, %d)" % self.batch_size)
+        ids = ids.to(self.device)
         self._sync_tables()
         key = (self.obj_reg.version, tile_size)
         if getattr(self, "_frame_atlas_key", None) != key:

@@ -19,11 +19,24 @@ int check_cfg(const MgConfig* c) {
     if (c->prestige_mask && (c->prestige_sprite_tile < 0 || c->prestige_sprite_tile + 4 > c->n_tiles)) return MG_E_ARG;
     if (!c->obj || !c->atlas) return MG_E_ARG;
     if (c->max_steps < 1) return MG_E_ARG;
+    if (c->spawn_x0 < 0 || c->spawn_y0 < 0 || c->spawn_x1 > c->W || c->spawn_y1 > c->H || c->spawn_x1 <= c->spawn_x0 ||
+        c->spawn_y1 <= c->spawn_y0 || c->spawn_max_tries < 1 || c->spawn_max_tries > 100000)
+        return MG_E_ARG;
+    return MG_OK;
+}
+
+int check_prog(const MgConfig* cfg, const MgGenProgram* prog) {
+    if (!prog || !prog->template_grid || prog->n_ops < 0 || prog->n_ops > MG_MAX_GEN) return MG_E_ARG;
+    for (int i = 0; i < prog->n_ops; i++) {
+        const MgGenOp& op = prog->ops[i];
+        if (op.obj <= 0 || op.obj >= cfg->n_obj || op.count < 0) return MG_E_ARG;
+        if (op.x0 < 0 || op.y0 < 0 || op.x1 > cfg->W || op.y1 > cfg->H || op.x1 <= op.x0 || op.y1 <= op.y0) return MG_E_ARG;
+    }
     return MG_OK;
 }
 
 int check_state(const MgState* s) {
-    if (!s || !s->grid || !s->agents || !s->mt || !s->mt_pos || !s->step_count || !s->done || !s->error)
+    if (!s || !s->grid || !s->agents || !s->mt || !s->mt_pos || !s->mt_head || !s->step_count || !s->done || !s->error)
         return MG_E_ARG;
     return MG_OK;
 }
@@ -45,6 +58,17 @@ extern "C" {
 
 int32_t mg_abi_version(void) { return MG_ABI_VERSION; }
 
+#ifndef MG_BUILD_ID
+#define MG_BUILD_ID "unknown"
+#endif
+const char* mg_build_info(void) {
+#if defined(MG_AB_VARIANTS)
+    return "libmarlgrid_hip_ab gfx950 abi2 " MG_BUILD_ID " (measurement variants: tools/ only)";
+#else
+    return "libmarlgrid_hip gfx950 abi2 " MG_BUILD_ID;
+#endif
+}
+
 const char* mg_error_string(int32_t code) {
     switch (code) {
     case MG_OK: return "ok";
@@ -60,32 +84,28 @@ const char* mg_error_string(int32_t code) {
 }
 
 int32_t mg_mt_seed(int32_t B, const uint32_t* keys, const int32_t* key_len, uint32_t* mt, int32_t* mt_pos,
-                   void* stream) {
-    if (B < 0 || !keys || !key_len || !mt || !mt_pos) return MG_E_ARG;
-    return rc(mg::launch_mt_seed(B, keys, key_len, mt, mt_pos, (hipStream_t)stream));
+                   uint32_t* mt_head, void* stream) {
+    if (B < 0 || !keys || !key_len || !mt || !mt_pos || !mt_head) return MG_E_ARG;
+    return rc(mg::launch_mt_seed(B, keys, key_len, mt, mt_pos, mt_head, (hipStream_t)stream));
 }
 
 int32_t mg_reset(const MgConfig* cfg, const MgState* st, const MgGenProgram* prog, const uint8_t* env_mask,
                  void* stream) {
     int e = check_both(cfg, st);
     if (e) return e;
-    if (!prog || !prog->template_grid || prog->n_ops < 0 || prog->n_ops > MG_MAX_GEN) return MG_E_ARG;
-    for (int i = 0; i < prog->n_ops; i++)
-    {
-        const MgGenOp& op = prog->ops[i];
-        if (op.obj <= 0 || op.obj >= cfg->n_obj || op.count < 0) return MG_E_ARG;
-        if (op.x0 < 0 || op.y0 < 0 || op.x1 > cfg->W || op.y1 > cfg->H || op.x1 <= op.x0 || op.y1 <= op.y0) return MG_E_ARG;
-    }
+    e = check_prog(cfg, prog);
+    if (e) return e;
     return rc(mg::launch_reset(*cfg, *st, *prog, env_mask, (hipStream_t)stream));
 }
 
 int32_t mg_step(const MgConfig* cfg, const MgState* st, const void* actions, int32_t action_bytes, float* rewards,
-                void* stream) {
+                const MgGenProgram* auto_reset, void* stream) {
     int e = check_both(cfg, st);
     if (e) return e;
     if (!actions || !rewards) return MG_E_ARG;
     if (action_bytes != 1 && action_bytes != 4 && action_bytes != 8) return MG_E_ARG;
-    return rc(mg::launch_step(*cfg, *st, actions, action_bytes, rewards, (hipStream_t)stream));
+    if (auto_reset && (e = check_prog(cfg, auto_reset))) return e;
+    return rc(mg::launch_step(*cfg, *st, actions, action_bytes, rewards, auto_reset, (hipStream_t)stream));
 }
 
 int32_t mg_render_obs(const MgConfig* cfg, const MgState* st, uint8_t* obs, uint8_t* view_cells,

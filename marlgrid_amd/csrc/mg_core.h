@@ -1,0 +1,569 @@
+// mg_core.h — the lane-per-env bodies of the engine (seed / reset / step / live placement) as plain
+// inline functions: one call advances ONE env.  On the GPU every lane of a kernel runs one of them
+// for its own env (mg_step.hip, mg_reset.hip, mg_rng.hip); the same text compiles with g++ for the
+// host harness under tests/native, which steps the oracle's scenarios through these bodies on the
+// CPU (a development check of the state machine — the product never loads it).
+//
+// Nothing here touches a GPU builtin: scratch that a kernel keeps in LDS is handed in as pointers
+// with an element stride (`S`: the workgroup size on the device — column `tid` of an [n][S] array —
+// and 1 on the host).
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#include "marlgrid_hip.h"
+
+#if defined(__HIPCC__)
+#define MG_HD __host__ __device__ __forceinline__
+#else
+#define MG_HD inline
+#endif
+
+namespace mg {
+
+// ---- packed agent record (include/marlgrid_hip.h MG_AG_*) -------------------------------------
+MG_HD uint32_t rec_byte(uint64_t r, int i) { return (uint32_t)(r >> (8 * i)) & 0xFFu; }
+MG_HD uint64_t rec_set(uint64_t r, int i, uint32_t v) {
+    return (r & ~(0xFFull << (8 * i))) | ((uint64_t)(v & 0xFFu) << (8 * i));
+}
+MG_HD uint32_t rec_xy(uint64_t r) { return (uint32_t)r & 0xFFFFu; }  // x | y<<8
+
+// forward vector per dir: agents.py:183  [(1,0),(0,1),(-1,0),(0,-1)]
+MG_HD int dir_dx(int d) { return d == 0 ? 1 : (d == 2 ? -1 : 0); }
+MG_HD int dir_dy(int d) { return d == 1 ? 1 : (d == 3 ? -1 : 0); }
+
+// ---- per-env MT19937: lazy regeneration + a look-ahead head ------------------------------------
+// numpy's RandomState regenerates all 624 words when a block is exhausted.  The same sequence
+// falls out of regenerating word `pos` only when it is needed (x[k+624] = f(x[k], x[k+1], x[k+397])
+// reads exactly the values the in-place block loop reads), which needs no 624-iteration twist stall
+// in one lane.  State per env: w[624] with `pos` = the next word to regenerate, and `head` = the
+// MG_MT_HEAD tempered outputs x[G-16 .. G) that were generated last and are not consumed yet (G the
+// generation count, pos = G mod 624).  A kernel draws from the head first — a contiguous 64 B per
+// env that is read with the rest of the env's record, so the shuffle of a step needs no dependent
+// memory round trip — and only then generates further words one by one; when it is done it tops the
+// head up again (mt_finish), all loads of that refill in flight together.
+MG_HD uint32_t mt_temper(uint32_t v) {
+    v ^= (v >> 11);
+    v ^= (v << 7) & 0x9d2c5680u;
+    v ^= (v << 15) & 0xefc60000u;
+    v ^= (v >> 18);
+    return v;
+}
+MG_HD uint32_t mt_twist(uint32_t wi, uint32_t wi1, uint32_t wim) {
+    const uint32_t y = (wi & 0x80000000u) | (wi1 & 0x7fffffffu);
+    return wim ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+
+struct Mt {
+    uint32_t* w;            // this env's 624 words (HBM)
+    int pos;                // next word to regenerate
+    const uint32_t* head;   // head word i at head[i * hstride] (HBM: stride 1; LDS column: stride S)
+    int hstride;
+    int used;               // draws taken since the kernel started
+
+    MG_HD uint32_t next() {
+        uint32_t v;
+        if (used < MG_MT_HEAD) {
+            v = head[used * hstride];
+        } else {   // beyond the head: regenerate word `pos` and consume it at once (3 loads + 1 store)
+            const int i = pos;
+            const int i1 = (i + 1 == MG_MT_N) ? 0 : i + 1;
+            int im = i + 397;
+            if (im >= MG_MT_N) im -= MG_MT_N;
+            const uint32_t x = mt_twist(w[i], w[i1], w[im]);
+            w[i] = x;
+            pos = i1;
+            v = mt_temper(x);
+        }
+        used++;
+        return v;
+    }
+    // numpy legacy masked rejection (RandomState.randint with array bounds / shuffle's
+    // random_interval): smallest 2^k-1 >= max; redraw until (w & mask) <= max; max==0 draws nothing
+    MG_HD uint32_t bounded(uint32_t max) {
+        if (max == 0) return 0;
+        const uint32_t mask = 0xFFFFFFFFu >> __builtin_clz(max);
+        uint32_t v;
+        do { v = next() & mask; } while (v > max);
+        return v;
+    }
+};
+
+// Regenerate the next `cnt` (<= 8) words in place and return them tempered.  Every operand is read
+// before anything is written: word i+1 must be read in its OLD state (the loop form reads it before
+// regenerating it), and x[k+397] of a batch of 8 never lies inside the batch.
+MG_HD void mt_generate(uint32_t* w, int& pos, int cnt, uint32_t* out) {
+    uint32_t a[8], b[8], c[8];
+    int at[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        if (i < cnt) {
+            int p = pos + i;
+            if (p >= MG_MT_N) p -= MG_MT_N;
+            const int p1 = (p + 1 == MG_MT_N) ? 0 : p + 1;
+            int pm = p + 397;
+            if (pm >= MG_MT_N) pm -= MG_MT_N;
+            at[i] = p;
+            a[i] = w[p]; b[i] = w[p1]; c[i] = w[pm];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        if (i < cnt) {
+            const uint32_t x = mt_twist(a[i], b[i], c[i]);
+            w[at[i]] = x;
+            out[i] = mt_temper(x);
+        }
+    }
+    int p = pos + cnt;
+    if (p >= MG_MT_N) p -= MG_MT_N;
+    pos = p;
+}
+
+// After the env's last draw of the kernel: new head = x[C' .. C'+16) with C' = C + used — what is
+// left of the old head slides down, the rest is generated.  `head_out`: the env's 16 head words in
+// HBM (may be the array `mt.head` points at: the copy runs upwards, dst < src).
+MG_HD void mt_finish(Mt& mt, uint32_t* head_out) {
+    const int k = mt.used;
+    if (k == 0) return;
+    const int keep = k < MG_MT_HEAD ? MG_MT_HEAD - k : 0;
+    for (int j = 0; j < keep; j++) head_out[j] = mt.head[(j + k) * mt.hstride];
+    for (int j = keep; j < MG_MT_HEAD; j += 8) {
+        const int cnt = (MG_MT_HEAD - j) < 8 ? (MG_MT_HEAD - j) : 8;
+        uint32_t t[8];
+        mt_generate(mt.w, mt.pos, cnt, t);
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if (i < cnt) head_out[j + i] = t[i];
+    }
+    mt.used = 0;
+}
+
+// MultiGridEnv.seed -> gym seeding.np_random -> RandomState.seed([k0(, k1)]) = init_by_array
+// (base.py:371-374), then the first head.
+MG_HD void mt_seed_env(const uint32_t* key, int klen, uint32_t* mt, int32_t* mt_pos, uint32_t* head) {
+    if (klen < 1) klen = 1;
+    if (klen > MG_KEY_WORDS) klen = MG_KEY_WORDS;
+    uint32_t prev = 19650218u;   // init_genrand(19650218)
+    mt[0] = prev;
+    for (int i = 1; i < MG_MT_N; i++) {
+        prev = 1812433253u * (prev ^ (prev >> 30)) + (uint32_t)i;
+        mt[i] = prev;
+    }
+    int i = 1, j = 0;
+    prev = mt[0];
+    for (int k = MG_MT_N; k; k--) {   // max(N, key_len) == N for key_len <= 2
+        const uint32_t kj = (j == 0) ? key[0] : key[1];
+        const uint32_t v = (mt[i] ^ ((prev ^ (prev >> 30)) * 1664525u)) + kj + (uint32_t)j;
+        mt[i] = v;
+        prev = v;
+        i++; j++;
+        if (i >= MG_MT_N) { mt[0] = prev; i = 1; }
+        if (j >= klen) j = 0;
+    }
+    for (int k = MG_MT_N - 1; k; k--) {
+        const uint32_t v = (mt[i] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)i;
+        mt[i] = v;
+        prev = v;
+        i++;
+        if (i >= MG_MT_N) { mt[0] = prev; i = 1; }
+    }
+    mt[0] = 0x80000000u;
+    // numpy's pos == 624 (nothing generated yet) is pos 0 of the lazy form; then the first head
+    int pos = 0;
+    for (int h = 0; h < MG_MT_HEAD; h += 8) mt_generate(mt, pos, 8, head + h);
+    *mt_pos = pos;
+}
+
+// ---- placement helpers ---------------------------------------------------------------------------
+// agents of this env standing on cell xy (x | y << 8); records in an [n][S] array, column `col`
+MG_HD int agents_on(const uint64_t* rec, int S, int col, int n, uint32_t xy) {
+    int cnt = 0;
+    for (int j = 0; j < n; j++) {
+        const uint64_t rj = rec[j * S + col];
+        cnt += ((rec_byte(rj, MG_AG_FLAGS) & MG_AF_PLACED) && rec_xy(rj) == xy) ? 1 : 0;
+    }
+    return cnt;
+}
+// arrival: agent k gets the highest rank, everyone above its old rank slides down (the reference's
+// `obj.agents.append`, base.py:547-552 / 684-686)
+MG_HD uint64_t arrive(uint64_t* rec, int S, int col, int n, uint64_t r) {
+    const uint32_t old_rank = rec_byte(r, MG_AG_RANK);
+    for (int j = 0; j < n; j++) {
+        const uint64_t rj = rec[j * S + col];
+        const uint32_t rk = rec_byte(rj, MG_AG_RANK);
+        if (rk > old_rank) rec[j * S + col] = rec_set(rj, MG_AG_RANK, rk - 1);
+    }
+    return rec_set(r, MG_AG_RANK, (uint32_t)(n - 1));
+}
+
+// place_obj(agent, **agent_spawn_kwargs) (base.py:690-708 over try_place_obj :664-688) for agent k,
+// which is off the grid: rejection-sample a cell of the spawn rectangle whose object can be
+// overlapped (or that is empty) and, without ghost_mode, holds no agent.  `keep_flags`: flag bits
+// that survive (a live re-seat keeps DONE).  Returns false when max_tries draws all failed.
+MG_HD bool place_agent(const MgConfig& cfg, const uint8_t* oflags, uint8_t* g, Mt& mt, uint64_t* rec, int S, int col,
+                       int k, uint32_t keep_flags) {
+    const int n = cfg.n_agents, H = cfg.H;
+    uint64_t r = rec[k * S + col];
+    const int x0 = cfg.spawn_x0, y0 = cfg.spawn_y0;
+    const uint32_t mx = (uint32_t)(cfg.spawn_x1 - x0 - 1), my = (uint32_t)(cfg.spawn_y1 - y0 - 1);
+    for (int t = 0; t < cfg.spawn_max_tries; t++) {
+        // np_random.randint(top, bottom): low + bounded(high - low - 1) per coordinate
+        const int x = x0 + (int)mt.bounded(mx);
+        const int y = y0 + (int)mt.bounded(my);
+        const uint32_t base = g[x * H + y];
+        const uint32_t xy = (uint32_t)x | ((uint32_t)y << 8);
+        const int cnt = agents_on(rec, S, col, n, xy);
+        if ((base == 0 || (oflags[base] & MG_OF_CAN_OVERLAP)) && (cnt == 0 || (cfg.ghost_mode & 2))) {
+            r = arrive(rec, S, col, n, r);
+            r = rec_set(r, MG_AG_X, (uint32_t)x);
+            r = rec_set(r, MG_AG_Y, (uint32_t)y);
+            r = rec_set(r, MG_AG_FLAGS, (rec_byte(r, MG_AG_FLAGS) & keep_flags) | MG_AF_ACTIVE | MG_AF_PLACED);
+            rec[k * S + col] = r;
+            return true;
+        }
+    }
+    return false;
+}
+
+// ---- reset (base.py:402-416) ----------------------------------------------------------------------
+// `_gen_grid` as a static template + ordered rejection-sampled placements (base.py:664-708;
+// envs/cluttered.py:25-36, envs/empty.py:9-16, envs/goalcycle.py:30-51), then agent.reset(
+// new_episode=True) (agents.py:161-170; dir survives) and place_obj + activate in index order
+// (base.py:409-412).  Works on the env's records in rec[.][col] (read: old dir; written: the new
+// records) and on its grid slice `g` in HBM; the caller stores the records and the counters.
+MG_HD int reset_env(const MgConfig& cfg, const MgState& st, const MgGenProgram& prog, const uint8_t* oflags, int b,
+                    uint8_t* g, Mt& mt, uint64_t* rec, int S, int col) {
+    const int n = cfg.n_agents, H = cfg.H;
+    {   // self.grid = MultiGrid(...); wall_rect; put_obj — the static part of _gen_grid (16-byte vectors)
+        typedef struct { uint32_t v[4]; } __attribute__((aligned(16))) q16;
+        const q16* src = reinterpret_cast<const q16*>(prog.template_grid);
+        q16* dst = reinterpret_cast<q16*>(g);
+        for (int i = 0; i < cfg.cells_stride / 16; i++) dst[i] = src[i];
+    }
+    int err = 0;
+    // place_obj(obj, max_tries) for non-agent objects: only an empty cell accepts (try_place_obj,
+    // base.py:669-679; no agent is on the fresh grid yet)
+    for (int o = 0; o < prog.n_ops && !err; o++) {
+        const MgGenOp op = prog.ops[o];
+        for (int c = 0; c < op.count && !err; c++) {
+            bool ok = false;
+            for (int t = 0; t < op.max_tries; t++) {
+                const int x = op.x0 + (int)mt.bounded((uint32_t)(op.x1 - op.x0 - 1));
+                const int y = op.y0 + (int)mt.bounded((uint32_t)(op.y1 - op.y0 - 1));
+                const int cell = x * H + y;
+                if (g[cell] == 0) { g[cell] = (uint8_t)op.obj; ok = true; break; }
+            }
+            if (!ok) err = MG_ERR_RECURSION;
+        }
+    }
+    for (int k = 0; k < n; k++) {
+        uint64_t nr = 0;
+        nr = rec_set(nr, MG_AG_DIR, rec_byte(rec[k * S + col], MG_AG_DIR) & 3u);
+        nr = rec_set(nr, MG_AG_RANK, (uint32_t)k);
+        nr = rec_set(nr, MG_AG_BONUS, 0xFFu);
+        rec[k * S + col] = nr;
+        if (cfg.prestige_mask) st.prestige[(size_t)b * n + k] = 0.0;   // new_episode=True: agents.py:167-168
+    }
+    // ranks 0..n-1 in index order, and `arrive` keeps them a permutation: an agent placed now gets
+    // the highest rank, i.e. stacks above every agent placed before it, as the reference's append does
+    for (int k = 0; k < n && !err; k++) {
+        if (cfg.spawn_delay[k] != 0) continue;    // later spawns happen in step (base.py:503-506)
+        if (!place_agent(cfg, oflags, g, mt, rec, S, col, k, 0)) err = MG_ERR_RECURSION;
+    }
+    return err;
+}
+
+// ---- step (base.py:501-649) -------------------------------------------------------------------------
+// Per env the reference is strictly sequential: agents act in a freshly shuffled order
+// (base.py:514-516) and each action sees the grid left by the previous one.
+//
+// Flat state model that reproduces the reference's object graph: a cell holds a
+// base object id (0 = none) and any number of agents; the ordered stack the reference keeps in
+// `obj.agents` lists (append on entry base.py:547-552, remove on exit :555-559, re-seat left-behind
+// agents in order :562-569) is exactly "agents in this cell sorted by arrival", carried as a rank
+// permutation: a successful move gives the mover the highest rank.
+struct StepScratch {        // per-workgroup arrays, this env is column `col`, element stride S
+    uint64_t* rec;          // [n][S] agent records
+    uint32_t* head;         // [MG_MT_HEAD][S] look-ahead RNG words
+    uint8_t* order;         // [n][S] shuffled agent order
+    uint8_t* act;           // [n][S] action (0xFF: invalid)
+    uint8_t* fb;            // [n][S] front-cell base id
+    const MgObjDesc* obj;   // [n_obj] object table (shared)
+    const uint8_t* oflags;  // [MG_MAX_OBJ] object flags (shared)
+    int S, col;
+};
+struct StepEnv { int pos0, sc0; };
+
+// round trip 1: everything whose address is known up front, all of it contiguous across the batch
+template <typename ActT>
+MG_HD StepEnv step_load(const MgConfig& cfg, const MgState& st, const ActT* actions, int b, const StepScratch& sc) {
+    const int n = cfg.n_agents, S = sc.S, col = sc.col;
+    for (int k = 0; k < n; k++) sc.rec[k * S + col] = st.agents[(size_t)b * n + k];
+    for (int k = 0; k < n; k++) {
+        const long long a = (long long)actions[(size_t)b * n + k];
+        sc.act[k * S + col] = (a >= 0 && a <= 6) ? (uint8_t)a : (uint8_t)0xFF;
+    }
+    for (int i = 0; i < MG_MT_HEAD; i++) sc.head[i * S + col] = st.mt_head[(size_t)b * MG_MT_HEAD + i];
+    StepEnv e;
+    e.pos0 = st.mt_pos[b];
+    e.sc0 = st.step_count[b];
+    return e;
+}
+
+// auto_reset: an env whose episode ends in this step starts its next one right away (`prog`; reset
+// fused into the step: the done flag still reports the end).
+MG_HD void step_run(const MgConfig& cfg, const MgState& st, const MgGenProgram& prog, bool auto_reset, float* rewards,
+                    int b, const StepEnv& env, const StepScratch& sc) {
+    const int n = cfg.n_agents, W = cfg.W, H = cfg.H, S = sc.S, col = sc.col;
+    uint64_t* s_rec = sc.rec;
+    uint8_t* g = st.grid + (size_t)b * cfg.cells_stride;
+    Mt mt{st.mt + (size_t)b * MG_MT_N, env.pos0, sc.head + col, S, 0};
+    int err = 0;
+
+    // late spawns (base.py:503-506), before step_count is incremented and before the shuffle: any agent
+    // that is neither active nor done (spawn_delay not reached at reset, or lifted off the grid by a
+    // failed live placement) is placed as soon as step_count >= its spawn_delay
+    for (int k = 0; k < n; k++) {
+        const uint32_t f = rec_byte(s_rec[k * S + col], MG_AG_FLAGS);
+        if (!(f & (MG_AF_ACTIVE | MG_AF_DONE)) && env.sc0 >= cfg.spawn_delay[k])
+            if (!place_agent(cfg, sc.oflags, g, mt, s_rec, S, col, k, 0)) err = err ? err : MG_ERR_RECURSION;
+    }
+
+    // round trip 2: every agent's front cell.  An agent's position and heading are only ever changed
+    // by its own action, so its front cell is known before the loop; the cell's *content* can only be
+    // changed by a pickup / drop / toggle earlier in this step (grid_dirty), in which case it is re-read.
+    for (int k = 0; k < n; k++) {
+        const uint64_t r = s_rec[k * S + col];
+        const int dir = (int)rec_byte(r, MG_AG_DIR);
+        const int fx = (int)rec_byte(r, MG_AG_X) + dir_dx(dir), fy = (int)rec_byte(r, MG_AG_Y) + dir_dy(dir);
+        const bool ok = (rec_byte(r, MG_AG_FLAGS) & MG_AF_ACTIVE) && fx >= 0 && fx < W && fy >= 0 && fy < H;
+        sc.fb[k * S + col] = ok ? g[fx * H + fy] : (uint8_t)0;
+    }
+    bool grid_dirty = false;
+
+    int step_count = env.sc0 + 1;   // base.py:512
+    // reward decay factor, float64 like the reference (base.py:579)
+    const double decay = cfg.reward_decay ? (1.0 - 0.9 * ((double)step_count / (double)cfg.max_steps)) : 1.0;
+
+    // iter_order = arange(n); np_random.shuffle(iter_order)  (base.py:514-516): legacy Fisher-Yates
+    // over numpy's masked-rejection bounded draws — served from the look-ahead head
+    for (int k = 0; k < n; k++) sc.order[k * S + col] = (uint8_t)k;
+    for (int i = n - 1; i >= 1; i--) {
+        const int j = (int)mt.bounded((uint32_t)i);
+        const uint8_t t = sc.order[i * S + col];
+        sc.order[i * S + col] = sc.order[j * S + col];
+        sc.order[j * S + col] = t;
+    }
+
+    for (int oi = 0; oi < n; oi++) {
+        const int k = sc.order[oi * S + col];
+        float rew = 0.0f;
+        bool rewarded = false;      // agent.reward(rwd) was called (prestige bookkeeping)
+        double rwd_applied = 0.0;
+        uint64_t r = s_rec[k * S + col];
+        const uint32_t flags = rec_byte(r, MG_AG_FLAGS);
+        if (flags & MG_AF_ACTIVE) {   // base.py:521
+            const int action = (int)sc.act[k * S + col];
+            const int cx = (int)rec_byte(r, MG_AG_X), cy = (int)rec_byte(r, MG_AG_Y);
+            const int dir = (int)rec_byte(r, MG_AG_DIR);
+            const int fx = cx + dir_dx(dir), fy = cy + dir_dy(dir);   // agent.front_pos agents.py:194-198
+            if (fx < 0 || fx >= W || fy < 0 || fy >= H) {
+                err = err ? err : MG_ERR_ASSERT;   // grid.get asserts (base.py:154-156)
+            } else {
+                const int fcell = fx * H + fy;
+                const uint32_t fbase = grid_dirty ? (uint32_t)g[fcell] : (uint32_t)sc.fb[k * S + col];
+                const uint32_t fxy = (uint32_t)fx | ((uint32_t)fy << 8);
+                const uint32_t fflags = sc.oflags[fbase];
+                if (action == 0) {                                   // left  base.py:530-531
+                    r = rec_set(r, MG_AG_DIR, (uint32_t)((dir + 3) & 3));
+                } else if (action == 1) {                            // right :534-535
+                    r = rec_set(r, MG_AG_DIR, (uint32_t)((dir + 1) & 3));
+                } else if (action == 2 || action == 4) {             // forward :538-585 / drop :600-606
+                    const int agents_there = agents_on(s_rec, S, col, n, fxy);
+                    if (action == 2) {
+                        // fwd_cell is None, or it can_overlap(); the top object is the base object if
+                        // there is one, else the first agent standing there (agents overlap)
+                        bool can_move = fbase ? (fflags & MG_OF_CAN_OVERLAP) != 0 : true;
+                        if (!(cfg.ghost_mode & 1) && fbase == 0 && agents_there > 0) can_move = false;  // :541-542
+                        if (can_move) {
+                            r = arrive(s_rec, S, col, n, r);
+                            r = rec_set(r, MG_AG_X, (uint32_t)fx);
+                            r = rec_set(r, MG_AG_Y, (uint32_t)fy);
+                            if (fbase) {
+                                const MgObjDesc od = sc.obj[fbase];
+                                if (od.reward_kind) {                 // hasattr(fwd_cell,'get_reward') :576-581
+                                    double rwd;
+                                    if (od.reward_kind == 1) {
+                                        rwd = od.reward;              // Goal.get_reward objects.py:219-220
+                                    } else {                          // BonusTile.get_reward objects.py:180-206
+                                        int bs = (int)rec_byte(r, MG_AG_BONUS);
+                                        bool first_bonus = false;
+                                        const int nb = od.n_bonus ? od.n_bonus : 1;
+                                        if (bs == 0xFF) { bs = ((int)od.bonus_id - 1 + nb) % nb; first_bonus = true; }
+                                        if (bs == od.bonus_id) rwd = -fabs(od.penalty);
+                                        else if ((bs + 1) % nb == od.bonus_id) { bs = od.bonus_id; rwd = od.reward; }
+                                        else rwd = -fabs(od.penalty);
+                                        if (od.bonus_flags & 2) bs = od.bonus_id;
+                                        if (first_bonus && !(od.bonus_flags & 1)) rwd = 0.0;
+                                        r = rec_set(r, MG_AG_BONUS, (uint32_t)bs);
+                                    }
+                                    rwd_applied = rwd * decay;
+                                    rewarded = true;
+                                    rew = (float)rwd_applied;
+                                }
+                                if (fflags & MG_OF_ENDS_EPISODE) r = rec_set(r, MG_AG_FLAGS, flags | MG_AF_DONE);  // :584-585
+                            }
+                        }
+                    } else {
+                        // drop: `if not fwd_cell and agent.carrying`
+                        const uint32_t carry = rec_byte(r, MG_AG_CARRY);
+                        if (fbase == 0 && agents_there == 0 && carry) {
+                            g[fcell] = (uint8_t)carry;
+                            grid_dirty = true;
+                            r = rec_set(r, MG_AG_CARRY, 0);
+                        }
+                    }
+                } else if (action == 3) {                            // pickup :590-597
+                    if (fbase && (fflags & MG_OF_CAN_PICKUP) && rec_byte(r, MG_AG_CARRY) == 0) {
+                        r = rec_set(r, MG_AG_CARRY, fbase);
+                        g[fcell] = 0;
+                        grid_dirty = true;
+                    }
+                } else if (action == 5) {                            // toggle :609-613
+                    if (fbase) {
+                        if (fflags & MG_OF_IS_BOX) {
+                            err = err ? err : MG_ERR_TYPE;           // Box.toggle arity objects.py:381-382
+                        } else if (fflags & MG_OF_IS_DOOR) {         // Door.toggle objects.py:333-346
+                            const MgObjDesc od = sc.obj[fbase];
+                            if (fflags & MG_OF_DOOR_LOCKED) {
+                                const uint32_t carry = rec_byte(r, MG_AG_CARRY);
+                                if (carry) {
+                                    const MgObjDesc cd = sc.obj[carry];
+                                    if ((cd.flags & MG_OF_IS_KEY) && cd.color_idx == od.color_idx)
+                                        { g[fcell] = od.unlock_next; grid_dirty = true; }
+                                }
+                            } else {
+                                g[fcell] = od.toggle_next;
+                                grid_dirty = true;
+                            }
+                        }
+                    }
+                } else if (action == 6) {                            // done :616-617
+                } else {
+                    err = err ? err : MG_ERR_VALUE;                  // :619-620
+                }
+            }
+            s_rec[k * S + col] = r;
+            if (cfg.prestige_mask) {
+                // agent.reward(rwd) then agent.on_step(): agents.py:141-153 (allow_negative_prestige=False)
+                double* pp = st.prestige + (size_t)b * n + k;
+                double p = *pp;
+                if (rewarded) p = (rwd_applied >= 0) ? p + rwd_applied : 0.0;
+                *pp = p * cfg.prestige_beta[k];
+            }
+        }
+        rewards[(size_t)b * n + k] = rew;
+    }
+
+    // done agents (base.py:627-646), in index order: without respawn they are deactivated but stay
+    // where they are; with respawn they leave their cell (an agent only ever becomes done on a Goal /
+    // Lava, i.e. inside that object's stack, so nothing is left behind), drop what they carry
+    // (agent.reset(new_episode=False), agents.py:161-166) and are re-placed by rejection sampling
+    // among the agents currently on the grid.  Then episode done (base.py:649).
+    bool all_done = true;
+    for (int k = 0; k < n; k++) {
+        uint64_t r = s_rec[k * S + col];
+        const uint32_t f = rec_byte(r, MG_AG_FLAGS);
+        if (f & MG_AF_DONE) {
+            if (cfg.respawn) {
+                r = rec_set(r, MG_AG_FLAGS, 0);
+                r = rec_set(r, MG_AG_CARRY, 0);
+                s_rec[k * S + col] = r;                      // off the grid while sampling
+                if (!place_agent(cfg, sc.oflags, g, mt, s_rec, S, col, k, 0)) err = err ? err : MG_ERR_RECURSION;
+                all_done = false;
+            } else {
+                s_rec[k * S + col] = rec_set(r, MG_AG_FLAGS, f & ~MG_AF_ACTIVE);
+            }
+        } else all_done = false;
+    }
+    const bool done = (step_count >= cfg.max_steps) || all_done;
+    if (done && auto_reset) {
+        const int e2 = reset_env(cfg, st, prog, sc.oflags, b, g, mt, s_rec, S, col);
+        err = err ? err : e2;
+        step_count = 0;
+    }
+    for (int k = 0; k < n; k++) st.agents[(size_t)b * n + k] = s_rec[k * S + col];
+    st.step_count[b] = step_count;
+    mt_finish(mt, st.mt_head + (size_t)b * MG_MT_HEAD);
+    st.mt_pos[b] = mt.pos;
+    st.done[b] = (uint8_t)done;
+    if (err && st.error[b] == 0) st.error[b] = err;
+}
+
+// ---- MultiGridEnv.reset for one env (explicit reset; the auto-reset runs inside step_run) ---------
+MG_HD void reset_run(const MgConfig& cfg, const MgState& st, const MgGenProgram& prog, const uint8_t* oflags, int b,
+                     bool clear_done, uint64_t* rec, int S, int col) {
+    const int n = cfg.n_agents;
+    uint8_t* g = st.grid + (size_t)b * cfg.cells_stride;
+    uint32_t* head = st.mt_head + (size_t)b * MG_MT_HEAD;
+    Mt mt{st.mt + (size_t)b * MG_MT_N, st.mt_pos[b], head, 1, 0};
+    for (int k = 0; k < n; k++) rec[k * S + col] = st.agents[(size_t)b * n + k];
+    const int err = reset_env(cfg, st, prog, oflags, b, g, mt, rec, S, col);
+    for (int k = 0; k < n; k++) st.agents[(size_t)b * n + k] = rec[k * S + col];
+    mt_finish(mt, head);
+    st.mt_pos[b] = mt.pos;
+    st.step_count[b] = 0;
+    if (clear_done) st.done[b] = 0;
+    if (err && st.error[b] == 0) st.error[b] = err;
+}
+
+// ---- MultiGridEnv.place_obj / try_place_obj on a live grid (base.py:664-708) for one env -------------
+MG_HD void place_run(const MgConfig& cfg, const MgState& st, const uint8_t* oflags, int b, int what, int x0, int y0,
+                     int x1, int y1, int max_tries, const int32_t* fixed_pos, int32_t* out_pos, uint8_t* out_ok,
+                     uint64_t* rec, int S, int col) {
+    const int n = cfg.n_agents, H = cfg.H;
+    uint8_t* g = st.grid + (size_t)b * cfg.cells_stride;
+    uint32_t* head = st.mt_head + (size_t)b * MG_MT_HEAD;
+    Mt mt{st.mt + (size_t)b * MG_MT_N, st.mt_pos[b], head, 1, 0};
+    for (int k = 0; k < n; k++) rec[k * S + col] = st.agents[(size_t)b * n + k];
+    const bool is_agent = what < 0;
+    const int k = -(what + 1);
+    if (is_agent) {   // off the grid while a cell is looked for
+        const uint64_t r = rec[k * S + col];
+        rec[k * S + col] = rec_set(r, MG_AG_FLAGS, rec_byte(r, MG_AG_FLAGS) & ~(MG_AF_PLACED | MG_AF_ACTIVE));
+    }
+    bool ok = false;
+    int x = -1, y = -1;
+    const int tries = fixed_pos ? 1 : max_tries;
+    for (int t = 0; t < tries && !ok; t++) {
+        if (fixed_pos) { x = fixed_pos[2 * b]; y = fixed_pos[2 * b + 1]; if (x < 0 || x >= cfg.W || y < 0 || y >= H) break; }
+        else {
+            x = x0 + (int)mt.bounded((uint32_t)(x1 - x0 - 1));
+            y = y0 + (int)mt.bounded((uint32_t)(y1 - y0 - 1));
+        }
+        const uint32_t base = g[x * H + y];
+        const uint32_t xy = (uint32_t)x | ((uint32_t)y << 8);
+        const int cnt = agents_on(rec, S, col, n, xy);
+        if (!is_agent) {
+            // only an empty cell (no object, no agent) accepts a non-agent object (base.py:672-679)
+            if (base == 0 && cnt == 0) { g[x * H + y] = (uint8_t)what; ok = true; }
+        } else if ((base == 0 || (oflags[base] & MG_OF_CAN_OVERLAP)) && (cnt == 0 || (cfg.ghost_mode & 2))) {
+            uint64_t r = arrive(rec, S, col, n, rec[k * S + col]);
+            r = rec_set(r, MG_AG_X, (uint32_t)x);
+            r = rec_set(r, MG_AG_Y, (uint32_t)y);
+            r = rec_set(r, MG_AG_FLAGS, (rec_byte(r, MG_AG_FLAGS) & MG_AF_DONE) | MG_AF_ACTIVE | MG_AF_PLACED);
+            rec[k * S + col] = r;
+            ok = true;
+        }
+    }
+    for (int j = 0; j < n; j++) st.agents[(size_t)b * n + j] = rec[j * S + col];
+    mt_finish(mt, head);
+    st.mt_pos[b] = mt.pos;
+    if (out_pos) { out_pos[2 * b] = ok ? x : -1; out_pos[2 * b + 1] = ok ? y : -1; }
+    if (out_ok) out_ok[b] = ok ? 1 : 0;
+    if (!ok && !fixed_pos && st.error[b] == 0) st.error[b] = MG_ERR_RECURSION;
+}
+
+}  // namespace mg

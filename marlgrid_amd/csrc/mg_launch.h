@@ -6,11 +6,11 @@
 
 namespace mg {
 hipError_t launch_mt_seed(int B, const uint32_t* keys, const int32_t* key_len, uint32_t* mt, int32_t* mt_pos,
-                          hipStream_t s);
+                          uint32_t* mt_head, hipStream_t s);
 hipError_t launch_reset(const MgConfig& cfg, const MgState& st, const MgGenProgram& prog, const uint8_t* mask,
                         hipStream_t s);
 hipError_t launch_step(const MgConfig& cfg, const MgState& st, const void* actions, int action_bytes,
-                       float* rewards, hipStream_t s);
+                       float* rewards, const MgGenProgram* auto_reset, hipStream_t s);
 hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, uint8_t* view_cells,
                          uint8_t* view_agent, uint8_t* vis_mask, hipStream_t s);
 int render_min_lds_bytes(const MgConfig& cfg);

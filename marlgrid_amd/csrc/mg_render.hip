@@ -20,9 +20,10 @@
 //     8), or as aligned dwords cut out of contiguous atlas runs (any other tile size).
 // No MFMA: there is no contraction anywhere in this path.
 #include "mg_device.h"
-#include <stdlib.h>
-
 #include "mg_launch.h"
+#if defined(MG_AB_VARIANTS)
+#include <stdlib.h>   // getenv: the measurement build only (libmarlgrid_hip_ab.so, loaded by tools/)
+#endif
 #include "mg_occlude.h"
 
 namespace mg {
@@ -603,7 +604,9 @@ static hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_
     // env-time in ~6).  Registers (~87 VGPRs) admit 5 waves per SIMD = 20 per CU.
     int per_cu = (int)((160 * 1024) / (lds ? lds : 1));
     if (per_cu > 20 / WPB) per_cu = 20 / WPB;
-    if (const char* f = getenv("MG_RENDER_PER_CU")) { const int v = atoi(f); if (v >= 1 && v < per_cu) per_cu = v; }   // (measurement)
+#if defined(MG_AB_VARIANTS)
+    if (const char* f = getenv("MG_RENDER_PER_CU")) { const int v = atoi(f); if (v >= 1 && v < per_cu) per_cu = v; }
+#endif
     if (per_cu < 1) per_cu = 1;
     const int max_blocks = 256 * per_cu;
     const int need = (cfg.B + WPB - 1) / WPB;   // workgroups if every wave took one env
@@ -625,7 +628,9 @@ int render_min_lds_bytes(const MgConfig& cfg) {
 // over 4-wave workgroups at the bench batch.  Small batches keep 4-wave workgroups so that they
 // still spread over all CUs.
 static int choose_wpb(const MgConfig& cfg) {
+#if defined(MG_AB_VARIANTS)
     if (const char* f = getenv("MG_RENDER_WPB")) { int w = atoi(f); if (w == 4 || w == 8 || w == 16) return w; }
+#endif
     const int tile_bytes = cfg.tile_size * cfg.tile_size * 3;
     const RenderScratch L = render_scratch_for(cfg, 16);
     size_t lds16 = (size_t)round_up(4 * cfg.n_tiles * tile_bytes, 16) + kRenderShared + 16 * (size_t)L.total;
@@ -678,15 +683,17 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
         }
     }
     if (ts == 8 && vs == 7) {
-        const int variant = getenv("MG_RENDER_VARIANT") ? atoi(getenv("MG_RENDER_VARIANT")) : 0;
-        switch (variant) {   // measurement variants (tools/ab_render.py), see render_kernel
+#if defined(MG_AB_VARIANTS)
+        switch (getenv("MG_RENDER_VARIANT") ? atoi(getenv("MG_RENDER_VARIANT")) : 0) {   // tools/ab_render.py
         case 2: return MG_RENDER_DISPATCH(7, 8, 2);
         case 3: return MG_RENDER_DISPATCH(7, 8, 3);
         case 4: return MG_RENDER_DISPATCH(7, 8, 4);
         case 6: return MG_RENDER_DISPATCH(7, 8, 6);
         case 11: return MG_RENDER_DISPATCH(7, 8, 11);
-        default: return MG_RENDER_DISPATCH8(7, 8, 0);
+        default: break;
         }
+#endif
+        return MG_RENDER_DISPATCH8(7, 8, 0);
     }
     if (ts == 8 && vs == 9) return MG_RENDER_DISPATCH(9, 8, 0);
     if (ts == 8 && vs == 5) return MG_RENDER_DISPATCH(5, 8, 0);

@@ -43,3 +43,45 @@ def batch_keys(seeds):
         keys[i, :len(w)] = w
         lens[i] = len(w)
     return keys, lens
+
+
+_UPPER, _LOWER, _MAG = 0x80000000, 0x7FFFFFFF, 0x9908B0DF
+
+
+def numpy_form(mt, gen_pos, head):
+    """Device RNG state -> numpy's (key[624], pos).
+
+    The device keeps MT19937 in *lazy* form with a look-ahead head (csrc/mg_core.h): slots below
+    `gen_pos` hold words of the current block, slots from `gen_pos` on still hold the previous
+    block's, and the `head` outputs before `gen_pos` are generated but not consumed, i.e. the stream
+    position is gen_pos - head.  numpy always holds one whole block:
+      * position inside the current block: regenerate the tail [gen_pos, 624) the way numpy's block
+        loop would have;
+      * position still in the previous block (gen_pos <= head): wind the slots [0, gen_pos) back.
+        x_new[i] = x_old[i+397] ^ twist(x_old[i] & UPPER | x_old[i+1] & LOWER) gives the top bit of
+        x_old[i] and the low 31 bits of x_old[i+1]; the low 31 bits of x_old[0] are not recoverable —
+        and never read again by MT19937 — and are returned as 0.
+    """
+    mt = [int(v) for v in mt]
+    G = int(gen_pos)
+    if G > head:
+        for kk in range(G, 624):
+            y = (mt[kk] & _UPPER) | (mt[(kk + 1) % 624] & _LOWER)
+            mt[kk] = mt[(kk + 397) % 624] ^ (y >> 1) ^ (_MAG if y & 1 else 0)
+        return np.array(mt, np.uint32), G - head
+    ys = []
+    for i in range(G):
+        t = mt[i] ^ mt[i + 397]
+        ys.append((((t ^ _MAG) << 1) | 1) & 0xFFFFFFFF if t & _UPPER else (t << 1) & 0xFFFFFFFF)
+    for i in range(G):
+        mt[i] = (ys[i] & _UPPER) | ((ys[i - 1] & _LOWER) if i > 0 else 0)
+    return np.array(mt, np.uint32), G - head + 624
+
+
+def same_stream(a, b):
+    """Two numpy-form states (key, pos) describe the same MT19937 stream: equal position, equal
+    words 1..623 and equal top bit of word 0 (the generator's state is 19937 bits: the low 31 bits
+    of word 0 are never read)."""
+    (ka, pa), (kb, pb) = a, b
+    ka, kb = np.asarray(ka, np.uint32), np.asarray(kb, np.uint32)
+    return int(pa) == int(pb) and np.array_equal(ka[1:], kb[1:]) and (int(ka[0]) >> 31) == (int(kb[0]) >> 31)

@@ -1,0 +1,124 @@
+"""TEST INFRASTRUCTURE — the engine's lane-per-env bodies (marlgrid_amd/csrc/mg_core.h) run on the host.
+
+`HostEmu` drives tests/native/libmg_hostemu.so (g++ build of the very text the HIP kernels run per
+lane) with numpy buffers in place of HBM tensors, using the product's own host-side code for
+everything around it (a `_dry` MultiGridEnv: `_gen_grid` recorder, object table, launch config, seed
+hashing).  It exists so that the step / reset / placement state machine and its RNG handling can be
+checked against the oracle in a container without a GPU.  It renders nothing, and nothing under
+marlgrid_amd/ imports it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from marlgrid_amd import _native as N
+from marlgrid_amd import seeding
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        subprocess.check_call(["make", "-s", "-C", HERE])
+        L = C.CDLL(os.path.join(HERE, "libmg_hostemu.so"))
+        for i, t in enumerate((N.Config, N.State, N.GenProgram, N.ObjDesc)):
+            assert L.emu_sizeof(i) == C.sizeof(t), (t, L.emu_sizeof(i), C.sizeof(t))
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+class HostEmu(object):
+    def __init__(self, name, B, seeds, auto_reset=False, **kw):
+        import product_envs
+        self.L = lib()
+        self.env = env = product_envs.build(name, batch_size=B, seeds=[int(s) for s in seeds], _dry=True, **kw)
+        self.B, self.n = B, env.num_agents
+        self.auto_reset = auto_reset
+        ctor_trace = env._dry_trace                     # what the constructor's reset() recorded
+        self.grid = np.zeros((B, env.cells_stride), np.uint8)
+        self.rec = np.zeros((B, self.n), np.uint64)
+        self.mt = np.zeros((B, N.MT_N), np.uint32)
+        self.mt_pos = np.zeros(B, np.int32)
+        self.mt_head = np.zeros((B, N.MT_HEAD), np.uint32)
+        self.step_count = np.zeros(B, np.int32)
+        self.done = np.zeros(B, np.uint8)
+        self.error = np.zeros(B, np.int32)
+        self.prestige = np.zeros((B, self.n), np.float64)
+        self.rewards = np.zeros((B, self.n), np.float32)
+        self.state = N.State(_ptr(self.grid), _ptr(self.rec), _ptr(self.mt), _ptr(self.mt_pos), _ptr(self.step_count),
+                             _ptr(self.done), _ptr(self.error), _ptr(self.prestige), _ptr(self.mt_head))
+        keys, lens = seeding.batch_keys(env.seeds)
+        self.L.emu_mt_seed(B, _ptr(keys), _ptr(lens), _ptr(self.mt), _ptr(self.mt_pos), _ptr(self.mt_head))
+        self._tables_version = None
+        self._reset_with(ctor_trace, None)              # MultiGridEnv.__init__ ends with reset()
+
+    def _cfg(self):
+        env = self.env
+        if self._tables_version != env.obj_reg.version:
+            self.cfg, self._obj_raw, _, _ = env._host_tables()
+            self.cfg.obj = self._obj_raw.ctypes.data
+            self._tables_version = env.obj_reg.version
+        else:
+            env._refresh_cfg(self.cfg)
+        return self.cfg
+
+    def _prog(self, trace):
+        template, ops = trace
+        env = self.env
+        t = np.zeros(env.cells_stride, np.uint8)
+        t[:env.width * env.height] = template.reshape(-1)
+        prog = N.GenProgram()
+        prog._keep = t
+        prog.template_grid = t.ctypes.data
+        prog.n_ops = len(ops)
+        for i, (obj, count, max_tries, x0, y0, x1, y1) in enumerate(ops):
+            o = prog.ops[i]
+            o.obj, o.count, o.max_tries, o.x0, o.y0, o.x1, o.y1 = obj, count, max_tries, x0, y0, x1, y1
+        return prog
+
+    def _reset_with(self, trace, mask):
+        self._last_prog = prog = self._prog(trace)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        self.L.emu_reset(C.byref(self._cfg()), C.byref(self.state), C.byref(prog), None if m is None else _ptr(m))
+
+    def reset(self, env_mask=None):
+        self.env.reset()                                # re-records `_gen_grid` (dry: nothing else)
+        self._reset_with(self.env._dry_trace, env_mask)
+
+    def step(self, actions):
+        a = np.ascontiguousarray(actions, np.int64).reshape(self.B, self.n)
+        prog = None
+        if self.auto_reset:
+            self.env.reset()
+            self._last_prog = self._prog(self.env._dry_trace)
+            prog = C.byref(self._last_prog)
+        rc = self.L.emu_step(C.byref(self._cfg()), C.byref(self.state), _ptr(a), 8, _ptr(self.rewards), prog)
+        assert rc == 0
+        return self.rewards.copy(), self.done.astype(bool)
+
+    def place(self, what, region, max_tries=100000, fixed_pos=None, mask=None):
+        x0, y0, x1, y1 = region
+        pos = np.zeros((self.B, 2), np.int32)
+        ok = np.zeros(self.B, np.uint8)
+        fp = None if fixed_pos is None else np.ascontiguousarray(np.broadcast_to(fixed_pos, (self.B, 2)), np.int32)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        self.L.emu_place(C.byref(self._cfg()), C.byref(self.state), what, x0, y0, x1, y1, int(max_tries),
+                         None if fp is None else _ptr(fp), None if m is None else _ptr(m), _ptr(pos), _ptr(ok))
+        return pos, ok.astype(bool)
+
+    def canonical(self):
+        import product_envs
+        W, H = self.env.width, self.env.height
+        return product_envs.canonical_arrays(self.env.scenario_spec(), self.grid[:, :W * H].reshape(self.B, W, H),
+                                             self.rec, self.step_count)
+
+    def numpy_rng_state(self, b):
+        return seeding.numpy_form(self.mt[b], self.mt_pos[b], N.MT_HEAD)

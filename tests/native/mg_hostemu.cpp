@@ -1,0 +1,85 @@
+// mg_hostemu.cpp — TEST INFRASTRUCTURE, not product code.
+//
+// The lane-per-env bodies of the engine (marlgrid_amd/csrc/mg_core.h: seed / reset / step / live
+// placement) compiled for the host with g++ and driven one env at a time, so that the state
+// machine the HIP kernels run per lane can be stepped against the oracle in THIS container, which
+// has no GPU (tests/test_core_hostemu.py).  Nothing under marlgrid_amd/ loads this library, and it
+// renders no observations: the obs raster exists only as HIP kernels.
+#include <string.h>
+
+#include <vector>
+
+#include "mg_core.h"
+
+namespace {
+struct Scratch {
+    std::vector<uint64_t> rec;
+    std::vector<uint32_t> head;
+    std::vector<uint8_t> order, act, fb, oflags;
+    mg::StepScratch sc;
+    Scratch(const MgConfig* cfg) : rec(MG_MAX_AGENTS), head(MG_MT_HEAD), order(MG_MAX_AGENTS), act(MG_MAX_AGENTS),
+                                   fb(MG_MAX_AGENTS), oflags(MG_MAX_OBJ, 0) {
+        for (int i = 1; i < cfg->n_obj; i++) oflags[i] = cfg->obj[i].flags;
+        sc.rec = rec.data(); sc.head = head.data(); sc.order = order.data(); sc.act = act.data(); sc.fb = fb.data();
+        sc.obj = cfg->obj; sc.oflags = oflags.data(); sc.S = 1; sc.col = 0;
+    }
+};
+}  // namespace
+
+extern "C" {
+
+int emu_mt_seed(int B, const uint32_t* keys, const int32_t* key_len, uint32_t* mt, int32_t* mt_pos, uint32_t* head) {
+    for (int b = 0; b < B; b++)
+        mg::mt_seed_env(keys + (size_t)b * MG_KEY_WORDS, key_len[b], mt + (size_t)b * MG_MT_N, mt_pos + b,
+                        head + (size_t)b * MG_MT_HEAD);
+    return 0;
+}
+
+int emu_reset(const MgConfig* cfg, const MgState* st, const MgGenProgram* prog, const uint8_t* mask) {
+    Scratch s(cfg);
+    for (int b = 0; b < cfg->B; b++) {
+        if (mask && !mask[b]) continue;
+        mg::reset_run(*cfg, *st, *prog, s.oflags.data(), b, mask != st->done, s.rec.data(), 1, 0);
+    }
+    return 0;
+}
+
+int emu_step(const MgConfig* cfg, const MgState* st, const void* actions, int action_bytes, float* rewards,
+             const MgGenProgram* auto_reset) {
+    Scratch s(cfg);
+    MgGenProgram none;
+    memset(&none, 0, sizeof(none));
+    const MgGenProgram& prog = auto_reset ? *auto_reset : none;
+    for (int b = 0; b < cfg->B; b++) {
+        mg::StepEnv e;
+        if (action_bytes == 8) e = mg::step_load(*cfg, *st, (const int64_t*)actions, b, s.sc);
+        else if (action_bytes == 4) e = mg::step_load(*cfg, *st, (const int32_t*)actions, b, s.sc);
+        else if (action_bytes == 1) e = mg::step_load(*cfg, *st, (const uint8_t*)actions, b, s.sc);
+        else return -100;
+        mg::step_run(*cfg, *st, prog, auto_reset != nullptr, rewards, b, e, s.sc);
+    }
+    return 0;
+}
+
+int emu_place(const MgConfig* cfg, const MgState* st, int what, int x0, int y0, int x1, int y1, int max_tries,
+              const int32_t* fixed_pos, const uint8_t* mask, int32_t* out_pos, uint8_t* out_ok) {
+    Scratch s(cfg);
+    for (int b = 0; b < cfg->B; b++) {
+        if (mask && !mask[b]) continue;
+        mg::place_run(*cfg, *st, s.oflags.data(), b, what, x0, y0, x1, y1, max_tries, fixed_pos, out_pos, out_ok,
+                      s.rec.data(), 1, 0);
+    }
+    return 0;
+}
+
+int emu_sizeof(int which) {
+    switch (which) {
+    case 0: return (int)sizeof(MgConfig);
+    case 1: return (int)sizeof(MgState);
+    case 2: return (int)sizeof(MgGenProgram);
+    case 3: return (int)sizeof(MgObjDesc);
+    default: return -1;
+    }
+}
+
+}  // extern "C"

@@ -42,17 +42,21 @@ def _region_env_class():
 
 def canonical(env, b=None):
     """canonical id-free state of every env (list) or env b (dict)"""
+    out = canonical_arrays(env.scenario_spec(), env.grid.grid.cpu().numpy(), env.agent_state.cpu().numpy(),
+                           env.step_count.cpu().numpy())
+    return out if b is None else out[b]
+
+
+def canonical_arrays(spec, base, rec, sc):
+    """the same from plain arrays: base (B, W, H) object ids, rec (B, n) packed agent records, sc (B,)"""
     import _native_consts as K
-    spec = env.scenario_spec()
-    B, n = env.batch_size, env.num_agents
-    base = env.grid.grid.cpu().numpy()
-    rec = env.agent_state.cpu().numpy().astype(np.uint64)
+    rec = np.asarray(rec).astype(np.uint64)
+    B, n = rec.shape
     by = lambda i: ((rec >> np.uint64(8 * i)) & np.uint64(0xFF)).astype(np.int64)
     x, y, d, fl, ca, rk = by(K.AG_X), by(K.AG_Y), by(K.AG_DIR), by(K.AG_FLAGS), by(K.AG_CARRY), by(K.AG_RANK)
     placed = (fl & K.AF_PLACED) != 0
-    sc = env.step_count.cpu().numpy()
     out = []
-    for bb in (range(B) if b is None else [b]):
+    for bb in range(B):
         pos = np.stack([np.where(placed[bb], x[bb], -1), np.where(placed[bb], y[bb], -1)], axis=1)
         ordinal = np.full(n, -1)
         for k in range(n):
@@ -61,4 +65,4 @@ def canonical(env, b=None):
                 ordinal[k] = int((same & (rk[bb] < rk[bb, k])).sum())
         out.append(canon.from_ids(spec, base[bb], pos, d[bb], (fl[bb] & K.AF_ACTIVE) != 0,
                                   (fl[bb] & K.AF_DONE) != 0, ca[bb], ordinal, sc[bb]))
-    return out if b is None else out[0]
+    return out

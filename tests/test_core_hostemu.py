@@ -1,0 +1,91 @@
+"""The engine's lane-per-env bodies (marlgrid_amd/csrc/mg_core.h — the text every lane of the HIP
+seed / reset / step / place kernels runs) compiled for the host and stepped against the oracle.
+
+What this pins without a GPU: the flat state machine (grid + packed agent records + stack ranks),
+the fused auto-reset, the RNG stream (lazy MT19937 + look-ahead head, incl. the refill and the
+conversion back to numpy's form) and rewards / done.  What it cannot pin: anything about the kernels
+around the bodies (LDS staging, launch shapes) and the whole observation raster — those are the
+`-m gpu` tests.  tests/native is test infrastructure; the product never loads it.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "native"))
+
+import canon  # noqa: E402
+import scenarios  # noqa: E402
+from marlgrid_amd import seeding  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+REW_TOL = 1e-6
+
+
+def _same_state(emu, orc, what):
+    st = emu.canonical()
+    for b in range(emu.B):
+        canon.assert_same(st[b], canon.oracle_canonical(orc.envs[b]), "%s env %d" % (what, b))
+        assert seeding.same_stream(emu.numpy_rng_state(b), orc.envs[b].mt_state()), "%s env %d: RNG" % (what, b)
+
+
+def test_numpy_form_round_trip():
+    """lazy + head form -> numpy's (key, pos) for every phase of the block, against numpy itself"""
+    import hostemu
+    L = hostemu.lib()
+    keys, lens = seeding.batch_keys([1337])
+    mt = np.zeros((1, 624), np.uint32)
+    pos = np.zeros(1, np.int32)
+    head = np.zeros((1, 16), np.uint32)
+    L.emu_mt_seed(1, hostemu._ptr(keys), hostemu._ptr(lens), hostemu._ptr(mt), hostemu._ptr(pos), hostemu._ptr(head))
+    rs = np.random.RandomState()
+    key = np.array(seeding.seed_words(1337), np.uint32)
+    rs.seed(key)
+    want = rs.get_state()
+    got = seeding.numpy_form(mt[0], pos[0], 16)
+    assert got[1] == want[2] == 624 and np.array_equal(got[0], want[1])
+    # the head is the stream's first 16 outputs
+    assert np.array_equal(head[0], rs.randint(0, 2 ** 32, size=16, dtype=np.uint64).astype(np.uint32))
+
+
+@pytest.mark.parametrize("name,B,T,auto", [
+    ("MarlGrid-3AgentCluttered11x11-v0", 48, 130, False),
+    ("MarlGrid-3AgentCluttered15x15-v0", 32, 260, True),       # bench workload, auto-reset fused in step
+    ("MarlGrid-4AgentEmpty9x9-v0", 40, 120, True),
+    ("Custom-8AgentCluttered30x30", 8, 80, True),
+    ("Test-4AgentEmpty5x5-crowded", 64, 100, True),
+    ("Goalcycle-demo-solo-v0", 24, 300, True),
+    ("Test-3AgentCluttered9x9-respawn", 48, 200, True),
+    ("Test-4AgentEmpty5x5-respawn-noghost", 48, 150, False),
+    ("Test-3AgentEmpty7x7-spawn-delay", 48, 90, True),
+    ("Edge-16AgentEmpty6x6-view7", 16, 60, True),
+    ("Edge-12AgentCluttered9x9-view3", 16, 80, False),
+    ("Test-3AgentCluttered9x9-prestige-mixed", 32, 200, True),
+    ("Test-2AgentRegion9x9", 32, 60, True),
+])
+def test_core_bodies_vs_oracle(name, B, T, auto):
+    import hostemu
+    seeds = 4200 + np.arange(B)
+    emu = hostemu.HostEmu(name, B, seeds, auto_reset=auto)
+    orc = O.OracleBatch(scenarios.registered(name), seeds)
+    _same_state(emu, orc, "%s ctor" % name)
+    emu.reset()
+    orc.reset()
+    _same_state(emu, orc, "%s reset" % name)
+    rng = np.random.RandomState(5)
+    n = emu.n
+    for t in range(T):
+        a = rng.randint(0, 7, size=(B, n))
+        r, d = emu.step(a)
+        _o, r2, d2, _ = orc.step(a, render=False, auto_reset=auto)
+        what = "%s step %d" % (name, t)
+        assert np.abs(r.astype(np.float64) - r2).max() <= REW_TOL, what
+        assert np.array_equal(d, d2), what
+        if not auto and d.any():
+            emu.reset(env_mask=d)
+            for b in np.nonzero(d)[0]:
+                orc.envs[b].reset()
+        if t % 7 == 0 or t == T - 1:
+            _same_state(emu, orc, what)
+    assert not emu.error.any()

@@ -24,9 +24,22 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), name
     L.mg_abi_version.restype = ctypes.c_int32
-    assert L.mg_abi_version() == 1
+    assert L.mg_abi_version() == 2
     from marlgrid_amd import _native
     assert sorted(_native.SYMBOLS) == declared
+
+
+def test_production_library_has_no_measurement_switches():
+    """the shipped libmarlgrid_hip.so reads no environment variable and carries none of the A/B variants
+    (those live in libmarlgrid_hip_ab.so, built with -DMG_AB_VARIANTS and loaded by tools/ only)"""
+    so = os.path.join(ROOT, "marlgrid_amd", "csrc", "libmarlgrid_hip.so")
+    blob = open(so, "rb").read()
+    for needle in (b"MG_RENDER", b"MG_STEP", b"getenv"):
+        assert needle not in blob, needle
+    L = ctypes.CDLL(so)
+    L.mg_build_info.restype = ctypes.c_char_p
+    info = L.mg_build_info().decode()
+    assert info.startswith("libmarlgrid_hip gfx950 abi2 src-") and "variants" not in info
 
 
 def test_product_never_imports_the_oracle():
@@ -37,6 +50,7 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"import\s+oracle|from\s+oracle|from\s+\.+oracle|oracle/|oracle\.|libmgoracle|mgo_",
                                      src), os.path.join(dp, f)
+                assert not re.search(r"hostemu|emu_", src), os.path.join(dp, f)      # nor the host test harness
 
 
 @pytest.mark.parametrize("name", ["MarlGrid-1AgentCluttered15x15-v0", "MarlGrid-3AgentCluttered11x11-v0",
