@@ -3,25 +3,229 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch-per-gpu B]
 
-A "step" is one `env.step(actions)` over the whole per-GPU batch: action apply (mg_step), device
-auto-reset of finished episodes (mg_reset with the done flags as mask) and the observation raster
-(mg_render_obs), with every input already resident in HBM.  The env batch shards over GPUs with no
-collective on the data path (weak scaling: 32 768 envs per GPU; 8 GPUs = BASELINE.json's 262 144).
-For N > 1 launch with torch.distributed.run (one rank per GPU); rank 0 prints ONE JSON line.
+A "step" is one `env.step(actions)` over the whole per-GPU batch: two launches on one stream —
+mg_step (action apply + the reset of every env whose episode just ended, fused into its tail) and
+mg_render_obs (the observation raster) — with every input already resident in HBM.  The env batch
+shards over GPUs with no collective on the data path (weak scaling: 32 768 envs per GPU; 8 GPUs =
+BASELINE.json's 262 144).  For N > 1 launch with torch.distributed.run (one rank per GPU); rank 0
+prints ONE JSON line.
+
+How the line is measured (one self-consistent measurement, not a collage):
+  * after W warm-up steps, BLOCKS of exactly K steps are timed, each bracketed by barrier +
+    synchronize on both sides and MAX-reduced over ranks, until >= --min-seconds of timed steps
+    (the driver's K = 20 is 4 ms: far below what clocks and samplers resolve).  `value` and
+    `ms_per_step` are the MEDIAN block; min / max / first / last are in `blocks`.
+  * every other block is instrumented: an event is recorded on the launch stream before mg_step,
+    between the two launches and after mg_render_obs, K times.  The per-launch intervals of those
+    same steps are `kernels.*_interval_ms` (an interval runs to the start of the next launch, so it
+    includes the dispatch gap); their sum is compared with that block's ms_per_step in `closure`.
+    `roofline.kernel_ms` is the raster's interval — the same launches, the same thermal state.
+  * `clocks` holds rocm-smi samples before the first and after the last block; `roofline.traffic`
+    is measured in this run (tools/pmc.py: rocprofv3 --pmc passes in a child process, N = 1 only).
+  * `extra.strong_n1`: the full headline batch (262 144 envs) on ONE GPU, same fields.
+The run refuses to start if an MG_* / MARLGRID_* environment variable is set, and echoes the
+library's build id.
 """
 import argparse
-import ctypes as C
 import json
 import os
+import statistics
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 WORKLOAD = "MarlGrid-3AgentCluttered15x15-v0"
+METRIC = "agent-steps/sec at batch B, 3AgentCluttered15x15, 1/2/4/8 MI355X"
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+class Control(object):
+    """The benchmark's control plane: barriers and scalar reductions over ranks.  Nothing on the data
+    path goes through it.  backend 'nccl' (= RCCL, one rank per GPU) or 'gloo' (ranks that share a
+    GPU: --oversubscribe, and the CPU self-test)."""
+
+    def __init__(self, backend, device=None):
+        import torch.distributed as dist
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.device = device if backend == "nccl" else None
+        self.backend = backend if self.world > 1 else None
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            if backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=device)
+            else:
+                dist.init_process_group(backend="gloo")
+
+    def barrier(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    def gather(self, values):
+        """every rank's tuple of floats, on every rank (list of `world` lists)"""
+        if self.world == 1:
+            return [[float(v) for v in values]]
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=self.device)
+        out = [torch.zeros_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t)
+        return [[float(x) for x in o.tolist()] for o in out]
+
+    def close(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
+
+
+def timed_blocks(step_fn, sync_fn, ctl, K, min_seconds, max_blocks, probe_ctl=None):
+    """Blocks of exactly K steps, each bracketed by sync + barrier + sync on both sides; the block
+    time is the MAX over ranks.  Odd blocks are instrumented when `probe_ctl` is given.  Returns a list
+    of dicts (one per block)."""
+    blocks, total, i = [], 0.0, 0
+    while True:
+        instrumented = probe_ctl is not None and (i % 2 == 1)
+        if instrumented:
+            probe_ctl.arm()
+        sync_fn()
+        ctl.barrier()
+        sync_fn()
+        t0 = time.perf_counter()
+        for j in range(K):
+            step_fn(i * K + j)
+        sync_fn()
+        own = time.perf_counter() - t0                # this rank's K steps alone (a straggler shows here)
+        ctl.barrier()
+        sync_fn()
+        mine = time.perf_counter() - t0
+        both = ctl.gather((mine, own))
+        elapsed = max(b[0] for b in both)             # the slowest rank defines the step time
+        b = {"elapsed_s": elapsed, "instrumented": instrumented, "per_rank_s": [x[1] for x in both]}
+        if instrumented:
+            b["kernels"] = probe_ctl.collect()
+        blocks.append(b)
+        total += elapsed
+        i += 1
+        # `total` comes out of an all_gather: identical on every rank, so all ranks stop together
+        if (total >= min_seconds and i >= 4) or i >= max_blocks:
+            return blocks
+
+
+class Probes(object):
+    """HIP events on the launch stream (torch's current stream IS the stream the C ABI launches on:
+    MultiGridEnv passes torch.cuda.current_stream().cuda_stream to every call)."""
+
+    def __init__(self, env, K):
+        import torch
+        self.env, self.K = env, K
+        self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * K)]
+        self.i = 0
+        self.on = False
+
+    def __call__(self, tag):
+        if self.on:
+            self.ev[self.i].record()
+            self.i += 1
+
+    def arm(self):
+        self.i, self.on = 0, True
+
+    def collect(self):
+        self.on = False
+        K, ev = self.K, self.ev
+        assert self.i == 3 * K
+        step = [ev[3 * j].elapsed_time(ev[3 * j + 1]) for j in range(K)]
+        render = [ev[3 * j + 1].elapsed_time(ev[3 * j + 2]) for j in range(K)]
+        between = [ev[3 * j + 2].elapsed_time(ev[3 * j + 3]) for j in range(K - 1)]   # host gap between steps
+        span = ev[0].elapsed_time(ev[3 * K - 1])
+        return {"step_interval_ms": sum(step) / K, "render_interval_ms": sum(render) / K,
+                "between_steps_ms": sum(between) / max(1, K - 1), "gpu_span_ms_per_step": span / K}
+
+
+def summarise(blocks, K):
+    def stats(bs):
+        ms = [b["elapsed_s"] / K * 1e3 for b in bs]
+        return {"count": len(ms), "median": statistics.median(ms), "min": min(ms), "max": max(ms),
+                "first": ms[0], "last": ms[-1]}
+    plain = [b for b in blocks if not b["instrumented"]]
+    inst = [b for b in blocks if b["instrumented"]]
+    out = {"plain": stats(plain), "seconds_timed": sum(b["elapsed_s"] for b in blocks)}
+    if inst:
+        out["instrumented"] = stats(inst)
+        ks = [b["kernels"] for b in inst]
+        mean = lambda key: sum(k[key] for k in ks) / len(ks)      # noqa: E731
+        kern = {key: mean(key) for key in ks[0]}
+        kern["render_interval_ms_first"] = ks[0]["render_interval_ms"]
+        kern["render_interval_ms_last"] = ks[-1]["render_interval_ms"]
+        kern["render_interval_ms_min"] = min(k["render_interval_ms"] for k in ks)
+        kern["render_interval_ms_max"] = max(k["render_interval_ms"] for k in ks)
+        out["kernels"] = kern
+        launches = kern["step_interval_ms"] + kern["render_interval_ms"] + kern["between_steps_ms"]
+        out["closure"] = {
+            "event_intervals_ms": launches,
+            "vs_instrumented_ms_per_step": launches / out["instrumented"]["median"],
+            "vs_ms_per_step": launches / out["plain"]["median"],
+            "note": "(mg_step + mg_render_obs + between-steps event intervals of the instrumented blocks) / "
+                    "host-timed ms_per_step of those blocks, and / the contract's ms_per_step"}
+    return out
+
+
+def build_env(wl, B, dev, seeds):
+    from marlgrid_amd.envs import make
+    if wl == "Custom-8AgentCluttered30x30":     # BASELINE.json configs[4]; not a registered id upstream
+        from marlgrid_amd.agents import GridAgentInterface
+        from marlgrid_amd.envs import ClutteredMultiGrid
+        cols = ["red", "blue", "purple", "orange", "olive", "pink", "cyan", "yellow"]
+        return ClutteredMultiGrid(agents=[GridAgentInterface(color=c, view_size=9, view_tile_size=8) for c in cols],
+                                  grid_size=30, clutter_density=0.15, batch_size=B, device=dev, seeds=seeds,
+                                  auto_reset=True, strict=False)
+    return make(wl, batch_size=B, device=dev, seeds=seeds, auto_reset=True, strict=False)
+
+
+def measure(wl, B, dev, ctl, seeds, K, Wm, min_seconds, max_blocks, action_seed):
+    import torch
+    env = build_env(wl, B, dev, seeds)
+    env.reset()
+    n = env.num_agents
+    g = torch.Generator(device="cpu").manual_seed(action_seed)
+    pool = [torch.randint(0, 7, (B, n), generator=g).to(dev) for _ in range(64)]
+    probes = Probes(env, K)
+    env._probe = probes
+    for i in range(Wm):
+        env.step(pool[i % 64])
+    blocks = timed_blocks(lambda i: env.step(pool[(Wm + i) % 64]), lambda: torch.cuda.synchronize(dev), ctl, K,
+                          min_seconds, max_blocks, probes)
+    env._probe = None
+    env.check_errors()
+    return env, summarise(blocks, K), blocks
+
+
+def roofline_of(env, B, summary, traffic):
+    vs, ts, n = env.view_size, env.tile_size, env.num_agents
+    P = vs * ts
+    alg = P * P * 3 + vs * vs + 8 * n                    # SURVEY.md section 8(d): bytes per agent-step
+    k = summary.get("kernels")
+    if not k:
+        return None
+    ms = k["render_interval_ms"]
+    ach = B * n * alg / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "mg::render_kernel<%d, %d, %d, 0>" % (vs, ts, 16 if B >= 4096 else 4),
+            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "kernel_ms": ms, "kernel_ms_first": k["render_interval_ms_first"],
+            "kernel_ms_last": k["render_interval_ms_last"], "kernel_ms_min": k["render_interval_ms_min"],
+            "kernel_ms_max": k["render_interval_ms_max"],
+            "kernel_ms_source": "HIP events on the launch stream around every mg_render_obs of the instrumented "
+                                "K-step blocks (interval to the next launch: includes the dispatch gap)",
+            "algorithmic_bytes_per_agent_step": alg, "algorithmic_bytes_per_launch": B * n * alg,
+            "traffic": traffic.get("render", {}).get("hbm_bytes_per_launch") if traffic else None,
+            "traffic_unit": "bytes per launch (PMC, this run: WRITE_SIZE + FETCH_SIZE, calibrated; see pmc)"}
 
 
 def main():
@@ -30,119 +234,133 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch-per-gpu", type=int, default=32768)
+    ap.add_argument("--min-seconds", type=float, default=1.0, help="keep timing K-step blocks until this much is timed")
+    ap.add_argument("--max-blocks", type=int, default=2000)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic = null)")
+    ap.add_argument("--no-strong", action="store_true", help="skip the 262 144-env single-GPU point")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="ranks map to local_rank %% device_count and the control plane runs on gloo: the N > 1 code "
+                         "path on a box with fewer GPUs than ranks (plumbing check, not a scaling number)")
+    ap.add_argument("--selftest-cpu", action="store_true",
+                    help="run the distributed measurement skeleton with a sleep() in place of the engine (gloo, no GPU)")
     ap.add_argument("--workload", default=WORKLOAD, help="exploration only; the contract line uses the default")
     args = ap.parse_args()
 
-    import numpy as np
-    import torch
-    import torch.distributed as dist
+    bad = sorted(k for k in os.environ if k.startswith("MG_") or k.startswith("MARLGRID_"))
+    if bad:
+        print("bench.py: refusing to run with %s set (measurement switches must not touch the contract line)"
+              % ", ".join(bad), file=sys.stderr)
+        sys.exit(2)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = world > 1
-    if distributed:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if distributed:
-        dist.init_process_group(backend="nccl", device_id=dev)
-    n_gpus = world if distributed else 1
-    if args.gpus != n_gpus and rank == 0:
+    K, Wm = args.steps, args.warmup
+    if args.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d (launch with torch.distributed.run)" % (args.gpus, world),
               file=sys.stderr)
 
-    from marlgrid_amd.envs import make
+    if args.selftest_cpu:
+        ctl = Control("gloo")
+        blocks = timed_blocks(lambda i: time.sleep(0.001 * (1 + rank)), lambda: None, ctl, K, args.min_seconds,
+                              args.max_blocks)
+        s = summarise(blocks, K)
+        if rank == 0:
+            print(json.dumps({"metric": "selftest (sleep in place of the engine)", "value": None, "n_gpus": world,
+                              "steps": K, "warmup": Wm, "ms_per_step": s["plain"]["median"], "data": "selftest",
+                              "blocks": s["plain"],
+                              "per_rank_ms_per_step": [x / K * 1e3 for x in blocks[-1]["per_rank_s"]]}), flush=True)
+        ctl.close()
+        return
+
+    import torch
     from marlgrid_amd import _native as N
     from marlgrid_amd import sharding
+    import smi
+
+    ndev = torch.cuda.device_count()
+    shared = args.oversubscribe and world > ndev
+    dev_index = local_rank % ndev if args.oversubscribe else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    ctl = Control("gloo" if args.oversubscribe else "nccl", dev)
+    n_gpus = world
     B = args.batch_per_gpu
+    wl = args.workload
+    build_info = N.lib().mg_build_info().decode()
+
     # the env batch shards embarrassingly: rank r owns global envs [r*B, (r+1)*B), seeds 1337 + id
     seeds = sharding.shard_seeds(1337, B * n_gpus, rank, n_gpus)
     assert len(seeds) == B
-    wl = args.workload
-    if wl == "Custom-8AgentCluttered30x30":     # BASELINE.json configs[4]; not a registered id upstream
-        from marlgrid_amd.agents import GridAgentInterface
-        from marlgrid_amd.envs import ClutteredMultiGrid
-        cols = ["red", "blue", "purple", "orange", "olive", "pink", "cyan", "yellow"]
-        env = ClutteredMultiGrid(agents=[GridAgentInterface(color=c, view_size=9, view_tile_size=8) for c in cols],
-                                 grid_size=30, clutter_density=0.15, batch_size=B, device=dev, seeds=seeds,
-                                 auto_reset=True, strict=False)
-    else:
-        env = make(wl, batch_size=B, device=dev, seeds=seeds, auto_reset=True, strict=False)
-    env.reset()
-    n = env.num_agents
-    K, Wm = args.steps, args.warmup
-    g = torch.Generator(device="cpu").manual_seed(rank)
-    pool = [torch.randint(0, 7, (B, n), generator=g).to(dev) for _ in range(min(K + Wm, 64))]
-
-    for i in range(Wm):
-        env.step(pool[i % len(pool)])
-    torch.cuda.synchronize(dev)
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for i in range(K):
-        env.step(pool[(Wm + i) % len(pool)])
-    torch.cuda.synchronize(dev)
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    elapsed = sharding.max_over_ranks(elapsed, device=dev)      # the slowest rank defines the step time
-    env.check_errors()
-
-    # dominant kernel: mg_render_obs, timed live with HIP events on the launch stream
-    vs, ts = env.view_size, env.tile_size
+    clocks_before = smi.sample(dev_index) if rank == 0 else None
+    env, summary, blocks = measure(wl, B, dev, ctl, seeds, K, Wm, args.min_seconds, args.max_blocks, rank)
+    clocks_after = smi.sample(dev_index) if rank == 0 else None
+    n, vs, ts = env.num_agents, env.view_size, env.tile_size
     P = vs * ts
-    alg_bytes_per_agent_step = P * P * 3 + vs * vs + 8 * n
-    avg_ms = C.c_float(0)
-    N.check(env._lib.mg_time_render_obs(C.byref(env._cfg), C.byref(env._state), env.obs.data_ptr(), 50,
-                                        C.byref(avg_ms), env._stream()))
-    render_s = avg_ms.value * 1e-3
-    achieved = B * n * alg_bytes_per_agent_step / render_s / 1e9
-    # HBM bytes per launch from the PMC passes (rocprofv3 --pmc WRITE_SIZE / --pmc FETCH_SIZE, collected
-    # separately and corrected as MI355X_MICROARCH.md prescribes; summary under profiles/): only valid
-    # for the exact workload / batch they were collected on
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01", "pmc_hbm_bytes.json")
-    if wl == WORKLOAD and B == 32768 and os.path.exists(pmc):
-        try:
-            t = json.load(open(pmc)).get("render_kernel_hbm_bytes_per_launch")
-            traffic = float(t) if t else None
-        except Exception:
-            traffic = None
 
     out = None
     if rank == 0:
-        total_agent_steps = n_gpus * B * n * K
+        ms = summary["plain"]["median"]
         out = {
-            "metric": "agent-steps/sec at batch B, 3AgentCluttered15x15, 1/2/4/8 MI355X",
-            "value": total_agent_steps / elapsed,
+            "metric": METRIC,
+            "value": n_gpus * B * n / (ms * 1e-3),
             "unit": "agent-steps/s",
             "n_gpus": n_gpus, "steps": K, "warmup": Wm,
-            "ms_per_step": elapsed / K * 1e3,
+            "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": wl, "batch_per_gpu": B, "global_batch": B * n_gpus, "n_agents": n,
                        "view_size": vs, "tile_size": ts, "obs_shape": [B * n_gpus, n, P, P, 3],
                        "actions": "uniform over 7 ids, torch.randint seed=rank", "auto_reset": True,
+                       "launches_per_step": ["mg_step (+ fused reset of finished episodes)", "mg_render_obs"],
                        "sharding": "env batch split contiguously, no collectives"},
-            "roofline": {"bound": "hbm", "kernel": "mg::render_kernel<%d, %d, %d, 0>" % (vs, ts, 16 if B >= 4096 else 4), "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "kernel_ms": avg_ms.value, "algorithmic_bytes_per_agent_step": alg_bytes_per_agent_step,
-                         "algorithmic_bytes_per_launch": B * n * alg_bytes_per_agent_step,
-                         "traffic": traffic, "traffic_unit": "bytes per launch (PMC: WRITE_SIZE + 2*FETCH_SIZE)"},
+            "timing": {"what": "median of K-step blocks, each bracketed by barrier + synchronize, MAX over ranks",
+                       "blocks": summary["plain"], "seconds_timed": summary["seconds_timed"],
+                       "instrumented_blocks": summary.get("instrumented"),
+                       "per_rank_ms_per_step_last_block": [x / K * 1e3 for x in blocks[-1]["per_rank_s"]],
+                       "control_plane": ctl.backend, "ranks_share_a_gpu": bool(shared)},
+            "kernels": summary.get("kernels"),
+            "closure": summary.get("closure"),
+            "clocks": {"before": clocks_before, "after": clocks_after, "source": "rocm-smi"},
+            "library": build_info,
         }
+    del env
+    torch.cuda.empty_cache()
+
+    # the dominant kernel's HBM traffic from the PMC counters, measured now (child processes under
+    # rocprofv3 on this GPU; N = 1 only: the counters are per process and the workload is per GPU)
+    traffic = None
+    if rank == 0 and n_gpus == 1 and not args.no_pmc:
+        import pmc
+        traffic = pmc.measure(wl, B)
+    if rank == 0:
+        # roofline needs the env's geometry only
+        class _Geo(object):
+            view_size, tile_size, num_agents = vs, ts, n
+        out["roofline"] = roofline_of(_Geo, B, summary, traffic)
+        out["pmc"] = traffic
+
+    # strong-scaling N = 1 point: BASELINE.json's whole headline batch on one GPU
+    if n_gpus == 1 and not args.no_strong and wl == WORKLOAD:
+        Bs = 262144
+        seeds_s = sharding.shard_seeds(1337, Bs, 0, 1)
+        env_s, sum_s, _ = measure(wl, Bs, dev, ctl, seeds_s, K, min(Wm, 5), min(args.min_seconds, 1.0), 400, 0)
+        ms_s = sum_s["plain"]["median"]
+        out.setdefault("extra", {})["strong_n1"] = {
+            "what": "the full headline batch (262 144 envs) on ONE GPU: the N = 1 point of a strong-scaling curve",
+            "value": Bs * n / (ms_s * 1e-3), "unit": "agent-steps/s", "ms_per_step": ms_s,
+            "global_batch": Bs, "timing": sum_s["plain"], "kernels": sum_s.get("kernels"),
+            "closure": sum_s.get("closure"), "roofline": roofline_of(env_s, Bs, sum_s, None)}
+        del env_s
+        torch.cuda.empty_cache()
+
+    if rank == 0:
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, wl)
         print(json.dumps(out), flush=True)
-    if distributed:
-        dist.barrier()
-        dist.destroy_process_group()
+    ctl.close()
 
 
 def cpu_baseline(budget_s, workload=WORKLOAD):

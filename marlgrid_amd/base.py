@@ -274,6 +274,7 @@ class MultiGridEnv(object):
         self._prog_cache = {}
         self._spec_ctor = None
         self._spec_last = None
+        self._probe = None
         self.grid = None
 
         if not self._dry:
@@ -734,12 +735,19 @@ class MultiGridEnv(object):
                 self._reset_prog = self._program(template, ops)
                 self._retrace = False
             prog = C.byref(self._reset_prog)
+        probe = self._probe          # bench.py: records an event on the launch stream around each launch
+        if probe is not None:
+            probe(0)
         N.check(self._lib.mg_step(C.byref(self._cfg), C.byref(self._state), actions.data_ptr(),
                                   actions.element_size(), self.rewards.data_ptr(), prog, stream))
+        if probe is not None:
+            probe(1)
         # obs / rewards / done are views of the current buffer set (see `obs_buffers`)
         done = self.done_b
         N.check(self._lib.mg_render_obs(C.byref(self._cfg), C.byref(self._state), self.obs.data_ptr(), None, None,
                                         None, stream))
+        if probe is not None:
+            probe(2)
         if self.strict:
             self.check_errors()
         return self._package_obs(), self.rewards, done, {}
@@ -791,8 +799,9 @@ class MultiGridEnv(object):
         if a.observe_rewards:
             ret["reward"] = torch.zeros(self.batch_size, device=self.device)   # always 0 upstream (base.py:464,519)
         if a.observe_position:
-            wh = torch.tensor([self.width, self.height], dtype=torch.float32, device=self.device)
-            pos = self.agent_pos[:, k].to(torch.float32)
+            # np.array(pos) / np.array([W, H], dtype=float), `pos is None -> (0, 0)`: float64 like upstream
+            wh = torch.tensor([self.width, self.height], dtype=torch.float64, device=self.device)
+            pos = self.agent_pos[:, k].to(torch.float64)
             placed = (self.agent_flags[:, k] & N.AF_PLACED) != 0
             ret["position"] = torch.where(placed[:, None], pos, torch.zeros_like(pos)) / wh
         if a.observe_orientation:
@@ -972,8 +981,15 @@ class MultiGridEnv(object):
                 d["hide_item_types"] = list(a.hide_item_types)
             if a.color == "prestige":
                 d.update(prestige_beta=a.prestige_beta, prestige_scale=a.prestige_scale)
+            if a.observation_style == "rich":
+                d["rich"] = {k: True for k in ("observe_rewards", "observe_position", "observe_orientation")
+                             if getattr(a, k)}
             return d
-        return dict(W=self.width, H=self.height, agents=[aspec(a) for a in self.agents],
+        extra = {}
+        if self.agent_spawn_kwargs:
+            extra["agent_spawn"] = {k: (tuple(v) if k in ("top", "size") else v)
+                                    for k, v in self.agent_spawn_kwargs.items()}
+        return dict(W=self.width, H=self.height, agents=[aspec(a) for a in self.agents], **extra,
                     view_size=self.view_size, tile_size=self.tile_size, view_offset=self.view_offset,
                     see_through_walls=self.see_through_walls, max_steps=self.max_steps,
                     reward_decay=bool(self.reward_decay), ghost_mode=self.ghost_mode,

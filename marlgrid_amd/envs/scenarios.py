@@ -42,6 +42,12 @@ class _WalledRoom(MultiGridEnv):
     def _corner_goal(self, width, height):
         self.put_obj(Goal(color="green", reward=1), width - 2, height - 2)
 
+    def _spawn_anywhere(self):
+        """Every shipped upstream scenario ends `_gen_grid` with `self.agent_spawn_kwargs = {}`
+        (empty.py:15, cluttered.py:35, goalcycle.py:50, viz_test.py:14): constructor-supplied spawn
+        kwargs only survive in scenario classes that do not do this."""
+        self.agent_spawn_kwargs = {}
+
 
 class EmptyMultiGrid(_WalledRoom):
     """A walled room with the goal in the bottom-right corner."""
@@ -50,6 +56,7 @@ class EmptyMultiGrid(_WalledRoom):
     def _gen_grid(self, width, height):
         self._room(width, height)
         self._corner_goal(width, height)
+        self._spawn_anywhere()
 
 
 class ClutteredMultiGrid(_WalledRoom):
@@ -70,6 +77,7 @@ class ClutteredMultiGrid(_WalledRoom):
         else:
             self._corner_goal(width, height)
         self._scatter(Wall, getattr(self, "n_clutter", 0))
+        self._spawn_anywhere()
 
 
 class ClutteredGoalCycleEnv(_WalledRoom):
@@ -98,6 +106,7 @@ class ClutteredGoalCycleEnv(_WalledRoom):
         for bonus_id in range(getattr(self, "n_bonus_tiles", 0)):
             self.place_obj(self._bonus_tile(bonus_id), max_tries=100)
         self._scatter(Wall, getattr(self, "n_clutter", 0))
+        self._spawn_anywhere()
 
 
 class VisibilityTestEnv(_WalledRoom):
@@ -107,3 +116,4 @@ class VisibilityTestEnv(_WalledRoom):
     def _gen_grid(self, width, height):
         self._room(width, height)
         self.grid.horz_wall(0, height // 2, width - 3, obj_type=Wall)
+        self._spawn_anywhere()

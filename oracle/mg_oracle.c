@@ -361,6 +361,12 @@ static int place_obj_in(MgoEnv* e, int val, double max_tries_in, int x0, int y0,
 static int place_obj(MgoEnv* e, int val, double max_tries_in) {
     return place_obj_in(e, val, max_tries_in, 0, 0, e->sh->cfg.W, e->sh->cfg.H, 0, 0);
 }
+/* self.place_obj(agent, **self.agent_spawn_kwargs) — base.py:411, 505, 643 */
+static int place_agent_spawn(MgoEnv* e, int k) {
+    const MgoConfig* cfg = &e->sh->cfg;
+    return place_obj_in(e, MGO_AGENT_BASE + k, (double)cfg->spawn_max_tries, cfg->spawn_x0, cfg->spawn_y0,
+                        cfg->spawn_x1, cfg->spawn_y1, 0, 0);
+}
 /* top / size already clamped to [x0,x1) x [y0,y1) as base.py:692-695 does */
 static int place_obj_in(MgoEnv* e, int val, double max_tries_in, int x0, int y0, int x1, int y1, int* ox, int* oy) {
     double mt = max_tries_in < 1e5 ? max_tries_in : 1e5;
@@ -441,7 +447,7 @@ int32_t mgo_reset(MgoEnv* e, int32_t which_gen) {
     if (rc != MGO_OK) return rc;
     for (int k = 0; k < cfg->n_agents; k++) {      /* base.py:409-412 */
         if (cfg->spawn_delay[k] != 0) continue;
-        rc = place_obj(e, MGO_AGENT_BASE + k, 1e5);
+        rc = place_agent_spawn(e, k);
         if (rc != MGO_OK) return rc;
         e->aactive[k] = 1;                         /* agent.activate() */
     }
@@ -488,7 +494,7 @@ int32_t mgo_step(MgoEnv* e, const int32_t* actions, double* rewards, int32_t* ep
     /* spawn agents if it's time — base.py:503-506 (before step_count is incremented) */
     for (int k = 0; k < n; k++)
         if (!e->aactive[k] && !e->adone[k] && e->step_count >= cfg->spawn_delay[k]) {
-            int prc = place_obj(e, MGO_AGENT_BASE + k, 1e5);
+            int prc = place_agent_spawn(e, k);
             if (prc != MGO_OK) rc = prc;
             e->aactive[k] = 1;
         }
@@ -624,7 +630,7 @@ int32_t mgo_step(MgoEnv* e, const int32_t* actions, double* rewards, int32_t* ep
             }
             /* agent.reset(new_episode=False) — agents.py:161-166 */
             e->adone[k] = 0; e->aactive[k] = 0; e->ax[k] = e->ay[k] = -1; e->acarry[k] = 0;
-            int prc = place_obj(e, MGO_AGENT_BASE + k, 1e5);
+            int prc = place_agent_spawn(e, k);
             if (prc != MGO_OK) rc = prc;
             e->aactive[k] = 1;
         } else {
@@ -877,6 +883,18 @@ void mgo_get_state(const MgoEnv* e, uint8_t* base, int32_t* agents7, int32_t* st
 
 void mgo_get_prestige(const MgoEnv* e, double* out) {
     for (int k = 0; k < e->sh->cfg.n_agents; k++) out[k] = e->aprestige[k];
+}
+
+/* the non-image fields of a 'rich' observation — base.py:461-471: reward is `agent.step_reward`, which
+ * step() only ever sets to 0 (base.py:519) and which does not exist before the first step (getattr
+ * default 0); position is pos / (W, H) in float64 with `pos is None -> (0, 0)`; orientation is dir. */
+void mgo_rich_obs(const MgoEnv* e, int32_t k, double* reward, double* position2, int32_t* orientation) {
+    const MgoConfig* cfg = &e->sh->cfg;
+    const int placed = e->ax[k] >= 0;
+    *reward = 0.0;
+    position2[0] = (double)(placed ? e->ax[k] : 0) / (double)cfg->W;
+    position2[1] = (double)(placed ? e->ay[k] : 0) / (double)cfg->H;
+    *orientation = e->adir[k];
 }
 
 void mgo_get_mt(const MgoEnv* e, uint32_t* mt624, int32_t* pos) {

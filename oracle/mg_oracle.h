@@ -88,6 +88,10 @@ typedef struct {
     double prestige_beta[MGO_MAX_AGENTS], prestige_scale[MGO_MAX_AGENTS]; /* agents.py:31-32,54-56 */
     uint32_t hide_type_mask[MGO_MAX_AGENTS];                      /* hide_item_types: bit t = type_idx t,
                                                                    * bit 31 = 'Agent' (base.py:441-449) */
+    int32_t spawn_x0, spawn_y0, spawn_x1, spawn_y1;               /* place_obj(agent, **agent_spawn_kwargs):
+                                                                   * top / size clamped as base.py:692-695
+                                                                   * (base.py:411, 505, 643) */
+    int32_t spawn_max_tries;                                      /* agent_spawn_kwargs max_tries (<= 1e5) */
 } MgoConfig;
 
 typedef struct MgoEnv MgoEnv;
@@ -127,6 +131,8 @@ void mgo_set_carrying(MgoEnv* e, int32_t k, int32_t obj);
 /* test helper: overwrite a cell with a non-agent object id (env.put_obj, base.py:655-662) */
 int32_t mgo_put_obj(MgoEnv* e, int32_t obj, int32_t x, int32_t y);
 /* test helper: teleport an (already placed) agent; re-seats stacks like a fresh placement */
+/* reward / position / orientation of agent k's 'rich' observation (base.py:461-471) */
+void mgo_rich_obs(const MgoEnv* e, int32_t k, double* reward, double* position2, int32_t* orientation);
 int32_t mgo_place_obj(MgoEnv* e, int32_t what, int32_t x0, int32_t y0, int32_t x1, int32_t y1, int32_t max_tries,
                       int32_t* out_xy);
 int32_t mgo_try_place_obj(MgoEnv* e, int32_t what, int32_t x, int32_t y);

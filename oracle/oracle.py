@@ -82,7 +82,9 @@ class Config(C.Structure):
                 ("wall_obj", C.c_int32), ("n_gen", C.c_int32 * 2), ("gen", (GenOp * MAX_GEN) * 2),
                 ("spawn_delay", C.c_int32 * MAX_AGENTS), ("is_prestige", C.c_int32 * MAX_AGENTS),
                 ("prestige_beta", C.c_double * MAX_AGENTS), ("prestige_scale", C.c_double * MAX_AGENTS),
-                ("hide_type_mask", C.c_uint32 * MAX_AGENTS)]
+                ("hide_type_mask", C.c_uint32 * MAX_AGENTS),
+                ("spawn_x0", C.c_int32), ("spawn_y0", C.c_int32), ("spawn_x1", C.c_int32), ("spawn_y1", C.c_int32),
+                ("spawn_max_tries", C.c_int32)]
 
 
 _lib = None
@@ -120,6 +122,8 @@ def lib():
         L.mgo_get_state.argtypes = [vp, u8p, i32p, i32p]
         L.mgo_get_mt.argtypes = [vp, u32p, i32p]
         L.mgo_get_prestige.argtypes = [vp, f64p]
+        L.mgo_rich_obs.restype = None
+        L.mgo_rich_obs.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), f64p, C.POINTER(C.c_int32)]
         L.mgo_set_agent_dir.argtypes = [vp, C.c_int32, C.c_int32]
         L.mgo_set_carrying.argtypes = [vp, C.c_int32, C.c_int32]
         L.mgo_regen_grid.argtypes = [vp, C.c_int32]
@@ -229,6 +233,14 @@ def make_config(spec):
     gm = spec.get("ghost_mode", True)      # bit 1: `is not False` (base.py:541), bit 2: truthy (base.py:683)
     cfg.ghost_mode = (1 if gm is not False else 0) | (2 if gm else 0)
     cfg.respawn = int(bool(spec.get("respawn", False)))
+    # place_obj(agent, **agent_spawn_kwargs) (base.py:411, 505, 643): top / size clamped as base.py:692-695
+    sp = spec.get("agent_spawn", {})
+    top = sp.get("top", (0, 0))
+    top = (max(top[0], 0), max(top[1], 0))
+    size = sp.get("size") or (cfg.W, cfg.H)
+    cfg.spawn_x0, cfg.spawn_y0 = top
+    cfg.spawn_x1, cfg.spawn_y1 = min(top[0] + size[0], cfg.W), min(top[1] + size[1], cfg.H)
+    cfg.spawn_max_tries = int(max(1, min(sp.get("max_tries", 1e5), 1e5)))
     cfg.agent_type_idx = TYPE_IDX["GridAgentInterface"]
     for k, a in enumerate(agents):
         cfg.agent_color_idx[k] = COLOR_TO_IDX[a["color"]]
@@ -394,6 +406,12 @@ class OracleEnv(object):
         out = np.zeros(self.n, np.float64)
         self.L.mgo_get_prestige(self.h, _p(out, C.c_double))
         return out
+
+    def rich_obs(self, k):
+        """the non-image fields of agent k's 'rich' observation (base.py:461-471)"""
+        rew, pos, ori = C.c_double(0), np.zeros(2, np.float64), C.c_int32(0)
+        self.L.mgo_rich_obs(self.h, k, C.byref(rew), _p(pos, C.c_double), C.byref(ori))
+        return dict(reward=rew.value, position=pos, orientation=ori.value)
 
     def mt_state(self):
         mt = np.zeros(624, np.uint32)

@@ -46,6 +46,8 @@ TRAJ = {  # scenario -> (n_seeds, n_steps, n_full_obs_seeds)
     "Test-4AgentEmpty5x5-hide": (8, 150, 2),
     "Test-3AgentCluttered9x9-hide": (6, 120, 2),
     "Test-2AgentRegion9x9": (6, 100, 1),
+    "Test-3AgentSpawnRect9x9": (8, 150, 1),
+    "Test-3AgentEmpty7x7-rich": (6, 90, 2),
     "Test-2AgentGoalcycle9x9-prestige": (8, 120, 2),
     "Test-1AgentGoalcycle11x11-prestige-ts11": (4, 100, 1),
     "Test-3AgentCluttered9x9-prestige-mixed": (8, 150, 2),
@@ -169,14 +171,38 @@ def gen_traj(name, out):
     obs_reset_full = np.zeros((F, n, P, P, 3), np.uint8)
     mt_final = np.zeros((S, 624), np.uint32)
     mt_final_pos = np.zeros(S, np.int32)
+    # 'rich' agents (base.py:461-471): the non-image fields, exactly as the reference hands them out
+    # (NaN where the agent does not observe that field); index 0 on the time axis = reset(), t+1 = step t
+    is_rich = any("rich" in a for a in spec["agents"])
+    rich_reward = np.full((S, T + 1, n), np.nan)
+    rich_position = np.full((S, T + 1, n, 2), np.nan)
+    rich_orientation = np.full((S, T + 1, n), np.nan)
+
+    def pov(o):
+        return [x["pov"] if isinstance(x, dict) else x for x in o]
+
+    def note_rich(si, ti, o):
+        for k, x in enumerate(o):
+            if isinstance(x, dict):
+                assert set(x) <= {"pov", "reward", "position", "orientation"}
+                if "reward" in x:
+                    rich_reward[si, ti, k] = x["reward"]
+                if "position" in x:
+                    assert x["position"].dtype == np.float64
+                    rich_position[si, ti, k] = x["position"]
+                if "orientation" in x:
+                    rich_orientation[si, ti, k] = x["orientation"]
+
     for si, seed in enumerate(seeds):
         env = refstate.make_ref_env(spec, recipe, seed=int(seed))
         c = refstate.canonical(env)
         for k in CANON:
             ctor[k].append(c[k])
-        o = env.gen_obs()
+        o = pov(env.gen_obs())
         crc_ctor[si] = [refstate.crc(x) for x in o]
         o = env.reset()
+        note_rich(si, 0, o)
+        o = pov(o)
         c = refstate.canonical(env)
         for k in CANON:
             rst[k].append(c[k])
@@ -188,6 +214,8 @@ def gen_traj(name, out):
         per = {k: [] for k in CANON}
         for t in range(T):
             o, r, dn, _ = env.step(actions[si, t])
+            note_rich(si, t + 1, o)
+            o = pov(o)
             assert all(x.min() >= 0 and x.max() <= 255 for x in o)
             c = refstate.canonical(env)
             for k in CANON:
@@ -212,6 +240,8 @@ def gen_traj(name, out):
     d.update(rewards=rewards, ep_done=ep_done, reset_after=reset_after, order=order, encode=enc,
              obs_crc=crc, obs_crc_reset=crc_reset, obs_crc_ctor=crc_ctor, obs_full=obs_full,
              obs_reset_full=obs_reset_full, mt_final=mt_final, mt_final_pos=mt_final_pos)
+    if is_rich:
+        d.update(rich_reward=rich_reward, rich_position=rich_position, rich_orientation=rich_orientation)
     np.savez_compressed(out, **d)
 
 

@@ -17,14 +17,37 @@ def make_ref_env(spec, recipe, seed=1337):
                                  view_tile_size=spec["tile_size"], view_offset=spec["view_offset"],
                                  see_through_walls=spec["see_through_walls"], spawn_delay=a.get("spawn_delay", 0),
                                  hide_item_types=list(a.get("hide_item_types", [])),
-                                 prestige_beta=a.get("prestige_beta", 0.95), prestige_scale=a.get("prestige_scale", 2))
+                                 prestige_beta=a.get("prestige_beta", 0.95), prestige_scale=a.get("prestige_scale", 2),
+                                 **(dict(observation_style="rich", **a["rich"]) if "rich" in a else {}))
               for a in spec["agents"]]
     kw = dict(kwargs)
     kw.setdefault("max_steps", spec["max_steps"])
     kw["seed"] = seed
     if cls_name == "RegionTestEnv":
         return _region_env_class()(agents=agents, **kw)
+    if cls_name == "SpawnRectTestEnv":
+        return _spawn_rect_env_class()(agents=agents, **kw)
     return getattr(E, cls_name)(agents=agents, **kw)
+
+
+def _spawn_rect_env_class():
+    """A test-only scenario ON TOP OF the reference's classes whose `_gen_grid` does not overwrite
+    `agent_spawn_kwargs` (every shipped scenario sets it to {}), so the constructor's kwargs reach
+    place_obj(agent, **agent_spawn_kwargs) at reset, late spawn and respawn (base.py:411, 505, 643)."""
+    from marlgrid.base import MultiGridEnv, MultiGrid
+    from marlgrid.objects import Goal, Wall
+
+    class SpawnRectTestEnv(MultiGridEnv):
+        mission = ""
+        metadata = {}
+
+        def _gen_grid(self, width, height):
+            self.grid = MultiGrid((width, height))
+            self.grid.wall_rect(0, 0, width, height)
+            self.put_obj(Goal(color="green", reward=1), 2, height - 2)
+            for _ in range(4):
+                self.place_obj(Wall(), max_tries=100)
+    return SpawnRectTestEnv
 
 
 def _region_env_class():

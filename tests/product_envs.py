@@ -16,10 +16,13 @@ def build(name, **kw):
                                  view_offset=spec["view_offset"], see_through_walls=spec["see_through_walls"],
                                  spawn_delay=a.get("spawn_delay", 0),
                                  hide_item_types=list(a.get("hide_item_types", [])),
-                                 prestige_beta=a.get("prestige_beta", 0.95), prestige_scale=a.get("prestige_scale", 2))
+                                 prestige_beta=a.get("prestige_beta", 0.95), prestige_scale=a.get("prestige_scale", 2),
+                                 **(dict(observation_style="rich", **a["rich"]) if "rich" in a else {}))
               for a in spec["agents"]]
     if cls_name == "RegionTestEnv":
         return _region_env_class()(agents=agents, **{**kwargs, **kw})
+    if cls_name == "SpawnRectTestEnv":
+        return _spawn_rect_env_class()(agents=agents, **{**kwargs, **kw})
     return getattr(E, cls_name)(agents=agents, **{**kwargs, **kw})
 
 
@@ -38,6 +41,21 @@ def _region_env_class():
             for _ in range(3):
                 self.place_obj(Wall(), top=(width // 2 + 1, 2), size=(width, height - 3), max_tries=50)
     return RegionTestEnv
+
+
+def _spawn_rect_env_class():
+    """the product-side twin of tests/golden/refstate.py:_spawn_rect_env_class (same _gen_grid text)"""
+    from marlgrid_amd.base import MultiGridEnv, MultiGrid
+    from marlgrid_amd.objects import Goal, Wall
+
+    class SpawnRectTestEnv(MultiGridEnv):
+        def _gen_grid(self, width, height):
+            self.grid = MultiGrid((width, height))
+            self.grid.wall_rect(0, 0, width, height)
+            self.put_obj(Goal(color="green", reward=1), 2, height - 2)
+            for _ in range(4):
+                self.place_obj(Wall(), max_tries=100)
+    return SpawnRectTestEnv
 
 
 def canonical(env, b=None):

@@ -115,6 +115,9 @@ def ref_recipe(name):
         "Test-4AgentEmpty5x5-hide": ("EmptyMultiGrid", dict(grid_size=5)),
         "Test-3AgentCluttered9x9-hide": ("ClutteredMultiGrid", dict(grid_size=9, n_clutter=8)),
         "Test-2AgentRegion9x9": ("RegionTestEnv", dict(grid_size=9)),
+        "Test-3AgentSpawnRect9x9": ("SpawnRectTestEnv", dict(grid_size=9, respawn=True, max_steps=60,
+                                                             agent_spawn_kwargs=dict(top=(1, 1), size=(3, 9), max_tries=500))),
+        "Test-3AgentEmpty7x7-rich": ("EmptyMultiGrid", dict(grid_size=7, max_steps=40)),
         "Test-2AgentGoalcycle9x9-prestige": ("ClutteredGoalCycleEnv", dict(grid_size=9, n_clutter=4, n_bonus_tiles=3,
                                                                            penalty=-1.5, max_steps=60)),
         "Test-1AgentGoalcycle11x11-prestige-ts11": ("ClutteredGoalCycleEnv", dict(grid_size=11, clutter_density=0.1,
@@ -164,6 +167,29 @@ def region_spec():
     return s
 
 
+def spawn_rect_spec():
+    """test-only scenario whose `_gen_grid` leaves `agent_spawn_kwargs` alone (the shipped scenarios overwrite
+    it with {}: empty.py:15, cluttered.py:35, goalcycle.py:50), so that reset / late spawn / respawn place
+    agents in the spawn rectangle (base.py:411, 505, 643): see tests/golden/refstate.py:_spawn_rect_env_class"""
+    s = _base(3, 9, 7, respawn=True, max_steps=60)
+    W = H = 9
+    s["objects"] = [None, WALL, GOAL]
+    s["wall_obj"] = 1
+    prog = [("wall_rect", 0, 0, W, H), ("put", 2, 2, H - 2), ("place", 1, 4, 100)]
+    s["gen_ctor"], s["gen_reset"] = prog, prog
+    s["agent_spawn"] = dict(top=(1, 1), size=(3, 9), max_tries=500)
+    s["agents"][2]["spawn_delay"] = 5
+    return s
+
+
+def _with_rich(spec, rich):
+    """observation_style='rich' for the agents whose entry is a dict of observe_* flags (agents.py:24-31)"""
+    for a, r in zip(spec["agents"], rich):
+        if r is not None:
+            a["rich"] = dict(r)
+    return spec
+
+
 _MANY = ["red", "orange", "green", "blue", "cyan", "purple", "yellow", "olive", "grey", "worst", "pink", "white"]
 
 
@@ -192,6 +218,11 @@ def registered(name):   # noqa: F811  (extends the table above with test-only sc
         "Test-4AgentEmpty5x5-hide": lambda: _with_hide(empty_spec(4, 5, 5), [["Agent"], ["Goal"], ["Wall", "Goal", "Agent"], []]),
         "Test-3AgentCluttered9x9-hide": lambda: _with_hide(cluttered_spec(3, 9, 7, n_clutter=8), [["Wall"], ["Agent", "Goal"], []]),
         "Test-2AgentRegion9x9": lambda: region_spec(),
+        "Test-3AgentSpawnRect9x9": lambda: spawn_rect_spec(),
+        "Test-3AgentEmpty7x7-rich": lambda: _with_rich(_with_delays(empty_spec(3, 7, 5, max_steps=40), [0, 3, 7]),
+                                                       [dict(observe_rewards=True, observe_position=True,
+                                                             observe_orientation=True), None,
+                                                        dict(observe_position=True)]),
         "Test-2AgentGoalcycle9x9-prestige": lambda: goalcycle_spec(2, 9, 7, n_clutter=4, n_bonus_tiles=3, penalty=-1.5,
                                                                    max_steps=60, colors=["prestige", "prestige"]),
         "Test-1AgentGoalcycle11x11-prestige-ts11": lambda: goalcycle_spec(1, 11, 7, clutter_density=0.1, n_bonus_tiles=3,
@@ -277,7 +308,7 @@ ALL_SCENARIOS = [
     "Test-3AgentEmpty7x7-spawn-delay", "Test-4AgentEmpty5x5-hide", "Test-3AgentCluttered9x9-hide",
     "Test-2AgentRegion9x9", "Test-2AgentGoalcycle9x9-prestige", "Test-1AgentGoalcycle11x11-prestige-ts11",
     "Test-3AgentCluttered9x9-prestige-mixed", "Test-4AgentEmpty5x5-ghost0", "Test-3AgentEmpty7x11-nonsquare",
-    "Test-3AgentCluttered12x6-nonsquare",
+    "Test-3AgentCluttered12x6-nonsquare", "Test-3AgentSpawnRect9x9", "Test-3AgentEmpty7x7-rich",
 ]
 
 

@@ -63,6 +63,8 @@ def test_numpy_form_round_trip():
     ("Edge-12AgentCluttered9x9-view3", 16, 80, False),
     ("Test-3AgentCluttered9x9-prestige-mixed", 32, 200, True),
     ("Test-2AgentRegion9x9", 32, 60, True),
+    ("Test-3AgentSpawnRect9x9", 48, 200, True),      # agent_spawn_kwargs: reset, late spawn and respawn
+    ("Test-3AgentSpawnRect9x9", 16, 130, False),
 ])
 def test_core_bodies_vs_oracle(name, B, T, auto):
     import hostemu

@@ -22,6 +22,31 @@ TRAJ = sorted(f[5:-4] for f in os.listdir(GOLD) if f.startswith("traj_"))
 REW_TOL = 1e-6
 
 
+def _pov(obs):
+    """(B, n, P, P, 3) uint8 array of what reset()/step() returned: the tensor, or — with 'rich' agents —
+    the per-agent list of (B, P, P, 3) views / dicts with a 'pov' entry (base.py:459-471)"""
+    if isinstance(obs, (list, tuple)):
+        return np.stack([(x["pov"] if isinstance(x, dict) else x).cpu().numpy() for x in obs], axis=1)
+    return obs.cpu().numpy()
+
+
+def _cmp_rich(obs, g, ti, what):
+    """'rich' fields against the reference's (NaN in the fixture = field not observed): all three
+    exactly — position is the same float64 divide"""
+    S = g["rich_position"].shape[0]
+    for k, x in enumerate(obs):
+        want_keys = {"pov"}
+        for key, arr in (("reward", g["rich_reward"]), ("orientation", g["rich_orientation"])):
+            if not np.isnan(arr[0, ti, k]):
+                want_keys.add(key)
+                assert np.array_equal(x[key].cpu().numpy().astype(np.float64), arr[:, ti, k]), (what, k, key)
+        if not np.isnan(g["rich_position"][0, ti, k]).any():
+            want_keys.add("position")
+            got = x["position"].cpu().numpy()
+            assert got.dtype == np.float64 and np.array_equal(got, g["rich_position"][:, ti, k]), (what, k)
+        assert (set(x) if isinstance(x, dict) else {"pov"}) == want_keys, (what, k)
+
+
 def _cmp_canon(got, g, prefix, si, t, what):
     for k in canon.KEYS[:-1]:
         want = g[prefix + k][si] if t is None else g[prefix + k][si, t]
@@ -41,11 +66,15 @@ def test_golden_trajectory(name):
     ps = env.scenario_spec()
     assert ps["gen_ctor"] == spec["gen_ctor"]
     st = product_envs.canonical(env)
-    obs = env.gen_obs().cpu().numpy()
+    obs = _pov(env.gen_obs())
     for si in range(S):
         _cmp_canon(st[si], g, "ctor_", si, None, "%s ctor seed %d" % (name, si))
         assert [refstate.crc(x) for x in obs[si]] == list(g["obs_crc_ctor"][si])
-    obs = env.reset().cpu().numpy()
+    rich = "rich_position" in g.files
+    obs = env.reset()
+    if rich:
+        _cmp_rich(obs, g, 0, "%s reset" % name)
+    obs = _pov(obs)
     ps = env.scenario_spec()
     assert ps["gen_reset"] == spec["gen_reset"] and ps["objects"] == spec["objects"]
     st = product_envs.canonical(env)
@@ -56,7 +85,9 @@ def test_golden_trajectory(name):
             assert np.array_equal(obs[si], g["obs_reset_full"][si])
     for t in range(T):
         o, r, dn, _ = env.step(torch.from_numpy(g["actions"][:, t].astype(np.int64)))
-        o, r, dn = o.cpu().numpy(), r.cpu().numpy(), dn.cpu().numpy()
+        if rich:
+            _cmp_rich(o, g, t + 1, "%s step %d" % (name, t))
+        o, r, dn = _pov(o), r.cpu().numpy(), dn.cpu().numpy()
         st = product_envs.canonical(env)
         enc = env.grid.encode().cpu().numpy()
         for si in range(S):
@@ -688,3 +719,49 @@ def test_objects_zoo_vs_oracle():
     st = product_envs.canonical(env)
     for b in range(0, B, 5):
         canon.assert_same(st[b], canon.oracle_canonical(orc.envs[b]), "env %d" % b)
+
+
+def test_auto_reset_survives_a_table_rebuild():
+    """A new object kind registered on a live auto-reset env rebuilds the device tables; the reset program
+    the fused auto-reset replays (and the template tensor it points at) must stay valid — compared with an
+    env that is reset by hand after every finished episode."""
+    import torch
+    from marlgrid_amd.objects import Ball, Key
+    name, B = "MarlGrid-3AgentCluttered11x11-v0", 256
+    seeds = 300 + np.arange(B)
+    e1 = product_envs.build(name, batch_size=B, seeds=seeds, auto_reset=True)
+    e2 = product_envs.build(name, batch_size=B, seeds=seeds)
+    e1.reset(); e2.reset()
+    rng = np.random.RandomState(9)
+    junk = []
+    for t in range(150):
+        if t in (3, 40):       # a kind the registry has not seen: tables + atlas are rebuilt and re-uploaded
+            obj = Key("blue") if t == 3 else Ball("red")
+            for e in (e1, e2):
+                e.put_obj(obj, 4, 4 + (t == 40))
+            junk = [torch.full((e1.cells_stride,), 0xEE, dtype=torch.uint8, device=e1.device) for _ in range(64)]
+        a = torch.from_numpy(rng.randint(0, 3, size=(B, 3)))
+        o1, r1, d1, _ = e1.step(a)
+        o2, r2, d2, _ = e2.step(a)
+        assert torch.equal(d1, d2) and torch.equal(r1, r2), t
+        if d2.any():
+            o2 = e2.reset(env_mask=d2)
+        assert torch.equal(o1, o2), t
+    assert len(junk) == 64
+
+
+def test_settings_are_read_every_step():
+    """max_steps / respawn / ghost_mode changed between steps take effect on the next step, as in the
+    reference (which reads the attributes inside step())"""
+    import torch
+    env = product_envs.build("MarlGrid-2AgentEmpty9x9-v0", batch_size=32, seeds=np.arange(32))
+    env.reset()
+    a = torch.zeros((32, 2), dtype=torch.int64)
+    for t in range(5):
+        _, _, d, _ = env.step(a)
+    assert not d.any()
+    env.max_steps = 6
+    _, _, d, _ = env.step(a)
+    assert d.all()
+    with pytest.raises(IndexError):
+        env.render(env_ids=[0, 32])

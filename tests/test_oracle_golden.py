@@ -22,6 +22,19 @@ def _canon_at(g, prefix, si, t=None):
     return out
 
 
+def _cmp_rich(orc, g, si, ti, what):
+    """the oracle's 'rich' fields == what the reference handed out (exactly: float64 divides); NaN in the
+    fixture = the agent does not observe that field"""
+    for k in range(orc.n):
+        r = orc.rich_obs(k)
+        for key, want in (("reward", g["rich_reward"][si, ti, k]), ("orientation", g["rich_orientation"][si, ti, k])):
+            if not np.isnan(want):
+                assert r[key] == want, (what, k, key)
+        want = g["rich_position"][si, ti, k]
+        if not np.isnan(want).any():
+            assert np.array_equal(r["position"], want), (what, k, r["position"], want)
+
+
 def _cmp(orc, gold, what):
     c = canon.oracle_canonical(orc)
     for k in canon.KEYS[:-1]:
@@ -44,6 +57,9 @@ def test_trajectory(name):
         assert [refstate.crc(x) for x in o] == list(g["obs_crc_reset"][si])
         if si < F:
             assert np.array_equal(o, g["obs_reset_full"][si])
+        rich = "rich_position" in g.files
+        if rich:
+            _cmp_rich(orc, g, si, 0, "%s seed %d reset" % (name, si))
         for t in range(T):
             o, r, dn, _, order = orc.step(g["actions"][si, t], return_order=True)
             what = "%s seed %d step %d" % (name, si, t)
@@ -55,6 +71,8 @@ def test_trajectory(name):
             assert [refstate.crc(x) for x in o] == list(g["obs_crc"][si, t]), what
             if si < F:
                 assert np.array_equal(o, g["obs_full"][si, t]), what
+            if rich:
+                _cmp_rich(orc, g, si, t + 1, what)
             if g["reset_after"][si, t]:
                 orc.reset()
         mt, pos = orc.mt_state()

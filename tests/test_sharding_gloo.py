@@ -64,3 +64,34 @@ def test_shard_range_properties():
             assert prev == G
     with pytest.raises(ValueError):
         shard_range(8, 2, 2)
+
+
+def test_bench_skeleton_two_ranks_gloo():
+    """bench.py's own N > 1 skeleton — process-group init, the barrier / synchronize bracket around every
+    K-step block, the per-rank gather, MAX over ranks, rank 0's single JSON line — launched exactly as the
+    driver launches it (torch.distributed.run, 2 ranks), with a sleep in place of the engine: rank 1
+    sleeps twice as long, so the slowest rank must define ms_per_step and show up as the straggler."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not (k.startswith("MG_") or k.startswith("MARLGRID_"))}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "5", "--warmup", "1", "--selftest-cpu", "--min-seconds", "0.05"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                      # ONE line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 5 and out["data"] == "selftest"
+    per_rank = out["per_rank_ms_per_step"]
+    assert len(per_rank) == 2 and per_rank[1] > per_rank[0] >= 1.0
+    assert out["ms_per_step"] >= 2.0 and out["blocks"]["count"] >= 4
+
+
+def test_bench_refuses_measurement_switches():
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--selftest-cpu"], capture_output=True,
+                       text=True, timeout=120, env=dict(os.environ, MG_RENDER_VARIANT="4"))
+    assert r.returncode == 2 and "MG_RENDER_VARIANT" in r.stderr

@@ -6,7 +6,10 @@ import os
 import statistics
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+# the measurement build (marlgrid_amd/csrc/build.sh ab): the product library has no switches to flip
+os.environ.setdefault("MARLGRID_HIP_LIB", os.path.join(ROOT, "marlgrid_amd", "csrc", "libmarlgrid_hip_ab.so"))
 import torch  # noqa: E402
 from marlgrid_amd import _native as N  # noqa: E402
 from marlgrid_amd.envs import make  # noqa: E402

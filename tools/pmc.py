@@ -1,0 +1,76 @@
+"""HBM bytes per obs-render launch from the PMC counters, measured live.
+
+Two separate rocprofv3 passes (--pmc WRITE_SIZE, --pmc FETCH_SIZE: they cannot share a pass — FETCH_SIZE
+takes 3 of the 4 TCC slots) over tools/profile_render.py, which first runs known-size calibration
+kernels (1 GiB fill, 1 GiB copy) so both counters are calibrated on this box in the very pass they
+are read in.  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half the bytes of a wide streaming
+read (x2 correction; checked here against the 1 GiB copy), WRITE_SIZE is calibrated on the fill.
+
+    measure(workload, batch) -> dict (bench.py's roofline.traffic), or {"error": ...}
+"""
+import collections
+import csv
+import glob
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GiB_KiB = 1048576.0
+
+
+def _pass(counter, workload, batch, iters, outdir, timeout):
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    d = os.path.join(outdir, counter.lower())
+    cmd = [exe, "--pmc", counter, "-d", d, "-o", "pmc", "--output-format", "csv", "--",
+           sys.executable, os.path.join(ROOT, "tools", "profile_render.py"), "--iters", str(iters),
+           "--batch", str(batch), "--workload", workload]
+    env = dict(os.environ, TMPDIR="/tmp")
+    r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
+    files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    if r.returncode != 0 or not files:
+        raise RuntimeError("rocprofv3 --pmc %s failed (rc %d): %s" % (counter, r.returncode, r.stderr[-400:]))
+    acc = collections.OrderedDict()
+    for row in csv.DictReader(open(files[0])):
+        if row["Counter_Name"] == counter:
+            acc.setdefault(row["Kernel_Name"].split("(")[0][:80], []).append(float(row["Counter_Value"]))
+    return acc
+
+
+def measure(workload="MarlGrid-3AgentCluttered15x15-v0", batch=32768, iters=4, timeout=240, keep_dir=None):
+    outdir = keep_dir or tempfile.mkdtemp(prefix="mg_pmc_", dir="/tmp")
+    try:
+        wr = _pass("WRITE_SIZE", workload, batch, iters, outdir, timeout)
+        rd = _pass("FETCH_SIZE", workload, batch, iters, outdir, timeout)
+    except Exception as e:       # noqa: BLE001 — the bench line then carries traffic: null and the reason
+        return {"error": str(e)[:300]}
+    finally:
+        if keep_dir is None:
+            shutil.rmtree(outdir, ignore_errors=True)
+
+    def kern(acc, needle):
+        ks = [k for k in acc if needle in k]
+        return acc[ks[0]] if ks else []
+    fill_w = [v for v in kern(wr, "FillFunctor<unsig") if v > 0.9 * GiB_KiB]
+    copy_r = [v for v in kern(rd, "copyBuffer") if v > 0.4 * GiB_KiB]
+    cal_w = GiB_KiB / (sum(fill_w) / len(fill_w)) if fill_w else None
+    cal_r = GiB_KiB / (sum(copy_r) / len(copy_r)) if copy_r else None
+    out = {"calibration": {"write_x": cal_w, "fetch_x": cal_r,
+                           "note": "1 GiB fill -> WRITE_SIZE, 1 GiB copy -> FETCH_SIZE, same passes"}}
+    for name, needle in (("render", "render_kernel"), ("step", "step_kernel")):
+        w, r = kern(wr, needle), kern(rd, needle)
+        if not w or not r:
+            continue
+        wb = sum(w) / len(w) * 1024 * (cal_w or 1.0)
+        rb = sum(r) / len(r) * 1024 * (cal_r or 2.0)
+        out[name] = {"write_bytes": wb, "fetch_bytes": rb, "hbm_bytes_per_launch": wb + rb, "launches": len(w)}
+    return out
+
+
+if __name__ == "__main__":
+    import json
+    print(json.dumps(measure(*(sys.argv[1:2] or ["MarlGrid-3AgentCluttered15x15-v0"]),
+                             batch=int(sys.argv[2]) if len(sys.argv) > 2 else 32768,
+                             keep_dir=sys.argv[3] if len(sys.argv) > 3 else None), indent=1))

@@ -31,12 +31,13 @@ def timed(fn, iters=200):
     return a.elapsed_time(b) / iters
 
 
-def k_step(i):
-    N.check(L.mg_step(cfg, st, acts[i % 16].data_ptr(), 8, env.rewards.data_ptr(), env._stream()))
+def k_step(i):      # action loop + the fused reset of finished episodes
+    N.check(L.mg_step(cfg, st, acts[i % 16].data_ptr(), 8, env.rewards.data_ptr(), C.byref(env._reset_prog),
+                      env._stream()))
 
 
-def k_reset(i):
-    N.check(L.mg_reset(cfg, st, C.byref(env._reset_prog), C.c_void_p(env.done_t.data_ptr()), env._stream()))
+def k_step_only(i):  # action loop alone (finished envs stay finished: state drifts towards all-done)
+    N.check(L.mg_step(cfg, st, acts[i % 16].data_ptr(), 8, env.rewards.data_ptr(), None, env._stream()))
 
 
 def k_render(i):
@@ -47,7 +48,7 @@ def k_all(i):
     env.step(acts[i % 16])
 
 
-for name, fn in (("step+reset (state advances)", lambda i: (k_step(i), k_reset(i))), ("render", k_render),
-                 ("env.step (all three + python)", k_all)):
+for name, fn in (("mg_step with fused auto-reset", k_step), ("render", k_render),
+                 ("env.step (both launches + python)", k_all), ("mg_step without reset program", k_step_only)):
     print("%-34s %.4f ms" % (name, timed(fn)))
 env.check_errors()
