@@ -58,13 +58,13 @@ constexpr int kRenderShared = 3 * MG_MAX_OBJ + 2 * MG_MAX_AGENTS * 8;
 
 // per-wave LDS scratch of the obs-render kernel (bytes), shared by host launch code and kernel
 struct RenderScratch {
-    int grid, rec, pres, first, second, vbase, vshow, trow, vis, tmap, dyn, seg, total;
+    int grid, rec, pres, first, second, vbase, vshow, trow, vis, tmap, dyn, out, total;
     int stage_envs;    // envs whose inputs (grid + agent records) are staged per batch: 1..8
     int rec_stride;    // u64 records per staged env
-    int seg_entries;   // 0: no segment table (tile size on the 16-byte-chunk path, or it would not fit)
+    int piece_rows;    // assemble-and-stream raster: pixel rows assembled in LDS per piece (0: chunk raster)
 };
 __host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride, int n, int vs, int stage_envs = 1,
-                                                               int dyn_bytes = 0, int seg_entries = 0) {
+                                                               int dyn_bytes = 0, int out_bytes = 0, int piece_rows = 0) {
     RenderScratch s;
     int o = 0;
     s.stage_envs = stage_envs;
@@ -80,30 +80,38 @@ __host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride,
     s.vis = o;   o += round_up(n * vs * 4, 16);
     s.tmap = o;  o += round_up(n * vs * vs * 2, 16);
     s.dyn = o;   o += round_up(dyn_bytes, 16);   // per-env recoloured ('prestige') agent tiles
-    s.seg = o;   o += round_up(seg_entries * 4, 16);   // per-env segment source table (size-generic raster)
-    s.seg_entries = seg_entries;
+    s.out = o;   o += round_up(out_bytes, 16);   // assemble-and-stream raster: the piece being assembled
+    s.piece_rows = piece_rows;
     s.total = o;
     return s;
 }
+// the tile sizes the 16-byte-chunk raster is instantiated for (whole pairs of dwords per tile row);
+// everything else — and `mode` 1, measurement builds — takes the assemble-and-stream raster
+__host__ __device__ inline bool render_chunk_raster(const MgConfig& cfg, int mode) {
+    return (cfg.tile_size == 8 || cfg.tile_size == 16 || cfg.tile_size == 32) && mode == 0;
+}
 // The layout a launch of the obs kernel uses, from the config and the workgroup size alone (kernel and
-// launcher agree): recoloured-tile space when some agent is 'prestige'; for tile sizes off the
-// 16-byte-chunk path a table with the atlas source of every (pixel row, view column) segment of the
-// env's images — n*P*VS entries — when it is small enough to sit next to the atlas and 4 waves of
-// scratch; and as many staged envs per batch (8, 4, 2 or 1) as `wpb` waves of scratch leave room for.
-__host__ __device__ inline RenderScratch render_scratch_for(const MgConfig& cfg, int wpb) {
+// launcher agree): recoloured-tile space when some agent is 'prestige'; for the assemble-and-stream raster
+// (tile sizes off the 16-byte-chunk path; `mode` 1 forces it — measurement builds) the piece buffer: as
+// many whole pixel rows as fit ~4 KiB (at least one) plus 32 bytes for the carried-over partial chunk;
+// and as many staged envs per batch (8, 4, 2 or 1) as `wpb` waves of scratch leave room for.
+__host__ __device__ inline RenderScratch render_scratch_for(const MgConfig& cfg, int wpb, int mode = 0) {
     const int n = cfg.n_agents, vs = cfg.view_size, ts = cfg.tile_size;
     const int dyn = cfg.prestige_mask ? (cfg.any_hide ? 2 : 1) * n * 4 * ts * ts * 3 : 0;
     const int atlas_b = round_up(4 * cfg.n_tiles * ts * ts * 3, 16), misc = 1024;
-    const RenderScratch b = render_scratch_layout(cfg.cells_stride, n, vs, 1, dyn, 0);
-    const int resident = (atlas_b + 4 * b.total + misc <= 160 * 1024) ? atlas_b : 0;   // else the atlas is read in place
-    int seg = 0;
-    if (ts % 8 != 0) {
-        const int entries = n * vs * ts * vs + 2, bytes = round_up(entries * 4, 16);
-        if (bytes <= 16 * 1024 && resident + 4 * (b.total + bytes) + misc <= 160 * 1024) seg = entries;
+    int rows = 0, out = 0;
+    if (!render_chunk_raster(cfg, mode)) {
+        const int rb = 3 * vs * ts;
+        rows = 4096 / rb;
+        if (rows < 1) rows = 1;
+        if (rows > n * vs * ts) rows = n * vs * ts;
+        out = 32 + rows * rb;
     }
+    const RenderScratch b = render_scratch_layout(cfg.cells_stride, n, vs, 1, dyn, out, rows);
+    const int resident = (atlas_b + 4 * b.total + misc <= 160 * 1024) ? atlas_b : 0;   // else the atlas is read in place
     int k = 8;
-    while (k > 1 && resident + wpb * render_scratch_layout(cfg.cells_stride, n, vs, k, dyn, seg).total + misc > 160 * 1024) k >>= 1;
-    return render_scratch_layout(cfg.cells_stride, n, vs, k, dyn, seg);
+    while (k > 1 && resident + wpb * render_scratch_layout(cfg.cells_stride, n, vs, k, dyn, out, rows).total + misc > 160 * 1024) k >>= 1;
+    return render_scratch_layout(cfg.cells_stride, n, vs, k, dyn, out, rows);
 }
 
 }  // namespace mg

@@ -15,9 +15,14 @@
 //     shadow-casting pass as row bit-masks (log-step floods), and the wave writes a per-view-cell
 //     atlas offset map (tmap) to LDS;
 //   * the raster then emits the env's n*P*P*3 contiguous output bytes as 16-byte
-//     (global_store_dwordx4) chunks, consecutive lanes -> consecutive chunks, each chunk assembled
-//     from two 8-byte LDS look-ups atlas[tmap[cell] + row*TD + k] (tile sizes that are a multiple of
-//     8), or as aligned dwords cut out of contiguous atlas runs (any other tile size).
+//     (global_store_dwordx4) chunks, consecutive lanes -> consecutive chunks.  Tile sizes that are a
+//     multiple of 8: each chunk is assembled in registers from two 8-byte LDS look-ups
+//     atlas[tmap[cell] + row*TD + k].  Any other tile size: a few KiB of whole pixel rows at a time are
+//     first ASSEMBLED in an LDS piece buffer — one lane per (row, view column) segment copies its 3*TS
+//     bytes from the atlas tile row with unaligned 8-byte DS accesses — and then STREAMED out as linear
+//     ds_read_b128 -> aligned dwordx4 stores; the bytes of a chunk that straddles two pieces (or two
+//     envs of the wave's run) are carried over in the buffer, so everything but the first and last
+//     <16 bytes of a wave's whole run leaves as aligned 16-byte stores.
 // No MFMA: there is no contraction anywhere in this path.
 #include "mg_device.h"
 #include "mg_launch.h"
@@ -31,14 +36,14 @@ namespace mg {
 // ---- the kernel ----------------------------------------------------------------------------------
 // TS_ % 8 == 0: 16-byte-chunk fast raster (tile rows are an even number of dwords); VS_ > 0 also
 //              fixes the view size at compile time (the shipped view sizes), VS_ == 0 reads it from cfg.
-// TS_ == 0:    any view / tile size: per-byte look-ups assembled into aligned dword stores.
+// otherwise (or RM_ == 1): the assemble-and-stream raster; TS_ == 0 reads the tile size from cfg.
 // V_: 0 = production; 8 = production with the atlas read from global memory (chosen by the launcher
 //     when it does not fit LDS); 9 = production with per-env recoloured tiles for 'prestige' agents;
 //     12 = both (recoloured tiles in LDS, the static atlas in global memory).  2..7 = measurement variants for tools/ab_render.py (MG_RENDER_VARIANT,
 //     <7,8> only): 2 nontemporal stores, 3 raster only (phases 2-5 skipped), 4 stores only (no LDS
 //     look-ups), 6 no store bursts, 11 phases 2-5 executed twice.
 // WPB = waves per workgroup (4 or 16; MG_RENDER_WPB overrides the launcher's choice).
-template <int VS_, int TS_, int WPB, int V_ = 0>
+template <int VS_, int TS_, int WPB, int V_ = 0, int RM_ = 0>
 __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState st, uint8_t* __restrict__ obs,
                                                         uint8_t* __restrict__ dbg_cells,
                                                         uint8_t* __restrict__ dbg_agent,
@@ -82,7 +87,8 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     }
     __syncthreads();
 
-    const RenderScratch L = render_scratch_for(cfg, WPB);
+    constexpr bool kChunkRaster = TS_ > 0 && (TS_ % 8) == 0 && RM_ == 0;
+    const RenderScratch L = render_scratch_for(cfg, WPB, RM_);
     uint8_t* ws = smem + atlas_bytes + kRenderShared + (size_t)wave * L.total;
     uint8_t* w_stage_g = ws + L.grid;                                      // [stage_envs][cells_stride] grids of a batch of envs
     uint64_t* w_stage_r = reinterpret_cast<uint64_t*>(ws + L.rec);        // [stage_envs][rec_stride] their agent records
@@ -95,7 +101,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     uint32_t* w_vis = reinterpret_cast<uint32_t*>(ws + L.vis);
     uint16_t* w_tmap = reinterpret_cast<uint16_t*>(ws + L.tmap);
     uint8_t* w_dyn = ws + L.dyn;                               // [n][4 orientations][tile_bytes]
-    uint32_t* w_seg = reinterpret_cast<uint32_t*>(ws + L.seg); // [n*P*VS + 2] segment sources (size-generic raster)
+    uint8_t* w_out = ws + L.out;                               // assemble-and-stream raster: [32 + piece_rows * 3 * P]
     const uint32_t dyn_off = (uint32_t)(w_dyn - smem);         // byte offset from the atlas base
     const uint32_t NT4 = 4u * (uint32_t)cfg.n_tiles;           // first virtual tile index of the dynamic tiles
 
@@ -122,6 +128,18 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     const int per_wave = (cfg.B + gridDim.x * WPB - 1) / (gridDim.x * WPB);
     const int e0 = (blockIdx.x * WPB + wave) * per_wave;
     const int e_end = min(cfg.B, e0 + per_wave);
+
+    // assemble-and-stream raster: the wave's run of envs is ONE contiguous output stream.  w_out[0] is
+    // the byte at the 16-byte-aligned global address out_base; w_out[0 .. carry) are pending bytes of a
+    // chunk that is not complete yet (at the start of the run: `head` bytes that belong to the wave before)
+    uintptr_t out_base = 0;
+    uint32_t carry = 0, head = 0;
+    if constexpr (!kChunkRaster) {
+        const uintptr_t a0 = reinterpret_cast<uintptr_t>(obs) + (size_t)e0 * n * img_bytes;
+        head = (uint32_t)(a0 & 15);
+        carry = head;
+        out_base = a0 - head;
+    }
 
     for (int eb = e0; eb < e_end; eb += K) {
         const int kb = min(K, e_end - eb);
@@ -315,7 +333,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                     dyn = true;
                 }
             }
-            if constexpr (TS_ > 0 && (TS_ % 8) == 0 && !kGlobalAtlas)             // dword offset from the atlas base
+            if constexpr (kChunkRaster && !kGlobalAtlas)                          // dword offset from the atlas base
                 w_tmap[it] = (uint16_t)(dyn ? dyn_off / 4 + (vt - NT4) * (TS_ * TS_ * 3 / 4) : vt * (TS_ * TS_ * 3 / 4));
             else
                 w_tmap[it] = (uint16_t)vt;
@@ -331,7 +349,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
         }
         wave_lds_sync();
         // 6. raster: stream the env's n images out
-        if constexpr (TS_ > 0 && (TS_ % 8) == 0) {
+        if constexpr (kChunkRaster) {
             // The env's n images are one contiguous run of 8-byte *pairs*: PR pairs per pixel row,
             // PT per tile row (TD even => a pair never straddles a tile row, and every pair is
             // 8-byte aligned in the atlas: ds_read_b64).  A 16-byte chunk is pairs (2c, 2c+1).
@@ -400,185 +418,72 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 put(c, v);
             }
         } else {
-            // Any tile size: the env's n*P*P*3 output bytes are still one contiguous run, but it starts
-            // wherever e*S falls, and tile rows are not whole dwords.  A pixel row is VS segments of
-            // SEG = 3*TS bytes, each a contiguous run of one atlas tile row, so an output dword is 4
-            // contiguous atlas bytes at an arbitrary byte offset (two aligned dword reads +
-            // v_alignbyte) merged — when it straddles a segment boundary — with the start of the next
-            // segment.  Two implementations: the segment-table raster (normal case) and, when that
-            // table does not fit in LDS, per-dword (row, column) arithmetic on 16-byte chunks.  Bytes
-            // before the first aligned address / after the last whole unit are stored singly.
-            const uint32_t P = (uint32_t)(VS * TS), RB = P * 3u;           // bytes per pixel row
-            const uint32_t S = (uint32_t)n * P * RB;                       // bytes per env
+            // Any tile size: the env's n*P*P*3 output bytes are the next S bytes of the wave's stream;
+            // tile rows are SEG = 3*TS bytes at arbitrary byte offsets.  Piece by piece (piece_rows whole
+            // pixel rows, ~4 KiB): ASSEMBLE — segment g of the piece (pixel row g / VS, view column
+            // g % VS) is SEG contiguous bytes of one atlas tile row, copied by one lane with unaligned
+            // 8-byte accesses (the last one overlapping backwards) to w_out[carry + g*SEG]; then STREAM
+            // the complete 16-byte chunks of w_out (linear ds_read_b128 -> global_store_dwordx4) and move
+            // the incomplete tail to the front, where the next piece — or the next env — continues.
+            const uint32_t SEG = 3u * (uint32_t)TS, P = (uint32_t)(VS * TS), RB = P * 3u;
             const uint32_t NR = (uint32_t)n * P;                           // pixel rows per env
-            const size_t gb = (size_t)e * S;                               // first byte, relative to obs
-            const uintptr_t A = reinterpret_cast<uintptr_t>(obs) + gb;
-            const uint32_t head = (uint32_t)min((uintptr_t)S, ((A + 15) & ~(uintptr_t)15) - A);
-            const uint32_t nq = (S - head) / 16u;                          // whole aligned chunks
-            const uint32_t tail0 = head + nq * 16u;
-            const uint32_t mTS = TS > 1 ? 0xFFFFFFFFu / (uint32_t)TS + 1u : 0u;
-            auto div_ts = [&](uint32_t v) -> uint32_t { return TS > 1 ? __umulhi(v, mTS) : v; };
+            const uint32_t mVS = 0xFFFFFFFFu / (uint32_t)VS + 1u, mTS = TS > 1 ? 0xFFFFFFFFu / (uint32_t)TS + 1u : 0u;
+            typedef uint64_t u64u __attribute__((aligned(1)));
             auto tile_off = [&](uint32_t vt) -> uint32_t {                 // virtual tile index -> byte offset
                 if constexpr (kSplit) return vt < NT4 ? vt * (uint32_t)tile_bytes : (kInLds | (dyn_off + (vt - NT4) * (uint32_t)tile_bytes));
                 else if constexpr (kPrestige) return vt < NT4 ? vt * (uint32_t)tile_bytes : dyn_off + (vt - NT4) * (uint32_t)tile_bytes;
                 else return vt * (uint32_t)tile_bytes;
             };
-            auto byte_at = [&](uint32_t R, uint32_t cb) -> uint32_t {      // R: global pixel row, cb < RB
-                const uint32_t col = __umulhi(cb, 0x55555556u), ch = cb - col * 3u;
-                const uint32_t va = div_ts(col), cc = col - va * (uint32_t)TS;
-                const uint32_t vb = div_ts(R), rr = R - vb * (uint32_t)TS;
-                const uint32_t so = tile_off((uint32_t)w_tmap[vb * (uint32_t)VS + va]) + (rr * (uint32_t)TS + cc) * 3u + ch;
-                if constexpr (kSplit) return (so & kInLds) ? s_atlas[so & ~kInLds] : cfg.atlas[so];
-                else if constexpr (kGlobalAtlas) return cfg.atlas[so];
-                else return s_atlas[so];
-            };
-            const uint32_t SEG = 3u * (uint32_t)TS;
-            const uint32_t mSEG = 0xFFFFFFFFu / SEG + 1u;                    // SEG >= 3
-            auto fetch4 = [&](uint32_t so) -> uint32_t {
-                const uint32_t a = (so & ~kInLds) >> 2, sh = so & 3u;
-                uint32_t lo, hi;
-                if (kSplit && (so & kInLds)) {
-                    const uint32_t* l32 = reinterpret_cast<const uint32_t*>(s_atlas);
-                    lo = l32[a]; hi = l32[a + 1];
-                } else if constexpr (kGlobalAtlas) {
-                    const uint32_t* g32 = reinterpret_cast<const uint32_t*>(cfg.atlas);
-                    lo = g32[a]; hi = g32[a + 1];
-                } else {
-                    const uint32_t* l32 = reinterpret_cast<const uint32_t*>(s_atlas);
-                    lo = l32[a]; hi = l32[a + 1];
+            for (uint32_t R0 = 0; R0 < NR; R0 += (uint32_t)L.piece_rows) {
+                const uint32_t rows = min((uint32_t)L.piece_rows, NR - R0), nseg = rows * (uint32_t)VS;
+                uint8_t* dst0 = w_out + carry;
+                for (uint32_t g = lane; g < nseg; g += kWave) {
+                    const uint32_t Rl = __umulhi(g, mVS), col = g - Rl * (uint32_t)VS, R = R0 + Rl;
+                    const uint32_t band = TS > 1 ? __umulhi(R, mTS) : R, rr = R - band * (uint32_t)TS;
+                    const uint32_t so = tile_off((uint32_t)w_tmap[band * (uint32_t)VS + col]) + rr * SEG;
+                    uint8_t* d = dst0 + g * SEG;
+                    const uint8_t* src;
+                    if constexpr (kSplit) src = (so & kInLds) ? s_atlas + (so & ~kInLds) : cfg.atlas + so;
+                    else if constexpr (kGlobalAtlas) src = cfg.atlas + so;
+                    else src = s_atlas + so;
+                    if (SEG >= 8u) {
+                        uint32_t o = 0;
+                        for (; o + 8u <= SEG; o += 8u) *reinterpret_cast<u64u*>(d + o) = *reinterpret_cast<const u64u*>(src + o);
+                        if (o < SEG) *reinterpret_cast<u64u*>(d + SEG - 8u) = *reinterpret_cast<const u64u*>(src + SEG - 8u);
+                    } else {
+                        for (uint32_t o = 0; o < SEG; o++) d[o] = src[o];
+                    }
                 }
-                return __builtin_amdgcn_alignbyte(hi, lo, sh);
-            };
-            auto fetch8 = [&](uint32_t so) -> uint2 {                      // the two aligned dwords around `so`
-                const uint32_t a = (so & ~kInLds) >> 2;
-                if (kSplit && (so & kInLds)) {
-                    const uint32_t* l32 = reinterpret_cast<const uint32_t*>(s_atlas);
-                    return make_uint2(l32[a], l32[a + 1]);
-                } else if constexpr (kGlobalAtlas) {
-                    const uint32_t* g32 = reinterpret_cast<const uint32_t*>(cfg.atlas);
-                    return make_uint2(g32[a], g32[a + 1]);
-                } else {
-                    const uint32_t* l32 = reinterpret_cast<const uint32_t*>(s_atlas);
-                    return make_uint2(l32[a], l32[a + 1]);
-                }
-            };
-            auto seg_src = [&](uint32_t R, uint32_t seg) -> uint32_t {     // atlas byte offset of a segment start
-                const uint32_t vb = div_ts(R), rr = R - vb * (uint32_t)TS;
-                return tile_off((uint32_t)w_tmap[vb * (uint32_t)VS + seg]) + rr * SEG;
-            };
-            auto dword_at = [&](uint32_t R, uint32_t cb) -> uint32_t {     // 4 output bytes from (R, cb), cb < RB
-                const uint32_t seg = __umulhi(cb, mSEG), off = cb - seg * SEG, left = SEG - off;
-                uint32_t R2 = R, seg2 = seg + 1u;
-                if (seg2 == (uint32_t)VS) { seg2 = 0; R2++; }
-                if (R2 >= NR) R2 = R;                                        // (never used then: left >= 4)
-                const uint32_t v = fetch4(seg_src(R, seg) + off);
-                const uint32_t v2 = fetch4(seg_src(R2, seg2));
-                const uint32_t sh = left < 4u ? 8u * left : 0u;
-                const uint32_t keep = left < 4u ? (1u << sh) - 1u : 0xFFFFFFFFu;
-                return (v & keep) | ((v2 << sh) & ~keep);
-            };
-            if (L.seg_entries) {
-                // Segment-table raster.  The env's output is a linear stream of SEG-byte segments
-                // (segment g = pixel row g / VS, view column g % VS), so one table of their atlas
-                // sources absorbs the row / band / tile structure; a dword then needs only its
-                // (segment, offset) — carried incrementally — and the sources of segments g, g + 1.
-                // Built per (band, column) pair: its TS rows are TS entries VS apart, SEG bytes apart
-                // in the atlas tile (p is the tmap index of the pair).
-                const uint32_t NG = NR * (uint32_t)VS;
-                const uint32_t mVS = 0xFFFFFFFFu / (uint32_t)VS + 1u;
-                for (uint32_t p = lane; p < (uint32_t)(n * VV); p += kWave) {
-                    const uint32_t vb = __umulhi(p, mVS);
-                    uint32_t gg = p + vb * (uint32_t)(VS * (TS - 1));            // (vb*TS)*VS + seg
-                    uint32_t src = tile_off((uint32_t)w_tmap[p]);
-                    for (int rr = 0; rr < TS; rr++) { w_seg[gg] = src; gg += (uint32_t)VS; src += SEG; }
-                }
-                if (lane < 2) w_seg[NG + (uint32_t)lane] = 0u;                  // read (not used) past the last segment
                 wave_lds_sync();
-                const uint32_t nd = (S - head) / 4u;                           // whole dwords after the head
-                const uint32_t tail4 = head + nd * 4u;
-                const uint32_t STEP_G = (4u * kWave) / SEG, STEP_O = (4u * kWave) - STEP_G * SEG;
-                uint32_t o = head + 4u * (uint32_t)lane;
-                uint32_t g = o / SEG, off = o - g * SEG;
-                uint32_t* out32 = reinterpret_cast<uint32_t*>(obs + gb + head);
-                // One trip = kU dwords per lane, staged so that the LDS round trips of the kU dwords
-                // overlap: positions (VALU only) -> kU table look-ups -> 2*kU atlas fetches -> merge.
-                constexpr int kU = 4;
-                auto seg_trip = [&](uint32_t (&v)[kU]) {
-                    uint32_t go[kU], oo[kU], s0[kU], s1[kU];
-#pragma unroll
-                    for (int i = 0; i < kU; i++) {
-                        go[i] = kGlobalAtlas ? min(g, NG) : g;   // lanes past the end (last trip) must stay in the table
-                        oo[i] = off;                             // when its values address global memory
-                        off += STEP_O; g += STEP_G;
-                        if (off >= SEG) { off -= SEG; g++; }
+                const uint32_t total = carry + rows * RB, full = total >> 4;
+                if (full) {
+                    uint32_t c0 = 0;
+                    if (head) {   // chunk 0 is shared with the wave before this one: only our bytes of it
+                        if ((uint32_t)lane >= head && lane < 16) reinterpret_cast<uint8_t*>(out_base)[lane] = w_out[lane];
+                        head = 0;
+                        c0 = 1;
                     }
-#pragma unroll
-                    for (int i = 0; i < kU; i++) { s0[i] = w_seg[go[i]]; s1[i] = w_seg[go[i] + 1u]; }
-                    __builtin_amdgcn_sched_barrier(0);
-                    uint2 pa[kU], pb[kU];
-#pragma unroll
-                    for (int i = 0; i < kU; i++) { s0[i] += oo[i]; pa[i] = fetch8(s0[i]); pb[i] = fetch8(s1[i]); }
-                    __builtin_amdgcn_sched_barrier(0);   // all 2*kU fetches in flight before the first use
-#pragma unroll
-                    for (int i = 0; i < kU; i++) {
-                        const uint32_t a = __builtin_amdgcn_alignbyte(pa[i].y, pa[i].x, s0[i]);   // (shift = low 2 bits)
-                        const uint32_t b = __builtin_amdgcn_alignbyte(pb[i].y, pb[i].x, s1[i]);
-                        // nl = bytes that come from the next segment (0 unless the dword straddles):
-                        // {b, a << 8 nl} >> 8 nl = a's valid low bytes, then b's first nl bytes
-                        const uint32_t nl = (uint32_t)max((int)oo[i] + 4 - (int)SEG, 0);
-                        v[i] = __builtin_amdgcn_alignbyte(b, a << (8u * nl), nl);
+                    const uint4* src16 = reinterpret_cast<const uint4*>(w_out);
+                    uint4* dst16 = reinterpret_cast<uint4*>(out_base);
+                    uint32_t c = c0 + (uint32_t)lane;
+                    for (; c + 3u * kWave < full; c += 4u * kWave) {
+                        const uint4 v0 = src16[c], v1 = src16[c + kWave], v2 = src16[c + 2 * kWave], v3 = src16[c + 3 * kWave];
+                        dst16[c] = v0; dst16[c + kWave] = v1; dst16[c + 2 * kWave] = v2; dst16[c + 3 * kWave] = v3;
                     }
-                };
-                uint32_t d = lane;
-                for (; d + (kU - 1) * kWave < nd; d += kU * kWave) {
-                    uint32_t v[kU];
-                    seg_trip(v);
-#pragma unroll
-                    for (int i = 0; i < kU; i++) out32[d + i * kWave] = v[i];
+                    for (; c < full; c += kWave) dst16[c] = src16[c];
+                    const uint32_t tail = total - (full << 4);
+                    const uint8_t tb = (uint32_t)lane < tail ? w_out[(full << 4) + lane] : (uint8_t)0;
+                    wave_lds_sync();
+                    if ((uint32_t)lane < tail) w_out[lane] = tb;
+                    out_base += (uintptr_t)full << 4;
+                    carry = tail;
+                } else {
+                    carry = total;
                 }
-                if (d < nd) {                                                  // last, partial trip
-                    uint32_t v[kU];
-                    seg_trip(v);
-#pragma unroll
-                    for (int i = 0; i < kU; i++) if (d + i * kWave < nd) out32[d + i * kWave] = v[i];
-                }
-                if (lane < 32) {                                               // head / tail bytes
-                    const uint32_t ob = lane < 16 ? (uint32_t)lane : tail4 + (uint32_t)(lane - 16);
-                    const bool on = lane < 16 ? (uint32_t)lane < head : ob < S;
-                    if (on) {
-                        const uint32_t R = ob / RB, cb = ob - R * RB;
-                        obs[gb + ob] = (uint8_t)byte_at(R, cb);
-                    }
-                }
-            } else {
-            if (nq) {
-                const uint32_t STEP_Rb = (16u * kWave) / RB, STEP_B = (16u * kWave) - STEP_Rb * RB;
-                uint32_t o = head + 16u * (uint32_t)lane;                    // this lane's first byte offset
-                uint32_t R = o / RB, cb = o - R * RB;
-                uint4* out16 = reinterpret_cast<uint4*>(obs + gb + head);
-                for (uint32_t q = lane; q < nq; q += kWave) {
-                    uint32_t v[4];
-                    uint32_t Ri = R, ci = cb;
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        v[i] = dword_at(Ri, ci);
-                        ci += 4u;
-                        if (ci >= RB) { ci -= RB; Ri++; }
-                    }
-                    out16[q] = make_uint4(v[0], v[1], v[2], v[3]);
-                    R += STEP_Rb; cb += STEP_B;
-                    if (cb >= RB) { cb -= RB; R++; }
-                }
+                wave_lds_sync();
             }
-            // head / tail bytes (at most 15 each)
-            if (lane < 32) {
-                const uint32_t o = lane < 16 ? (uint32_t)lane : tail0 + (uint32_t)(lane - 16);
-                const bool on = lane < 16 ? (uint32_t)lane < head : o < S;
-                if (on) {
-                    const uint32_t R = o / RB, cb = o - R * RB;
-                    obs[gb + o] = (uint8_t)byte_at(R, cb);
-                }
-            }
+            if (e + 1 == e_end && carry > head) {   // end of the run: the bytes of the last, incomplete chunk
+                if ((uint32_t)lane >= head && (uint32_t)lane < carry) reinterpret_cast<uint8_t*>(out_base)[lane] = w_out[lane];
             }
         }
         wave_lds_sync();   // scratch is reused by the next env
@@ -586,16 +491,17 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     }
 }
 
-template <int VS_, int TS_, int WPB, int V_ = 0>
+template <int VS_, int TS_, int WPB, int V_ = 0, int RM_ = 0>
 static hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_t* obs, uint8_t* c, uint8_t* a,
                                   uint8_t* v, hipStream_t s) {
     const int tile_bytes = cfg.tile_size * cfg.tile_size * 3;
-    const RenderScratch L = render_scratch_for(cfg, WPB);
+    static_assert(RM_ == 1 || TS_ == 0 || (TS_ % 8) != 0 || TS_ == 8 || TS_ == 16 || TS_ == 32, "see render_chunk_raster");
+    const RenderScratch L = render_scratch_for(cfg, WPB, RM_);
     size_t lds = ((V_ == 8 || V_ == 12) ? 0 : (size_t)round_up(4 * cfg.n_tiles * tile_bytes, 16)) + kRenderShared +
                  WPB * (size_t)L.total;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<VS_, TS_, WPB, V_>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<VS_, TS_, WPB, V_, RM_>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
@@ -612,7 +518,7 @@ static hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_
     const int need = (cfg.B + WPB - 1) / WPB;   // workgroups if every wave took one env
     const int rounds = (need + max_blocks - 1) / max_blocks;
     const int blocks = (need + rounds - 1) / rounds;
-    hipLaunchKernelGGL((render_kernel<VS_, TS_, WPB, V_>), dim3(blocks), dim3(WPB * 64), lds, s, cfg, st, obs, c, a, v);
+    hipLaunchKernelGGL((render_kernel<VS_, TS_, WPB, V_, RM_>), dim3(blocks), dim3(WPB * 64), lds, s, cfg, st, obs, c, a, v);
     return hipGetLastError();
 }
 
@@ -692,6 +598,9 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
         case 11: return MG_RENDER_DISPATCH(7, 8, 11);
         default: break;
         }
+        if (getenv("MG_RENDER_RASTER") && atoi(getenv("MG_RENDER_RASTER")) == 1)   // assemble-and-stream at tile 8
+            return wpb == 16 ? launch_render_t<7, 8, 16, 0, 1>(cfg, st, obs, view_cells, view_agent, vis_mask, s)
+                             : launch_render_t<7, 8, 4, 0, 1>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
 #endif
         return MG_RENDER_DISPATCH8(7, 8, 0);
     }

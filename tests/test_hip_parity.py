@@ -433,20 +433,33 @@ def test_rich_observations():
 
 
 def test_grid_recorder_roundtrip(tmp_path):
+    """video.py:55-178 semantics: a frame BEFORE every step, the final frame when reset() ends the episode,
+    auto-saved as frames_<reset_count>/frame_<t>.png; export_both writes <id>_frames/"""
     import torch
     from PIL import Image
     from marlgrid_amd.utils.video import GridRecorder
     env = product_envs.build("MarlGrid-3AgentCluttered11x11-v0", batch_size=8)
-    rec = GridRecorder(env, save_root=str(tmp_path), max_steps=10, env_index=3)
+    rec = GridRecorder(env, save_root=str(tmp_path), max_steps=10, env_index=3, auto_save_videos=False)
+    assert rec.video_kwargs == {"fps": 20, "rescale_factor": 1} and rec.max_steps == 11
     rec.recording = True
     rec.reset()
+    assert rec.ptr == 0 and rec.reset_count == 1
+    shots = []
     for t in range(4):
+        shots.append(env.render(env_ids=[3])[0].cpu().numpy())     # the state the action is taken in
         rec.step(torch.randint(0, 3, (8, 3)))
+    assert rec.ptr == 4 and all(np.array_equal(rec.frames[t], shots[t]) for t in range(4))
     last = env.render(env_ids=[3])[0].cpu().numpy()
-    path = rec.export_frames("ep0")
-    assert rec.ptr == 5 and sorted(os.listdir(path)) == ["frame_%d.png" % i for i in range(5)]
-    back = np.asarray(Image.open(os.path.join(path, "frame_4.png")))
-    assert np.array_equal(back, last) and np.array_equal(rec.frames[4], last)
+    try:
+        rec.export_both("ep0")                                     # frames first, then the video ...
+    except ImportError:
+        pass                                                       # ... which needs moviepy (optional upstream too)
+    assert sorted(os.listdir(str(tmp_path / "ep0_frames"))) == ["frame_%d.png" % i for i in range(4)]
+    rec.reset()                                                    # appends the final frame, auto-saves
+    path = str(tmp_path / "frames_1")
+    assert sorted(os.listdir(path)) == ["frame_%d.png" % i for i in range(5)]
+    assert np.array_equal(np.asarray(Image.open(os.path.join(path, "frame_4.png"))), last)
+    assert rec.ptr == 0 and rec.reset_count == 2 and rec.last_save == 1
 
 
 def test_readme_loop_with_independent_learners():
