@@ -39,10 +39,11 @@ MG_HD int dir_dy(int d) { return d == 1 ? 1 : (d == 3 ? -1 : 0); }
 // reads exactly the values the in-place block loop reads), which needs no 624-iteration twist stall
 // in one lane.  State per env: w[624] with `pos` = the next word to regenerate, and `head` = the
 // MG_MT_HEAD tempered outputs x[G-16 .. G) that were generated last and are not consumed yet (G the
-// generation count, pos = G mod 624).  A kernel draws from the head first — a contiguous 64 B per
-// env that is read with the rest of the env's record, so the shuffle of a step needs no dependent
-// memory round trip — and only then generates further words one by one; when it is done it tops the
-// head up again (mt_finish), all loads of that refill in flight together.
+// generation count, pos = G mod 624).  A kernel draws from the head — a contiguous 64 B per env that
+// is read with the rest of the env's record, so the shuffle of a step needs no dependent memory
+// round trip; a kernel that needs more than 16 draws (placements, resets) regenerates the head 16
+// words at a time, and when it is done it tops the head up again (mt_finish) — every refill with all
+// of its loads in flight together.
 MG_HD uint32_t mt_temper(uint32_t v) {
     v ^= (v >> 11);
     v ^= (v << 7) & 0x9d2c5680u;
@@ -54,41 +55,6 @@ MG_HD uint32_t mt_twist(uint32_t wi, uint32_t wi1, uint32_t wim) {
     const uint32_t y = (wi & 0x80000000u) | (wi1 & 0x7fffffffu);
     return wim ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
 }
-
-struct Mt {
-    uint32_t* w;            // this env's 624 words (HBM)
-    int pos;                // next word to regenerate
-    const uint32_t* head;   // head word i at head[i * hstride] (HBM: stride 1; LDS column: stride S)
-    int hstride;
-    int used;               // draws taken since the kernel started
-
-    MG_HD uint32_t next() {
-        uint32_t v;
-        if (used < MG_MT_HEAD) {
-            v = head[used * hstride];
-        } else {   // beyond the head: regenerate word `pos` and consume it at once (3 loads + 1 store)
-            const int i = pos;
-            const int i1 = (i + 1 == MG_MT_N) ? 0 : i + 1;
-            int im = i + 397;
-            if (im >= MG_MT_N) im -= MG_MT_N;
-            const uint32_t x = mt_twist(w[i], w[i1], w[im]);
-            w[i] = x;
-            pos = i1;
-            v = mt_temper(x);
-        }
-        used++;
-        return v;
-    }
-    // numpy legacy masked rejection (RandomState.randint with array bounds / shuffle's
-    // random_interval): smallest 2^k-1 >= max; redraw until (w & mask) <= max; max==0 draws nothing
-    MG_HD uint32_t bounded(uint32_t max) {
-        if (max == 0) return 0;
-        const uint32_t mask = 0xFFFFFFFFu >> __builtin_clz(max);
-        uint32_t v;
-        do { v = next() & mask; } while (v > max);
-        return v;
-    }
-};
 
 // Regenerate the next `cnt` (<= 8) words in place and return them tempered.  Every operand is read
 // before anything is written: word i+1 must be read in its OLD state (the loop form reads it before
@@ -121,13 +87,49 @@ MG_HD void mt_generate(uint32_t* w, int& pos, int cnt, uint32_t* out) {
     pos = p;
 }
 
-// After the env's last draw of the kernel: new head = x[C' .. C'+16) with C' = C + used — what is
-// left of the old head slides down, the rest is generated.  `head_out`: the env's 16 head words in
-// HBM (may be the array `mt.head` points at: the copy runs upwards, dst < src).
+struct Mt {
+    uint32_t* w;            // this env's 624 words (HBM)
+    int pos;                // next word to regenerate
+    uint32_t* head;         // head word i at head[i * hstride] (HBM: stride 1; LDS column: stride S)
+    int hstride;
+    int used;               // draws taken since the kernel started
+
+    // The head is consumed as a ring: draw number `used` is head[used % 16]; when a whole head has
+    // been consumed and more is needed (placements, resets) the next 16 outputs are generated into it
+    // in two batches of 8 — two memory round trips per 16 draws instead of one per draw.
+    MG_HD uint32_t next() {
+        const int r = used & (MG_MT_HEAD - 1);
+        if (r == 0 && used != 0) {
+#pragma unroll
+            for (int h = 0; h < MG_MT_HEAD; h += 8) {
+                uint32_t t[8];
+                mt_generate(w, pos, 8, t);
+#pragma unroll
+                for (int i = 0; i < 8; i++) head[(h + i) * hstride] = t[i];
+            }
+        }
+        used++;
+        return head[r * hstride];
+    }
+    // numpy legacy masked rejection (RandomState.randint with array bounds / shuffle's
+    // random_interval): smallest 2^k-1 >= max; redraw until (w & mask) <= max; max==0 draws nothing
+    MG_HD uint32_t bounded(uint32_t max) {
+        if (max == 0) return 0;
+        const uint32_t mask = 0xFFFFFFFFu >> __builtin_clz(max);
+        uint32_t v;
+        do { v = next() & mask; } while (v > max);
+        return v;
+    }
+};
+
+// After the env's last draw of the kernel: what is left of the current head slides down to the front,
+// the rest is generated, so that the head again holds the next 16 outputs.  `head_out`: the env's 16
+// head words in HBM (may be the array `mt.head` points at: the copy runs upwards, dst < src).
 MG_HD void mt_finish(Mt& mt, uint32_t* head_out) {
-    const int k = mt.used;
-    if (k == 0) return;
-    const int keep = k < MG_MT_HEAD ? MG_MT_HEAD - k : 0;
+    if (mt.used == 0) return;
+    const int r = mt.used & (MG_MT_HEAD - 1);
+    const int k = r ? r : MG_MT_HEAD;           // words consumed from the current head
+    const int keep = MG_MT_HEAD - k;
     for (int j = 0; j < keep; j++) head_out[j] = mt.head[(j + k) * mt.hstride];
     for (int j = keep; j < MG_MT_HEAD; j += 8) {
         const int cnt = (MG_MT_HEAD - j) < 8 ? (MG_MT_HEAD - j) : 8;

@@ -60,6 +60,8 @@ constexpr int kRenderShared = 3 * MG_MAX_OBJ + 2 * MG_MAX_AGENTS * 8;
 struct RenderScratch {
     int grid, rec, pres, first, second, vbase, vshow, trow, vis, tmap, dyn, out, total;
     int stage_envs;    // envs whose inputs (grid + agent records) are staged per batch: 1..8
+    int tmap_slots;    // tmaps a wave can hold at once (= stage_envs): the look-ahead depth of its env loop
+    int tmap_stride;   // bytes per tmap slot
     int rec_stride;    // u64 records per staged env
     int piece_rows;    // assemble-and-stream raster: pixel rows assembled in LDS per piece (0: chunk raster)
 };
@@ -78,7 +80,9 @@ __host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride,
     s.vshow = o; o += round_up(n * vs * vs, 16);
     s.trow = o;  o += round_up(n * vs * 4, 16);
     s.vis = o;   o += round_up(n * vs * 4, 16);
-    s.tmap = o;  o += round_up(n * vs * vs * 2, 16);
+    s.tmap_slots = stage_envs;
+    s.tmap_stride = round_up(n * vs * vs * 2, 16);
+    s.tmap = o;  o += s.tmap_slots * s.tmap_stride;
     s.dyn = o;   o += round_up(dyn_bytes, 16);   // per-env recoloured ('prestige') agent tiles
     s.out = o;   o += round_up(out_bytes, 16);   // assemble-and-stream raster: the piece being assembled
     s.piece_rows = piece_rows;

@@ -19,7 +19,8 @@
 //     multiple of 8: each chunk is assembled in registers from two 8-byte LDS look-ups
 //     atlas[tmap[cell] + row*TD + k].  Any other tile size: a few KiB of whole pixel rows at a time are
 //     first ASSEMBLED in an LDS piece buffer — one lane per (row, view column) segment copies its 3*TS
-//     bytes from the atlas tile row with unaligned 8-byte DS accesses — and then STREAMED out as linear
+//     bytes from the atlas tile row (aligned dwords cut with v_alignbyte, single bytes at the two ends:
+//     unaligned DS accesses are serialised on gfx950) — and then STREAMED out as linear
 //     ds_read_b128 -> aligned dwordx4 stores; the bytes of a chunk that straddles two pieces (or two
 //     envs of the wave's run) are carried over in the buffer, so everything but the first and last
 //     <16 bytes of a wave's whole run leaves as aligned 16-byte stores.
@@ -32,6 +33,46 @@
 #include "mg_occlude.h"
 
 namespace mg {
+
+// ---- one (pixel row, view column) segment of the assemble-and-stream raster ------------------------
+// SEG bytes from sb[sa ...] (any alignment) to d[0 ...] (any alignment; `dl` = d's LDS byte address) with
+// ALIGNED accesses only — an unaligned DS access is serialised lane by lane on gfx950 (measured: 15 x
+// slower).  The source is read as aligned dwords and cut with v_alignbyte: single bytes up to d's next
+// dword boundary, whole destination dwords, then the last 0..3 bytes.  All reads of a step are issued
+// before its writes (source and destination both live in LDS: the compiler cannot reorder them itself).
+// SEGC: SEG when the tile size is a compile-time constant (loops unroll), else 0.
+template <int SEGC>
+__device__ __forceinline__ void copy_segment(const uint8_t* __restrict__ sb, uint32_t sa, uint8_t* __restrict__ d,
+                                             uint32_t dl, uint32_t SEG) {
+    const uint32_t hd = min((4u - (dl & 3u)) & 3u, SEG);
+    const uint32_t s2 = sa + hd, nd = (SEG - hd) >> 2, tl = (SEG - hd) & 3u;
+    const uint32_t* W = reinterpret_cast<const uint32_t*>(sb + (sa & ~3u));
+    const uint32_t* A = reinterpret_cast<const uint32_t*>(sb + (s2 & ~3u));
+    uint32_t* D = reinterpret_cast<uint32_t*>(d + hd);
+    const uint32_t hv = hd ? __builtin_amdgcn_alignbyte(W[1], W[0], sa & 3u) : 0u;      // the 4 bytes at sa
+    constexpr int CH = SEGC ? (SEGC / 4 < 8 ? SEGC / 4 : 8) : 8;                          // interior dwords per step
+    uint32_t lo = A[0];
+    for (uint32_t i0 = 0; i0 < nd; i0 += CH) {
+        uint32_t w[CH + 1];
+        w[0] = lo;
+#pragma unroll
+        for (int i = 0; i < CH; i++) w[i + 1] = (i0 + i < nd) ? A[i0 + i + 1] : 0u;
+#pragma unroll
+        for (int i = 0; i < CH; i++)
+            if (i0 + i < nd) D[i0 + i] = __builtin_amdgcn_alignbyte(w[i + 1], w[i], s2 & 3u);
+        lo = w[CH];
+    }
+    if (hd > 0) d[0] = (uint8_t)hv;
+    if (hd > 1) d[1] = (uint8_t)(hv >> 8);
+    if (hd > 2) d[2] = (uint8_t)(hv >> 16);
+    if (tl) {
+        const uint32_t tv = __builtin_amdgcn_alignbyte(A[nd + 1], A[nd], s2 & 3u);        // the 4 bytes at s2 + 4*nd
+        uint8_t* t = d + hd + 4u * nd;
+        t[0] = (uint8_t)tv;
+        if (tl > 1) t[1] = (uint8_t)(tv >> 8);
+        if (tl > 2) t[2] = (uint8_t)(tv >> 16);
+    }
+}
 
 // ---- the kernel ----------------------------------------------------------------------------------
 // TS_ % 8 == 0: 16-byte-chunk fast raster (tile rows are an even number of dwords); VS_ > 0 also
@@ -47,7 +88,7 @@ template <int VS_, int TS_, int WPB, int V_ = 0, int RM_ = 0>
 __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState st, uint8_t* __restrict__ obs,
                                                         uint8_t* __restrict__ dbg_cells,
                                                         uint8_t* __restrict__ dbg_agent,
-                                                        uint8_t* __restrict__ dbg_vis) {
+                                                        uint8_t* __restrict__ dbg_vis, int depth_mode) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int VS = VS_ ? VS_ : cfg.view_size;
     const int TS = TS_ ? TS_ : cfg.tile_size;
@@ -99,7 +140,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     uint8_t* w_vshow = ws + L.vshow;
     uint32_t* w_trow = reinterpret_cast<uint32_t*>(ws + L.trow);
     uint32_t* w_vis = reinterpret_cast<uint32_t*>(ws + L.vis);
-    uint16_t* w_tmap = reinterpret_cast<uint16_t*>(ws + L.tmap);
+    uint16_t* w_tmap0 = reinterpret_cast<uint16_t*>(ws + L.tmap);   // [tmap_slots][n*VV]
     uint8_t* w_dyn = ws + L.dyn;                               // [n][4 orientations][tile_bytes]
     uint8_t* w_out = ws + L.out;                               // assemble-and-stream raster: [32 + piece_rows * 3 * P]
     const uint32_t dyn_off = (uint32_t)(w_dyn - smem);         // byte offset from the atlas base
@@ -141,6 +182,12 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
         out_base = a0 - head;
     }
 
+    // look-ahead depth of this wave (see the env loop): 1, 2, 4, 8 by wave; depth_mode > 0 (measurement
+    // builds) forces one depth for all.  Per-env recoloured tiles ('prestige') have one slot only.
+    int depth = depth_mode > 0 ? depth_mode : (1 << (wave & 3));
+    if (depth > L.tmap_slots) depth = L.tmap_slots;
+    if constexpr (kPrestige) depth = 1;
+
     for (int eb = e0; eb < e_end; eb += K) {
         const int kb = min(K, e_end - eb);
         {   // 0. stage the batch (contiguous in HBM): loads first, all in flight, then one wait
@@ -171,10 +218,18 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             if (r1i < nr) { const int j = r1i / n; w_stage_r[j * rec_stride + (r1i - j * n)] = rv1; if constexpr (kPrestige) w_stage_p[j * rec_stride + (r1i - j * n)] = pv1; }
         }
         wave_lds_sync();
-    for (int ej = 0; ej < kb; ej++) {
+    // `depth` envs at a time: first all their views (phases 1-5 -> one tmap slot each), then all their
+    // rasters.  Waves of a workgroup use different depths (1, 2, 4, 8): otherwise every wave of the chip —
+    // they all start together and do identical work — would sit in the store-free phases 1-5 at the same
+    // moments, env after env, and the HBM write stream would stall chip-wide each time.
+    for (int ej0 = 0; ej0 < kb; ej0 += depth)
+    for (int pass = 0; pass < 2; pass++)
+    for (int ej = ej0; ej < min(kb, ej0 + depth); ej++) {
         const int e = eb + ej;
         const uint8_t* w_grid = w_stage_g + (size_t)ej * cfg.cells_stride;
         const uint64_t* w_rec = w_stage_r + (size_t)ej * rec_stride;
+        uint16_t* w_tmap = w_tmap0 + (size_t)(ej - ej0) * (L.tmap_stride / 2);
+        if (pass == 0) {
         // 1. per-env scratch
         for (int i = lane; i < gdw; i += kWave) {
             reinterpret_cast<uint32_t*>(w_first)[i] = 0xFFFFFFFFu;
@@ -348,6 +403,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
         }
         }
         wave_lds_sync();
+        } else {
         // 6. raster: stream the env's n images out
         if constexpr (kChunkRaster) {
             // The env's n images are one contiguous run of 8-byte *pairs*: PR pairs per pixel row,
@@ -421,14 +477,13 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             // Any tile size: the env's n*P*P*3 output bytes are the next S bytes of the wave's stream;
             // tile rows are SEG = 3*TS bytes at arbitrary byte offsets.  Piece by piece (piece_rows whole
             // pixel rows, ~4 KiB): ASSEMBLE — segment g of the piece (pixel row g / VS, view column
-            // g % VS) is SEG contiguous bytes of one atlas tile row, copied by one lane with unaligned
-            // 8-byte accesses (the last one overlapping backwards) to w_out[carry + g*SEG]; then STREAM
+            // g % VS) is SEG contiguous bytes of one atlas tile row, copied by one lane to
+            // w_out[carry + g*SEG]; then STREAM
             // the complete 16-byte chunks of w_out (linear ds_read_b128 -> global_store_dwordx4) and move
             // the incomplete tail to the front, where the next piece — or the next env — continues.
             const uint32_t SEG = 3u * (uint32_t)TS, P = (uint32_t)(VS * TS), RB = P * 3u;
             const uint32_t NR = (uint32_t)n * P;                           // pixel rows per env
             const uint32_t mVS = 0xFFFFFFFFu / (uint32_t)VS + 1u, mTS = TS > 1 ? 0xFFFFFFFFu / (uint32_t)TS + 1u : 0u;
-            typedef uint64_t u64u __attribute__((aligned(1)));
             auto tile_off = [&](uint32_t vt) -> uint32_t {                 // virtual tile index -> byte offset
                 if constexpr (kSplit) return vt < NT4 ? vt * (uint32_t)tile_bytes : (kInLds | (dyn_off + (vt - NT4) * (uint32_t)tile_bytes));
                 else if constexpr (kPrestige) return vt < NT4 ? vt * (uint32_t)tile_bytes : dyn_off + (vt - NT4) * (uint32_t)tile_bytes;
@@ -442,17 +497,12 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                     const uint32_t band = TS > 1 ? __umulhi(R, mTS) : R, rr = R - band * (uint32_t)TS;
                     const uint32_t so = tile_off((uint32_t)w_tmap[band * (uint32_t)VS + col]) + rr * SEG;
                     uint8_t* d = dst0 + g * SEG;
-                    const uint8_t* src;
-                    if constexpr (kSplit) src = (so & kInLds) ? s_atlas + (so & ~kInLds) : cfg.atlas + so;
-                    else if constexpr (kGlobalAtlas) src = cfg.atlas + so;
-                    else src = s_atlas + so;
-                    if (SEG >= 8u) {
-                        uint32_t o = 0;
-                        for (; o + 8u <= SEG; o += 8u) *reinterpret_cast<u64u*>(d + o) = *reinterpret_cast<const u64u*>(src + o);
-                        if (o < SEG) *reinterpret_cast<u64u*>(d + SEG - 8u) = *reinterpret_cast<const u64u*>(src + SEG - 8u);
-                    } else {
-                        for (uint32_t o = 0; o < SEG; o++) d[o] = src[o];
-                    }
+                    const uint8_t* sb;       // source base the offset `sa` counts from
+                    uint32_t sa = so;
+                    if constexpr (kSplit) { sb = (so & kInLds) ? s_atlas : cfg.atlas; sa = so & ~kInLds; }
+                    else if constexpr (kGlobalAtlas) sb = cfg.atlas;
+                    else sb = s_atlas;
+                    copy_segment<TS_ * 3>(sb, sa, d, (uint32_t)(d - smem), SEG);
                 }
                 wave_lds_sync();
                 const uint32_t total = carry + rows * RB, full = total >> 4;
@@ -486,6 +536,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 if ((uint32_t)lane >= head && (uint32_t)lane < carry) reinterpret_cast<uint8_t*>(out_base)[lane] = w_out[lane];
             }
         }
+        }
         wave_lds_sync();   // scratch is reused by the next env
     }
     }
@@ -518,7 +569,12 @@ static hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_
     const int need = (cfg.B + WPB - 1) / WPB;   // workgroups if every wave took one env
     const int rounds = (need + max_blocks - 1) / max_blocks;
     const int blocks = (need + rounds - 1) / rounds;
-    hipLaunchKernelGGL((render_kernel<VS_, TS_, WPB, V_, RM_>), dim3(blocks), dim3(WPB * 64), lds, s, cfg, st, obs, c, a, v);
+    int depth_mode = 0;
+#if defined(MG_AB_VARIANTS)
+    if (const char* f = getenv("MG_RENDER_DEPTH")) depth_mode = atoi(f);   // 1: every wave view -> raster env by env
+#endif
+    hipLaunchKernelGGL((render_kernel<VS_, TS_, WPB, V_, RM_>), dim3(blocks), dim3(WPB * 64), lds, s, cfg, st, obs, c, a, v,
+                       depth_mode);
     return hipGetLastError();
 }
 
