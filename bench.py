@@ -120,12 +120,15 @@ def timed_blocks(step_fn, sync_fn, ctl, K, min_seconds, max_blocks, probe_ctl=No
 
 class Probes(object):
     """HIP events on the launch stream (torch's current stream IS the stream the C ABI launches on:
-    MultiGridEnv passes torch.cuda.current_stream().cuda_stream to every call)."""
+    MultiGridEnv passes torch.cuda.current_stream().cuda_stream to every call).  MultiGridEnv.step calls
+    the probe before its first launch (tag 0), between mg_step and mg_render_obs when it runs as two
+    launches (tag 1), and after its last launch (tag 2)."""
 
     def __init__(self, env, K):
         import torch
         self.env, self.K = env, K
-        self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * K)]
+        self.per_step = 2 if env.fused_step else 3
+        self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(self.per_step * K)]
         self.i = 0
         self.on = False
 
@@ -139,14 +142,16 @@ class Probes(object):
 
     def collect(self):
         self.on = False
-        K, ev = self.K, self.ev
-        assert self.i == 3 * K
-        step = [ev[3 * j].elapsed_time(ev[3 * j + 1]) for j in range(K)]
-        render = [ev[3 * j + 1].elapsed_time(ev[3 * j + 2]) for j in range(K)]
-        between = [ev[3 * j + 2].elapsed_time(ev[3 * j + 3]) for j in range(K - 1)]   # host gap between steps
-        span = ev[0].elapsed_time(ev[3 * K - 1])
-        return {"step_interval_ms": sum(step) / K, "render_interval_ms": sum(render) / K,
-                "between_steps_ms": sum(between) / max(1, K - 1), "gpu_span_ms_per_step": span / K}
+        K, ev, m = self.K, self.ev, self.per_step
+        assert self.i == m * K
+        between = [ev[m * j + m - 1].elapsed_time(ev[m * j + m]) for j in range(K - 1)]   # gap between steps
+        out = {"between_steps_ms": sum(between) / max(1, K - 1), "gpu_span_ms_per_step": ev[0].elapsed_time(ev[m * K - 1]) / K}
+        if m == 2:
+            out["step_render_interval_ms"] = sum(ev[2 * j].elapsed_time(ev[2 * j + 1]) for j in range(K)) / K
+        else:
+            out["step_interval_ms"] = sum(ev[3 * j].elapsed_time(ev[3 * j + 1]) for j in range(K)) / K
+            out["render_interval_ms"] = sum(ev[3 * j + 1].elapsed_time(ev[3 * j + 2]) for j in range(K)) / K
+        return out
 
 
 def summarise(blocks, K):
@@ -162,22 +167,25 @@ def summarise(blocks, K):
         ks = [b["kernels"] for b in inst]
         mean = lambda key: sum(k[key] for k in ks) / len(ks)      # noqa: E731
         kern = {key: mean(key) for key in ks[0]}
-        kern["render_interval_ms_first"] = ks[0]["render_interval_ms"]
-        kern["render_interval_ms_last"] = ks[-1]["render_interval_ms"]
-        kern["render_interval_ms_min"] = min(k["render_interval_ms"] for k in ks)
-        kern["render_interval_ms_max"] = max(k["render_interval_ms"] for k in ks)
+        dom = "step_render_interval_ms" if "step_render_interval_ms" in kern else "render_interval_ms"
+        kern["dominant"] = dom
+        kern[dom + "_first"] = ks[0][dom]
+        kern[dom + "_last"] = ks[-1][dom]
+        kern[dom + "_min"] = min(k[dom] for k in ks)
+        kern[dom + "_max"] = max(k[dom] for k in ks)
         out["kernels"] = kern
-        launches = kern["step_interval_ms"] + kern["render_interval_ms"] + kern["between_steps_ms"]
+        launches = sum(v for key, v in kern.items() if key in ("step_render_interval_ms", "step_interval_ms",
+                                                                 "render_interval_ms", "between_steps_ms"))
         out["closure"] = {
             "event_intervals_ms": launches,
             "vs_instrumented_ms_per_step": launches / out["instrumented"]["median"],
             "vs_ms_per_step": launches / out["plain"]["median"],
-            "note": "(mg_step + mg_render_obs + between-steps event intervals of the instrumented blocks) / "
-                    "host-timed ms_per_step of those blocks, and / the contract's ms_per_step"}
+            "note": "(launch + between-steps event intervals of the instrumented blocks) / host-timed "
+                    "ms_per_step of those blocks, and / the contract's ms_per_step"}
     return out
 
 
-def build_env(wl, B, dev, seeds):
+def build_env(wl, B, dev, seeds, fused=True):
     from marlgrid_amd.envs import make
     if wl == "Custom-8AgentCluttered30x30":     # BASELINE.json configs[4]; not a registered id upstream
         from marlgrid_amd.agents import GridAgentInterface
@@ -185,13 +193,13 @@ def build_env(wl, B, dev, seeds):
         cols = ["red", "blue", "purple", "orange", "olive", "pink", "cyan", "yellow"]
         return ClutteredMultiGrid(agents=[GridAgentInterface(color=c, view_size=9, view_tile_size=8) for c in cols],
                                   grid_size=30, clutter_density=0.15, batch_size=B, device=dev, seeds=seeds,
-                                  auto_reset=True, strict=False)
-    return make(wl, batch_size=B, device=dev, seeds=seeds, auto_reset=True, strict=False)
+                                  auto_reset=True, strict=False, fused_step=fused)
+    return make(wl, batch_size=B, device=dev, seeds=seeds, auto_reset=True, strict=False, fused_step=fused)
 
 
-def measure(wl, B, dev, ctl, seeds, K, Wm, min_seconds, max_blocks, action_seed):
+def measure(wl, B, dev, ctl, seeds, K, Wm, min_seconds, max_blocks, action_seed, fused=True):
     import torch
-    env = build_env(wl, B, dev, seeds)
+    env = build_env(wl, B, dev, seeds, fused)
     env.reset()
     n = env.num_agents
     g = torch.Generator(device="cpu").manual_seed(action_seed)
@@ -207,24 +215,40 @@ def measure(wl, B, dev, ctl, seeds, K, Wm, min_seconds, max_blocks, action_seed)
     return env, summarise(blocks, K), blocks
 
 
-def roofline_of(env, B, summary, traffic):
+def raster_only_ms(env, iters=50):
+    """the obs raster alone (mg_render_obs launched back to back on the launch stream, HIP events): what the
+    fused launch's raster part costs without the step in front of it"""
+    import ctypes as C
+    from marlgrid_amd import _native as N
+    ms = C.c_float(0)
+    N.check(env._lib.mg_time_render_obs(C.byref(env._cfg), C.byref(env._state), env.obs.data_ptr(), iters, C.byref(ms),
+                                        env._stream()))
+    return ms.value
+
+
+def roofline_of(env, B, summary, traffic, raster_ms=None):
     vs, ts, n = env.view_size, env.tile_size, env.num_agents
     P = vs * ts
     alg = P * P * 3 + vs * vs + 8 * n                    # SURVEY.md section 8(d): bytes per agent-step
     k = summary.get("kernels")
     if not k:
         return None
-    ms = k["render_interval_ms"]
+    dom = k["dominant"]
+    fused = dom == "step_render_interval_ms"
+    ms = k[dom]
     ach = B * n * alg / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "mg::render_kernel<%d, %d, %d, 0>" % (vs, ts, 16 if B >= 4096 else 4),
+    kname = "mg::render_kernel<%d, %d, %d, 0>" % (vs, ts, 16 if B >= 4096 else 4)
+    return {"bound": "hbm", "kernel": kname + (" launched by mg_step_render (the env step fused in front of the raster)"
+                                                  if fused else ""),
             "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-            "kernel_ms": ms, "kernel_ms_first": k["render_interval_ms_first"],
-            "kernel_ms_last": k["render_interval_ms_last"], "kernel_ms_min": k["render_interval_ms_min"],
-            "kernel_ms_max": k["render_interval_ms_max"],
-            "kernel_ms_source": "HIP events on the launch stream around every mg_render_obs of the instrumented "
-                                "K-step blocks (interval to the next launch: includes the dispatch gap)",
+            "kernel_ms": ms, "kernel_ms_first": k[dom + "_first"], "kernel_ms_last": k[dom + "_last"],
+            "kernel_ms_min": k[dom + "_min"], "kernel_ms_max": k[dom + "_max"],
+            "kernel_ms_source": "HIP events on the launch stream around every launch of the instrumented K-step "
+                                "blocks (interval to the next event: includes the dispatch gap)",
+            "raster_only_ms": raster_ms,
+            "raster_only_GBps": (B * n * alg / (raster_ms * 1e-3) / 1e9) if raster_ms else None,
             "algorithmic_bytes_per_agent_step": alg, "algorithmic_bytes_per_launch": B * n * alg,
-            "traffic": traffic.get("render", {}).get("hbm_bytes_per_launch") if traffic else None,
+            "traffic": traffic.get("step_render" if fused else "render", {}).get("hbm_bytes_per_launch") if traffic else None,
             "traffic_unit": "bytes per launch (PMC, this run: WRITE_SIZE + FETCH_SIZE, calibrated; see pmc)"}
 
 
@@ -240,6 +264,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic = null)")
     ap.add_argument("--no-strong", action="store_true", help="skip the 262 144-env single-GPU point")
+    ap.add_argument("--unfused", action="store_true",
+                    help="env.step() as two launches (mg_step, mg_render_obs) instead of one (mg_step_render): A/B only")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="ranks map to local_rank %% device_count and the control plane runs on gloo: the N > 1 code "
                          "path on a box with fewer GPUs than ranks (plumbing check, not a scaling number)")
@@ -295,8 +321,10 @@ def main():
     seeds = sharding.shard_seeds(1337, B * n_gpus, rank, n_gpus)
     assert len(seeds) == B
     clocks_before = smi.sample(dev_index) if rank == 0 else None
-    env, summary, blocks = measure(wl, B, dev, ctl, seeds, K, Wm, args.min_seconds, args.max_blocks, rank)
+    fused = not args.unfused
+    env, summary, blocks = measure(wl, B, dev, ctl, seeds, K, Wm, args.min_seconds, args.max_blocks, rank, fused)
     clocks_after = smi.sample(dev_index) if rank == 0 else None
+    raster_ms = raster_only_ms(env) if rank == 0 else None
     n, vs, ts = env.num_agents, env.view_size, env.tile_size
     P = vs * ts
 
@@ -314,7 +342,9 @@ def main():
             "config": {"workload": wl, "batch_per_gpu": B, "global_batch": B * n_gpus, "n_agents": n,
                        "view_size": vs, "tile_size": ts, "obs_shape": [B * n_gpus, n, P, P, 3],
                        "actions": "uniform over 7 ids, torch.randint seed=rank", "auto_reset": True,
-                       "launches_per_step": ["mg_step (+ fused reset of finished episodes)", "mg_render_obs"],
+                       "launches_per_step": (["mg_step_render (action loop + reset of finished episodes + obs raster)"]
+                                             if fused else ["mg_step (+ fused reset of finished episodes)",
+                                                            "mg_render_obs"]),
                        "sharding": "env batch split contiguously, no collectives"},
             "timing": {"what": "median of K-step blocks, each bracketed by barrier + synchronize, MAX over ranks",
                        "blocks": summary["plain"], "seconds_timed": summary["seconds_timed"],
@@ -339,20 +369,21 @@ def main():
         # roofline needs the env's geometry only
         class _Geo(object):
             view_size, tile_size, num_agents = vs, ts, n
-        out["roofline"] = roofline_of(_Geo, B, summary, traffic)
+        out["roofline"] = roofline_of(_Geo, B, summary, traffic, raster_ms)
         out["pmc"] = traffic
 
     # strong-scaling N = 1 point: BASELINE.json's whole headline batch on one GPU
     if n_gpus == 1 and not args.no_strong and wl == WORKLOAD:
         Bs = 262144
         seeds_s = sharding.shard_seeds(1337, Bs, 0, 1)
-        env_s, sum_s, _ = measure(wl, Bs, dev, ctl, seeds_s, K, min(Wm, 5), min(args.min_seconds, 1.0), 400, 0)
+        env_s, sum_s, _ = measure(wl, Bs, dev, ctl, seeds_s, K, min(Wm, 5), min(args.min_seconds, 1.0), 400, 0, fused)
+        raster_s = raster_only_ms(env_s, 10)
         ms_s = sum_s["plain"]["median"]
         out.setdefault("extra", {})["strong_n1"] = {
             "what": "the full headline batch (262 144 envs) on ONE GPU: the N = 1 point of a strong-scaling curve",
             "value": Bs * n / (ms_s * 1e-3), "unit": "agent-steps/s", "ms_per_step": ms_s,
             "global_batch": Bs, "timing": sum_s["plain"], "kernels": sum_s.get("kernels"),
-            "closure": sum_s.get("closure"), "roofline": roofline_of(env_s, Bs, sum_s, None)}
+            "closure": sum_s.get("closure"), "roofline": roofline_of(env_s, Bs, sum_s, None, raster_s)}
         del env_s
         torch.cuda.empty_cache()
 

@@ -13,6 +13,7 @@
  *                                        envs/cluttered.py:25-36, envs/goalcycle.py:30-51)
  *   mg_step         MultiGridEnv.step action loop, rewards, done  (base.py:501-649); with a reset
  *                   program also the reset() of every env whose episode just ended (auto-reset)
+ *   mg_step_render  the two above + mg_render_obs in one launch: the whole MultiGridEnv.step (base.py:501-653)
  *   mg_render_obs   MultiGridEnv.gen_obs / gen_agent_obs / gen_obs_grid, MultiGrid.slice,
  *                   MultiGrid.opacity, GridAgentInterface.process_vis / occlude_mask,
  *                   MultiGrid.render / render_tile / blend_tiles
@@ -189,6 +190,13 @@ int32_t mg_reset(const MgConfig* cfg, const MgState* st, const MgGenProgram* pro
  * (done[b] keeps reporting the end; step_count[b] = 0 afterwards). */
 int32_t mg_step(const MgConfig* cfg, const MgState* st, const void* actions, int32_t action_bytes,
                 float* rewards, const MgGenProgram* auto_reset, void* stream);
+
+/* MultiGridEnv.step as ONE launch: mg_step (arguments as above) and mg_render_obs fused — the wave that
+ * renders an env steps it first (one lane per env), so the whole base.py:501-653 step is a single kernel and
+ * nothing separates the action loop from the observation raster.  Results are identical to mg_step
+ * followed by mg_render_obs. */
+int32_t mg_step_render(const MgConfig* cfg, const MgState* st, const void* actions, int32_t action_bytes,
+                       float* rewards, const MgGenProgram* auto_reset, uint8_t* obs, void* stream);
 
 /* obs: device uint8 [B][n][P][P][3].  Optional debug outputs (NULL to skip):
  * view_cells uint8 [B][n][vs][vs] (object id of the rotated sub-grid, index [i][j]),

@@ -68,7 +68,8 @@ class GenProgram(C.Structure):
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmarlgrid_hip.so")
 
 # every symbol include/marlgrid_hip.h declares
-SYMBOLS = ["mg_abi_version", "mg_build_info", "mg_error_string", "mg_mt_seed", "mg_reset", "mg_step", "mg_render_obs",
+SYMBOLS = ["mg_abi_version", "mg_build_info", "mg_error_string", "mg_mt_seed", "mg_reset", "mg_step", "mg_step_render",
+           "mg_render_obs",
            "mg_encode", "mg_put_obj", "mg_place", "mg_render_frame", "mg_time_render_obs",
            "mg_render_obs_lds_bytes"]
 
@@ -106,6 +107,7 @@ def lib():
     L.mg_mt_seed.argtypes = [i32, vp, vp, vp, vp, vp, vp]
     L.mg_reset.argtypes = [C.POINTER(Config), C.POINTER(State), C.POINTER(GenProgram), vp, vp]
     L.mg_step.argtypes = [C.POINTER(Config), C.POINTER(State), vp, i32, vp, C.POINTER(GenProgram), vp]
+    L.mg_step_render.argtypes = [C.POINTER(Config), C.POINTER(State), vp, i32, vp, C.POINTER(GenProgram), vp, vp]
     L.mg_render_obs.argtypes = [C.POINTER(Config), C.POINTER(State), vp, vp, vp, vp, vp]
     L.mg_encode.argtypes = [C.POINTER(Config), C.POINTER(State), vp, vp, vp]
     L.mg_put_obj.argtypes = [C.POINTER(Config), C.POINTER(State), i32, i32, i32, vp, vp]

@@ -239,7 +239,7 @@ class MultiGridEnv(object):
     def __init__(self, agents=[], grid_size=None, width=None, height=None, max_steps=100,
                  reward_decay=True, seed=1337, respawn=False, ghost_mode=True, agent_spawn_kwargs={},
                  batch_size=1, device=None, seeds=None, auto_reset=False, strict=True, obs_buffers=2,
-                 _dry=False):
+                 fused_step=True, _dry=False):
         if grid_size is not None:
             assert width is None and height is None
             width, height = grid_size, grid_size
@@ -254,6 +254,7 @@ class MultiGridEnv(object):
         self.auto_reset = bool(auto_reset)
         self.strict = bool(strict)
         self.obs_buffers = max(1, int(obs_buffers))
+        self.fused_step = bool(fused_step)     # step() = one launch (mg_step_render) instead of mg_step + mg_render_obs
         self._dry = bool(_dry)
         if self.batch_size < 1:
             raise ValueError("batch_size must be >= 1")
@@ -738,14 +739,21 @@ class MultiGridEnv(object):
         probe = self._probe          # bench.py: records an event on the launch stream around each launch
         if probe is not None:
             probe(0)
-        N.check(self._lib.mg_step(C.byref(self._cfg), C.byref(self._state), actions.data_ptr(),
-                                  actions.element_size(), self.rewards.data_ptr(), prog, stream))
-        if probe is not None:
-            probe(1)
         # obs / rewards / done are views of the current buffer set (see `obs_buffers`)
         done = self.done_b
-        N.check(self._lib.mg_render_obs(C.byref(self._cfg), C.byref(self._state), self.obs.data_ptr(), None, None,
-                                        None, stream))
+        if self.fused_step:
+            # the whole step — action loop, reset of finished episodes, observation raster — is ONE launch:
+            # the wave that renders an env steps it first
+            N.check(self._lib.mg_step_render(C.byref(self._cfg), C.byref(self._state), actions.data_ptr(),
+                                             actions.element_size(), self.rewards.data_ptr(), prog,
+                                             self.obs.data_ptr(), stream))
+        else:
+            N.check(self._lib.mg_step(C.byref(self._cfg), C.byref(self._state), actions.data_ptr(),
+                                      actions.element_size(), self.rewards.data_ptr(), prog, stream))
+            if probe is not None:
+                probe(1)
+            N.check(self._lib.mg_render_obs(C.byref(self._cfg), C.byref(self._state), self.obs.data_ptr(), None,
+                                            None, None, stream))
         if probe is not None:
             probe(2)
         if self.strict:

@@ -116,6 +116,24 @@ int32_t mg_render_obs(const MgConfig* cfg, const MgState* st, uint8_t* obs, uint
     return rc(mg::launch_render(*cfg, *st, obs, view_cells, view_agent, vis_mask, (hipStream_t)stream));
 }
 
+int32_t mg_step_render(const MgConfig* cfg, const MgState* st, const void* actions, int32_t action_bytes, float* rewards,
+                       const MgGenProgram* auto_reset, uint8_t* obs, void* stream) {
+    int e = check_both(cfg, st);
+    if (e) return e;
+    if (!actions || !rewards || !obs) return MG_E_ARG;
+    if (action_bytes != 1 && action_bytes != 4 && action_bytes != 8) return MG_E_ARG;
+    if (auto_reset && (e = check_prog(cfg, auto_reset))) return e;
+    mg::FusedStep fs;
+    fs.actions = actions;
+    fs.rewards = rewards;
+    fs.action_bytes = action_bytes;
+    fs.enabled = 1;
+    fs.has_prog = auto_reset ? 1 : 0;
+    if (auto_reset) fs.prog = *auto_reset;
+    else { fs.prog.template_grid = nullptr; fs.prog.n_ops = 0; }
+    return rc(mg::launch_render(*cfg, *st, obs, nullptr, nullptr, nullptr, (hipStream_t)stream, &fs));
+}
+
 int32_t mg_encode(const MgConfig* cfg, const MgState* st, const uint8_t* vis_mask, uint8_t* out, void* stream) {
     int e = check_cfg(cfg);
     if (e) return e;

@@ -298,13 +298,17 @@ struct StepScratch {        // per-workgroup arrays, this env is column `col`, e
 };
 struct StepEnv { int pos0, sc0; };
 
-// round trip 1: everything whose address is known up front, all of it contiguous across the batch
-template <typename ActT>
-MG_HD StepEnv step_load(const MgConfig& cfg, const MgState& st, const ActT* actions, int b, const StepScratch& sc) {
+// round trip 1: everything whose address is known up front, all of it contiguous across the batch.
+// actions: [B][n] little-endian integers of `action_bytes` (1, 4 or 8) bytes each.
+MG_HD StepEnv step_load(const MgConfig& cfg, const MgState& st, const void* actions, int action_bytes, int b,
+                        const StepScratch& sc) {
     const int n = cfg.n_agents, S = sc.S, col = sc.col;
     for (int k = 0; k < n; k++) sc.rec[k * S + col] = st.agents[(size_t)b * n + k];
     for (int k = 0; k < n; k++) {
-        const long long a = (long long)actions[(size_t)b * n + k];
+        const size_t i = (size_t)b * n + k;
+        const long long a = action_bytes == 8 ? (long long)static_cast<const int64_t*>(actions)[i]
+                          : action_bytes == 4 ? (long long)static_cast<const int32_t*>(actions)[i]
+                                              : (long long)static_cast<const uint8_t*>(actions)[i];
         sc.act[k * S + col] = (a >= 0 && a <= 6) ? (uint8_t)a : (uint8_t)0xFF;
     }
     for (int i = 0; i < MG_MT_HEAD; i++) sc.head[i * S + col] = st.mt_head[(size_t)b * MG_MT_HEAD + i];

@@ -53,12 +53,20 @@ __device__ inline void prestige_pixel(uint32_t alpha, const PrestigeColor& col, 
     out[0] = (uint8_t)v[0]; out[1] = (uint8_t)v[1]; out[2] = (uint8_t)v[2];
 }
 
+// What mg_step_render adds to a launch of the obs kernel: the wave that renders an env first steps it.
+struct FusedStep {
+    const void* actions;      // [B][n], action_bytes each
+    float* rewards;           // [B][n]
+    int32_t action_bytes, enabled, has_prog;
+    MgGenProgram prog;        // auto-reset program (has_prog)
+};
+
 // block-shared LDS of the obs-render kernel after the atlas: object flags, overlap slots, hide masks, prestige scales, flags2
-constexpr int kRenderShared = 3 * MG_MAX_OBJ + 2 * MG_MAX_AGENTS * 8;
+constexpr int kRenderShared = 3 * MG_MAX_OBJ + 2 * MG_MAX_AGENTS * 8 + MG_MAX_OBJ * 32;   // ... + the object table (fused step)
 
 // per-wave LDS scratch of the obs-render kernel (bytes), shared by host launch code and kernel
 struct RenderScratch {
-    int grid, rec, pres, first, second, vbase, vshow, trow, vis, tmap, dyn, out, total;
+    int grid, rec, pres, first, second, vbase, vshow, trow, vis, tmap, dyn, out, step, total;
     int stage_envs;    // envs whose inputs (grid + agent records) are staged per batch: 1..8
     int tmap_slots;    // tmaps a wave can hold at once (= stage_envs): the look-ahead depth of its env loop
     int tmap_stride;   // bytes per tmap slot
@@ -86,6 +94,8 @@ __host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride,
     s.dyn = o;   o += round_up(dyn_bytes, 16);   // per-env recoloured ('prestige') agent tiles
     s.out = o;   o += round_up(out_bytes, 16);   // assemble-and-stream raster: the piece being assembled
     s.piece_rows = piece_rows;
+    // fused step (mg_step_render): lane j < stage_envs steps staged env j; its [item][8] columns
+    s.step = o;  o += round_up(n * 8 * 8 + MG_MT_HEAD * 8 * 4 + 3 * n * 8, 16);
     s.total = o;
     return s;
 }

@@ -11,8 +11,9 @@ hipError_t launch_reset(const MgConfig& cfg, const MgState& st, const MgGenProgr
                         hipStream_t s);
 hipError_t launch_step(const MgConfig& cfg, const MgState& st, const void* actions, int action_bytes,
                        float* rewards, const MgGenProgram* auto_reset, hipStream_t s);
+struct FusedStep;
 hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, uint8_t* view_cells,
-                         uint8_t* view_agent, uint8_t* vis_mask, hipStream_t s);
+                         uint8_t* view_agent, uint8_t* vis_mask, hipStream_t s, const FusedStep* fused_step = nullptr);
 int render_min_lds_bytes(const MgConfig& cfg);
 hipError_t launch_encode(const MgConfig& cfg, const MgState& st, const uint8_t* vis_mask, uint8_t* out,
                          hipStream_t s);

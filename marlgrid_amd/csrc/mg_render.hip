@@ -74,6 +74,31 @@ __device__ __forceinline__ void copy_segment(const uint8_t* __restrict__ sb, uin
     }
 }
 
+// ---- mg_step_render: the step of a batch of staged envs, lane j < kb steps env eb + j (mg_core.h) ----
+// The step's memory round trips happen once per wave and batch, before the wave's first store of the batch.
+// (Inlined: as a call, the by-value launch structs would be copied to per-lane scratch.  The 16-wave
+// workgroups run at the 128-VGPR limit; the few dwords the step's live ranges spill are spilled and
+// reloaded around this region, once per batch — checked in the ISA: no scratch access in the raster loops.)
+__device__ __forceinline__ void fused_step_batch(const MgConfig& cfg, const MgState& st, const FusedStep& fs,
+                                                           int eb, int kb, int lane, uint8_t* sp, const MgObjDesc* s_obj,
+                                                           const uint8_t* s_oflags) {
+    const int n = cfg.n_agents;
+    StepScratch sc;
+    sc.rec = reinterpret_cast<uint64_t*>(sp);                                   // [n][8]
+    sc.head = reinterpret_cast<uint32_t*>(sp + n * 8 * 8);                      // [MG_MT_HEAD][8]
+    sc.order = sp + n * 8 * 8 + MG_MT_HEAD * 8 * 4;                             // [n][8]
+    sc.act = sc.order + n * 8;
+    sc.fb = sc.act + n * 8;
+    sc.obj = s_obj;
+    sc.oflags = s_oflags;
+    sc.S = 8;
+    sc.col = lane;
+    if (lane < kb) {
+        const StepEnv se = step_load(cfg, st, fs.actions, fs.action_bytes, eb + lane, sc);
+        step_run(cfg, st, fs.prog, fs.has_prog != 0, fs.rewards, eb + lane, se, sc);
+    }
+}
+
 // ---- the kernel ----------------------------------------------------------------------------------
 // TS_ % 8 == 0: 16-byte-chunk fast raster (tile rows are an even number of dwords); VS_ > 0 also
 //              fixes the view size at compile time (the shipped view sizes), VS_ == 0 reads it from cfg.
@@ -88,13 +113,15 @@ template <int VS_, int TS_, int WPB, int V_ = 0, int RM_ = 0>
 __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState st, uint8_t* __restrict__ obs,
                                                         uint8_t* __restrict__ dbg_cells,
                                                         uint8_t* __restrict__ dbg_agent,
-                                                        uint8_t* __restrict__ dbg_vis, int depth_mode) {
+                                                        uint8_t* __restrict__ dbg_vis, int depth_mode, FusedStep fs) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int VS = VS_ ? VS_ : cfg.view_size;
     const int TS = TS_ ? TS_ : cfg.tile_size;
     const int n = cfg.n_agents, W = cfg.W, H = cfg.H;
     const int tile_bytes = TS * TS * 3;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the wave index is uniform: told to the compiler, everything derived from it (the wave's scratch
+    // pointers, its run of envs, loop bounds) lives in SGPRs instead of one VGPR each
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int VV = VS * VS;
 
     // ---- block-shared: atlas + object flags ----
@@ -111,6 +138,12 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     uint64_t* s_hide = reinterpret_cast<uint64_t*>(s_oslot + MG_MAX_OBJ);   // [MG_MAX_AGENTS] hide_obj_mask
     double* s_pscale = reinterpret_cast<double*>(s_hide + MG_MAX_AGENTS);     // [MG_MAX_AGENTS] prestige_scale
     uint8_t* s_oflags2 = reinterpret_cast<uint8_t*>(s_pscale + MG_MAX_AGENTS); // [MG_MAX_OBJ]
+    MgObjDesc* s_obj = reinterpret_cast<MgObjDesc*>(s_oflags2 + MG_MAX_OBJ);      // [MG_MAX_OBJ] (fused step only)
+    if (fs.enabled) {
+        const uint4* src = reinterpret_cast<const uint4*>(cfg.obj);
+        uint4* dst = reinterpret_cast<uint4*>(s_obj);
+        for (int i = tid; i < cfg.n_obj * 2; i += WPB * 64) dst[i] = src[i];
+    }
     {
         const uint4* src = reinterpret_cast<const uint4*>(cfg.atlas);
         uint4* dst = reinterpret_cast<uint4*>(s_atlas);
@@ -190,6 +223,13 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
 
     for (int eb = e0; eb < e_end; eb += K) {
         const int kb = min(K, e_end - eb);
+        if (fs.enabled) {
+            // mg_step_render: MultiGridEnv.step for the batch's envs, one lane per env, before they are
+            // staged and rendered — the whole env.step() is this one launch.
+            fused_step_batch(cfg, st, fs, eb, kb, lane, ws + L.step, s_obj, s_oflags);
+            // the staging loads below read what these lanes just stored (same wave, same L1: in order)
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        }
         {   // 0. stage the batch (contiguous in HBM): loads first, all in flight, then one wait
             const uint32_t* gsrc = reinterpret_cast<const uint32_t*>(st.grid + (size_t)eb * cfg.cells_stride);
             const uint64_t* rsrc = st.agents + (size_t)eb * n;
@@ -544,7 +584,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
 
 template <int VS_, int TS_, int WPB, int V_ = 0, int RM_ = 0>
 static hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_t* obs, uint8_t* c, uint8_t* a,
-                                  uint8_t* v, hipStream_t s) {
+                                  uint8_t* v, hipStream_t s, const FusedStep* fs) {
     const int tile_bytes = cfg.tile_size * cfg.tile_size * 3;
     static_assert(RM_ == 1 || TS_ == 0 || (TS_ % 8) != 0 || TS_ == 8 || TS_ == 16 || TS_ == 32, "see render_chunk_raster");
     const RenderScratch L = render_scratch_for(cfg, WPB, RM_);
@@ -574,7 +614,7 @@ static hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_
     if (const char* f = getenv("MG_RENDER_DEPTH")) depth_mode = atoi(f);   // 1: every wave view -> raster env by env
 #endif
     hipLaunchKernelGGL((render_kernel<VS_, TS_, WPB, V_, RM_>), dim3(blocks), dim3(WPB * 64), lds, s, cfg, st, obs, c, a, v,
-                       depth_mode);
+                       depth_mode, *fs);
     return hipGetLastError();
 }
 
@@ -600,19 +640,28 @@ static int choose_wpb(const MgConfig& cfg) {
 }
 
 #define MG_RENDER_DISPATCH(VS, TS, V)                                                                      \
-    (wpb == 16 ? launch_render_t<VS, TS, 16, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s)           \
-               : launch_render_t<VS, TS, 4, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s))
+    (wpb == 16 ? launch_render_t<VS, TS, 16, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)           \
+               : launch_render_t<VS, TS, 4, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs))
 // run-time view size: its MG_MAX_VIEW-entry shadow-cast arrays need more than the 128 VGPRs a 16-wave
 // workgroup leaves per lane (spills would be VMEM traffic in the middle of the run): 8-wave workgroups
 #define MG_RENDER_DISPATCH_RT(TS, V)                                                                       \
-    (wpb == 16 ? launch_render_t<0, TS, 8, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s)             \
-               : launch_render_t<0, TS, 4, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s))
+    (wpb == 16 ? launch_render_t<0, TS, 8, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)             \
+               : launch_render_t<0, TS, 4, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs))
 #define MG_RENDER_DISPATCH8(VS, TS, V)                                                                     \
-    (wpb == 8 ? launch_render_t<VS, TS, 8, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s) : MG_RENDER_DISPATCH(VS, TS, V))
+    (wpb == 8 ? launch_render_t<VS, TS, 8, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs) : MG_RENDER_DISPATCH(VS, TS, V))
 
 hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, uint8_t* view_cells,
-                         uint8_t* view_agent, uint8_t* vis_mask, hipStream_t s) {
+                         uint8_t* view_agent, uint8_t* vis_mask, hipStream_t s, const FusedStep* fs) {
     if (cfg.B <= 0) return hipSuccess;
+    FusedStep none;
+    none.enabled = 0;
+    none.has_prog = 0;
+    none.actions = nullptr;
+    none.rewards = nullptr;
+    none.action_bytes = 8;
+    none.prog.template_grid = nullptr;
+    none.prog.n_ops = 0;
+    if (!fs) fs = &none;
     if ((view_cells || view_agent || vis_mask) && !(view_cells && view_agent && vis_mask)) return hipErrorInvalidValue;
     const int vs = cfg.view_size, ts = cfg.tile_size;
     const int wpb = choose_wpb(cfg);
@@ -621,27 +670,33 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
         const size_t lds4 = (size_t)round_up(4 * cfg.n_tiles * ts * ts * 3, 16) + kRenderShared +
                             4 * (size_t)L.total;
         if (lds4 > 160 * 1024) {   // the static atlas stays in global memory
-            if (ts == 8) return launch_render_t<0, 8, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
-            if (ts == 16) return launch_render_t<0, 16, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
-            if (ts == 32) return launch_render_t<0, 32, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
-            return launch_render_t<0, 0, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
+            if (ts == 8) return launch_render_t<0, 8, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
+            if (ts == 16) return launch_render_t<0, 16, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
+            if (ts == 32) return launch_render_t<0, 32, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
+            return launch_render_t<0, 0, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
         }
-        if (vs == 7 && ts == 8) return MG_RENDER_DISPATCH(7, 8, 9);     // the shipped view: compile-time size,
-        if (vs == 7 && (ts % 8) != 0) return MG_RENDER_DISPATCH(7, 0, 9);   // 16-wave workgroups when they fit
-        if (ts == 8) return launch_render_t<0, 8, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
-        if (ts == 16) return launch_render_t<0, 16, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
-        if (ts == 32) return launch_render_t<0, 32, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
-        return launch_render_t<0, 0, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
+        // the shipped view: compile-time size; 8-wave workgroups when they fit (the recolouring code needs
+        // more than the 128 VGPRs a 16-wave workgroup leaves per lane)
+        if (vs == 7 && ts == 8)
+            return wpb == 16 ? launch_render_t<7, 8, 8, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)
+                             : launch_render_t<7, 8, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
+        if (vs == 7 && (ts % 8) != 0)
+            return wpb == 16 ? launch_render_t<7, 0, 8, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)
+                             : launch_render_t<7, 0, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
+        if (ts == 8) return launch_render_t<0, 8, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
+        if (ts == 16) return launch_render_t<0, 16, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
+        if (ts == 32) return launch_render_t<0, 32, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
+        return launch_render_t<0, 0, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
     }
     {   // atlas too large for LDS (next to 4 waves of scratch): read it from global memory instead
         const RenderScratch L = render_scratch_for(cfg, 4);
         const size_t lds4 = (size_t)round_up(4 * cfg.n_tiles * ts * ts * 3, 16) + kRenderShared +
                             4 * (size_t)L.total;
         if (lds4 > 160 * 1024) {
-            if (ts == 8) return launch_render_t<0, 8, 4, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
-            if (ts == 16) return launch_render_t<0, 16, 4, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
-            if (ts == 32) return launch_render_t<0, 32, 4, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
-            return launch_render_t<0, 0, 4, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
+            if (ts == 8) return launch_render_t<0, 8, 4, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
+            if (ts == 16) return launch_render_t<0, 16, 4, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
+            if (ts == 32) return launch_render_t<0, 32, 4, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
+            return launch_render_t<0, 0, 4, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
         }
     }
     if (ts == 8 && vs == 7) {
@@ -655,8 +710,8 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
         default: break;
         }
         if (getenv("MG_RENDER_RASTER") && atoi(getenv("MG_RENDER_RASTER")) == 1)   // assemble-and-stream at tile 8
-            return wpb == 16 ? launch_render_t<7, 8, 16, 0, 1>(cfg, st, obs, view_cells, view_agent, vis_mask, s)
-                             : launch_render_t<7, 8, 4, 0, 1>(cfg, st, obs, view_cells, view_agent, vis_mask, s);
+            return wpb == 16 ? launch_render_t<7, 8, 16, 0, 1>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)
+                             : launch_render_t<7, 8, 4, 0, 1>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
 #endif
         return MG_RENDER_DISPATCH8(7, 8, 0);
     }

@@ -23,9 +23,10 @@
 
 namespace mg {
 
-template <typename ActT, int BS>
+template <int BS>
 __global__ __launch_bounds__(BS) void step_kernel(MgConfig cfg, MgState st, MgGenProgram prog, int has_prog,
-                                                  const ActT* __restrict__ actions, float* __restrict__ rewards) {
+                                                  const void* __restrict__ actions, int action_bytes,
+                                                  float* __restrict__ rewards) {
     extern __shared__ __attribute__((aligned(16))) uint64_t s_mem[];
     const int n = cfg.n_agents;
     StepScratch sc;
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(BS) void step_kernel(MgConfig cfg, MgState st, MgGe
         for (int i = tid; i < MG_MAX_OBJ; i += BS) s_oflags[i] = (i > 0 && i < cfg.n_obj) ? cfg.obj[i].flags : 0;
     }
     StepEnv env{0, 0};
-    if (live) env = step_load(cfg, st, actions, b, sc);
+    if (live) env = step_load(cfg, st, actions, action_bytes, b, sc);
     __syncthreads();
     if (!live) return;
     step_run(cfg, st, prog, has_prog != 0, rewards, b, env, sc);
@@ -69,14 +70,8 @@ static hipError_t launch_step_bs(const MgConfig& cfg, const MgState& st, const v
     none.n_ops = 0;
     const MgGenProgram& p = prog ? *prog : none;
     const int has = prog ? 1 : 0;
-    if (action_bytes == 8)
-        hipLaunchKernelGGL((step_kernel<int64_t, BS>), grid, block, lds, s, cfg, st, p, has, (const int64_t*)actions, rewards);
-    else if (action_bytes == 4)
-        hipLaunchKernelGGL((step_kernel<int32_t, BS>), grid, block, lds, s, cfg, st, p, has, (const int32_t*)actions, rewards);
-    else if (action_bytes == 1)
-        hipLaunchKernelGGL((step_kernel<uint8_t, BS>), grid, block, lds, s, cfg, st, p, has, (const uint8_t*)actions, rewards);
-    else
-        return hipErrorInvalidValue;
+    if (action_bytes != 1 && action_bytes != 4 && action_bytes != 8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((step_kernel<BS>), grid, block, lds, s, cfg, st, p, has, actions, action_bytes, rewards);
     return hipGetLastError();
 }
 

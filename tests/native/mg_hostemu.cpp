@@ -51,11 +51,8 @@ int emu_step(const MgConfig* cfg, const MgState* st, const void* actions, int ac
     memset(&none, 0, sizeof(none));
     const MgGenProgram& prog = auto_reset ? *auto_reset : none;
     for (int b = 0; b < cfg->B; b++) {
-        mg::StepEnv e;
-        if (action_bytes == 8) e = mg::step_load(*cfg, *st, (const int64_t*)actions, b, s.sc);
-        else if (action_bytes == 4) e = mg::step_load(*cfg, *st, (const int32_t*)actions, b, s.sc);
-        else if (action_bytes == 1) e = mg::step_load(*cfg, *st, (const uint8_t*)actions, b, s.sc);
-        else return -100;
+        if (action_bytes != 1 && action_bytes != 4 && action_bytes != 8) return -100;
+        const mg::StepEnv e = mg::step_load(*cfg, *st, actions, action_bytes, b, s.sc);
         mg::step_run(*cfg, *st, prog, auto_reset != nullptr, rewards, b, e, s.sc);
     }
     return 0;

@@ -778,3 +778,43 @@ def test_settings_are_read_every_step():
     assert d.all()
     with pytest.raises(IndexError):
         env.render(env_ids=[0, 32])
+
+
+@pytest.mark.parametrize("name,B,T", [("MarlGrid-3AgentCluttered15x15-v0", 4100, 130),
+                                       ("MarlGrid-3AgentCluttered11x11-v0", 37, 120),
+                                       ("Test-3AgentCluttered9x9-respawn", 300, 120),
+                                       ("Test-3AgentEmpty7x7-spawn-delay", 64, 60),
+                                       ("Test-3AgentSpawnRect9x9", 129, 90),
+                                       ("Test-3AgentCluttered9x9-prestige-mixed", 5000, 60),
+                                       ("Edge-3AgentCluttered15x15-default-tiles", 4099, 40),
+                                       ("Custom-8AgentCluttered30x30", 64, 40),
+                                       ("Edge-16AgentEmpty6x6-view7", 40, 30)])
+def test_fused_step_equals_two_launches(name, B, T):
+    """mg_step_render (the env step fused in front of the raster: one launch) == mg_step then mg_render_obs,
+    every step: observations, rewards, done, state, RNG — with auto-reset on, so resets run in both forms"""
+    import torch
+    seeds = 31000 + np.arange(B)
+    e1 = product_envs.build(name, batch_size=B, seeds=seeds, auto_reset=True, fused_step=True)
+    e2 = product_envs.build(name, batch_size=B, seeds=seeds, auto_reset=True, fused_step=False)
+    assert torch.equal(e1.reset(), e2.reset())
+    rng = np.random.RandomState(4)
+    n = e1.num_agents
+    for t in range(T):
+        a = torch.from_numpy(rng.randint(0, 7, size=(B, n)))
+        o1, r1, d1, _ = e1.step(a)
+        o2, r2, d2, _ = e2.step(a)
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2), t
+    for k in ("grid_state", "agent_state", "mt_state", "mt_pos", "mt_head", "step_count_t", "error_t"):
+        assert torch.equal(getattr(e1, k), getattr(e2, k)), k
+    orc = O.OracleBatch(scenarios.registered(name), seeds[:8])     # and both equal the oracle
+    e3 = product_envs.build(name, batch_size=8, seeds=seeds[:8], fused_step=True)
+    e3.reset(); orc.reset()
+    for t in range(min(T, 40)):
+        a = rng.randint(0, 7, size=(8, n))
+        o, r, d, _ = e3.step(torch.from_numpy(a))
+        o2, r2, d2, _ = orc.step(a)
+        assert np.array_equal(o.cpu().numpy(), o2) and np.array_equal(d.cpu().numpy(), d2), t
+        if d2.any():
+            e3.reset(env_mask=d2)
+            for b in np.nonzero(d2)[0]:
+                orc.envs[b].reset()

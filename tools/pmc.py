@@ -59,13 +59,16 @@ def measure(workload="MarlGrid-3AgentCluttered15x15-v0", batch=32768, iters=4, t
     cal_r = GiB_KiB / (sum(copy_r) / len(copy_r)) if copy_r else None
     out = {"calibration": {"write_x": cal_w, "fetch_x": cal_r,
                            "note": "1 GiB fill -> WRITE_SIZE, 1 GiB copy -> FETCH_SIZE, same passes"}}
-    for name, needle in (("render", "render_kernel"), ("step", "step_kernel")):
-        w, r = kern(wr, needle), kern(rd, needle)
-        if not w or not r:
+    # tools/profile_render.py launches `iters` pure rasters (gen_obs) and then `iters` env.step() — each of
+    # those ONE launch of the same kernel with the step fused in front (mg_step_render)
+    w, r = kern(wr, "render_kernel"), kern(rd, "render_kernel")
+    for name, sl in (("render", slice(0, iters)), ("step_render", slice(iters, 2 * iters))):
+        ww, rr = w[sl], r[sl]
+        if not ww or not rr:
             continue
-        wb = sum(w) / len(w) * 1024 * (cal_w or 1.0)
-        rb = sum(r) / len(r) * 1024 * (cal_r or 2.0)
-        out[name] = {"write_bytes": wb, "fetch_bytes": rb, "hbm_bytes_per_launch": wb + rb, "launches": len(w)}
+        wb = sum(ww) / len(ww) * 1024 * (cal_w or 1.0)
+        rb = sum(rr) / len(rr) * 1024 * (cal_r or 2.0)
+        out[name] = {"write_bytes": wb, "fetch_bytes": rb, "hbm_bytes_per_launch": wb + rb, "launches": len(ww)}
     return out
 
 
