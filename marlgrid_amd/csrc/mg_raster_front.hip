@@ -1,0 +1,166 @@
+// mg_raster_front.hip — the observation raster as a DENSE MOVING FRONT over the obs tensor.
+//
+// Why a second raster.  Measured on MI355X (tools/microbench/store_patterns{2..5}.hip, profiles/r02):
+// HBM absorbs 6.6 TB/s when, at any moment, the chip writes ONE contiguous ~1 MiB window in aligned
+// 4 KiB blocks from four waves per CU (a plain fill: 6.9), but only 5.3-5.5 TB/s when every wave or
+// workgroup streams its own contiguous span — whatever the span's size, alignment or parity, the waves
+// per CU, the store width or flavour.  mg_render.hip is of the second kind by construction: a wave owns
+// whole envs, because deriving an env's view (crop, occlusion, tile selection) is per-env work.  Here
+// that coupling is cut: the view kernel (mg_render.hip in views-only mode, with the env step fused in
+// front) leaves each env's tmap — n * VS * VS atlas offsets, 2 bytes each — in HBM, and this kernel
+// turns tmaps into pixels in pure address order: in sub-round q, workgroup w writes the 4 KiB block
+// q * gridDim + w of the tensor, whichever env(s) it belongs to.
+//
+// Shape: one workgroup per CU, 5 waves.  Waves 0-3 are STREAMERS: lane t of the workgroup owns chunk t
+// (16 bytes) of each of the round's 4 blocks; a chunk is two 8-byte pairs, each a ds_read_b64 from the
+// LDS-resident atlas at tmap[cell] + row * TD + k, exactly as in mg_render.hip's chunk raster; the 4
+// stores are issued back to back.  Wave 4 is the LOADER: it fetches the few dozen tmap entries each block
+// of the NEXT round needs (one contiguous run per block: tmaps are laid out [B][n*VS*VS]) into an LDS
+// double buffer — a wave that never stores, so that no load ever queues behind the streamers' stores
+// (vmcnt is shared and in order on gfx950).  One s_barrier per round hands the buffer over.  The
+// (env, chunk-in-env) coordinates of a lane's chunks advance by a constant per round: no division in
+// the loop.
+#include "mg_device.h"
+#include "mg_launch.h"
+
+namespace mg {
+
+constexpr int kFrontSub = 4;       // 4 KiB blocks per workgroup and round
+constexpr int kFrontSlice = 64;    // tmap entries staged per block (host checks the geometry fits)
+
+// LDS hand-over: DS operations drained, then the workgroup barrier.  (Not __syncthreads(): its release
+// fence would also drain the streamers' global stores — vmcnt(0) — once per round.)
+__device__ __forceinline__ void front_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int VS_, int TS_>
+__global__ __launch_bounds__(320) void raster_front_kernel(MgConfig cfg, const uint16_t* __restrict__ tmap,
+                                                           uint8_t* __restrict__ obs) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr uint32_t TD = TS_ * 3 / 4, PT = TD / 2, PR = VS_ * PT;     // dwords / pairs per tile row, pairs per pixel row
+    constexpr uint32_t P = VS_ * TS_, VV = VS_ * VS_;
+    const uint32_t n = (uint32_t)cfg.n_agents, NV = n * VV;
+    const uint32_t CPE = n * P * PR / 2;                                  // 16-byte chunks per env
+    const uint32_t nchunks = (uint32_t)cfg.B * CPE;                       // (host: < 2^31)
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const uint32_t G = gridDim.x, w = blockIdx.x;
+
+    const int atlas_bytes = round_up(4 * cfg.n_tiles * TS_ * TS_ * 3, 16);
+    const uint32_t* atlas32 = reinterpret_cast<const uint32_t*>(smem);
+    uint16_t* s_slice = reinterpret_cast<uint16_t*>(smem + atlas_bytes);                       // [2][kFrontSub][kFrontSlice]
+    uint32_t* s_base = reinterpret_cast<uint32_t*>(s_slice + 2 * kFrontSub * kFrontSlice);     // [2][kFrontSub]
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(cfg.atlas);
+        uint4* dst = reinterpret_cast<uint4*>(smem);
+        for (int i = tid; i < atlas_bytes / 16; i += 320) dst[i] = src[i];
+    }
+    const uint32_t nblocks = (nchunks + 255u) >> 8;
+    const uint32_t per_round = G * kFrontSub;
+    const uint32_t rounds = (nblocks + per_round - 1) / per_round;
+
+    // the loader's work for one round: per block, the contiguous run of tmap entries it needs
+    auto load_round = [&](uint32_t R, int buf) {
+#pragma unroll
+        for (int j = 0; j < kFrontSub; j++) {
+            const uint32_t b = (R * kFrontSub + (uint32_t)j) * G + w;
+            if (b >= nblocks) continue;
+            const uint32_t C0 = b << 8, C1 = min(C0 + 255u, nchunks - 1u);
+            const uint32_t e0 = C0 / CPE, ci0 = C0 - e0 * CPE, e1 = C1 / CPE, ci1 = C1 - e1 * CPE;
+            const uint32_t vb0 = ((2u * ci0) / PR) / (uint32_t)TS_, vb1 = ((2u * ci1 + 1u) / PR) / (uint32_t)TS_;
+            const uint32_t s0 = e0 * NV + vb0 * VS_, s1 = e1 * NV + vb1 * VS_ + VS_;
+            if ((uint32_t)lane < s1 - s0) s_slice[(buf * kFrontSub + j) * kFrontSlice + lane] = tmap[(size_t)s0 + lane];
+            if (lane == 0) s_base[buf * kFrontSub + j] = s0;
+        }
+    };
+
+    // a streamer lane's chunk of sub-block j: (env * NV, chunk in env), advanced by a constant per round
+    uint32_t eNV[kFrontSub], ci[kFrontSub];
+    const uint32_t stride = per_round << 8;                      // chunks between a lane's chunks of consecutive rounds
+    const uint32_t qs = stride / CPE, rs = stride - qs * CPE;
+    if (wave < 4) {
+#pragma unroll
+        for (int j = 0; j < kFrontSub; j++) {
+            const uint32_t C = (((uint32_t)j * G + w) << 8) + (uint32_t)tid;
+            const uint32_t e = C / CPE;
+            eNV[j] = e * NV;
+            ci[j] = C - e * CPE;
+        }
+    }
+    if (wave == 4) load_round(0, 0);
+    __syncthreads();                                             // atlas + round 0 slices
+
+    for (uint32_t R = 0; R < rounds; R++) {
+        const int buf = (int)(R & 1u);
+        if (wave == 4) {
+            if (R + 1 < rounds) load_round(R + 1, buf ^ 1);
+        } else {
+            uint4 v[kFrontSub];
+            bool on[kFrontSub];
+#pragma unroll
+            for (int j = 0; j < kFrontSub; j++) {
+                const uint32_t C = (((R * kFrontSub + (uint32_t)j) * G + w) << 8) + (uint32_t)tid;
+                on[j] = C < nchunks;
+                const uint32_t base = s_base[buf * kFrontSub + j];
+                const uint16_t* sl = s_slice + (buf * kFrontSub + j) * kFrontSlice;
+                // pair p = 2 * ci: pixel row r (counted over the env's n images), pair pr in the row
+                const uint32_t p0 = 2u * ci[j];
+                const uint32_t r0 = p0 / PR, pr0 = p0 - r0 * PR;
+                uint32_t r1 = r0, pr1 = pr0 + 1u;
+                if (pr1 == PR) { pr1 = 0; r1++; }
+                const uint32_t va0 = pr0 / PT, kp0 = pr0 - va0 * PT, vb0 = r0 / (uint32_t)TS_, rr0 = r0 - vb0 * (uint32_t)TS_;
+                const uint32_t va1 = pr1 / PT, kp1 = pr1 - va1 * PT, vb1 = r1 / (uint32_t)TS_, rr1 = r1 - vb1 * (uint32_t)TS_;
+                uint2 a = make_uint2(0, 0), c = make_uint2(0, 0);
+                if (on[j]) {
+                    const uint32_t t0 = sl[eNV[j] + vb0 * VS_ + va0 - base], t1 = sl[eNV[j] + vb1 * VS_ + va1 - base];
+                    a = *reinterpret_cast<const uint2*>(atlas32 + t0 + rr0 * TD + kp0 * 2u);
+                    c = *reinterpret_cast<const uint2*>(atlas32 + t1 + rr1 * TD + kp1 * 2u);
+                }
+                v[j] = make_uint4(a.x, a.y, c.x, c.y);
+                // next round
+                eNV[j] += qs * NV;
+                ci[j] += rs;
+                if (ci[j] >= CPE) { ci[j] -= CPE; eNV[j] += NV; }
+            }
+            uint4* out = reinterpret_cast<uint4*>(obs);
+#pragma unroll
+            for (int j = 0; j < kFrontSub; j++) {
+                const size_t C = ((size_t)((R * kFrontSub + (uint32_t)j) * G + w) << 8) + (size_t)tid;
+                if (on[j]) out[C] = v[j];
+            }
+        }
+        front_barrier();
+    }
+}
+
+// Can this configuration take the two-kernel form?  The chunk raster's tile sizes with the atlas resident
+// in LDS, static agent colours, an env of at least one block (a block then touches at most two envs), a
+// per-block tmap run that fits the staging slots, 32-bit chunk indices, and enough blocks to fill the chip.
+bool raster_front_eligible(const MgConfig& cfg) {
+    const int vs = cfg.view_size, ts = cfg.tile_size, n = cfg.n_agents;
+    if (!((ts == 8 && (vs == 7 || vs == 9 || vs == 5)) || (ts == 16 && vs == 7))) return false;
+    if (cfg.prestige_mask) return false;
+    const long long atlas_b = round_up(4 * cfg.n_tiles * ts * ts * 3, 16);
+    if (atlas_b + 4096 > 64 * 1024) return false;
+    const long long P = (long long)vs * ts, S = (long long)n * P * P * 3, cpe = S / 16;
+    if (cpe < 256 || (long long)cfg.B * cpe >= (1ll << 31)) return false;
+    const long long band_bytes = P * 3 * ts;
+    if ((4096 / band_bytes + 2) * vs > kFrontSlice) return false;
+    return (long long)cfg.B * cpe >= 256ll * 256 * 8;            // >= 8 rounds of 256 workgroups x 4 KiB... x 4
+}
+
+template <int VS_, int TS_>
+static hipError_t launch_front_t(const MgConfig& cfg, const uint16_t* tmap, uint8_t* obs, hipStream_t s) {
+    const size_t lds = (size_t)round_up(4 * cfg.n_tiles * TS_ * TS_ * 3, 16) + 2 * kFrontSub * kFrontSlice * 2 + 2 * kFrontSub * 4;
+    hipLaunchKernelGGL((raster_front_kernel<VS_, TS_>), dim3(256), dim3(320), lds, s, cfg, tmap, obs);
+    return hipGetLastError();
+}
+
+hipError_t launch_raster_front(const MgConfig& cfg, const uint16_t* tmap, uint8_t* obs, hipStream_t s) {
+    const int vs = cfg.view_size, ts = cfg.tile_size;
+    if (ts == 8 && vs == 7) return launch_front_t<7, 8>(cfg, tmap, obs, s);
+    if (ts == 8 && vs == 9) return launch_front_t<9, 8>(cfg, tmap, obs, s);
+    if (ts == 8 && vs == 5) return launch_front_t<5, 8>(cfg, tmap, obs, s);
+    if (ts == 16 && vs == 7) return launch_front_t<7, 16>(cfg, tmap, obs, s);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace mg

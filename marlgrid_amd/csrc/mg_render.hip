@@ -113,7 +113,8 @@ template <int VS_, int TS_, int WPB, int V_ = 0, int RM_ = 0>
 __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState st, uint8_t* __restrict__ obs,
                                                         uint8_t* __restrict__ dbg_cells,
                                                         uint8_t* __restrict__ dbg_agent,
-                                                        uint8_t* __restrict__ dbg_vis, int depth_mode, FusedStep fs) {
+                                                        uint8_t* __restrict__ dbg_vis, int depth_mode, FusedStep fs,
+                                                        uint16_t* __restrict__ view_out) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int VS = VS_ ? VS_ : cfg.view_size;
     const int TS = TS_ ? TS_ : cfg.tile_size;
@@ -443,6 +444,16 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
         }
         }
         wave_lds_sync();
+        if constexpr (kChunkRaster && V_ == 0) {
+            // two-kernel form (mg_raster_front.hip): this launch only derives the views; the env's tmap —
+            // n * VS * VS atlas offsets, 2 bytes each — goes to HBM and a dense-front kernel rasters from it
+            if (view_out) {
+                uint16_t* vo = view_out + (size_t)e * n * VV;
+                for (int it = lane; it < n * VV; it += kWave) vo[it] = w_tmap[it];
+            }
+        }
+        } else if (kChunkRaster && V_ == 0 && view_out) {
+            // (views only: nothing to raster here)
         } else {
         // 6. raster: stream the env's n images out
         if constexpr (kChunkRaster) {
@@ -584,7 +595,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
 
 template <int VS_, int TS_, int WPB, int V_ = 0, int RM_ = 0>
 static hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_t* obs, uint8_t* c, uint8_t* a,
-                                  uint8_t* v, hipStream_t s, const FusedStep* fs) {
+                                  uint8_t* v, hipStream_t s, const FusedStep* fs, uint16_t* view_out = nullptr) {
     const int tile_bytes = cfg.tile_size * cfg.tile_size * 3;
     static_assert(RM_ == 1 || TS_ == 0 || (TS_ % 8) != 0 || TS_ == 8 || TS_ == 16 || TS_ == 32, "see render_chunk_raster");
     const RenderScratch L = render_scratch_for(cfg, WPB, RM_);
@@ -614,7 +625,7 @@ static hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_
     if (const char* f = getenv("MG_RENDER_DEPTH")) depth_mode = atoi(f);   // 1: every wave view -> raster env by env
 #endif
     hipLaunchKernelGGL((render_kernel<VS_, TS_, WPB, V_, RM_>), dim3(blocks), dim3(WPB * 64), lds, s, cfg, st, obs, c, a, v,
-                       depth_mode, *fs);
+                       depth_mode, *fs, view_out);
     return hipGetLastError();
 }
 
@@ -640,19 +651,39 @@ static int choose_wpb(const MgConfig& cfg) {
 }
 
 #define MG_RENDER_DISPATCH(VS, TS, V)                                                                      \
-    (wpb == 16 ? launch_render_t<VS, TS, 16, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)           \
-               : launch_render_t<VS, TS, 4, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs))
+    (wpb == 16 ? launch_render_t<VS, TS, 16, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo)           \
+               : launch_render_t<VS, TS, 4, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo))
 // run-time view size: its MG_MAX_VIEW-entry shadow-cast arrays need more than the 128 VGPRs a 16-wave
 // workgroup leaves per lane (spills would be VMEM traffic in the middle of the run): 8-wave workgroups
 #define MG_RENDER_DISPATCH_RT(TS, V)                                                                       \
-    (wpb == 16 ? launch_render_t<0, TS, 8, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)             \
-               : launch_render_t<0, TS, 4, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs))
+    (wpb == 16 ? launch_render_t<0, TS, 8, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo)             \
+               : launch_render_t<0, TS, 4, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo))
 #define MG_RENDER_DISPATCH8(VS, TS, V)                                                                     \
-    (wpb == 8 ? launch_render_t<VS, TS, 8, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs) : MG_RENDER_DISPATCH(VS, TS, V))
+    (wpb == 8 ? launch_render_t<VS, TS, 8, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo) : MG_RENDER_DISPATCH(VS, TS, V))
+
+// The kernel launch(es) of mg_render_obs / mg_step_render.  With view scratch from the caller and a
+// configuration the dense-front raster covers (raster_front_eligible), two launches: this file's kernel in
+// views-only mode (env step fused in front when asked for), then mg_raster_front.hip; otherwise one.
+static hipError_t launch_render_one(const MgConfig& cfg, const MgState& st, uint8_t* obs, uint8_t* view_cells,
+                                    uint8_t* view_agent, uint8_t* vis_mask, hipStream_t s, const FusedStep* fs,
+                                    uint16_t* vo);
 
 hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, uint8_t* view_cells,
                          uint8_t* view_agent, uint8_t* vis_mask, hipStream_t s, const FusedStep* fs) {
     if (cfg.B <= 0) return hipSuccess;
+    bool front = st.view_scratch && !view_cells && !view_agent && !vis_mask && raster_front_eligible(cfg);
+#if defined(MG_AB_VARIANTS)
+    if (const char* f = getenv("MG_RENDER_FRONT")) front = front && atoi(f) != 0;
+#endif
+    if (!front) return launch_render_one(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, nullptr);
+    hipError_t e = launch_render_one(cfg, st, obs, nullptr, nullptr, nullptr, s, fs, st.view_scratch);
+    if (e != hipSuccess) return e;
+    return launch_raster_front(cfg, st.view_scratch, obs, s);
+}
+
+static hipError_t launch_render_one(const MgConfig& cfg, const MgState& st, uint8_t* obs, uint8_t* view_cells,
+                                    uint8_t* view_agent, uint8_t* vis_mask, hipStream_t s, const FusedStep* fs,
+                                    uint16_t* vo) {
     FusedStep none;
     none.enabled = 0;
     none.has_prog = 0;
@@ -670,33 +701,33 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
         const size_t lds4 = (size_t)round_up(4 * cfg.n_tiles * ts * ts * 3, 16) + kRenderShared +
                             4 * (size_t)L.total;
         if (lds4 > 160 * 1024) {   // the static atlas stays in global memory
-            if (ts == 8) return launch_render_t<0, 8, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
-            if (ts == 16) return launch_render_t<0, 16, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
-            if (ts == 32) return launch_render_t<0, 32, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
-            return launch_render_t<0, 0, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
+            if (ts == 8) return launch_render_t<0, 8, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
+            if (ts == 16) return launch_render_t<0, 16, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
+            if (ts == 32) return launch_render_t<0, 32, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
+            return launch_render_t<0, 0, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
         }
         // the shipped view: compile-time size; 8-wave workgroups when they fit (the recolouring code needs
         // more than the 128 VGPRs a 16-wave workgroup leaves per lane)
         if (vs == 7 && ts == 8)
-            return wpb == 16 ? launch_render_t<7, 8, 8, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)
-                             : launch_render_t<7, 8, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
+            return wpb == 16 ? launch_render_t<7, 8, 8, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo)
+                             : launch_render_t<7, 8, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
         if (vs == 7 && (ts % 8) != 0)
-            return wpb == 16 ? launch_render_t<7, 0, 8, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)
-                             : launch_render_t<7, 0, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
-        if (ts == 8) return launch_render_t<0, 8, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
-        if (ts == 16) return launch_render_t<0, 16, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
-        if (ts == 32) return launch_render_t<0, 32, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
-        return launch_render_t<0, 0, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
+            return wpb == 16 ? launch_render_t<7, 0, 8, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo)
+                             : launch_render_t<7, 0, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
+        if (ts == 8) return launch_render_t<0, 8, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
+        if (ts == 16) return launch_render_t<0, 16, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
+        if (ts == 32) return launch_render_t<0, 32, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
+        return launch_render_t<0, 0, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
     }
     {   // atlas too large for LDS (next to 4 waves of scratch): read it from global memory instead
         const RenderScratch L = render_scratch_for(cfg, 4);
         const size_t lds4 = (size_t)round_up(4 * cfg.n_tiles * ts * ts * 3, 16) + kRenderShared +
                             4 * (size_t)L.total;
         if (lds4 > 160 * 1024) {
-            if (ts == 8) return launch_render_t<0, 8, 4, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
-            if (ts == 16) return launch_render_t<0, 16, 4, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
-            if (ts == 32) return launch_render_t<0, 32, 4, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
-            return launch_render_t<0, 0, 4, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
+            if (ts == 8) return launch_render_t<0, 8, 4, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
+            if (ts == 16) return launch_render_t<0, 16, 4, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
+            if (ts == 32) return launch_render_t<0, 32, 4, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
+            return launch_render_t<0, 0, 4, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
         }
     }
     if (ts == 8 && vs == 7) {
@@ -710,8 +741,8 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
         default: break;
         }
         if (getenv("MG_RENDER_RASTER") && atoi(getenv("MG_RENDER_RASTER")) == 1)   // assemble-and-stream at tile 8
-            return wpb == 16 ? launch_render_t<7, 8, 16, 0, 1>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)
-                             : launch_render_t<7, 8, 4, 0, 1>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
+            return wpb == 16 ? launch_render_t<7, 8, 16, 0, 1>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo)
+                             : launch_render_t<7, 8, 4, 0, 1>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
 #endif
         return MG_RENDER_DISPATCH8(7, 8, 0);
     }

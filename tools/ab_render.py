@@ -31,7 +31,8 @@ for rep in range(7):
         f0 = v.split(":")[0]
         os.environ["MG_RENDER_RASTER"] = "1" if f0 == "R" else "0"   # "R": the assemble-and-stream raster at tile 8
         os.environ["MG_RENDER_DEPTH"] = f0[1:] if f0.startswith("D") else "0"   # "D<k>": every wave looks k envs ahead
-        os.environ["MG_RENDER_VARIANT"] = "0" if (f0 == "R" or f0.startswith("D")) else f0
+        os.environ["MG_RENDER_FRONT"] = "0" if f0 == "E" else "1"   # "E": env-by-env raster only (no dense-front kernel)
+        os.environ["MG_RENDER_VARIANT"] = "0" if (f0 in ("R", "E") or f0.startswith("D")) else f0
         os.environ["MG_RENDER_WPB"] = v.split(":")[1] if ":" in v else "0"
         os.environ["MG_RENDER_PER_CU"] = v.split(":")[2] if v.count(":") > 1 else "0"   # "V:wpb:workgroups per CU"
         N.check(env._lib.mg_time_render_obs(C.byref(env._cfg), C.byref(env._state), env.obs.data_ptr(), 40,
