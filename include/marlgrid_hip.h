@@ -154,10 +154,6 @@ typedef struct MgState {
     int32_t* error;
     double* prestige;     /* [B][n_agents] agent.prestige (agents.py:141-153); NULL unless prestige_mask != 0 */
     uint32_t* mt_head;    /* [B][MG_MT_HEAD] */
-    uint16_t* view_scratch; /* [B][n_agents * view_size^2] or NULL: where mg_render_obs / mg_step_render may leave
-                           * each env's derived view (one atlas offset per view cell) between their two launches;
-                           * with it, configurations the dense-front raster covers are rastered in address order
-                           * (csrc/mg_raster_front.hip) instead of env by env.  Contents are scratch. */
 } MgState;
 
 /* `_gen_grid` as data: a static template (walls / put_obj results) + ordered random placements */

@@ -53,7 +53,7 @@ class Config(C.Structure):
 class State(C.Structure):
     _fields_ = [("grid", C.c_void_p), ("agents", C.c_void_p), ("mt", C.c_void_p), ("mt_pos", C.c_void_p),
                 ("step_count", C.c_void_p), ("done", C.c_void_p), ("error", C.c_void_p), ("prestige", C.c_void_p),
-                ("mt_head", C.c_void_p), ("view_scratch", C.c_void_p)]
+                ("mt_head", C.c_void_p)]
 
 
 class GenOp(C.Structure):

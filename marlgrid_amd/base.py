@@ -352,8 +352,6 @@ class MultiGridEnv(object):
             self.mt_state = torch.zeros((B, N.MT_N), dtype=torch.int32, device=dev)
             self.mt_pos = torch.zeros((B,), dtype=torch.int32, device=dev)
             self.mt_head = torch.zeros((B, N.MT_HEAD), dtype=torch.int32, device=dev)
-            # scratch between the two launches of the obs raster's dense-front form (2 B per view cell)
-            self.view_scratch = torch.zeros((B, n * self.view_size * self.view_size), dtype=torch.int16, device=dev)
             self.step_count_t = torch.zeros((B,), dtype=torch.int32, device=dev)
             self.error_t = torch.zeros((B,), dtype=torch.int32, device=dev)
             # agent.prestige (agents.py:141-153): only needed when some agent's colour is 'prestige'
@@ -372,7 +370,7 @@ class MultiGridEnv(object):
                               self.mt_pos.data_ptr(), self.step_count_t.data_ptr(), self.done_t.data_ptr(),
                               self.error_t.data_ptr(),
                               self.prestige_t.data_ptr() if self.prestige_t is not None else None,
-                              self.mt_head.data_ptr(), self.view_scratch.data_ptr())
+                              self.mt_head.data_ptr())
 
     def _stream(self):
         import torch

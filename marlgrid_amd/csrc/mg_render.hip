@@ -113,8 +113,11 @@ template <int VS_, int TS_, int WPB, int V_ = 0, int RM_ = 0>
 __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState st, uint8_t* __restrict__ obs,
                                                         uint8_t* __restrict__ dbg_cells,
                                                         uint8_t* __restrict__ dbg_agent,
-                                                        uint8_t* __restrict__ dbg_vis, int depth_mode, FusedStep fs,
-                                                        uint16_t* __restrict__ view_out) {
+                                                        uint8_t* __restrict__ dbg_vis, int depth_mode, FusedStep fs
+#if defined(MG_AB_VARIANTS)
+                                                        , uint16_t* __restrict__ view_out   // measurement build: views only
+#endif
+                                                        ) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int VS = VS_ ? VS_ : cfg.view_size;
     const int TS = TS_ ? TS_ : cfg.tile_size;
@@ -444,9 +447,10 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
         }
         }
         wave_lds_sync();
+#if defined(MG_AB_VARIANTS)
         if constexpr (kChunkRaster && V_ == 0) {
-            // two-kernel form (mg_raster_front.hip): this launch only derives the views; the env's tmap —
-            // n * VS * VS atlas offsets, 2 bytes each — goes to HBM and a dense-front kernel rasters from it
+            // measurement build, two-kernel experiment (mg_raster_front.hip): this launch only derives the
+            // views; the env's tmap — n * VS * VS atlas offsets, 2 bytes each — goes to HBM
             if (view_out) {
                 uint16_t* vo = view_out + (size_t)e * n * VV;
                 for (int it = lane; it < n * VV; it += kWave) vo[it] = w_tmap[it];
@@ -454,6 +458,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
         }
         } else if (kChunkRaster && V_ == 0 && view_out) {
             // (views only: nothing to raster here)
+#endif
         } else {
         // 6. raster: stream the env's n images out
         if constexpr (kChunkRaster) {
@@ -624,8 +629,14 @@ static hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_
 #if defined(MG_AB_VARIANTS)
     if (const char* f = getenv("MG_RENDER_DEPTH")) depth_mode = atoi(f);   // 1: every wave view -> raster env by env
 #endif
+#if defined(MG_AB_VARIANTS)
     hipLaunchKernelGGL((render_kernel<VS_, TS_, WPB, V_, RM_>), dim3(blocks), dim3(WPB * 64), lds, s, cfg, st, obs, c, a, v,
                        depth_mode, *fs, view_out);
+#else
+    (void)view_out;
+    hipLaunchKernelGGL((render_kernel<VS_, TS_, WPB, V_, RM_>), dim3(blocks), dim3(WPB * 64), lds, s, cfg, st, obs, c, a, v,
+                       depth_mode, *fs);
+#endif
     return hipGetLastError();
 }
 
@@ -661,24 +672,29 @@ static int choose_wpb(const MgConfig& cfg) {
 #define MG_RENDER_DISPATCH8(VS, TS, V)                                                                     \
     (wpb == 8 ? launch_render_t<VS, TS, 8, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo) : MG_RENDER_DISPATCH(VS, TS, V))
 
-// The kernel launch(es) of mg_render_obs / mg_step_render.  With view scratch from the caller and a
-// configuration the dense-front raster covers (raster_front_eligible), two launches: this file's kernel in
-// views-only mode (env step fused in front when asked for), then mg_raster_front.hip; otherwise one.
+// The kernel launch of mg_render_obs / mg_step_render.  (Measurement build only: with view scratch set through
+// mg_ab_view_scratch and MG_RENDER_FRONT=1, the two-kernel experiment — this file's kernel in views-only mode,
+// then mg_raster_front.hip's dense-front raster; see profiles/r02 for why it is not the product path.)
 static hipError_t launch_render_one(const MgConfig& cfg, const MgState& st, uint8_t* obs, uint8_t* view_cells,
                                     uint8_t* view_agent, uint8_t* vis_mask, hipStream_t s, const FusedStep* fs,
                                     uint16_t* vo);
+#if defined(MG_AB_VARIANTS)
+static uint16_t* g_ab_view_scratch = nullptr;
+extern "C" void mg_ab_view_scratch(uint16_t* p) { g_ab_view_scratch = p; }
+#endif
 
 hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, uint8_t* view_cells,
                          uint8_t* view_agent, uint8_t* vis_mask, hipStream_t s, const FusedStep* fs) {
     if (cfg.B <= 0) return hipSuccess;
-    bool front = st.view_scratch && !view_cells && !view_agent && !vis_mask && raster_front_eligible(cfg);
 #if defined(MG_AB_VARIANTS)
-    if (const char* f = getenv("MG_RENDER_FRONT")) front = front && atoi(f) != 0;
+    const char* f = getenv("MG_RENDER_FRONT");
+    if (f && atoi(f) != 0 && g_ab_view_scratch && !view_cells && !view_agent && !vis_mask && raster_front_eligible(cfg)) {
+        hipError_t e = launch_render_one(cfg, st, obs, nullptr, nullptr, nullptr, s, fs, g_ab_view_scratch);
+        if (e != hipSuccess) return e;
+        return launch_raster_front(cfg, g_ab_view_scratch, obs, s);
+    }
 #endif
-    if (!front) return launch_render_one(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, nullptr);
-    hipError_t e = launch_render_one(cfg, st, obs, nullptr, nullptr, nullptr, s, fs, st.view_scratch);
-    if (e != hipSuccess) return e;
-    return launch_raster_front(cfg, st.view_scratch, obs, s);
+    return launch_render_one(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, nullptr);
 }
 
 static hipError_t launch_render_one(const MgConfig& cfg, const MgState& st, uint8_t* obs, uint8_t* view_cells,

@@ -54,7 +54,7 @@ class HostEmu(object):
         self.prestige = np.zeros((B, self.n), np.float64)
         self.rewards = np.zeros((B, self.n), np.float32)
         self.state = N.State(_ptr(self.grid), _ptr(self.rec), _ptr(self.mt), _ptr(self.mt_pos), _ptr(self.step_count),
-                             _ptr(self.done), _ptr(self.error), _ptr(self.prestige), _ptr(self.mt_head), None)
+                             _ptr(self.done), _ptr(self.error), _ptr(self.prestige), _ptr(self.mt_head))
         keys, lens = seeding.batch_keys(env.seeds)
         self.L.emu_mt_seed(B, _ptr(keys), _ptr(lens), _ptr(self.mt), _ptr(self.mt_pos), _ptr(self.mt_head))
         self._tables_version = None

@@ -18,6 +18,10 @@ variants = sys.argv[1:] or ["0", "2", "3", "4", "6", "11"]      # "V" or "V:wave
 B = int(os.environ.get("B", "32768"))
 env = make(os.environ.get("WL", "MarlGrid-3AgentCluttered15x15-v0"), batch_size=B, auto_reset=True, strict=False)
 env.reset()
+if os.environ.get("MARLGRID_HIP_LIB", "").endswith("_ab.so"):      # two-kernel experiment: its view scratch
+    _vs = torch.zeros((B, env.num_agents * env.view_size ** 2), dtype=torch.int16, device=env.device)
+    env._lib.mg_ab_view_scratch.restype = None
+    env._lib.mg_ab_view_scratch(C.c_void_p(_vs.data_ptr()))
 g = torch.Generator().manual_seed(0)
 for i in range(30):
     env.step(torch.randint(0, 7, (B, env.num_agents), generator=g).cuda())
@@ -31,8 +35,9 @@ for rep in range(7):
         f0 = v.split(":")[0]
         os.environ["MG_RENDER_RASTER"] = "1" if f0 == "R" else "0"   # "R": the assemble-and-stream raster at tile 8
         os.environ["MG_RENDER_DEPTH"] = f0[1:] if f0.startswith("D") else "0"   # "D<k>": every wave looks k envs ahead
-        os.environ["MG_RENDER_FRONT"] = "0" if f0 == "E" else "1"   # "E": env-by-env raster only (no dense-front kernel)
-        os.environ["MG_RENDER_VARIANT"] = "0" if (f0 in ("R", "E") or f0.startswith("D")) else f0
+        os.environ["MG_RENDER_FRONT"] = "1" if f0[0] in "FM" else "0"   # "F" / "M<k>": the two-kernel dense-front experiment
+        os.environ["MG_FRONT_MODE"] = f0[1:] if f0.startswith("M") else "0"   # "M<k>": dense-front measurement modes
+        os.environ["MG_RENDER_VARIANT"] = "0" if (f0 in ("R", "E", "F") or f0[0] in "DM") else f0
         os.environ["MG_RENDER_WPB"] = v.split(":")[1] if ":" in v else "0"
         os.environ["MG_RENDER_PER_CU"] = v.split(":")[2] if v.count(":") > 1 else "0"   # "V:wpb:workgroups per CU"
         N.check(env._lib.mg_time_render_obs(C.byref(env._cfg), C.byref(env._state), env.obs.data_ptr(), 40,
