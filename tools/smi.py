@@ -29,6 +29,8 @@ def sample(device=0, timeout=10):
         n = _num(v)
         if n is None:
             continue
+        if "clock level" in kl:
+            continue                              # "sclk clock level: 1" — the speed is in "... clock speed: (2100Mhz)"
         if "sclk" in kl:
             res["sclk_mhz"] = n
         elif "mclk" in kl:

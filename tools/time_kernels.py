@@ -44,11 +44,17 @@ def k_render(i):
     N.check(L.mg_render_obs(cfg, st, env.obs.data_ptr(), None, None, None, env._stream()))
 
 
+def k_fused(i):     # the same step as ONE launch: action loop + reset + raster
+    N.check(L.mg_step_render(cfg, st, acts[i % 16].data_ptr(), 8, env.rewards.data_ptr(), C.byref(env._reset_prog),
+                             env.obs.data_ptr(), env._stream()))
+
+
 def k_all(i):
     env.step(acts[i % 16])
 
 
 for name, fn in (("mg_step with fused auto-reset", k_step), ("render", k_render),
-                 ("env.step (both launches + python)", k_all), ("mg_step without reset program", k_step_only)):
+                 ("mg_step_render (one launch)", k_fused), ("env.step (python + launch)", k_all),
+                 ("mg_step without reset program", k_step_only)):
     print("%-34s %.4f ms" % (name, timed(fn)))
 env.check_errors()
