@@ -126,6 +126,14 @@ typedef struct MgConfig {
                                                                    * grid like base.py:692-695: agents are placed
                                                                    * in [x0,x1) x [y0,y1) (base.py:411, 505, 643) */
     int32_t spawn_max_tries;                                      /* agent_spawn_kwargs max_tries, 1..100000 */
+    int32_t n_view;                                               /* 0: every agent is rendered with the view
+                                                                   * parameters above.  k > 0: only the k agents
+                                                                   * view_agent[0..k) are (obs [B][k][P][P][3]) — an env
+                                                                   * whose agents differ in view size / tile size /
+                                                                   * offset (agents.py:19-35) is rendered group by group,
+                                                                   * one mg_render_obs per group with that group's
+                                                                   * view parameters and atlas */
+    uint8_t view_agent[MG_MAX_AGENTS];
     uint8_t agent_color_idx[MG_MAX_AGENTS];
     int32_t any_spawn_delay;                                      /* 1 if some spawn_delay != 0 */
     int32_t spawn_delay[MG_MAX_AGENTS];                           /* agents.py:34; base.py:409-412, 503-506 */

@@ -42,6 +42,7 @@ class Config(C.Structure):
                 ("n_tiles", C.c_int32), ("agent_type_idx", C.c_int32), ("auto_reset", C.c_int32),
                 ("spawn_x0", C.c_int32), ("spawn_y0", C.c_int32), ("spawn_x1", C.c_int32), ("spawn_y1", C.c_int32),
                 ("spawn_max_tries", C.c_int32),
+                ("n_view", C.c_int32), ("view_agent", C.c_uint8 * MAX_AGENTS),
                 ("agent_color_idx", C.c_uint8 * MAX_AGENTS),
                 ("any_spawn_delay", C.c_int32), ("spawn_delay", C.c_int32 * MAX_AGENTS),
                 ("prestige_mask", C.c_uint32), ("prestige_amax", C.c_uint8 * 4), ("prestige_sprite_tile", C.c_int32),

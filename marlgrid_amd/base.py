@@ -230,6 +230,18 @@ class MultiGrid(object):
         raise NotImplementedError      # as upstream (base.py:216-218)
 
 
+class _ViewGroup(object):
+    """agents that share one view geometry: their launch config, atlas and observation buffers"""
+
+    def __init__(self, key, members):
+        self.key, self.members = key, members            # (view_size, tile_size, view_offset, see_through), agent ids
+        self.view_size, self.tile_size, self.view_offset, self.see_through_walls = key
+        self.pixels = self.view_size * self.tile_size
+        self.cfg = self.atlas = self.atlas_dev = None
+        self.ring = []                                   # obs tensors (B, n_g, P, P, 3), one per buffer set
+        self.obs = None
+
+
 class MultiGridEnv(object):
     """See module docstring.  Constructor keeps the reference's kwargs (base.py:335-347) and adds
     `batch_size`, `device`, `seeds`, `auto_reset`, `strict`."""
@@ -310,23 +322,32 @@ class MultiGridEnv(object):
         n = len(self.agents)
         if n < 1 or n > N.MAX_AGENTS:
             raise ValueError("the batched engine supports 1..%d agents (got %d)" % (N.MAX_AGENTS, n))
-        a0 = self.agents[0]
-        for a in self.agents:
-            if (a.view_size, a.view_tile_size, a.view_offset, a.see_through_walls) != (
-                    a0.view_size, a0.view_tile_size, a0.view_offset, a0.see_through_walls):
-                raise NotImplementedError("all agents must share view_size / view_tile_size / view_offset / "
-                                          "see_through_walls (one (B, n, P, P, 3) observation tensor)")
+        # Every agent carries its own view (agents.py:19-35).  Agents that share (view_size, view_tile_size,
+        # view_offset, see_through_walls) form a VIEW GROUP: one (B, n_g, P, P, 3) observation tensor and one
+        # raster launch per group.  One group — every shipped scenario — is the fast path (one tensor, the
+        # env step fused into the raster launch); with several, reset()/step() return the per-agent list the
+        # reference returns.
+        self._groups = []
+        for k, a in enumerate(self.agents):
             if a.allow_negative_prestige:
                 raise NotImplementedError("allow_negative_prestige=True raises AttributeError upstream "
                                           "(agents.py:147-148) and is not supported")
-        if a0.view_size % 2 == 0 or a0.view_size > N.MAX_VIEW:
-            raise NotImplementedError("view_size must be odd and <= %d" % N.MAX_VIEW)
-        if not (0 <= a0.view_offset < a0.view_size):
-            raise ValueError("view_offset out of range")
+            if a.view_size % 2 == 0 or a.view_size > N.MAX_VIEW:
+                raise NotImplementedError("view_size must be odd and <= %d" % N.MAX_VIEW)
+            if not (0 <= a.view_offset < a.view_size):
+                raise ValueError("view_offset out of range")
+            key = (a.view_size, a.view_tile_size, a.view_offset, bool(a.see_through_walls))
+            for g in self._groups:
+                if g.key == key:
+                    g.members.append(k)
+                    break
+            else:
+                self._groups.append(_ViewGroup(key, [k]))
+        self._hetero = len(self._groups) > 1
         self._prestige = [a.color == "prestige" for a in self.agents]
         self._all_image = all(a.observation_style == "image" for a in self.agents)
-        self.view_size, self.tile_size = a0.view_size, a0.view_tile_size
-        self.view_offset, self.see_through_walls = a0.view_offset, a0.see_through_walls
+        # the first group's view parameters double as "the env's" (what uniform envs have always exposed)
+        self.view_size, self.tile_size, self.view_offset, self.see_through_walls = self._groups[0].key
         self.obs_pixels = self.view_size * self.tile_size
 
     @property
@@ -359,10 +380,14 @@ class MultiGridEnv(object):
             # step() outputs rotate through `obs_buffers` buffer sets (default 2), so what one step
             # returned stays intact while the next step is computed — the README loop
             # `save_step(obs, act, next_obs, rew, done)` sees two different observations.
-            self._ring = [dict(obs=torch.zeros((B, n, P, P, 3), dtype=torch.uint8, device=dev),
+            for g in self._groups:
+                g.ring = [torch.zeros((B, len(g.members), g.pixels, g.pixels, 3), dtype=torch.uint8, device=dev)
+                          for _ in range(self.obs_buffers)]
+                g.obs = g.ring[0]
+            self._ring = [dict(obs=self._groups[0].ring[i],
                                rewards=torch.zeros((B, n), dtype=torch.float32, device=dev),
                                done=torch.zeros((B,), dtype=torch.uint8, device=dev))
-                          for _ in range(self.obs_buffers)]
+                          for i in range(self.obs_buffers)]
             self._ring_i = 0
             self.obs, self.rewards, self.done_t = (self._ring[0][k] for k in ("obs", "rewards", "done"))
             self.done_b = self.done_t.view(torch.bool)      # the same bytes, as the bool tensor step() returns
@@ -519,7 +544,8 @@ class MultiGridEnv(object):
         pass    # deprecated no-op upstream as well (base.py:710-712)
 
     # ---- tables: object descriptors + atlas -----------------------------------------------------------
-    def _obj_table(self):
+    def _obj_table(self, tile_size=None):
+        tile_size = self.tile_size if tile_size is None else tile_size
         objs = self.obj_reg.objs
         tab = (N.ObjDesc * len(objs))()
         for i, o in enumerate(objs):
@@ -543,9 +569,9 @@ class MultiGridEnv(object):
                 d.toggle_next = self.obj_reg.find(Door(o.color, Door.OPEN if o.state == Door.CLOSED else Door.CLOSED))
             d.flags = f
             try:    # "a corner of the plain tile is black" (the border rule of render_tile, base.py:296-298)
-                plain = rendering.render_sprite(o.sprite_ops(), self.tile_size)
+                plain = rendering.render_sprite(o.sprite_ops(), tile_size)
             except NotImplementedError:
-                plain = np.zeros((self.tile_size, self.tile_size, 3), np.uint8)
+                plain = np.zeros((tile_size, tile_size, 3), np.uint8)
             d.flags2 = int((plain[[0, 0, -1, -1], [0, -1, 0, -1]] == 0).all(axis=-1).any())
             if isinstance(o, Goal):
                 d.reward_kind, d.reward = 1, float(o.reward)
@@ -555,14 +581,15 @@ class MultiGridEnv(object):
                 d.bonus_flags = (1 if o.initial_reward else 0) | (2 if o.reset_on_mistake else 0)
         return tab
 
-    def _host_tables(self):
+    def _host_tables(self, group=None):
         """Everything the kernels need that is derived on the host from the object registry and the agent
-        interfaces: (cfg without device pointers, object table bytes, atlas bytes, atlas array).  Pure
-        host work (no device access) — the upload is `_sync_tables`."""
+        interfaces, for one view group (default: the first): (cfg without device pointers, object table
+        bytes, atlas bytes, atlas array).  Pure host work (no device access) — the upload is `_sync_tables`."""
+        grp = self._groups[0] if group is None else group
         objs = self.obj_reg.objs
-        atlas, ovl_slot, n_slots = rendering.build_atlas(objs, [a.color for a in self.agents], self.tile_size,
+        atlas, ovl_slot, n_slots = rendering.build_atlas(objs, [a.color for a in self.agents], grp.tile_size,
                                                          prestige_sprites=any(self._prestige))
-        tab = self._obj_table()
+        tab = self._obj_table(grp.tile_size)
         for i in range(len(objs)):
             tab[i].ovl_slot = ovl_slot[i]
         raw = np.frombuffer(bytes(tab), dtype=np.uint8).copy()
@@ -571,8 +598,12 @@ class MultiGridEnv(object):
         flat = np.concatenate([flat, np.zeros(pad + 16, np.uint8)])
         cfg = N.Config()
         cfg.B, cfg.W, cfg.H, cfg.n_agents = self.batch_size, self.width, self.height, self.num_agents
-        cfg.view_size, cfg.tile_size = self.view_size, self.tile_size
-        cfg.view_offset, cfg.see_through_walls = self.view_offset, int(self.see_through_walls)
+        cfg.view_size, cfg.tile_size = grp.view_size, grp.tile_size
+        cfg.view_offset, cfg.see_through_walls = grp.view_offset, int(grp.see_through_walls)
+        if self._hetero:                       # this group's agents only are rendered with this geometry
+            cfg.n_view = len(grp.members)
+            for i, k in enumerate(grp.members):
+                cfg.view_agent[i] = k
         cfg.cells_stride = self.cells_stride
         cfg.n_obj, cfg.n_ovl_slots, cfg.n_tiles = len(objs), n_slots, atlas.shape[1]
         cfg.agent_type_idx = OBJECT_TYPES.index(GridAgentInterface)
@@ -627,27 +658,31 @@ class MultiGridEnv(object):
         cfg.any_spawn_delay = int(any(a.spawn_delay != 0 for a in self.agents))
 
     def _sync_tables(self):
-        """Make the launch config current: rebuild and upload the object table / atlas when a new object
-        kind was registered since the last launch, refresh the scalar settings always."""
+        """Make the launch configs current: rebuild and upload the object table / atlas of every view group
+        when a new object kind was registered since the last launch, refresh the scalar settings always."""
         if self._dry:
             return
         if self._tables_version == self.obj_reg.version:
-            self._refresh_cfg(self._cfg)
+            for g in self._groups:
+                self._refresh_cfg(g.cfg)
             return
         import torch
-        cfg, raw, flat, atlas = self._host_tables()
-        # the obs kernel keeps 4 waves of per-env scratch (and the atlas, when it fits) in one workgroup's
-        # LDS: ask the library, which owns that layout, before anything is uploaded
-        need = N.lib().mg_render_obs_lds_bytes(C.byref(cfg))
-        if need < 0 or need > 160 * 1024:
-            raise NotImplementedError(
-                "this configuration needs %d KiB of LDS per workgroup for 4 waves of per-env scratch; the obs "
-                "kernel has 160 KiB — reduce the grid size (or the tile size of 'prestige' agents)" % (need // 1024))
-        self._obj_dev = torch.from_numpy(raw).to(self.device)
-        self._atlas_dev = torch.from_numpy(flat).to(self.device)
-        self.atlas = atlas
-        cfg.obj, cfg.atlas = self._obj_dev.data_ptr(), self._atlas_dev.data_ptr()
-        self._cfg = cfg
+        for g in self._groups:
+            cfg, raw, flat, atlas = self._host_tables(g)
+            # the obs kernel keeps 4 waves of per-env scratch (and the atlas, when it fits) in one workgroup's
+            # LDS: ask the library, which owns that layout, before anything is uploaded
+            need = N.lib().mg_render_obs_lds_bytes(C.byref(cfg))
+            if need < 0 or need > 160 * 1024:
+                raise NotImplementedError(
+                    "this configuration needs %d KiB of LDS per workgroup for 4 waves of per-env scratch; the obs "
+                    "kernel has 160 KiB — reduce the grid size (or the tile size of 'prestige' agents)" % (need // 1024))
+            g.obj_dev = torch.from_numpy(raw).to(self.device)
+            g.atlas_dev = torch.from_numpy(flat).to(self.device)
+            g.atlas = atlas
+            cfg.obj, cfg.atlas = g.obj_dev.data_ptr(), g.atlas_dev.data_ptr()
+            g.cfg = cfg
+        g0 = self._groups[0]
+        self._cfg, self.atlas, self._obj_dev, self._atlas_dev = g0.cfg, g0.atlas, g0.obj_dev, g0.atlas_dev
         self._tables_version = self.obj_reg.version
 
     def _program(self, template, ops):
@@ -719,6 +754,8 @@ class MultiGridEnv(object):
             self._ring_i = (self._ring_i + 1) % self.obs_buffers
             r = self._ring[self._ring_i]
             self.obs, self.rewards, self.done_t = r["obs"], r["rewards"], r["done"]
+            for g in self._groups:
+                g.obs = g.ring[self._ring_i]
             self.done_b = self.done_t.view(torch.bool)
             self._state.done = self.done_t.data_ptr()
         stream = self._stream()
@@ -741,7 +778,7 @@ class MultiGridEnv(object):
             probe(0)
         # obs / rewards / done are views of the current buffer set (see `obs_buffers`)
         done = self.done_b
-        if self.fused_step:
+        if self.fused_step and not self._hetero:
             # the whole step — action loop, reset of finished episodes, observation raster — is ONE launch:
             # the wave that renders an env steps it first
             N.check(self._lib.mg_step_render(C.byref(self._cfg), C.byref(self._state), actions.data_ptr(),
@@ -752,27 +789,30 @@ class MultiGridEnv(object):
                                       actions.element_size(), self.rewards.data_ptr(), prog, stream))
             if probe is not None:
                 probe(1)
-            N.check(self._lib.mg_render_obs(C.byref(self._cfg), C.byref(self._state), self.obs.data_ptr(), None,
-                                            None, None, stream))
+            for g in self._groups:       # one raster launch per view group (one group unless the agents' views differ)
+                N.check(self._lib.mg_render_obs(C.byref(g.cfg), C.byref(self._state), g.obs.data_ptr(), None,
+                                                None, None, stream))
         if probe is not None:
             probe(2)
         if self.strict:
             self.check_errors()
         return self._package_obs(), self.rewards, done, {}
 
-    def _render(self, debug=False):
+    def _render(self, debug=False, group=None):
         import torch
         self._sync_tables()
         if debug:
-            B, n, vs = self.batch_size, self.num_agents, self.view_size
-            cells = torch.zeros((B, n, vs, vs), dtype=torch.uint8, device=self.device)
+            g = self._groups[0] if group is None else group
+            B, nv, vs = self.batch_size, len(g.members), g.view_size
+            cells = torch.zeros((B, nv, vs, vs), dtype=torch.uint8, device=self.device)
             shown = torch.zeros_like(cells)
             vis = torch.zeros_like(cells)
-            N.check(self._lib.mg_render_obs(C.byref(self._cfg), C.byref(self._state), self.obs.data_ptr(),
+            N.check(self._lib.mg_render_obs(C.byref(g.cfg), C.byref(self._state), g.obs.data_ptr(),
                                             cells.data_ptr(), shown.data_ptr(), vis.data_ptr(), self._stream()))
             return cells, shown, vis
-        N.check(self._lib.mg_render_obs(C.byref(self._cfg), C.byref(self._state), self.obs.data_ptr(), None, None,
-                                        None, self._stream()))
+        for g in self._groups:
+            N.check(self._lib.mg_render_obs(C.byref(g.cfg), C.byref(self._state), g.obs.data_ptr(), None, None,
+                                            None, self._stream()))
         return None
 
     @_on_device
@@ -786,7 +826,7 @@ class MultiGridEnv(object):
         style (the fast path), else — like the reference's list of per-agent observations — a list
         with one entry per agent: its (B, P, P, 3) view or, for 'rich' agents, a dict of batched
         fields (base.py:459-471)."""
-        if self._all_image:
+        if self._all_image and not self._hetero:
             return self.obs
         return [self._agent_obs(k) for k in range(self.num_agents)]
 
@@ -797,9 +837,17 @@ class MultiGridEnv(object):
         self._render()
         return self._agent_obs(k)
 
+    def _view_slot(self, k):
+        """(view group, index inside it) of agent k"""
+        for g in self._groups:
+            if k in g.members:
+                return g, g.members.index(k)
+        raise IndexError(k)
+
     def _agent_obs(self, k):
         a = self.agents[k]
-        pov = self.obs[:, k]
+        g, slot = self._view_slot(k)
+        pov = g.obs[:, slot]
         if a.observation_style == "image":
             return pov
         import torch
@@ -821,8 +869,9 @@ class MultiGridEnv(object):
         """(view cells (B, vs, vs) object ids indexed [i, j], visibility mask (B, vs, vs) bool) for one
         agent — base.py:418-451"""
         k = agent if isinstance(agent, int) else self.agents.index(agent)
-        cells, _shown, vis = self._render(debug=True)
-        return cells[:, k], vis[:, k].bool()
+        g, slot = self._view_slot(k)
+        cells, _shown, vis = self._render(debug=True, group=g)
+        return cells[:, slot], vis[:, slot].bool()
 
     @_on_device
     def _encode(self, vis_mask=None):
@@ -989,6 +1038,9 @@ class MultiGridEnv(object):
                 d["hide_item_types"] = list(a.hide_item_types)
             if a.color == "prestige":
                 d.update(prestige_beta=a.prestige_beta, prestige_scale=a.prestige_scale)
+            if self._hetero:
+                d["view"] = dict(view_size=a.view_size, tile_size=a.view_tile_size, view_offset=a.view_offset,
+                                 see_through_walls=bool(a.see_through_walls))
             if a.observation_style == "rich":
                 d["rich"] = {k: True for k in ("observe_rewards", "observe_position", "observe_orientation")
                              if getattr(a, k)}
@@ -1046,19 +1098,20 @@ class MultiGridEnv(object):
             tpw = int(Hp * agent_col_width_frac - 2 * agent_col_padding_px)
             tph = (Wp - 2 * agent_col_padding_px) // max_agents_per_col
             self._render()
-            P = self.obs_pixels
-            f = int(min(tpw / P, tph / P))
-            views = self.obs[ids.long()]                                    # (K, n, P, P, 3)
-            views = views.repeat_interleave(f, dim=2).repeat_interleave(f, dim=3) if f > 0 else views[:, :, :0, :0]
-            vh = vw = P * f
             cols = []
             for c0 in range(0, self.num_agents, max_agents_per_col):
                 col = torch.full((K, Hp, tpw + 2 * agent_col_padding_px, 3), pad_grey, dtype=torch.uint8,
                                  device=self.device)
                 for j, k in enumerate(range(c0, min(c0 + max_agents_per_col, self.num_agents))):
+                    g, slot = self._view_slot(k)                            # each view at its own integer zoom
+                    P = g.pixels
+                    f = int(min(tpw / P, tph / P))
+                    view = g.obs[ids.long(), slot]                          # (K, P, P, 3)
+                    view = view.repeat_interleave(f, dim=1).repeat_interleave(f, dim=2) if f > 0 else view[:, :0, :0]
+                    vh = vw = P * f
                     o0 = (tph - vw) // 2 + agent_col_padding_px + j * tph
                     o1 = (tpw - vh) // 2 + agent_col_padding_px
-                    col[:, o0:o0 + vh, o1:o1 + vw] = views[:, k]
+                    col[:, o0:o0 + vh, o1:o1 + vw] = view
                 cols.append(col)
             img = torch.cat([img] + cols, dim=2)
         return img[0] if single else img

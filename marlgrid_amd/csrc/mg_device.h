@@ -62,7 +62,7 @@ struct FusedStep {
 };
 
 // block-shared LDS of the obs-render kernel after the atlas: object flags, overlap slots, hide masks, prestige scales, flags2
-constexpr int kRenderShared = 3 * MG_MAX_OBJ + 2 * MG_MAX_AGENTS * 8 + MG_MAX_OBJ * 32;   // ... + the object table (fused step)
+constexpr int kRenderShared = 3 * MG_MAX_OBJ + 2 * MG_MAX_AGENTS * 8 + MG_MAX_OBJ * 32 + MG_MAX_AGENTS;   // ... + the object table (fused step), the viewer map
 
 // per-wave LDS scratch of the obs-render kernel (bytes), shared by host launch code and kernel
 struct RenderScratch {

@@ -143,6 +143,10 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     double* s_pscale = reinterpret_cast<double*>(s_hide + MG_MAX_AGENTS);     // [MG_MAX_AGENTS] prestige_scale
     uint8_t* s_oflags2 = reinterpret_cast<uint8_t*>(s_pscale + MG_MAX_AGENTS); // [MG_MAX_OBJ]
     MgObjDesc* s_obj = reinterpret_cast<MgObjDesc*>(s_oflags2 + MG_MAX_OBJ);      // [MG_MAX_OBJ] (fused step only)
+    uint8_t* s_vmap = reinterpret_cast<uint8_t*>(s_obj + MG_MAX_OBJ);             // [MG_MAX_AGENTS] viewer slot -> agent
+    // Viewers: the agents whose observations this launch renders.  All n by default; a subset when the
+    // env's agents differ in view size / tile size / offset and are rendered group by group (agents.py:19-35).
+    const int nv = cfg.n_view ? cfg.n_view : n;
     if (fs.enabled) {
         const uint4* src = reinterpret_cast<const uint4*>(cfg.obj);
         uint4* dst = reinterpret_cast<uint4*>(s_obj);
@@ -161,7 +165,11 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             s_oslot[tid] = sl;
             s_oflags2[tid] = f2;
         }
-        if (tid < MG_MAX_AGENTS) { s_hide[tid] = cfg.hide_obj_mask[tid]; s_pscale[tid] = cfg.prestige_scale[tid]; }
+        if (tid < MG_MAX_AGENTS) {
+            s_hide[tid] = cfg.hide_obj_mask[tid];
+            s_pscale[tid] = cfg.prestige_scale[tid];
+            s_vmap[tid] = cfg.n_view ? cfg.view_agent[tid] : (uint8_t)tid;
+        }
     }
     __syncthreads();
 
@@ -213,7 +221,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     uintptr_t out_base = 0;
     uint32_t carry = 0, head = 0;
     if constexpr (!kChunkRaster) {
-        const uintptr_t a0 = reinterpret_cast<uintptr_t>(obs) + (size_t)e0 * n * img_bytes;
+        const uintptr_t a0 = reinterpret_cast<uintptr_t>(obs) + (size_t)e0 * nv * img_bytes;
         head = (uint32_t)(a0 & 15);
         carry = head;
         out_base = a0 - head;
@@ -279,10 +287,10 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             reinterpret_cast<uint32_t*>(w_first)[i] = 0xFFFFFFFFu;
             reinterpret_cast<uint32_t*>(w_second)[i] = 0xFFFFFFFFu;
         }
-        for (int i = lane; i < n * VS; i += kWave) w_trow[i] = 0;
+        for (int i = lane; i < nv * VS; i += kWave) w_trow[i] = 0;
         wave_lds_sync();
         if constexpr (V_ == 3 || V_ == 4) {
-            for (int it = lane; it < n * VV; it += kWave) w_tmap[it] = 0;
+            for (int it = lane; it < nv * VV; it += kWave) w_tmap[it] = 0;
         } else {
         for (int rep = 0; rep < (V_ == 11 ? 2 : 1); rep++) {   // V_ == 11 (measurement): phases 2-5 twice
         // 2. first (lowest-rank) agent of every occupied cell: the reference's "cell object" when
@@ -304,8 +312,8 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
         }
         wave_lds_sync();
         // 3. egocentric crop + rotate: view cell (a = column, b = row) -> world cell
-        for (int it = lane; it < n * VV; it += kWave) {
-            const int k = it / VV, c = it - k * VV;
+        for (int it = lane; it < nv * VV; it += kWave) {
+            const int v = it / VV, c = it - v * VV, k = s_vmap[v];      // viewer slot v is agent k
             const int vb = c / VS, va = c - vb * VS;
             const uint64_t r = w_rec[k];
             const int x = (int)rec_byte(r, MG_AG_X), y = (int)rec_byte(r, MG_AG_Y), dir = (int)rec_byte(r, MG_AG_DIR);
@@ -322,7 +330,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 show = w_first[cell];
                 if (show != 0xFF && wx == x && wy == y) show = (uint32_t)k;   // viewer in the stack: base.py:282-291
             }
-            if (s_oflags[base] & MG_OF_SEE_BEHIND) atomicOr(&w_trow[k * VS + vb], 1u << va);   // opacity first
+            if (s_oflags[base] & MG_OF_SEE_BEHIND) atomicOr(&w_trow[v * VS + vb], 1u << va);   // opacity first
             if (cfg.any_hide && inb) {
                 // hide_item_types (base.py:441-449), applied after visibility: a hidden cell object is
                 // replaced by the first agent standing on it (or nothing) and that agent is drawn as
@@ -337,9 +345,9 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             w_vshow[it] = (uint8_t)show;
         }
         wave_lds_sync();
-        // 4. visibility per agent (lanes 0..n-1)
-        if (lane < n) {
-            const uint64_t r = w_rec[lane];
+        // 4. visibility per viewer (lanes 0..nv-1)
+        if (lane < nv) {
+            const uint64_t r = w_rec[s_vmap[lane]];
             uint32_t m[VS_ ? VS_ : MG_MAX_VIEW];
             if (!(rec_byte(r, MG_AG_FLAGS) & MG_AF_ACTIVE)) {           // base.py:420-425
                 for (int j = 0; j < VS; j++) m[j] = 0;
@@ -405,10 +413,10 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             wave_lds_sync();
         }
         // 5. tile selection (base.py:275-299) -> atlas byte offset / 4 per view cell
-        for (int it = lane; it < n * VV; it += kWave) {
-            const int k = it / VV, c = it - k * VV;
+        for (int it = lane; it < nv * VV; it += kWave) {
+            const int v = it / VV, c = it - v * VV, k = s_vmap[v];
             const int vb = c / VS, va = c - vb * VS;
-            const uint32_t visible = (w_vis[k * VS + vb] >> va) & 1u;
+            const uint32_t visible = (w_vis[v * VS + vb] >> va) & 1u;
             const uint32_t base = w_vbase[it], show = w_vshow[it];
             uint32_t tile = 0;   // shadow
             if (visible) {
@@ -437,7 +445,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             else
                 w_tmap[it] = (uint16_t)vt;
             if (dbg_cells) {
-                const size_t o = ((size_t)e * n + k) * VV + va * VS + vb;         // [i][j] like the reference
+                const size_t o = ((size_t)e * nv + v) * VV + va * VS + vb;        // [i][j] like the reference
                 dbg_cells[o] = (uint8_t)base;
                 dbg_agent[o] = (uint8_t)show;
                 dbg_vis[o] = (uint8_t)visible;
@@ -452,8 +460,8 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             // measurement build, two-kernel experiment (mg_raster_front.hip): this launch only derives the
             // views; the env's tmap — n * VS * VS atlas offsets, 2 bytes each — goes to HBM
             if (view_out) {
-                uint16_t* vo = view_out + (size_t)e * n * VV;
-                for (int it = lane; it < n * VV; it += kWave) vo[it] = w_tmap[it];
+                uint16_t* vo = view_out + (size_t)e * nv * VV;
+                for (int it = lane; it < nv * VV; it += kWave) vo[it] = w_tmap[it];
             }
         }
         } else if (kChunkRaster && V_ == 0 && view_out) {
@@ -481,8 +489,8 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 } else if constexpr (kGlobalAtlas) return *reinterpret_cast<const uint2*>(gatlas32 + a);
                 else return *reinterpret_cast<const uint2*>(atlas32 + a);
             };
-            uint4* out = reinterpret_cast<uint4*>(obs + (size_t)e * n * img_bytes);
-            const int total = (int)(n * (img_bytes / 16));
+            uint4* out = reinterpret_cast<uint4*>(obs + (size_t)e * nv * img_bytes);
+            const int total = (int)(nv * (img_bytes / 16));
             uint32_t r = rast_r0, pr = rast_p0;
             auto pair_addr = [&](uint32_t rr_, uint32_t pr_) -> uint32_t {
                 const uint32_t va = __umul24(pr_, M_PT) >> 16, kp = pr_ - __umul24(va, PT);
@@ -538,7 +546,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             // the complete 16-byte chunks of w_out (linear ds_read_b128 -> global_store_dwordx4) and move
             // the incomplete tail to the front, where the next piece — or the next env — continues.
             const uint32_t SEG = 3u * (uint32_t)TS, P = (uint32_t)(VS * TS), RB = P * 3u;
-            const uint32_t NR = (uint32_t)n * P;                           // pixel rows per env
+            const uint32_t NR = (uint32_t)nv * P;                          // pixel rows per env
             const uint32_t mVS = 0xFFFFFFFFu / (uint32_t)VS + 1u, mTS = TS > 1 ? 0xFFFFFFFFu / (uint32_t)TS + 1u : 0u;
             auto tile_off = [&](uint32_t vt) -> uint32_t {                 // virtual tile index -> byte offset
                 if constexpr (kSplit) return vt < NT4 ? vt * (uint32_t)tile_bytes : (kInLds | (dyn_off + (vt - NT4) * (uint32_t)tile_bytes));

@@ -447,6 +447,58 @@ class OracleEnv(object):
         _raise(self.L.mgo_place_agent_at(self.h, k, x, y))
 
 
+class OracleEnvViews(object):
+    """Agents with their own view geometry (agents.py:19-35).  Nothing in the state machine depends on how
+    an agent sees (views only shape observations), so one OracleEnv per distinct geometry is stepped in
+    lockstep on the same seed and actions, and agent k's observation is taken from the env that was built
+    with k's geometry.  Same surface as OracleEnv; observations come back as a list of n arrays."""
+
+    def __init__(self, spec, seed=1337):
+        import copy
+        self.spec = spec
+        views = [a.get("view") or {k: spec[k] for k in ("view_size", "tile_size", "view_offset", "see_through_walls")}
+                 for a in spec["agents"]]
+        self.keys = []
+        for v in views:
+            key = (v["view_size"], v["tile_size"], v["view_offset"], bool(v["see_through_walls"]))
+            if key not in self.keys:
+                self.keys.append(key)
+        self.owner = [self.keys.index((v["view_size"], v["tile_size"], v["view_offset"], bool(v["see_through_walls"])))
+                      for v in views]
+        self.envs = []
+        for key in self.keys:
+            sp = copy.deepcopy(spec)
+            sp.update(view_size=key[0], tile_size=key[1], view_offset=key[2], see_through_walls=key[3])
+            for a in sp["agents"]:
+                a.pop("view", None)
+            self.envs.append(OracleEnv(sp, seed))
+        self.n = self.envs[0].n
+
+    def _obs(self):
+        per = [e.gen_obs() for e in self.envs]
+        return [per[self.owner[k]][k] for k in range(self.n)]
+
+    def gen_obs(self):
+        return self._obs()
+
+    def reset(self):
+        for e in self.envs:
+            e.reset()
+        return self._obs()
+
+    def step(self, actions, return_order=False):
+        outs = [e.step(actions, return_order=return_order) for e in self.envs]
+        return (self._obs(),) + tuple(outs[0][1:])
+
+    def __getattr__(self, name):        # state / encode / mt_state / view ...: the state machine is shared
+        return getattr(self.envs[0], name)
+
+
+def make_env(spec, seed=1337):
+    """OracleEnv, or OracleEnvViews when the scenario's agents carry their own views"""
+    return OracleEnvViews(spec, seed) if any("view" in a for a in spec["agents"]) else OracleEnv(spec, seed=seed)
+
+
 class OracleBatch(object):
     """B independent oracle envs stepped with OpenMP — bench.py's cpu_baseline leg and the
     batched parity tests."""

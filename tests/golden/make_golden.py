@@ -48,6 +48,7 @@ TRAJ = {  # scenario -> (n_seeds, n_steps, n_full_obs_seeds)
     "Test-2AgentRegion9x9": (6, 100, 1),
     "Test-3AgentSpawnRect9x9": (8, 150, 1),
     "Test-3AgentEmpty7x7-rich": (6, 90, 2),
+    "Test-3AgentCluttered9x9-hetero-views": (6, 100, 2),
     "Test-2AgentGoalcycle9x9-prestige": (8, 120, 2),
     "Test-1AgentGoalcycle11x11-prestige-ts11": (4, 100, 1),
     "Test-3AgentCluttered9x9-prestige-mixed": (8, 150, 2),
@@ -151,6 +152,15 @@ def gen_traj(name, out):
     S, T, F = TRAJ[name]
     n, W, H = len(spec["agents"]), spec["W"], spec["H"]
     P = spec["view_size"] * spec["tile_size"]
+    # agents with their own views (agents.py:19-35): observations differ in shape, so the full observations of
+    # the first F seeds are kept per agent (obs_a<k>, obs_reset_a<k>) instead of in one stacked array
+    hetero = any("view" in a for a in spec["agents"])
+    Pk = [a.get("view", spec)["view_size"] * a.get("view", spec)["tile_size"] for a in spec["agents"]]
+    Fh = F if hetero else 0
+    obs_a = [np.zeros((Fh, T, Pk[k], Pk[k], 3), np.uint8) for k in range(n)]
+    obs_reset_a = [np.zeros((Fh, Pk[k], Pk[k], 3), np.uint8) for k in range(n)]
+    if hetero:
+        F = 0
     seeds = 1337 + np.arange(S)
     arng = np.random.RandomState(4242)
     # mostly navigation, all 7 ids present (pickup/drop/toggle/done are no-ops in these scenes)
@@ -209,6 +219,9 @@ def gen_traj(name, out):
         crc_reset[si] = [refstate.crc(x) for x in o]
         if si < F:
             obs_reset_full[si] = np.stack(o)
+        if si < Fh:
+            for k in range(n):
+                obs_reset_a[k][si] = o[k]
         spy = refstate.OrderSpy(env.np_random)
         env.np_random = spy
         per = {k: [] for k in CANON}
@@ -226,6 +239,9 @@ def gen_traj(name, out):
             crc[si, t] = [refstate.crc(x) for x in o]
             if si < F:
                 obs_full[si, t] = np.stack(o)
+            if si < Fh:
+                for k in range(n):
+                    obs_a[k][si, t] = o[k]
             if dn:
                 env.reset()          # caller-side reset after done (README loop)
                 reset_after[si, t] = True
@@ -242,6 +258,9 @@ def gen_traj(name, out):
              obs_reset_full=obs_reset_full, mt_final=mt_final, mt_final_pos=mt_final_pos)
     if is_rich:
         d.update(rich_reward=rich_reward, rich_position=rich_position, rich_orientation=rich_orientation)
+    if hetero:
+        for k in range(n):
+            d["obs_a%d" % k], d["obs_reset_a%d" % k] = obs_a[k], obs_reset_a[k]
     np.savez_compressed(out, **d)
 
 

@@ -13,9 +13,11 @@ def make_ref_env(spec, recipe, seed=1337):
     from marlgrid.agents import GridAgentInterface
     import marlgrid.envs as E
     cls_name, kwargs = recipe
-    agents = [GridAgentInterface(color=a["color"], view_size=spec["view_size"],
-                                 view_tile_size=spec["tile_size"], view_offset=spec["view_offset"],
-                                 see_through_walls=spec["see_through_walls"], spawn_delay=a.get("spawn_delay", 0),
+    def view(a, key):
+        return a.get("view", spec)[key]
+    agents = [GridAgentInterface(color=a["color"], view_size=view(a, "view_size"),
+                                 view_tile_size=view(a, "tile_size"), view_offset=view(a, "view_offset"),
+                                 see_through_walls=view(a, "see_through_walls"), spawn_delay=a.get("spawn_delay", 0),
                                  hide_item_types=list(a.get("hide_item_types", [])),
                                  prestige_beta=a.get("prestige_beta", 0.95), prestige_scale=a.get("prestige_scale", 2),
                                  **(dict(observation_style="rich", **a["rich"]) if "rich" in a else {}))

@@ -118,6 +118,7 @@ def ref_recipe(name):
         "Test-3AgentSpawnRect9x9": ("SpawnRectTestEnv", dict(grid_size=9, respawn=True, max_steps=60,
                                                              agent_spawn_kwargs=dict(top=(1, 1), size=(3, 9), max_tries=500))),
         "Test-3AgentEmpty7x7-rich": ("EmptyMultiGrid", dict(grid_size=7, max_steps=40)),
+        "Test-3AgentCluttered9x9-hetero-views": ("ClutteredMultiGrid", dict(grid_size=9, n_clutter=6, max_steps=50)),
         "Test-2AgentGoalcycle9x9-prestige": ("ClutteredGoalCycleEnv", dict(grid_size=9, n_clutter=4, n_bonus_tiles=3,
                                                                            penalty=-1.5, max_steps=60)),
         "Test-1AgentGoalcycle11x11-prestige-ts11": ("ClutteredGoalCycleEnv", dict(grid_size=11, clutter_density=0.1,
@@ -182,6 +183,16 @@ def spawn_rect_spec():
     return s
 
 
+def _with_views(spec, views):
+    """per-agent view geometry (agents.py:19-35); spec-level view_size / tile_size / ... stay the first agent's"""
+    for a, v in zip(spec["agents"], views):
+        a["view"] = dict(v)
+    v0 = views[0]
+    spec.update(view_size=v0["view_size"], tile_size=v0["tile_size"], view_offset=v0["view_offset"],
+                see_through_walls=v0["see_through_walls"])
+    return spec
+
+
 def _with_rich(spec, rich):
     """observation_style='rich' for the agents whose entry is a dict of observe_* flags (agents.py:24-31)"""
     for a, r in zip(spec["agents"], rich):
@@ -219,6 +230,13 @@ def registered(name):   # noqa: F811  (extends the table above with test-only sc
         "Test-3AgentCluttered9x9-hide": lambda: _with_hide(cluttered_spec(3, 9, 7, n_clutter=8), [["Wall"], ["Agent", "Goal"], []]),
         "Test-2AgentRegion9x9": lambda: region_spec(),
         "Test-3AgentSpawnRect9x9": lambda: spawn_rect_spec(),
+        # every agent its own view (agents.py:19-35): a 5x5 view at 8 px, a 7x7 view at 5 px looking through walls,
+        # a 5x5 view at 8 px again (same group as the first) with the agent one row up
+        "Test-3AgentCluttered9x9-hetero-views": lambda: _with_views(
+            cluttered_spec(3, 9, 5, n_clutter=6, max_steps=50),
+            [dict(view_size=5, tile_size=8, view_offset=0, see_through_walls=False),
+             dict(view_size=7, tile_size=5, view_offset=0, see_through_walls=True),
+             dict(view_size=5, tile_size=8, view_offset=1, see_through_walls=False)]),
         "Test-3AgentEmpty7x7-rich": lambda: _with_rich(_with_delays(empty_spec(3, 7, 5, max_steps=40), [0, 3, 7]),
                                                        [dict(observe_rewards=True, observe_position=True,
                                                              observe_orientation=True), None,
@@ -309,6 +327,7 @@ ALL_SCENARIOS = [
     "Test-2AgentRegion9x9", "Test-2AgentGoalcycle9x9-prestige", "Test-1AgentGoalcycle11x11-prestige-ts11",
     "Test-3AgentCluttered9x9-prestige-mixed", "Test-4AgentEmpty5x5-ghost0", "Test-3AgentEmpty7x11-nonsquare",
     "Test-3AgentCluttered12x6-nonsquare", "Test-3AgentSpawnRect9x9", "Test-3AgentEmpty7x7-rich",
+    "Test-3AgentCluttered9x9-hetero-views",
 ]
 
 

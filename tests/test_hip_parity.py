@@ -23,10 +23,14 @@ REW_TOL = 1e-6
 
 
 def _pov(obs):
-    """(B, n, P, P, 3) uint8 array of what reset()/step() returned: the tensor, or — with 'rich' agents —
-    the per-agent list of (B, P, P, 3) views / dicts with a 'pov' entry (base.py:459-471)"""
+    """what reset()/step() returned, indexable as [env][agent] -> (P, P, 3) uint8: the (B, n, P, P, 3) tensor,
+    or — with 'rich' agents or agents that have their own views — the per-agent list of (B, P_k, P_k, 3)
+    views / dicts with a 'pov' entry (base.py:459-471)"""
     if isinstance(obs, (list, tuple)):
-        return np.stack([(x["pov"] if isinstance(x, dict) else x).cpu().numpy() for x in obs], axis=1)
+        per_agent = [(x["pov"] if isinstance(x, dict) else x).cpu().numpy() for x in obs]
+        if len({a.shape for a in per_agent}) == 1:
+            return np.stack(per_agent, axis=1)
+        return [[a[b] for a in per_agent] for b in range(per_agent[0].shape[0])]
     return obs.cpu().numpy()
 
 
@@ -60,6 +64,7 @@ def test_golden_trajectory(name):
     g = np.load(os.path.join(GOLD, "traj_%s.npz" % name))
     S, T, n = g["actions"].shape
     F = g["obs_full"].shape[0]
+    Fh = g["obs_a0"].shape[0] if "obs_a0" in g.files else 0      # agents with their own views: per-agent arrays
     env = product_envs.build(name, batch_size=S, seeds=g["seeds"])
     # the product's own scenario description must equal the independent one the oracle was pinned with
     spec = scenarios.registered(name)
@@ -83,6 +88,8 @@ def test_golden_trajectory(name):
         assert [refstate.crc(x) for x in obs[si]] == list(g["obs_crc_reset"][si])
         if si < F:
             assert np.array_equal(obs[si], g["obs_reset_full"][si])
+        if si < Fh:
+            assert all(np.array_equal(obs[si][k], g["obs_reset_a%d" % k][si]) for k in range(n))
     for t in range(T):
         o, r, dn, _ = env.step(torch.from_numpy(g["actions"][:, t].astype(np.int64)))
         if rich:
@@ -99,6 +106,8 @@ def test_golden_trajectory(name):
             assert [refstate.crc(x) for x in o[si]] == list(g["obs_crc"][si, t]), what
             if si < F:
                 assert np.array_equal(o[si], g["obs_full"][si, t]), what
+            if si < Fh:
+                assert all(np.array_equal(o[si][k], g["obs_a%d" % k][si, t]) for k in range(n)), what
         if g["reset_after"][:, t].any():
             env.reset(env_mask=g["reset_after"][:, t])
     for si in range(S):
@@ -818,3 +827,37 @@ def test_fused_step_equals_two_launches(name, B, T):
             e3.reset(env_mask=d2)
             for b in np.nonzero(d2)[0]:
                 orc.envs[b].reset()
+
+
+def test_agents_with_their_own_views_vs_oracle():
+    """agents.py:19-35: every agent carries its own view_size / view_tile_size / view_offset / see_through_walls.
+    Agents are rendered group by group (one launch per distinct geometry); reset()/step() return the
+    per-agent list the reference returns.  Against the oracle on fresh seeds, incl. gen_obs_grid and render()."""
+    import torch
+    name, B = "Test-3AgentCluttered9x9-hetero-views", 96
+    spec = scenarios.registered(name)
+    seeds = 7000 + np.arange(B)
+    env = product_envs.build(name, batch_size=B, seeds=seeds, auto_reset=True)
+    assert len(env._groups) == 2 and env._groups[0].members == [0, 2] and env._groups[1].members == [1]
+    orcs = [O.make_env(spec, seed=int(s)) for s in seeds]
+    obs = env.reset()
+    assert isinstance(obs, list) and [tuple(o.shape) for o in obs] == [(B, 40, 40, 3), (B, 35, 35, 3), (B, 40, 40, 3)]
+    want = [o.reset() for o in orcs]
+    for k in range(3):
+        assert np.array_equal(obs[k].cpu().numpy(), np.stack([w[k] for w in want])), k
+    rng = np.random.RandomState(3)
+    for t in range(70):
+        a = rng.randint(0, 7, size=(B, 3))
+        obs, r, d, _ = env.step(torch.from_numpy(a))
+        outs = [o.step(a[b]) for b, o in enumerate(orcs)]
+        for b, o in enumerate(orcs):
+            if outs[b][2]:
+                outs[b] = (o.reset(),) + outs[b][1:]          # auto-reset: the returned obs is the new episode's
+        for k in range(3):
+            assert np.array_equal(obs[k].cpu().numpy(), np.stack([w[0][k] for w in outs])), (t, k)
+        assert np.abs(r.cpu().numpy().astype(np.float64) - np.stack([w[1] for w in outs])).max() <= REW_TOL
+        assert np.array_equal(d.cpu().numpy(), np.array([w[2] for w in outs]))
+    cells, vis = env.gen_obs_grid(1)
+    assert tuple(cells.shape) == (B, 7, 7) and bool(vis[env.agent_active[:, 1]].all())   # agent 1 sees through walls
+    img = env.render(env_ids=[0, 5])
+    assert img.shape[0] == 2 and img.shape[1] == 9 * 32

@@ -49,7 +49,7 @@ def test_trajectory(name):
     S, T, n = g["actions"].shape
     F = g["obs_full"].shape[0]
     for si in range(S):
-        orc = O.OracleEnv(spec, seed=int(g["seeds"][si]))
+        orc = O.make_env(spec, seed=int(g["seeds"][si]))
         _cmp(orc, _canon_at(g, "ctor_", si), "%s seed %d ctor" % (name, si))
         assert [refstate.crc(x) for x in orc.gen_obs()] == list(g["obs_crc_ctor"][si])
         o = orc.reset()
@@ -57,6 +57,9 @@ def test_trajectory(name):
         assert [refstate.crc(x) for x in o] == list(g["obs_crc_reset"][si])
         if si < F:
             assert np.array_equal(o, g["obs_reset_full"][si])
+        Fh = g["obs_a0"].shape[0] if "obs_a0" in g.files else 0      # agents with their own views: per-agent arrays
+        if si < Fh:
+            assert all(np.array_equal(o[k], g["obs_reset_a%d" % k][si]) for k in range(n))
         rich = "rich_position" in g.files
         if rich:
             _cmp_rich(orc, g, si, 0, "%s seed %d reset" % (name, si))
@@ -71,6 +74,8 @@ def test_trajectory(name):
             assert [refstate.crc(x) for x in o] == list(g["obs_crc"][si, t]), what
             if si < F:
                 assert np.array_equal(o, g["obs_full"][si, t]), what
+            if si < Fh:
+                assert all(np.array_equal(o[k], g["obs_a%d" % k][si, t]) for k in range(n)), what
             if rich:
                 _cmp_rich(orc, g, si, t + 1, what)
             if g["reset_after"][si, t]:
