@@ -829,16 +829,27 @@ def test_fused_step_equals_two_launches(name, B, T):
                 orc.envs[b].reset()
 
 
-def test_agents_with_their_own_views_vs_oracle():
+@pytest.mark.parametrize("shared", [False, True])
+def test_agents_with_their_own_views_vs_oracle(shared):
     """agents.py:19-35: every agent carries its own view_size / view_tile_size / view_offset / see_through_walls.
     Agents are rendered group by group (one launch per distinct geometry); reset()/step() return the
-    per-agent list the reference returns.  Against the oracle on fresh seeds, incl. gen_obs_grid and render()."""
+    per-agent list the reference returns.  Against the oracle on fresh seeds, incl. gen_obs_grid and render().
+    shared: agents 0 and 2 have the same geometry (a two-member group next to a one-member group)."""
+    import copy
     import torch
+    from marlgrid_amd.agents import GridAgentInterface
+    from marlgrid_amd.envs import ClutteredMultiGrid
     name, B = "Test-3AgentCluttered9x9-hetero-views", 96
-    spec = scenarios.registered(name)
+    spec = copy.deepcopy(scenarios.registered(name))
+    if shared:
+        spec["agents"][2]["view"] = dict(spec["agents"][0]["view"])
     seeds = 7000 + np.arange(B)
-    env = product_envs.build(name, batch_size=B, seeds=seeds, auto_reset=True)
-    assert len(env._groups) == 2 and env._groups[0].members == [0, 2] and env._groups[1].members == [1]
+    agents = [GridAgentInterface(color=a["color"], view_size=a["view"]["view_size"], view_tile_size=a["view"]["tile_size"],
+                                 view_offset=a["view"]["view_offset"], see_through_walls=a["view"]["see_through_walls"])
+              for a in spec["agents"]]
+    env = ClutteredMultiGrid(agents=agents, grid_size=9, n_clutter=6, max_steps=50, batch_size=B, seeds=seeds,
+                             auto_reset=True)
+    assert [g.members for g in env._groups] == ([[0, 2], [1]] if shared else [[0], [1], [2]])
     orcs = [O.make_env(spec, seed=int(s)) for s in seeds]
     obs = env.reset()
     assert isinstance(obs, list) and [tuple(o.shape) for o in obs] == [(B, 40, 40, 3), (B, 35, 35, 3), (B, 40, 40, 3)]
