@@ -72,6 +72,7 @@ struct RenderScratch {
     int tmap_stride;   // bytes per tmap slot
     int rec_stride;    // u64 records per staged env
     int piece_rows;    // assemble-and-stream raster: pixel rows assembled in LDS per piece (0: chunk raster)
+    int out_chunks;    // ... and the size of its piece buffer in 16-byte chunks
 };
 __host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride, int n, int vs, int stage_envs = 1,
                                                                int dyn_bytes = 0, int out_bytes = 0, int piece_rows = 0) {
@@ -94,6 +95,7 @@ __host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride,
     s.dyn = o;   o += round_up(dyn_bytes, 16);   // per-env recoloured ('prestige') agent tiles
     s.out = o;   o += round_up(out_bytes, 16);   // assemble-and-stream raster: the piece being assembled
     s.piece_rows = piece_rows;
+    s.out_chunks = round_up(out_bytes, 16) / 16;
     // fused step (mg_step_render): lane j < stage_envs steps staged env j; its [item][8] columns
     s.step = o;  o += round_up(n * 8 * 8 + MG_MT_HEAD * 8 * 4 + 3 * n * 8, 16);
     s.total = o;

@@ -9,26 +9,38 @@ namespace mg {
 // bit i of row j == mask[i, j].  The reference sweeps each row rightwards from the agent column
 // and leftwards from agent column + 1, propagating to the row above (first loop nest) or below
 // (second); out-of-range accesses of the unchecked numba code read False / are dropped.
+// W: the row width the flood has to cover (the view size when it is a compile-time constant, else
+// MG_MAX_VIEW): log2-many doubling steps — 3 for a 7-wide view.
+template <int W>
 __device__ __forceinline__ uint32_t flood_right(uint32_t m, uint32_t p) {
     // set bit i+1 whenever bit i is set and p[i] (p = transparency restricted to [ax, vs-2])
     m |= (m & p) << 1;
     uint32_t q = p & (p >> 1);
     m |= (m & q) << 2;
-    q = q & (q >> 2);
-    m |= (m & q) << 4;
-    q = q & (q >> 4);
-    m |= (m & q) << 8;
+    if (W > 4) {
+        q = q & (q >> 2);
+        m |= (m & q) << 4;
+    }
+    if (W > 8) {
+        q = q & (q >> 4);
+        m |= (m & q) << 8;
+    }
     return m;
 }
+template <int W>
 __device__ __forceinline__ uint32_t flood_left(uint32_t m, uint32_t p) {
     // set bit i-1 whenever bit i is set and p[i] (p = transparency restricted to [1, ax+1])
     m |= (m & p) >> 1;
     uint32_t q = p & (p << 1);
     m |= (m & q) >> 2;
-    q = q & (q << 2);
-    m |= (m & q) >> 4;
-    q = q & (q << 4);
-    m |= (m & q) >> 8;
+    if (W > 4) {
+        q = q & (q << 2);
+        m |= (m & q) >> 4;
+    }
+    if (W > 8) {
+        q = q & (q << 4);
+        m |= (m & q) >> 8;
+    }
     return m;
 }
 
@@ -51,10 +63,10 @@ __device__ __forceinline__ void occlude_rows(int vs_rt, int off, const uint32_t*
 #pragma unroll
     for (int j = N - 1; j >= 1; j--) {
         if (j < VS && j <= ay) {
-            uint32_t r = flood_right(m[j], t[j] & pr);
+            uint32_t r = flood_right<N>(m[j], t[j] & pr);
             uint32_t s = r & t[j] & hi;
             m[j - 1] |= (s | (s << 1)) & full;
-            r = flood_left(r, t[j] & lo);
+            r = flood_left<N>(r, t[j] & lo);
             s = r & t[j] & lo;
             m[j - 1] |= s | (s >> 1);
             m[j] = r;
@@ -64,10 +76,10 @@ __device__ __forceinline__ void occlude_rows(int vs_rt, int off, const uint32_t*
 #pragma unroll
     for (int j = 0; j < N; j++) {
         if (j < VS && j >= ay) {
-            uint32_t r = flood_right(m[j], t[j] & pr);
+            uint32_t r = flood_right<N>(m[j], t[j] & pr);
             uint32_t s = r & t[j] & hi;
             uint32_t down = (s | (s << 1)) & full;
-            r = flood_left(r, t[j] & lo);
+            r = flood_left<N>(r, t[j] & lo);
             s = r & t[j] & lo;
             down |= s | (s >> 1);
             m[j] = r;

@@ -18,8 +18,8 @@
 //     (global_store_dwordx4) chunks, consecutive lanes -> consecutive chunks.  Tile sizes that are a
 //     multiple of 8: each chunk is assembled in registers from two 8-byte LDS look-ups
 //     atlas[tmap[cell] + row*TD + k].  Any other tile size: a few KiB of whole pixel rows at a time are
-//     first ASSEMBLED in an LDS piece buffer — one lane per (row, view column) segment copies its 3*TS
-//     bytes from the atlas tile row (aligned dwords cut with v_alignbyte, single bytes at the two ends:
+//     first ASSEMBLED in an LDS piece buffer — one lane per (row, view column) segment ORs its 3*TS bytes
+//     from the atlas tile row into the zeroed buffer (aligned dwords cut with v_alignbyte and ds_or_b32:
 //     unaligned DS accesses are serialised on gfx950) — and then STREAMED out as linear
 //     ds_read_b128 -> aligned dwordx4 stores; the bytes of a chunk that straddles two pieces (or two
 //     envs of the wave's run) are carried over in the buffer, so everything but the first and last
@@ -35,42 +35,42 @@
 namespace mg {
 
 // ---- one (pixel row, view column) segment of the assemble-and-stream raster ------------------------
-// SEG bytes from sb[sa ...] (any alignment) to d[0 ...] (any alignment; `dl` = d's LDS byte address) with
-// ALIGNED accesses only — an unaligned DS access is serialised lane by lane on gfx950 (measured: 15 x
-// slower).  The source is read as aligned dwords and cut with v_alignbyte: single bytes up to d's next
-// dword boundary, whole destination dwords, then the last 0..3 bytes.  All reads of a step are issued
-// before its writes (source and destination both live in LDS: the compiler cannot reorder them itself).
-// SEGC: SEG when the tile size is a compile-time constant (loops unroll), else 0.
+// SEG bytes from sb[sa ...] (any alignment) into the piece buffer at byte address `dl` (any alignment) with
+// ALIGNED dword accesses only — an unaligned DS access is serialised lane by lane on gfx950 (measured: 15 x
+// slower), and single-byte edge copies cost more instructions than the copy itself.  The buffer is zero
+// before a piece is assembled, so a segment simply ORs (ds_or_b32) every dword it touches: the source is
+// read as aligned dwords and cut with v_alignbyte to the destination's phase, the first and last dword are
+// masked to the segment's own bytes — neighbouring segments, handled by other lanes, OR theirs into the
+// same dwords.  All reads of a step are issued before its writes.  SEGC: SEG when the tile size is a
+// compile-time constant (the loop unrolls), else 0.
 template <int SEGC>
-__device__ __forceinline__ void copy_segment(const uint8_t* __restrict__ sb, uint32_t sa, uint8_t* __restrict__ d,
-                                             uint32_t dl, uint32_t SEG) {
-    const uint32_t hd = min((4u - (dl & 3u)) & 3u, SEG);
-    const uint32_t s2 = sa + hd, nd = (SEG - hd) >> 2, tl = (SEG - hd) & 3u;
-    const uint32_t* W = reinterpret_cast<const uint32_t*>(sb + (sa & ~3u));
-    const uint32_t* A = reinterpret_cast<const uint32_t*>(sb + (s2 & ~3u));
-    uint32_t* D = reinterpret_cast<uint32_t*>(d + hd);
-    const uint32_t hv = hd ? __builtin_amdgcn_alignbyte(W[1], W[0], sa & 3u) : 0u;      // the 4 bytes at sa
-    constexpr int CH = SEGC ? (SEGC / 4 < 8 ? SEGC / 4 : 8) : 8;                          // interior dwords per step
-    uint32_t lo = A[0];
-    for (uint32_t i0 = 0; i0 < nd; i0 += CH) {
+__device__ __forceinline__ void or_segment(const uint8_t* __restrict__ sb, uint32_t sa, uint8_t* __restrict__ lds0,
+                                           uint32_t dl, uint32_t SEG) {
+    const uint32_t phi = dl & 3u, nc = (phi + SEG + 3u) >> 2;            // destination dwords touched
+    const int so = (int)sa - (int)phi;                                   // source byte that lands on byte 0 of dword 0
+    const int a0 = so >> 2;                                              // (-1 when so < 0: that word is masked out anyway)
+    const uint32_t sh = (uint32_t)so & 3u;
+    const uint32_t* A = reinterpret_cast<const uint32_t*>(sb);
+    uint32_t* D = reinterpret_cast<uint32_t*>(lds0 + (dl & ~3u));
+    const uint32_t end = (phi + SEG) & 3u;
+    const uint32_t m_first = 0xFFFFFFFFu << (8u * phi), m_last = end ? 0xFFFFFFFFu >> (8u * (4u - end)) : 0xFFFFFFFFu;
+    constexpr int CH = SEGC ? ((SEGC + 6) / 4 < 8 ? (SEGC + 6) / 4 : 8) : 8;
+    uint32_t lo = a0 >= 0 ? A[a0] : 0u;
+    for (uint32_t i0 = 0; i0 < nc; i0 += CH) {
         uint32_t w[CH + 1];
         w[0] = lo;
 #pragma unroll
-        for (int i = 0; i < CH; i++) w[i + 1] = (i0 + i < nd) ? A[i0 + i + 1] : 0u;
+        for (int i = 0; i < CH; i++) w[i + 1] = (i0 + i < nc) ? A[a0 + (int)(i0 + i) + 1] : 0u;
 #pragma unroll
-        for (int i = 0; i < CH; i++)
-            if (i0 + i < nd) D[i0 + i] = __builtin_amdgcn_alignbyte(w[i + 1], w[i], s2 & 3u);
+        for (int i = 0; i < CH; i++) {
+            if (i0 + i < nc) {
+                uint32_t v = __builtin_amdgcn_alignbyte(w[i + 1], w[i], sh);
+                if (i0 + i == 0) v &= m_first;
+                if (i0 + i == nc - 1u) v &= m_last;
+                atomicOr(&D[i0 + i], v);
+            }
+        }
         lo = w[CH];
-    }
-    if (hd > 0) d[0] = (uint8_t)hv;
-    if (hd > 1) d[1] = (uint8_t)(hv >> 8);
-    if (hd > 2) d[2] = (uint8_t)(hv >> 16);
-    if (tl) {
-        const uint32_t tv = __builtin_amdgcn_alignbyte(A[nd + 1], A[nd], s2 & 3u);        // the 4 bytes at s2 + 4*nd
-        uint8_t* t = d + hd + 4u * nd;
-        t[0] = (uint8_t)tv;
-        if (tl > 1) t[1] = (uint8_t)(tv >> 8);
-        if (tl > 2) t[2] = (uint8_t)(tv >> 16);
     }
 }
 
@@ -225,6 +225,8 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
         head = (uint32_t)(a0 & 15);
         carry = head;
         out_base = a0 - head;
+        for (int i = lane; i < L.out_chunks; i += kWave) reinterpret_cast<uint4*>(w_out)[i] = make_uint4(0, 0, 0, 0);
+        wave_lds_sync();
     }
 
     // look-ahead depth of this wave (see the env loop): 1, 2, 4, 8 by wave; depth_mode > 0 (measurement
@@ -541,8 +543,8 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             // Any tile size: the env's n*P*P*3 output bytes are the next S bytes of the wave's stream;
             // tile rows are SEG = 3*TS bytes at arbitrary byte offsets.  Piece by piece (piece_rows whole
             // pixel rows, ~4 KiB): ASSEMBLE — segment g of the piece (pixel row g / VS, view column
-            // g % VS) is SEG contiguous bytes of one atlas tile row, copied by one lane to
-            // w_out[carry + g*SEG]; then STREAM
+            // g % VS) is SEG contiguous bytes of one atlas tile row, ORed by one lane into the zeroed
+            // w_out at carry + g*SEG; then STREAM
             // the complete 16-byte chunks of w_out (linear ds_read_b128 -> global_store_dwordx4) and move
             // the incomplete tail to the front, where the next piece — or the next env — continues.
             const uint32_t SEG = 3u * (uint32_t)TS, P = (uint32_t)(VS * TS), RB = P * 3u;
@@ -555,18 +557,16 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             };
             for (uint32_t R0 = 0; R0 < NR; R0 += (uint32_t)L.piece_rows) {
                 const uint32_t rows = min((uint32_t)L.piece_rows, NR - R0), nseg = rows * (uint32_t)VS;
-                uint8_t* dst0 = w_out + carry;
                 for (uint32_t g = lane; g < nseg; g += kWave) {
                     const uint32_t Rl = __umulhi(g, mVS), col = g - Rl * (uint32_t)VS, R = R0 + Rl;
                     const uint32_t band = TS > 1 ? __umulhi(R, mTS) : R, rr = R - band * (uint32_t)TS;
                     const uint32_t so = tile_off((uint32_t)w_tmap[band * (uint32_t)VS + col]) + rr * SEG;
-                    uint8_t* d = dst0 + g * SEG;
                     const uint8_t* sb;       // source base the offset `sa` counts from
                     uint32_t sa = so;
                     if constexpr (kSplit) { sb = (so & kInLds) ? s_atlas : cfg.atlas; sa = so & ~kInLds; }
                     else if constexpr (kGlobalAtlas) sb = cfg.atlas;
                     else sb = s_atlas;
-                    copy_segment<TS_ * 3>(sb, sa, d, (uint32_t)(d - smem), SEG);
+                    or_segment<TS_ * 3>(sb, sa, w_out, carry + g * SEG, SEG);
                 }
                 wave_lds_sync();
                 const uint32_t total = carry + rows * RB, full = total >> 4;
@@ -588,7 +588,10 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                     const uint32_t tail = total - (full << 4);
                     const uint8_t tb = (uint32_t)lane < tail ? w_out[(full << 4) + lane] : (uint8_t)0;
                     wave_lds_sync();
-                    if ((uint32_t)lane < tail) w_out[lane] = tb;
+                    // the incomplete chunk moves to the front (zero-padded to 16 bytes); the rest of the buffer is
+                    // zeroed for the next piece's ORs
+                    if (lane < 16) w_out[lane] = tb;
+                    for (int i = 1 + lane; i < L.out_chunks; i += kWave) reinterpret_cast<uint4*>(w_out)[i] = make_uint4(0, 0, 0, 0);
                     out_base += (uintptr_t)full << 4;
                     carry = tail;
                 } else {
