@@ -345,7 +345,9 @@ def main():
                        "launches_per_step": (["mg_step_render (action loop + reset of finished episodes + obs raster)"]
                                              if fused else ["mg_step (+ fused reset of finished episodes)",
                                                             "mg_render_obs"]),
-                       "sharding": "env batch split contiguously, no collectives"},
+                       "sharding": "env batch split contiguously, no collectives",
+                       "obs_buffers": "chosen among candidate HBM allocations by timing the raster into each at "
+                                      "construction (MultiGridEnv._place_obs_buffers; ms per launch in obs_placement)"},
             "timing": {"what": "median of K-step blocks, each bracketed by barrier + synchronize, MAX over ranks",
                        "blocks": summary["plain"], "seconds_timed": summary["seconds_timed"],
                        "instrumented_blocks": summary.get("instrumented"),
@@ -355,6 +357,7 @@ def main():
             "closure": summary.get("closure"),
             "clocks": {"before": clocks_before, "after": clocks_after, "source": "rocm-smi"},
             "library": build_info,
+            "obs_placement": getattr(env._groups[0], "placement_ms", None),
         }
     del env
     torch.cuda.empty_cache()

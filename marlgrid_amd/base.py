@@ -251,7 +251,7 @@ class MultiGridEnv(object):
     def __init__(self, agents=[], grid_size=None, width=None, height=None, max_steps=100,
                  reward_decay=True, seed=1337, respawn=False, ghost_mode=True, agent_spawn_kwargs={},
                  batch_size=1, device=None, seeds=None, auto_reset=False, strict=True, obs_buffers=2,
-                 fused_step=True, _dry=False):
+                 fused_step=True, place_obs=True, _dry=False):
         if grid_size is not None:
             assert width is None and height is None
             width, height = grid_size, grid_size
@@ -267,6 +267,7 @@ class MultiGridEnv(object):
         self.strict = bool(strict)
         self.obs_buffers = max(1, int(obs_buffers))
         self.fused_step = bool(fused_step)     # step() = one launch (mg_step_render) instead of mg_step + mg_render_obs
+        self.place_obs = bool(place_obs)       # pick well-placed HBM buffers for the observations (see _place_obs_buffers)
         self._dry = bool(_dry)
         if self.batch_size < 1:
             raise ValueError("batch_size must be >= 1")
@@ -304,6 +305,8 @@ class MultiGridEnv(object):
         self._seeds_arg = seeds
         self.seed(seed=seed)
         self.reset()
+        if not self._dry and self.place_obs:
+            self._place_obs_buffers()
         self._spec_ctor = self._spec_last     # the constructor-time `_gen_grid` (base.py:369)
         self._retrace = True
 
@@ -396,6 +399,42 @@ class MultiGridEnv(object):
                               self.error_t.data_ptr(),
                               self.prestige_t.data_ptr() if self.prestige_t is not None else None,
                               self.mt_head.data_ptr())
+
+    @_on_device
+    def _place_obs_buffers(self, extra=14, min_bytes=64 << 20, iters=3, budget=48 << 30):
+        """Choose WHERE in HBM the observation buffers live.  Measured on MI355X (tools/microbench/
+        store_patterns6.hip, profiles/r02): the rate at which the raster's write pattern — thousands of
+        waves, each streaming its own env — is absorbed depends on the buffer it writes, reproducibly per
+        buffer and by up to 25 % (5.3 vs 6.6-6.8 TB/s; typically the first large allocations of a process
+        are the slow ones), while a dense fill of the same buffers is flat at 6.9 TB/s: a property of the
+        allocation's physical placement, not of the kernel.  So a few candidate buffers are allocated, the
+        raster itself is timed into each (HIP events, `iters` launches), and the fastest are kept."""
+        import torch
+        for g in self._groups:
+            nbytes = g.ring[0].numel()
+            if nbytes < min_bytes:
+                continue
+            free, _total = torch.cuda.mem_get_info(self.device)
+            n_extra = int(max(0, min(extra, min(free // 3, budget) // nbytes)))   # candidates are transient
+            if n_extra == 0:
+                continue
+            cands = list(g.ring) + [torch.empty_like(g.ring[0]) for _ in range(n_extra)]
+            ms = C.c_float(0)
+            cost = []
+            for c in cands:
+                N.check(self._lib.mg_time_render_obs(C.byref(g.cfg), C.byref(self._state), c.data_ptr(), iters,
+                                                     C.byref(ms), self._stream()))
+                cost.append(ms.value)
+            order = sorted(range(len(cands)), key=lambda i: cost[i])
+            g.ring = [cands[i] for i in order[:len(g.ring)]]
+            g.obs = g.ring[self._ring_i]
+            g.placement_ms = {"kept": [cost[i] for i in order[:len(g.ring)]], "all": cost}
+            del cands
+        for i, r in enumerate(self._ring):
+            r["obs"] = self._groups[0].ring[i]
+        self.obs = self._ring[self._ring_i]["obs"]
+        torch.cuda.empty_cache()            # the rejected candidates go back to the driver
+        self._render()                      # the current observation, into the buffer that is current now
 
     def _stream(self):
         import torch
