@@ -122,36 +122,42 @@ class Probes(object):
     """HIP events on the launch stream (torch's current stream IS the stream the C ABI launches on:
     MultiGridEnv passes torch.cuda.current_stream().cuda_stream to every call).  MultiGridEnv.step calls
     the probe before its first launch (tag 0), between mg_step and mg_render_obs when it runs as two
-    launches (tag 1), and after its last launch (tag 2)."""
+    launches (tag 1), and after its last launch (tag 2).  One launch per step (mg_step_render): one event
+    per step, after the launch — consecutive events are one launch interval apart (an event costs ~2 us of
+    stream time, so as few as the breakdown needs)."""
 
     def __init__(self, env, K):
         import torch
         self.env, self.K = env, K
-        self.per_step = 2 if env.fused_step else 3
-        self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(self.per_step * K)]
+        self.fused = bool(env.fused_step) and not env._hetero
+        n = (K + 1) if self.fused else 3 * K
+        self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
         self.i = 0
         self.on = False
 
     def __call__(self, tag):
-        if self.on:
+        if self.on and (tag == 2 or not self.fused):
             self.ev[self.i].record()
             self.i += 1
 
     def arm(self):
         self.i, self.on = 0, True
+        if self.fused:
+            self.ev[0].record()          # start of the block: the first launch interval begins here
+            self.i = 1
 
     def collect(self):
         self.on = False
-        K, ev, m = self.K, self.ev, self.per_step
-        assert self.i == m * K
-        between = [ev[m * j + m - 1].elapsed_time(ev[m * j + m]) for j in range(K - 1)]   # gap between steps
-        out = {"between_steps_ms": sum(between) / max(1, K - 1), "gpu_span_ms_per_step": ev[0].elapsed_time(ev[m * K - 1]) / K}
-        if m == 2:
-            out["step_render_interval_ms"] = sum(ev[2 * j].elapsed_time(ev[2 * j + 1]) for j in range(K)) / K
-        else:
-            out["step_interval_ms"] = sum(ev[3 * j].elapsed_time(ev[3 * j + 1]) for j in range(K)) / K
-            out["render_interval_ms"] = sum(ev[3 * j + 1].elapsed_time(ev[3 * j + 2]) for j in range(K)) / K
-        return out
+        K, ev = self.K, self.ev
+        if self.fused:
+            assert self.i == K + 1
+            iv = [ev[j].elapsed_time(ev[j + 1]) for j in range(K)]
+            return {"step_render_interval_ms": sum(iv) / K, "gpu_span_ms_per_step": ev[0].elapsed_time(ev[K]) / K}
+        assert self.i == 3 * K
+        between = [ev[3 * j + 2].elapsed_time(ev[3 * j + 3]) for j in range(K - 1)]   # gap between steps
+        return {"step_interval_ms": sum(ev[3 * j].elapsed_time(ev[3 * j + 1]) for j in range(K)) / K,
+                "render_interval_ms": sum(ev[3 * j + 1].elapsed_time(ev[3 * j + 2]) for j in range(K)) / K,
+                "between_steps_ms": sum(between) / max(1, K - 1), "gpu_span_ms_per_step": ev[0].elapsed_time(ev[3 * K - 1]) / K}
 
 
 def summarise(blocks, K):

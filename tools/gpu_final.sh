@@ -22,3 +22,5 @@ timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/prof_misc -o kt --output-fo
 (cd $R && timeout 200 python tools/ab_render.py 0 4 3 F R > $OUT/ab_render.log 2>&1); tail -n 6 $OUT/ab_render.log
 (cd $R && timeout 100 tools/microbench/store_patterns5 0.25 2 > $OUT/store_patterns5.log 2>&1); grep "^r1" $OUT/store_patterns5.log | cut -c1-110
 (cd $R && timeout 120 python tools/time_kernels.py > $OUT/time_kernels.log 2>&1); cat $OUT/time_kernels.log | grep -v amdgpu
+(cd $R && for k in 1 2; do timeout 100 tools/microbench/store_patterns6 6; echo "--- new process"; done > $OUT/store_patterns6.log 2>&1); grep -c "render pattern" $OUT/store_patterns6.log
+(cd $R && timeout 200 python tools/placement_probe.py 2>&1 | grep -v amdgpu > $OUT/placement_probe.log); tail -n 3 $OUT/placement_probe.log
