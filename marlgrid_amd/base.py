@@ -401,34 +401,61 @@ class MultiGridEnv(object):
                               self.mt_head.data_ptr())
 
     @_on_device
-    def _place_obs_buffers(self, extra=14, min_bytes=64 << 20, iters=3, budget=48 << 30):
+    def _place_obs_buffers(self, batch=16, max_candidates=96, min_bytes=64 << 20, iters=3, budget=96 << 30,
+                           gain=0.12, seconds=2.0):
         """Choose WHERE in HBM the observation buffers live.  Measured on MI355X (tools/microbench/
-        store_patterns6.hip, profiles/r02): the rate at which the raster's write pattern — thousands of
-        waves, each streaming its own env — is absorbed depends on the buffer it writes, reproducibly per
-        buffer and by up to 25 % (5.3 vs 6.6-6.8 TB/s; typically the first large allocations of a process
-        are the slow ones), while a dense fill of the same buffers is flat at 6.9 TB/s: a property of the
-        allocation's physical placement, not of the kernel.  So a few candidate buffers are allocated, the
-        raster itself is timed into each (HIP events, `iters` launches), and the fastest are kept."""
+        store_patterns6.hip, tools/placement_probe*.py, profiles/r02): the rate at which the raster's write
+        pattern — thousands of waves, each streaming its own env — is absorbed depends on the buffer it
+        writes, reproducibly per buffer and by up to 25 % (5.3 vs 6.6-6.8 TB/s), while a dense fill or a
+        dense write front over the same buffers is flat at 6.6-6.9 TB/s: a property of the allocation's
+        physical placement, not of the kernel, the size or the virtual address.  Well-placed allocations
+        are a minority on some boxes (1 in 10-20) and the rule on others.  So candidate buffers are
+        allocated a `batch` at a time and the raster itself is timed into each (HIP events, `iters`
+        launches), until the buffers that would be kept are `gain` faster than the median candidate (they
+        are in the fast class), or a full batch shows no spread worth searching (every candidate is in the
+        same class), or `max_candidates` / `budget` bytes / `seconds` are spent; the fastest are kept and
+        the rest go back to the driver (they are held until then: freed memory is what the next
+        allocation would get)."""
+        import time
         import torch
+        t_end = time.perf_counter() + seconds
         for g in self._groups:
             nbytes = g.ring[0].numel()
             if nbytes < min_bytes:
                 continue
-            free, _total = torch.cuda.mem_get_info(self.device)
-            n_extra = int(max(0, min(extra, min(free // 3, budget) // nbytes)))   # candidates are transient
-            if n_extra == 0:
-                continue
-            cands = list(g.ring) + [torch.empty_like(g.ring[0]) for _ in range(n_extra)]
             ms = C.c_float(0)
-            cost = []
-            for c in cands:
-                N.check(self._lib.mg_time_render_obs(C.byref(g.cfg), C.byref(self._state), c.data_ptr(), iters,
+
+            def cost_of(buf):
+                N.check(self._lib.mg_time_render_obs(C.byref(g.cfg), C.byref(self._state), buf.data_ptr(), iters,
                                                      C.byref(ms), self._stream()))
-                cost.append(ms.value)
+                return ms.value
+
+            keep = len(g.ring)
+            cands = list(g.ring)
+            cost = [cost_of(c) for c in cands]
+            free, _total = torch.cuda.mem_get_info(self.device)
+            cap = keep + int(max(0, min(max_candidates, min(free // 3, budget) // nbytes)))   # candidates are transient
+            why = "cap"
+            while len(cands) < cap:
+                for _ in range(min(batch, cap - len(cands))):
+                    cands.append(torch.empty_like(g.ring[0]))
+                    cost.append(cost_of(cands[-1]))
+                ranked = sorted(cost)
+                median = ranked[len(ranked) // 2]
+                if ranked[keep - 1] <= (1.0 - gain) * median:
+                    why = "kept set %d%% under the median candidate" % round(100 * (1 - ranked[keep - 1] / median))
+                    break
+                if ranked[-1] <= 1.05 * ranked[0]:
+                    why = "no spread among %d candidates" % len(cands)
+                    break
+                if time.perf_counter() > t_end:
+                    why = "time"
+                    break
             order = sorted(range(len(cands)), key=lambda i: cost[i])
-            g.ring = [cands[i] for i in order[:len(g.ring)]]
+            g.ring = [cands[i] for i in order[:keep]]
             g.obs = g.ring[self._ring_i]
-            g.placement_ms = {"kept": [cost[i] for i in order[:len(g.ring)]], "all": cost}
+            g.placement_ms = {"kept": [cost[i] for i in order[:keep]], "candidates": len(cands), "stopped": why,
+                              "all": cost}
             del cands
         for i, r in enumerate(self._ring):
             r["obs"] = self._groups[0].ring[i]

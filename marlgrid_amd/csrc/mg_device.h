@@ -64,6 +64,13 @@ struct FusedStep {
 // block-shared LDS of the obs-render kernel after the atlas: object flags, overlap slots, hide masks, prestige scales, flags2
 constexpr int kRenderShared = 3 * MG_MAX_OBJ + 2 * MG_MAX_AGENTS * 8 + MG_MAX_OBJ * 32 + MG_MAX_AGENTS;   // ... + the object table (fused step), the viewer map
 
+// x / d for small operands (x * d < 2^32) by multiply-high with ceil(2^32 / d): item index -> (slot, rest)
+struct SmallDiv {
+    uint32_t d, m;
+    __host__ __device__ explicit SmallDiv(uint32_t d_) : d(d_), m(d_ > 1 ? 0xFFFFFFFFu / d_ + 1u : 0u) {}
+    __device__ uint32_t div(uint32_t x) const { return d > 1 ? __umulhi(x, m) : x; }
+};
+
 // per-wave LDS scratch of the obs-render kernel (bytes), shared by host launch code and kernel
 struct RenderScratch {
     int grid, rec, pres, first, second, vbase, vshow, trow, vis, tmap, dyn, out, step, total;
@@ -73,9 +80,13 @@ struct RenderScratch {
     int rec_stride;    // u64 records per staged env
     int piece_rows;    // assemble-and-stream raster: pixel rows assembled in LDS per piece (0: chunk raster)
     int out_chunks;    // ... and the size of its piece buffer in 16-byte chunks
+    int view_slots;    // envs whose views are derived together: slots of first / second / trow (1, or stage_envs)
+    int cell_stride;   // bytes per slot of first / second
+    int trow_stride;   // dwords per slot of trow
 };
 __host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride, int n, int vs, int stage_envs = 1,
-                                                               int dyn_bytes = 0, int out_bytes = 0, int piece_rows = 0) {
+                                                               int dyn_bytes = 0, int out_bytes = 0, int piece_rows = 0,
+                                                               bool batch_views = false, bool any_hide = true) {
     RenderScratch s;
     int o = 0;
     s.stage_envs = stage_envs;
@@ -83,12 +94,19 @@ __host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride,
     s.grid = o;  o += stage_envs * round_up(cells_stride, 16);
     s.rec = o;   o += stage_envs * s.rec_stride * 8;
     s.pres = o;  o += dyn_bytes ? stage_envs * s.rec_stride * 8 : 0;   // agent.prestige of the staged envs
-    s.first = o; o += round_up(cells_stride, 16);
-    s.second = o; o += round_up(cells_stride, 16);
-    s.vbase = o; o += round_up(n * vs * vs, 16);
-    s.vshow = o; o += round_up(n * vs * vs, 16);
-    s.trow = o;  o += round_up(n * vs * 4, 16);
-    s.vis = o;   o += round_up(n * vs * 4, 16);
+    // Views one env at a time: first / second (agents of a cell), vbase / vshow (a view cell's object and
+    // agent, phase 3 -> 5), trow / vis (transparency and visibility rows).  Views of the whole batch at once
+    // (batch_views): a slot of first (second: only with hide_item_types) and trow per staged env; the
+    // (object, agent) pair waits in the env's tmap slot and visibility replaces transparency in place.
+    s.view_slots = batch_views ? stage_envs : 1;
+    s.cell_stride = round_up(cells_stride, 16);
+    s.trow_stride = round_up(n * vs * 4, 16) / 4;
+    s.first = o; o += s.view_slots * s.cell_stride;
+    s.second = o; o += (batch_views && !any_hide) ? 0 : s.view_slots * s.cell_stride;
+    s.vbase = o; o += batch_views ? 0 : round_up(n * vs * vs, 16);
+    s.vshow = o; o += batch_views ? 0 : round_up(n * vs * vs, 16);
+    s.trow = o;  o += s.view_slots * s.trow_stride * 4;
+    s.vis = batch_views ? s.trow : o; o += batch_views ? 0 : s.trow_stride * 4;
     s.tmap_slots = stage_envs;
     s.tmap_stride = round_up(n * vs * vs * 2, 16);
     s.tmap = o;  o += s.tmap_slots * s.tmap_stride;
@@ -123,11 +141,14 @@ __host__ __device__ inline RenderScratch render_scratch_for(const MgConfig& cfg,
         if (rows > n * vs * ts) rows = n * vs * ts;
         out = 32 + rows * rb;
     }
+    // assemble-and-stream raster without recoloured tiles: the views of a whole batch are derived together,
+    // one slot of view scratch per staged env (see the kernel's pass 0)
+    const bool batch_views = out > 0 && dyn == 0;
     const RenderScratch b = render_scratch_layout(cfg.cells_stride, n, vs, 1, dyn, out, rows);
     const int resident = (atlas_b + 4 * b.total + misc <= 160 * 1024) ? atlas_b : 0;   // else the atlas is read in place
     int k = 8;
-    while (k > 1 && resident + wpb * render_scratch_layout(cfg.cells_stride, n, vs, k, dyn, out, rows).total + misc > 160 * 1024) k >>= 1;
-    return render_scratch_layout(cfg.cells_stride, n, vs, k, dyn, out, rows);
+    while (k > 1 && resident + wpb * render_scratch_layout(cfg.cells_stride, n, vs, k, dyn, out, rows, batch_views, cfg.any_hide != 0).total + misc > 160 * 1024) k >>= 1;
+    return render_scratch_layout(cfg.cells_stride, n, vs, k, dyn, out, rows, batch_views, cfg.any_hide != 0);
 }
 
 }  // namespace mg

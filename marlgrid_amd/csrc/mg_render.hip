@@ -174,6 +174,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     __syncthreads();
 
     constexpr bool kChunkRaster = TS_ > 0 && (TS_ % 8) == 0 && RM_ == 0;
+    constexpr bool kBatchViews = !kChunkRaster && !kPrestige;   // as render_scratch_for: view scratch per staged env
     const RenderScratch L = render_scratch_for(cfg, WPB, RM_);
     uint8_t* ws = smem + atlas_bytes + kRenderShared + (size_t)wave * L.total;
     uint8_t* w_stage_g = ws + L.grid;                                      // [stage_envs][cells_stride] grids of a batch of envs
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     uint8_t* w_vbase = ws + L.vbase;
     uint8_t* w_vshow = ws + L.vshow;
     uint32_t* w_trow = reinterpret_cast<uint32_t*>(ws + L.trow);
-    uint32_t* w_vis = reinterpret_cast<uint32_t*>(ws + L.vis);
+    uint32_t* w_vis = reinterpret_cast<uint32_t*>(ws + L.vis);       // (views of a batch at once: the same rows as trow)
     uint16_t* w_tmap0 = reinterpret_cast<uint16_t*>(ws + L.tmap);   // [tmap_slots][n*VV]
     uint8_t* w_dyn = ws + L.dyn;                               // [n][4 orientations][tile_bytes]
     uint8_t* w_out = ws + L.out;                               // assemble-and-stream raster: [32 + piece_rows * 3 * P]
@@ -232,8 +233,10 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     // look-ahead depth of this wave (see the env loop): 1, 2, 4, 8 by wave; depth_mode > 0 (measurement
     // builds) forces one depth for all.  Per-env recoloured tiles ('prestige') have one slot only.
     int depth = depth_mode > 0 ? depth_mode : (1 << (wave & 3));
+    if (kBatchViews && TS < 8 && depth_mode <= 0) depth = L.tmap_slots;   // issue-bound: views of the whole batch at once
     if (depth > L.tmap_slots) depth = L.tmap_slots;
     if constexpr (kPrestige) depth = 1;
+    const SmallDiv by_n((uint32_t)n), by_nv((uint32_t)nv), by_nvVV((uint32_t)(nv * VV));   // item -> (slot, rest)
 
     for (int eb = e0; eb < e_end; eb += K) {
         const int kb = min(K, e_end - eb);
@@ -280,16 +283,25 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     for (int pass = 0; pass < 2; pass++)
     for (int ej = ej0; ej < min(kb, ej0 + depth); ej++) {
         const int e = eb + ej;
-        const uint8_t* w_grid = w_stage_g + (size_t)ej * cfg.cells_stride;
-        const uint64_t* w_rec = w_stage_r + (size_t)ej * rec_stride;
         uint16_t* w_tmap = w_tmap0 + (size_t)(ej - ej0) * (L.tmap_stride / 2);
         if (pass == 0) {
-        // 1. per-env scratch
-        for (int i = lane; i < gdw; i += kWave) {
+        // Views of G envs at once (phases 1-5 -> one tmap slot each).  G = 1, env by env, under the
+        // 16-byte-chunk raster (HBM-bound: these phases hide under the other waves' stores).  Under the
+        // assemble-and-stream raster the whole look-ahead group: its small-tile configurations are bound
+        // by instruction issue, phases 2 and 4 have one lane per AGENT — a lone env leaves 61 of 64 lanes
+        // idle — and 3 x 49 view cells fill 2.3 trips of 64 lanes where 8 envs fill 18.4 of 19.
+        if (kBatchViews && ej != ej0) continue;
+        const int G = kBatchViews ? min(kb, ej0 + depth) - ej0 : 1;
+        const int nvVV = nv * VV;
+        const uint8_t* g_grid = w_stage_g + (size_t)ej * cfg.cells_stride;      // env ej + g: + g * cells_stride
+        const uint64_t* g_rec = w_stage_r + (size_t)ej * rec_stride;            //            + g * rec_stride
+        // 1. scratch of the G slots
+        const bool has_second = !kBatchViews || cfg.any_hide;    // (batched: no `second` slots without hide_item_types)
+        for (int i = lane; i < G * (L.cell_stride / 4); i += kWave) {
             reinterpret_cast<uint32_t*>(w_first)[i] = 0xFFFFFFFFu;
-            reinterpret_cast<uint32_t*>(w_second)[i] = 0xFFFFFFFFu;
+            if (has_second) reinterpret_cast<uint32_t*>(w_second)[i] = 0xFFFFFFFFu;
         }
-        for (int i = lane; i < nv * VS; i += kWave) w_trow[i] = 0;
+        for (int i = lane; i < G * L.trow_stride; i += kWave) w_trow[i] = 0;
         wave_lds_sync();
         if constexpr (V_ == 3 || V_ == 4) {
             for (int it = lane; it < nv * VV; it += kWave) w_tmap[it] = 0;
@@ -297,27 +309,34 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
         for (int rep = 0; rep < (V_ == 11 ? 2 : 1); rep++) {   // V_ == 11 (measurement): phases 2-5 twice
         // 2. first (lowest-rank) agent of every occupied cell: the reference's "cell object" when
         //    the base is empty, and `obj.agents[0]` when agents stand on an overlappable object
-        if (lane < n) {
-            const uint64_t r = w_rec[lane];
+        auto first_of_cell = [&](const int g, const int a) {     // slot g, agent a
+            const uint64_t* w_rec = g_rec + g * rec_stride;
+            const uint64_t r = w_rec[a];
             if (rec_byte(r, MG_AG_FLAGS) & MG_AF_PLACED) {
                 int below = 0;   // agents of this cell that arrived earlier
                 for (int j = 0; j < n; j++) {
                     const uint64_t rj = w_rec[j];
-                    if (j != lane && (rec_byte(rj, MG_AG_FLAGS) & MG_AF_PLACED) && rec_xy(rj) == rec_xy(r) &&
+                    if (j != a && (rec_byte(rj, MG_AG_FLAGS) & MG_AF_PLACED) && rec_xy(rj) == rec_xy(r) &&
                         rec_byte(rj, MG_AG_RANK) < rec_byte(r, MG_AG_RANK))
                         below++;
                 }
-                const int cell = rec_byte(r, MG_AG_X) * H + rec_byte(r, MG_AG_Y);
-                if (below == 0) w_first[cell] = (uint8_t)lane;
-                else if (below == 1) w_second[cell] = (uint8_t)lane;   // only hide_item_types looks at it
+                const int cell = g * L.cell_stride + rec_byte(r, MG_AG_X) * H + rec_byte(r, MG_AG_Y);
+                if (below == 0) w_first[cell] = (uint8_t)a;
+                else if (below == 1 && has_second) w_second[cell] = (uint8_t)a;   // only hide_item_types looks at it
             }
-        }
+        };
+        if constexpr (kBatchViews) {
+            for (int it = lane; it < G * n; it += kWave) { const int g = (int)by_n.div((uint32_t)it); first_of_cell(g, it - g * n); }
+        } else if (lane < n) first_of_cell(0, lane);
         wave_lds_sync();
         // 3. egocentric crop + rotate: view cell (a = column, b = row) -> world cell
-        for (int it = lane; it < nv * VV; it += kWave) {
-            const int v = it / VV, c = it - v * VV, k = s_vmap[v];      // viewer slot v is agent k
+        for (int it = lane; it < G * nvVV; it += kWave) {
+            const int g = kBatchViews ? (int)by_nvVV.div((uint32_t)it) : 0, iv = it - g * nvVV;
+            const int v = iv / VV, c = iv - v * VV, k = s_vmap[v];      // viewer slot v is agent k
             const int vb = c / VS, va = c - vb * VS;
-            const uint64_t r = w_rec[k];
+            const uint8_t* w_grid = g_grid + g * cfg.cells_stride;
+            const uint8_t* s_first = w_first + g * L.cell_stride;
+            const uint64_t r = g_rec[g * rec_stride + k];
             const int x = (int)rec_byte(r, MG_AG_X), y = (int)rec_byte(r, MG_AG_Y), dir = (int)rec_byte(r, MG_AG_DIR);
             int wx, wy;
             if (dir == 3)      { wx = x - h + va;                 wy = y - (VS - 1) + off + vb; }
@@ -329,37 +348,45 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             if (inb) {
                 const int cell = wx * H + wy;
                 base = w_grid[cell];
-                show = w_first[cell];
+                show = s_first[cell];
                 if (show != 0xFF && wx == x && wy == y) show = (uint32_t)k;   // viewer in the stack: base.py:282-291
             }
-            if (s_oflags[base] & MG_OF_SEE_BEHIND) atomicOr(&w_trow[v * VS + vb], 1u << va);   // opacity first
+            if (s_oflags[base] & MG_OF_SEE_BEHIND) atomicOr(&w_trow[g * L.trow_stride + v * VS + vb], 1u << va);   // opacity first
             if (cfg.any_hide && inb) {
                 // hide_item_types (base.py:441-449), applied after visibility: a hidden cell object is
                 // replaced by the first agent standing on it (or nothing) and that agent is drawn as
                 // a plain cell object — the "viewer is in the stack" rule no longer applies to it
                 const int cell = wx * H + wy;
-                const uint32_t first = w_first[cell];
+                const uint32_t first = s_first[cell];
                 if (base && ((s_hide[k] >> base) & 1ull)) { base = 0; show = first; }
                 else if (base == 0 && first != 0xFF && first != (uint32_t)k && ((cfg.hide_agent_mask >> k) & 1u))
-                    show = w_second[cell];
+                    show = w_second[g * L.cell_stride + cell];
             }
-            w_vbase[it] = (uint8_t)base;
-            w_vshow[it] = (uint8_t)show;
+            if constexpr (kBatchViews) {   // the pair waits where phase 5 puts the tile it selects
+                w_tmap[(size_t)g * (L.tmap_stride / 2) + iv] = (uint16_t)(base | (show << 8));
+            } else {
+                w_vbase[iv] = (uint8_t)base;
+                w_vshow[iv] = (uint8_t)show;
+            }
         }
         wave_lds_sync();
-        // 4. visibility per viewer (lanes 0..nv-1)
-        if (lane < nv) {
-            const uint64_t r = w_rec[s_vmap[lane]];
+        // 4. visibility, one lane per viewer
+        auto visibility = [&](const int g, const int v) {         // slot g, viewer v
+            const uint64_t r = g_rec[g * rec_stride + s_vmap[v]];
+            const int row0 = g * L.trow_stride + v * VS;
             uint32_t m[VS_ ? VS_ : MG_MAX_VIEW];
             if (!(rec_byte(r, MG_AG_FLAGS) & MG_AF_ACTIVE)) {           // base.py:420-425
                 for (int j = 0; j < VS; j++) m[j] = 0;
             } else if (cfg.see_through_walls) {                          // agents.py:294-295
                 for (int j = 0; j < VS; j++) m[j] = (1u << VS) - 1u;
             } else {
-                occlude_rows<VS_>(VS, off, &w_trow[lane * VS], m);
+                occlude_rows<VS_>(VS, off, &w_trow[row0], m);
             }
-            for (int j = 0; j < VS; j++) w_vis[lane * VS + j] = m[j];
-        }
+            for (int j = 0; j < VS; j++) w_vis[row0 + j] = m[j];
+        };
+        if constexpr (kBatchViews) {
+            for (int it = lane; it < G * nv; it += kWave) { const int g = (int)by_nv.div((uint32_t)it); visibility(g, it - g * nv); }
+        } else if (lane < nv) visibility(0, lane);
         wave_lds_sync();
         if constexpr (kPrestige) {
             // 4b. tiles of active 'prestige' agents are recoloured per env (render_post) — and blended
@@ -371,6 +398,8 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             //     0 (the only pass with per-pixel arithmetic) and three rotated byte copies of it.
             const int npx = TS * TS;
             const uint8_t* abase = kGlobalAtlas ? cfg.atlas : s_atlas;
+            const uint8_t* w_grid = g_grid;      // (G == 1: per-env recoloured tiles have one slot)
+            const uint64_t* w_rec = g_rec;
             uint32_t* w_col = w_trow;
             if (lane < n && ((cfg.prestige_mask >> lane) & 1u)) {
                 const PrestigeColor c = prestige_color(w_stage_p[(size_t)ej * rec_stride + lane], s_pscale[lane]);
@@ -415,11 +444,17 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             wave_lds_sync();
         }
         // 5. tile selection (base.py:275-299) -> atlas byte offset / 4 per view cell
-        for (int it = lane; it < nv * VV; it += kWave) {
-            const int v = it / VV, c = it - v * VV, k = s_vmap[v];
+        for (int it = lane; it < G * nvVV; it += kWave) {
+            const int g = kBatchViews ? (int)by_nvVV.div((uint32_t)it) : 0, iv = it - g * nvVV;
+            const int v = iv / VV, c = iv - v * VV, k = s_vmap[v];
             const int vb = c / VS, va = c - vb * VS;
-            const uint32_t visible = (w_vis[v * VS + vb] >> va) & 1u;
-            const uint32_t base = w_vbase[it], show = w_vshow[it];
+            const uint8_t* w_grid = g_grid + g * cfg.cells_stride;
+            const uint64_t* w_rec = g_rec + g * rec_stride;
+            uint16_t* tmap = w_tmap + (size_t)g * (L.tmap_stride / 2);
+            const uint32_t visible = (w_vis[g * L.trow_stride + v * VS + vb] >> va) & 1u;
+            uint32_t base, show;
+            if constexpr (kBatchViews) { const uint32_t pair = tmap[iv]; base = pair & 0xFFu; show = pair >> 8; }
+            else { base = w_vbase[iv]; show = w_vshow[iv]; }
             uint32_t tile = 0;   // shadow
             if (visible) {
                 const uint32_t slot = s_oslot[base];
@@ -443,11 +478,11 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 }
             }
             if constexpr (kChunkRaster && !kGlobalAtlas)                          // dword offset from the atlas base
-                w_tmap[it] = (uint16_t)(dyn ? dyn_off / 4 + (vt - NT4) * (TS_ * TS_ * 3 / 4) : vt * (TS_ * TS_ * 3 / 4));
+                tmap[iv] = (uint16_t)(dyn ? dyn_off / 4 + (vt - NT4) * (TS_ * TS_ * 3 / 4) : vt * (TS_ * TS_ * 3 / 4));
             else
-                w_tmap[it] = (uint16_t)vt;
+                tmap[iv] = (uint16_t)vt;
             if (dbg_cells) {
-                const size_t o = ((size_t)e * nv + v) * VV + va * VS + vb;        // [i][j] like the reference
+                const size_t o = ((size_t)(e + g) * nv + v) * VV + va * VS + vb;  // [i][j] like the reference
                 dbg_cells[o] = (uint8_t)base;
                 dbg_agent[o] = (uint8_t)show;
                 dbg_vis[o] = (uint8_t)visible;
