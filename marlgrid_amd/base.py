@@ -401,15 +401,16 @@ class MultiGridEnv(object):
                               self.mt_head.data_ptr())
 
     @_on_device
-    def _place_obs_buffers(self, batch=16, max_candidates=96, min_bytes=64 << 20, iters=3, budget=96 << 30,
-                           gain=0.12, seconds=2.0):
+    def _place_obs_buffers(self, batch=16, max_candidates=192, min_bytes=64 << 20, iters=3, budget=192 << 30,
+                           gain=0.12, seconds=4.0):
         """Choose WHERE in HBM the observation buffers live.  Measured on MI355X (tools/microbench/
         store_patterns6.hip, tools/placement_probe*.py, profiles/r02): the rate at which the raster's write
         pattern — thousands of waves, each streaming its own env — is absorbed depends on the buffer it
         writes, reproducibly per buffer and by up to 25 % (5.3 vs 6.6-6.8 TB/s), while a dense fill or a
         dense write front over the same buffers is flat at 6.6-6.9 TB/s: a property of the allocation's
         physical placement, not of the kernel, the size or the virtual address.  Well-placed allocations
-        are a minority on some boxes (1 in 10-20) and the rule on others.  So candidate buffers are
+        are a minority on some boxes (1 in 25 over the whole HBM: placement_map_whole_hbm.txt) and the rule
+        on others.  So candidate buffers are
         allocated a `batch` at a time and the raster itself is timed into each (HIP events, `iters`
         launches), until the buffers that would be kept are `gain` faster than the median candidate (they
         are in the fast class), or a full batch shows no spread worth searching (every candidate is in the
@@ -418,7 +419,8 @@ class MultiGridEnv(object):
         allocation would get)."""
         import time
         import torch
-        t_end = time.perf_counter() + seconds
+        t_begin = time.perf_counter()
+        t_end = t_begin + seconds
         for g in self._groups:
             nbytes = g.ring[0].numel()
             if nbytes < min_bytes:
@@ -434,7 +436,7 @@ class MultiGridEnv(object):
             cands = list(g.ring)
             cost = [cost_of(c) for c in cands]
             free, _total = torch.cuda.mem_get_info(self.device)
-            cap = keep + int(max(0, min(max_candidates, min(free // 3, budget) // nbytes)))   # candidates are transient
+            cap = keep + int(max(0, min(max_candidates, min(free // 2, budget) // nbytes)))   # candidates are transient
             why = "cap"
             while len(cands) < cap:
                 for _ in range(min(batch, cap - len(cands))):
@@ -455,7 +457,7 @@ class MultiGridEnv(object):
             g.ring = [cands[i] for i in order[:keep]]
             g.obs = g.ring[self._ring_i]
             g.placement_ms = {"kept": [cost[i] for i in order[:keep]], "candidates": len(cands), "stopped": why,
-                              "all": cost}
+                              "seconds": time.perf_counter() - t_begin, "all": cost}
             del cands
         for i, r in enumerate(self._ring):
             r["obs"] = self._groups[0].ring[i]

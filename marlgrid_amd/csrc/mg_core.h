@@ -320,11 +320,13 @@ MG_HD StepEnv step_load(const MgConfig& cfg, const MgState& st, const void* acti
 
 // auto_reset: an env whose episode ends in this step starts its next one right away (`prog`; reset
 // fused into the step: the done flag still reports the end).
-MG_HD void step_run(const MgConfig& cfg, const MgState& st, const MgGenProgram& prog, bool auto_reset, float* rewards,
-                    int b, const StepEnv& env, const StepScratch& sc) {
+// `g`: the env's grid slice — its home in HBM (st.grid + b * cells_stride), or a staged copy of it (the obs
+// kernel steps the envs it is about to render on their LDS copies: no dependent HBM round trip per grid
+// look-up); returns whether the slice was written (the owner of a staged copy then writes it back).
+MG_HD bool step_run(const MgConfig& cfg, const MgState& st, const MgGenProgram& prog, bool auto_reset, float* rewards,
+                    int b, const StepEnv& env, const StepScratch& sc, uint8_t* g) {
     const int n = cfg.n_agents, W = cfg.W, H = cfg.H, S = sc.S, col = sc.col;
     uint64_t* s_rec = sc.rec;
-    uint8_t* g = st.grid + (size_t)b * cfg.cells_stride;
     Mt mt{st.mt + (size_t)b * MG_MT_N, env.pos0, sc.head + col, S, 0};
     int err = 0;
 
@@ -499,6 +501,7 @@ MG_HD void step_run(const MgConfig& cfg, const MgState& st, const MgGenProgram& 
         const int e2 = reset_env(cfg, st, prog, sc.oflags, b, g, mt, s_rec, S, col);
         err = err ? err : e2;
         step_count = 0;
+        grid_dirty = true;
     }
     for (int k = 0; k < n; k++) st.agents[(size_t)b * n + k] = s_rec[k * S + col];
     st.step_count[b] = step_count;
@@ -506,6 +509,7 @@ MG_HD void step_run(const MgConfig& cfg, const MgState& st, const MgGenProgram& 
     st.mt_pos[b] = mt.pos;
     st.done[b] = (uint8_t)done;
     if (err && st.error[b] == 0) st.error[b] = err;
+    return grid_dirty;
 }
 
 // ---- MultiGridEnv.reset for one env (explicit reset; the auto-reset runs inside step_run) ---------

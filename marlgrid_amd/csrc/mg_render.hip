@@ -75,13 +75,17 @@ __device__ __forceinline__ void or_segment(const uint8_t* __restrict__ sb, uint3
 }
 
 // ---- mg_step_render: the step of a batch of staged envs, lane j < kb steps env eb + j (mg_core.h) ----
-// The step's memory round trips happen once per wave and batch, before the wave's first store of the batch.
+// The wave steps the envs it is about to render ON THEIR STAGED COPIES: the loads whose addresses are known up
+// front (records, actions, RNG look-ahead, counters: step_load) are issued together with the batch's grid loads
+// — one HBM round trip — and every grid look-up of the action loop, of a respawn and of a fused reset is an
+// LDS access.  What the step changes goes back to HBM with stores nobody waits for: records and counters from
+// step_run, and the grid slices it reports as written (a pickup / drop / toggle, or a reset) from the wave.
+// The views and the raster then read the stepped state where it already is.
 // (Inlined: as a call, the by-value launch structs would be copied to per-lane scratch.  The 16-wave
 // workgroups run at the 128-VGPR limit; the few dwords the step's live ranges spill are spilled and
 // reloaded around this region, once per batch — checked in the ISA: no scratch access in the raster loops.)
-__device__ __forceinline__ void fused_step_batch(const MgConfig& cfg, const MgState& st, const FusedStep& fs,
-                                                           int eb, int kb, int lane, uint8_t* sp, const MgObjDesc* s_obj,
-                                                           const uint8_t* s_oflags) {
+__device__ __forceinline__ StepScratch fused_step_scratch(const MgConfig& cfg, int lane, uint8_t* sp, const MgObjDesc* s_obj,
+                                                          const uint8_t* s_oflags) {
     const int n = cfg.n_agents;
     StepScratch sc;
     sc.rec = reinterpret_cast<uint64_t*>(sp);                                   // [n][8]
@@ -93,11 +97,19 @@ __device__ __forceinline__ void fused_step_batch(const MgConfig& cfg, const MgSt
     sc.oflags = s_oflags;
     sc.S = 8;
     sc.col = lane;
-    if (lane < kb) {
-        const StepEnv se = step_load(cfg, st, fs.actions, fs.action_bytes, eb + lane, sc);
-        step_run(cfg, st, fs.prog, fs.has_prog != 0, fs.rewards, eb + lane, se, sc);
-    }
+    return sc;
 }
+
+#if defined(MG_AB_VARIANTS)
+// measurement build: wall_clock64 (100 MHz) of every wave's lane 0 at the phase boundaries of its FIRST batch —
+// 0 entry, 1 tables + atlas in LDS, 2 batch staged (and step_load done), 3 batch stepped, 4 first views, 5 first
+// env rastered, 6 wave done; 7: XCC_ID << 16 | HW_ID — read by tools/phase_stamps.py
+__device__ unsigned long long* d_ab_stamps = nullptr;
+extern "C" int mg_ab_stamps(unsigned long long* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(d_ab_stamps), &p, sizeof(p)); }
+#define MG_STAMP(slot) do { if (d_ab_stamps && lane == 0) d_ab_stamps[(size_t)(blockIdx.x * WPB + wave) * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define MG_STAMP(slot) do {} while (0)
+#endif
 
 // ---- the kernel ----------------------------------------------------------------------------------
 // TS_ % 8 == 0: 16-byte-chunk fast raster (tile rows are an even number of dwords); VS_ > 0 also
@@ -127,6 +139,13 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     // pointers, its run of envs, loop bounds) lives in SGPRs instead of one VGPR each
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int VV = VS * VS;
+    MG_STAMP(0);
+#if defined(MG_AB_VARIANTS)
+    if (d_ab_stamps && lane == 0)      // where this wave runs: XCC_ID (hwreg 20) << 16 | HW_ID (hwreg 4) [15:0]
+        d_ab_stamps[(size_t)(blockIdx.x * WPB + wave) * 8 + 7] =
+            ((unsigned long long)(__builtin_amdgcn_s_getreg((32 - 1) << 11 | 20) & 0xF) << 16) |
+            (unsigned long long)(__builtin_amdgcn_s_getreg((16 - 1) << 11 | 4) & 0xFFFF);
+#endif
 
     // ---- block-shared: atlas + object flags ----
     // V_ == 8: the atlas does not fit the 160 KiB of LDS next to the per-env scratch (large tiles);
@@ -172,6 +191,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
         }
     }
     __syncthreads();
+    MG_STAMP(1);
 
     constexpr bool kChunkRaster = TS_ > 0 && (TS_ % 8) == 0 && RM_ == 0;
     constexpr bool kBatchViews = !kChunkRaster && !kPrestige;   // as render_scratch_for: view scratch per staged env
@@ -240,24 +260,31 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
 
     for (int eb = e0; eb < e_end; eb += K) {
         const int kb = min(K, e_end - eb);
-        if (fs.enabled) {
-            // mg_step_render: MultiGridEnv.step for the batch's envs, one lane per env, before they are
-            // staged and rendered — the whole env.step() is this one launch.
-            fused_step_batch(cfg, st, fs, eb, kb, lane, ws + L.step, s_obj, s_oflags);
-            // the staging loads below read what these lanes just stored (same wave, same L1: in order)
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        }
-        {   // 0. stage the batch (contiguous in HBM): loads first, all in flight, then one wait
+        // 0. stage the batch (contiguous in HBM): loads first, all in flight, then one wait.  mg_step_render:
+        //    the step's own up-front loads ride the same round trip, the envs are stepped on the staged grids
+        //    (lane j: env eb + j) and their records are staged from the step's scratch.
+        //    (A workgroup-wide variant — the 128 envs of a batch stepped by two full waves between two
+        //    barriers instead of 8 lanes in each of 16 waves — was measured 4 us SLOWER per launch: the step is
+        //    bound by the latency of one wave's dependent chain, not by issue slots, and a 64-lane wave runs
+        //    the union of its lanes' branches — nearly always including a reset.)
+        {
             const uint32_t* gsrc = reinterpret_cast<const uint32_t*>(st.grid + (size_t)eb * cfg.cells_stride);
             const uint64_t* rsrc = st.agents + (size_t)eb * n;
             const int nd = kb * gdw, nr = kb * n;
             constexpr int kSR = 8;
             const int r0i = lane, r1i = lane + kWave;                       // kb * n <= 8 * 16 = 2 * kWave records
-            const uint64_t rv0 = r0i < nr ? rsrc[r0i] : 0ull, rv1 = r1i < nr ? rsrc[r1i] : 0ull;
+            uint64_t rv0 = 0ull, rv1 = 0ull;
+            if (!fs.enabled) { rv0 = r0i < nr ? rsrc[r0i] : 0ull; rv1 = r1i < nr ? rsrc[r1i] : 0ull; }
+            StepScratch sc;
+            StepEnv se = {0, 0};
             for (int i0 = 0; i0 < nd; i0 += kSR * kWave) {
                 uint32_t v[kSR];
 #pragma unroll
                 for (int q = 0; q < kSR; q++) { const int i = i0 + q * kWave + lane; v[q] = i < nd ? gsrc[i] : 0u; }
+                if (i0 == 0 && fs.enabled) {
+                    sc = fused_step_scratch(cfg, lane, ws + L.step, s_obj, s_oflags);
+                    if (lane < kb) se = step_load(cfg, st, fs.actions, fs.action_bytes, eb + lane, sc);
+                }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int q = 0; q < kSR; q++) {
@@ -265,16 +292,39 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                     if (i < nd) reinterpret_cast<uint32_t*>(w_stage_g)[i] = v[q];
                 }
             }
-            double pv0 = 0., pv1 = 0.;
-            if constexpr (kPrestige) {
-                const double* psrc = st.prestige + (size_t)eb * n;
-                if (r0i < nr) pv0 = psrc[r0i];
-                if (r1i < nr) pv1 = psrc[r1i];
+            if (eb == e0) MG_STAMP(2);
+            if (fs.enabled) {
+                wave_lds_sync();
+                bool wrote = false;
+                if (lane < kb) {
+                    wrote = step_run(cfg, st, fs.prog, fs.has_prog != 0, fs.rewards, eb + lane, se, sc,
+                                     w_stage_g + (size_t)lane * cfg.cells_stride);
+                    for (int k = 0; k < n; k++) w_stage_r[lane * rec_stride + k] = sc.rec[k * 8 + lane];
+                    if constexpr (kPrestige)   // agent.prestige as this lane left it in HBM
+                        for (int k = 0; k < n; k++) w_stage_p[lane * rec_stride + k] = st.prestige[(size_t)(eb + lane) * n + k];
+                }
+                uint64_t todo = __ballot(wrote);
+                wave_lds_sync();
+                while (todo) {      // grid slices the step wrote: back to HBM, the whole wave per slice
+                    const int j = __builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    const uint32_t* src = reinterpret_cast<const uint32_t*>(w_stage_g + (size_t)j * cfg.cells_stride);
+                    uint32_t* dst = reinterpret_cast<uint32_t*>(st.grid + (size_t)(eb + j) * cfg.cells_stride);
+                    for (int i = lane; i < gdw; i += kWave) dst[i] = src[i];
+                }
+            } else {
+                double pv0 = 0., pv1 = 0.;
+                if constexpr (kPrestige) {
+                    const double* psrc = st.prestige + (size_t)eb * n;
+                    if (r0i < nr) pv0 = psrc[r0i];
+                    if (r1i < nr) pv1 = psrc[r1i];
+                }
+                if (r0i < nr) { const int j = r0i / n; w_stage_r[j * rec_stride + (r0i - j * n)] = rv0; if constexpr (kPrestige) w_stage_p[j * rec_stride + (r0i - j * n)] = pv0; }
+                if (r1i < nr) { const int j = r1i / n; w_stage_r[j * rec_stride + (r1i - j * n)] = rv1; if constexpr (kPrestige) w_stage_p[j * rec_stride + (r1i - j * n)] = pv1; }
             }
-            if (r0i < nr) { const int j = r0i / n; w_stage_r[j * rec_stride + (r0i - j * n)] = rv0; if constexpr (kPrestige) w_stage_p[j * rec_stride + (r0i - j * n)] = pv0; }
-            if (r1i < nr) { const int j = r1i / n; w_stage_r[j * rec_stride + (r1i - j * n)] = rv1; if constexpr (kPrestige) w_stage_p[j * rec_stride + (r1i - j * n)] = pv1; }
         }
         wave_lds_sync();
+        if (eb == e0) MG_STAMP(3);
     // `depth` envs at a time: first all their views (phases 1-5 -> one tmap slot each), then all their
     // rasters.  Waves of a workgroup use different depths (1, 2, 4, 8): otherwise every wave of the chip —
     // they all start together and do identical work — would sit in the store-free phases 1-5 at the same
@@ -640,8 +690,10 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
         }
         }
         wave_lds_sync();   // scratch is reused by the next env
+        if (e == e0) MG_STAMP(pass == 0 ? 4 : 5);
     }
     }
+    MG_STAMP(6);
 }
 
 template <int VS_, int TS_, int WPB, int V_ = 0, int RM_ = 0>

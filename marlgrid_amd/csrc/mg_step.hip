@@ -56,7 +56,7 @@ __global__ __launch_bounds__(BS) void step_kernel(MgConfig cfg, MgState st, MgGe
     if (live) env = step_load(cfg, st, actions, action_bytes, b, sc);
     __syncthreads();
     if (!live) return;
-    step_run(cfg, st, prog, has_prog != 0, rewards, b, env, sc);
+    step_run(cfg, st, prog, has_prog != 0, rewards, b, env, sc, st.grid + (size_t)b * cfg.cells_stride);
 }
 
 template <int BS>

@@ -53,7 +53,13 @@ int emu_step(const MgConfig* cfg, const MgState* st, const void* actions, int ac
     for (int b = 0; b < cfg->B; b++) {
         if (action_bytes != 1 && action_bytes != 4 && action_bytes != 8) return -100;
         const mg::StepEnv e = mg::step_load(*cfg, *st, actions, action_bytes, b, s.sc);
-        mg::step_run(*cfg, *st, prog, auto_reset != nullptr, rewards, b, e, s.sc);
+        // stepped on a staged copy of the grid slice, as the obs kernel does (mg_render.hip): the copy goes
+        // back only when step_run reports it written — and must be unchanged when it does not
+        uint8_t* home = st->grid + (size_t)b * cfg->cells_stride;
+        std::vector<uint8_t> staged(home, home + cfg->cells_stride);
+        const bool wrote = mg::step_run(*cfg, *st, prog, auto_reset != nullptr, rewards, b, e, s.sc, staged.data());
+        if (wrote) memcpy(home, staged.data(), cfg->cells_stride);
+        else if (memcmp(home, staged.data(), cfg->cells_stride) != 0) return -101;
     }
     return 0;
 }

@@ -1,0 +1,16 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/c31
+mkdir -p $OUT
+cd $R
+timeout 900 python -m pytest tests -m gpu -q -x > $OUT/pytest.log 2>&1; tail -n 3 $OUT/pytest.log
+timeout 300 python bench.py --steps 20 --warmup 5 --no-pmc --no-strong --no-cpu-baseline > $OUT/b.log 2> $OUT/b.err
+python - $OUT/b.log <<'PY'
+import json,sys
+b=json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+p=b["obs_placement"]
+print("%.1f M  %.4f ms  kept %s  candidates %s  stopped: %s" % (b["value"]/1e6, b["ms_per_step"], ["%.4f"%x for x in p["kept"]], p.get("candidates"), p.get("stopped")))
+print(b["roofline"]["raster_only_ms"], b["kernels"])
+PY
+timeout 120 python tools/time_kernels.py 2>&1 | grep -v amdgpu
+timeout 400 python tools/profile_misc.py > $OUT/misc.jsonl 2> $OUT/misc.err; cut -c1-200 $OUT/misc.jsonl

@@ -1,0 +1,69 @@
+#!/usr/bin/env python
+"""Where does a wave of the fused launch spend its time before its first store?  Measurement build: every wave
+stamps wall_clock64 (100 MHz) at the phase boundaries of its first batch (mg_render.hip, MG_STAMP); this prints
+the per-phase durations over all waves of one mg_step_render launch (and of one mg_render_obs launch)."""
+import ctypes as C
+import os
+import sys
+
+os.environ["MARLGRID_HIP_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                              "marlgrid_amd", "csrc", "libmarlgrid_hip_ab.so")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from marlgrid_amd import _native as N  # noqa: E402
+from marlgrid_amd.envs import make  # noqa: E402
+
+B = int(os.environ.get("B", "32768"))
+env = make(os.environ.get("WL", "MarlGrid-3AgentCluttered15x15-v0"), batch_size=B, auto_reset=True, strict=False)
+env.reset()
+g = torch.Generator().manual_seed(0)
+acts = [torch.randint(0, 7, (B, env.num_agents), generator=g).cuda() for _ in range(16)]
+for i in range(40):
+    env.step(acts[i % 16])
+L, cfg, st = env._lib, C.byref(env._cfg), C.byref(env._state)
+stamps = torch.zeros(65536 * 8, dtype=torch.int64, device="cuda")
+names = ["tables + atlas -> LDS, barrier", "stage grids (+ step_load)", "step_run (+ records, write-back)",
+         "views of the first group", "raster of the first env", "rest of the run"]
+
+
+def report(title):
+    torch.cuda.synchronize()
+    t = stamps.view(-1, 8).cpu()
+    if os.environ.get("STAMPS_OUT"):
+        import numpy as np
+        np.save(os.path.join(os.environ["STAMPS_OUT"], "stamps_%s_%d.npy" % (title, report.n)), t[t[:, 6] != 0].numpy())
+        report.n += 1
+    t = t[t[:, 6] != 0].double() / 100.0          # us
+    t0 = t[:, 0].min()
+    print("%s: %d waves; first entry -> last exit %.1f us; entry skew %.1f us" %
+          (title, len(t), (t[:, 6].max() - t0).item(), (t[:, 0].max() - t0).item()))
+    for k in range(6):
+        d = t[:, k + 1] - t[:, k]
+        print("   %-36s mean %7.2f  min %7.2f  max %7.2f us" % (names[k], d.mean().item(), d.min().item(), d.max().item()))
+    ex = t[:, 6] - t0
+    q = torch.quantile(ex, torch.tensor([0.0, 0.01, 0.1, 0.5, 0.9, 0.99, 1.0], dtype=torch.float64))
+    print("   wave exit time after the first entry: min %.1f  p1 %.1f  p10 %.1f  median %.1f  p90 %.1f  p99 %.1f  max %.1f us" % tuple(q.tolist()))
+    fs = t[:, 4] - t0       # about when the wave's first store is issued
+    q = torch.quantile(fs, torch.tensor([0.0, 0.1, 0.5, 0.9, 1.0], dtype=torch.float64))
+    print("   first views done after the first entry: min %.1f  p10 %.1f  median %.1f  p90 %.1f  max %.1f us" % tuple(q.tolist()))
+    by_xcd = [ex[(torch.arange(len(ex)) // 16) % 8 == x].mean().item() for x in range(8)]   # workgroup b runs on XCD b % 8
+    print("   mean exit time by XCD (workgroup %% 8): %s" % " ".join("%.1f" % v for v in by_xcd))
+    by_wave = [ex[torch.arange(len(ex)) % 4 == w].mean().item() for w in range(4)]
+    print("   mean exit time by look-ahead depth 1/2/4/8 (wave %% 4): %s" % " ".join("%.1f" % v for v in by_wave))
+    d = t[:, 4] - t[:, 0]
+    print("   entry -> first views done            mean %7.2f  min %7.2f  max %7.2f us" % (d.mean().item(), d.min().item(), d.max().item()))
+    stamps.zero_()
+    torch.cuda.synchronize()
+
+
+report.n = 0
+L.mg_ab_stamps.restype = C.c_int
+assert L.mg_ab_stamps(C.c_void_p(stamps.data_ptr())) == 0
+for rep in range(2):
+    N.check(L.mg_step_render(cfg, st, acts[rep].data_ptr(), 8, env.rewards.data_ptr(), C.byref(env._reset_prog),
+                             env.obs.data_ptr(), env._stream()))
+    report("mg_step_render")
+    N.check(L.mg_render_obs(cfg, st, env.obs.data_ptr(), None, None, None, env._stream()))
+    report("mg_render_obs")
+L.mg_ab_stamps(C.c_void_p(0))
+env.check_errors()
