@@ -100,6 +100,46 @@ __device__ __forceinline__ StepScratch fused_step_scratch(const MgConfig& cfg, i
     return sc;
 }
 
+// step_load (mg_core.h) for the batch of a wave, with all 64 lanes: in step_load lane j reads env j's records,
+// actions and 16 RNG look-ahead words one after the other — 8 active lanes, every load instruction touching 8
+// different cache lines, ~25 instructions: 3 us of the launch's store-free head.  The batch's records, actions
+// and look-ahead words are each one CONTIGUOUS run in HBM, so the wave reads them as such (lane l: element l,
+// l + 64) and transposes into the step's [item][8] LDS columns.  Same result as step_load on lanes 0 .. kb-1.
+__device__ __forceinline__ StepEnv step_load_wave(const MgConfig& cfg, const MgState& st, const void* actions, int action_bytes,
+                                                  int eb, int kb, int lane, const StepScratch& sc) {
+    const int n = cfg.n_agents, nr = kb * n, nh = kb * MG_MT_HEAD;
+    const uint64_t* rsrc = st.agents + (size_t)eb * n;
+    const uint32_t* hsrc = st.mt_head + (size_t)eb * MG_MT_HEAD;
+    uint64_t rv[2] = {0ull, 0ull};
+    long long av[2] = {0, 0};
+    uint32_t hv[2] = {0u, 0u};
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int i = lane + q * kWave;
+        if (i < nr) {
+            const size_t a = (size_t)eb * n + i;
+            rv[q] = rsrc[i];
+            av[q] = action_bytes == 8 ? (long long)static_cast<const int64_t*>(actions)[a]
+                  : action_bytes == 4 ? (long long)static_cast<const int32_t*>(actions)[a]
+                                      : (long long)static_cast<const uint8_t*>(actions)[a];
+        }
+        if (i < nh) hv[q] = hsrc[i];
+    }
+    StepEnv e = {0, 0};
+    if (lane < kb) { e.pos0 = st.mt_pos[eb + lane]; e.sc0 = st.step_count[eb + lane]; }
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int i = lane + q * kWave;
+        if (i < nr) {
+            const int j = i / n, k = i - j * n;
+            sc.rec[k * 8 + j] = rv[q];
+            sc.act[k * 8 + j] = (av[q] >= 0 && av[q] <= 6) ? (uint8_t)av[q] : (uint8_t)0xFF;
+        }
+        if (i < nh) sc.head[(i % MG_MT_HEAD) * 8 + i / MG_MT_HEAD] = hv[q];
+    }
+    return e;
+}
+
 #if defined(MG_AB_VARIANTS)
 // measurement build: wall_clock64 (100 MHz) of every wave's lane 0 at the phase boundaries of its FIRST batch —
 // 0 entry, 1 tables + atlas in LDS, 2 batch staged (and step_load done), 3 batch stepped, 4 first views, 5 first
@@ -166,33 +206,6 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     // Viewers: the agents whose observations this launch renders.  All n by default; a subset when the
     // env's agents differ in view size / tile size / offset and are rendered group by group (agents.py:19-35).
     const int nv = cfg.n_view ? cfg.n_view : n;
-    if (fs.enabled) {
-        const uint4* src = reinterpret_cast<const uint4*>(cfg.obj);
-        uint4* dst = reinterpret_cast<uint4*>(s_obj);
-        for (int i = tid; i < cfg.n_obj * 2; i += WPB * 64) dst[i] = src[i];
-    }
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(cfg.atlas);
-        uint4* dst = reinterpret_cast<uint4*>(s_atlas);
-        if constexpr (!kGlobalAtlas)
-            for (int i = tid; i < atlas_bytes / 16; i += WPB * 64) dst[i] = src[i];
-        if (tid < MG_MAX_OBJ) {
-            uint8_t f = 0, sl = 0xFF, f2 = 0;
-            if (tid < cfg.n_obj) { f = cfg.obj[tid].flags; sl = cfg.obj[tid].ovl_slot; f2 = cfg.obj[tid].flags2; }
-            if (tid == 0) { f = MG_OF_SEE_BEHIND | MG_OF_CAN_OVERLAP; sl = 0; f2 = 1; }   // empty cell
-            s_oflags[tid] = f;
-            s_oslot[tid] = sl;
-            s_oflags2[tid] = f2;
-        }
-        if (tid < MG_MAX_AGENTS) {
-            s_hide[tid] = cfg.hide_obj_mask[tid];
-            s_pscale[tid] = cfg.prestige_scale[tid];
-            s_vmap[tid] = cfg.n_view ? cfg.view_agent[tid] : (uint8_t)tid;
-        }
-    }
-    __syncthreads();
-    MG_STAMP(1);
-
     constexpr bool kChunkRaster = TS_ > 0 && (TS_ % 8) == 0 && RM_ == 0;
     constexpr bool kBatchViews = !kChunkRaster && !kPrestige;   // as render_scratch_for: view scratch per staged env
     const RenderScratch L = render_scratch_for(cfg, WPB, RM_);
@@ -236,6 +249,79 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     const int e0 = (blockIdx.x * WPB + wave) * per_wave;
     const int e_end = min(cfg.B, e0 + per_wave);
 
+    // ---- prologue: tables + atlas -> LDS and the wave's FIRST batch staged, in ONE HBM round trip ----
+    // (tools/phase_stamps.py: with the atlas copied first and the batch staged after the barrier, the median
+    // wave waited 2 us + 5.5 us — 8.8 us with the env step's loads — before it could begin.)  Everything
+    // whose address is known now is loaded first: the first two atlas chunks of this thread, the object
+    // table, the first batch's grids and records — or, in mg_step_render, the step's own loads (step_load) —;
+    // then the LDS stores, then the barrier.
+    constexpr int kSR = 8;                                              // grid dwords per lane and round trip
+    const int kb0 = max(0, min(K, e_end - e0));
+    StepScratch sc0;
+    StepEnv se0 = {0, 0};
+    {
+        const int T = WPB * 64;
+        const uint32_t* gsrc = reinterpret_cast<const uint32_t*>(st.grid + (size_t)e0 * cfg.cells_stride);
+        const int nd0 = kb0 * gdw, nr0 = kb0 * n;
+        uint32_t v0[kSR];
+#pragma unroll
+        for (int q = 0; q < kSR; q++) { const int i = q * kWave + lane; v0[q] = i < nd0 ? gsrc[i] : 0u; }
+        const int r0i = lane, r1i = lane + kWave;
+        uint64_t rv0 = 0ull, rv1 = 0ull;
+        double pv0 = 0., pv1 = 0.;
+        if (!fs.enabled) {
+            const uint64_t* rsrc = st.agents + (size_t)e0 * n;
+            if (r0i < nr0) rv0 = rsrc[r0i];
+            if (r1i < nr0) rv1 = rsrc[r1i];
+            if constexpr (kPrestige) {
+                const double* psrc = st.prestige + (size_t)e0 * n;
+                if (r0i < nr0) pv0 = psrc[r0i];
+                if (r1i < nr0) pv1 = psrc[r1i];
+            }
+        }
+        const uint4* asrc = reinterpret_cast<const uint4*>(cfg.atlas);
+        uint4* adst = reinterpret_cast<uint4*>(s_atlas);
+        const int na = atlas_bytes / 16;                                // (0 when the atlas is read in place)
+        uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0, o0 = a0;
+        if (tid < na) a0 = asrc[tid];
+        if (tid + T < na) a1 = asrc[tid + T];
+        const int no = fs.enabled ? cfg.n_obj * 2 : 0;                  // object table (fused step): <= 128 chunks
+        if (tid < no) o0 = reinterpret_cast<const uint4*>(cfg.obj)[tid];
+        uint8_t f = 0, sl = 0xFF, f2 = 0;
+        if (tid < cfg.n_obj) { f = cfg.obj[tid].flags; sl = cfg.obj[tid].ovl_slot; f2 = cfg.obj[tid].flags2; }
+        if (tid == 0) { f = MG_OF_SEE_BEHIND | MG_OF_CAN_OVERLAP; sl = 0; f2 = 1; }   // empty cell
+        if (fs.enabled) {
+            sc0 = fused_step_scratch(cfg, lane, ws + L.step, s_obj, s_oflags);
+            se0 = step_load_wave(cfg, st, fs.actions, fs.action_bytes, e0, kb0, lane, sc0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (tid < na) adst[tid] = a0;
+        if (tid + T < na) adst[tid + T] = a1;
+        for (int i = tid + 2 * T; i < na; i += T) adst[i] = asrc[i];    // (larger atlases: the rest, a second trip)
+        if (tid < no) reinterpret_cast<uint4*>(s_obj)[tid] = o0;
+        if (tid < MG_MAX_OBJ) {
+            s_oflags[tid] = f;
+            s_oslot[tid] = sl;
+            s_oflags2[tid] = f2;
+        }
+        if (tid < MG_MAX_AGENTS) {
+            s_hide[tid] = cfg.hide_obj_mask[tid];
+            s_pscale[tid] = cfg.prestige_scale[tid];
+            s_vmap[tid] = cfg.n_view ? cfg.view_agent[tid] : (uint8_t)tid;
+        }
+#pragma unroll
+        for (int q = 0; q < kSR; q++) {
+            const int i = q * kWave + lane;
+            if (i < nd0) reinterpret_cast<uint32_t*>(w_stage_g)[i] = v0[q];
+        }
+        if (!fs.enabled) {
+            if (r0i < nr0) { const int j = r0i / n; w_stage_r[j * rec_stride + (r0i - j * n)] = rv0; if constexpr (kPrestige) w_stage_p[j * rec_stride + (r0i - j * n)] = pv0; }
+            if (r1i < nr0) { const int j = r1i / n; w_stage_r[j * rec_stride + (r1i - j * n)] = rv1; if constexpr (kPrestige) w_stage_p[j * rec_stride + (r1i - j * n)] = pv1; }
+        }
+    }
+    __syncthreads();
+    MG_STAMP(1);
+
     // assemble-and-stream raster: the wave's run of envs is ONE contiguous output stream.  w_out[0] is
     // the byte at the 16-byte-aligned global address out_base; w_out[0 .. carry) are pending bytes of a
     // chunk that is not complete yet (at the start of the run: `head` bytes that belong to the wave before)
@@ -262,28 +348,28 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
         const int kb = min(K, e_end - eb);
         // 0. stage the batch (contiguous in HBM): loads first, all in flight, then one wait.  mg_step_render:
         //    the step's own up-front loads ride the same round trip, the envs are stepped on the staged grids
-        //    (lane j: env eb + j) and their records are staged from the step's scratch.
+        //    (lane j: env eb + j) and their records are staged from the step's scratch.  The wave's first
+        //    batch was staged by the prologue (all but the grid dwords beyond its kSR per lane).
         //    (A workgroup-wide variant — the 128 envs of a batch stepped by two full waves between two
         //    barriers instead of 8 lanes in each of 16 waves — was measured 4 us SLOWER per launch: the step is
         //    bound by the latency of one wave's dependent chain, not by issue slots, and a 64-lane wave runs
         //    the union of its lanes' branches — nearly always including a reset.)
         {
+            const bool first = (eb == e0);
             const uint32_t* gsrc = reinterpret_cast<const uint32_t*>(st.grid + (size_t)eb * cfg.cells_stride);
             const uint64_t* rsrc = st.agents + (size_t)eb * n;
             const int nd = kb * gdw, nr = kb * n;
-            constexpr int kSR = 8;
             const int r0i = lane, r1i = lane + kWave;                       // kb * n <= 8 * 16 = 2 * kWave records
             uint64_t rv0 = 0ull, rv1 = 0ull;
-            if (!fs.enabled) { rv0 = r0i < nr ? rsrc[r0i] : 0ull; rv1 = r1i < nr ? rsrc[r1i] : 0ull; }
-            StepScratch sc;
-            StepEnv se = {0, 0};
-            for (int i0 = 0; i0 < nd; i0 += kSR * kWave) {
+            if (!fs.enabled && !first) { rv0 = r0i < nr ? rsrc[r0i] : 0ull; rv1 = r1i < nr ? rsrc[r1i] : 0ull; }
+            StepScratch sc = sc0;
+            StepEnv se = se0;
+            for (int i0 = first ? kSR * kWave : 0; i0 < nd; i0 += kSR * kWave) {
                 uint32_t v[kSR];
 #pragma unroll
                 for (int q = 0; q < kSR; q++) { const int i = i0 + q * kWave + lane; v[q] = i < nd ? gsrc[i] : 0u; }
                 if (i0 == 0 && fs.enabled) {
-                    sc = fused_step_scratch(cfg, lane, ws + L.step, s_obj, s_oflags);
-                    if (lane < kb) se = step_load(cfg, st, fs.actions, fs.action_bytes, eb + lane, sc);
+                    se = step_load_wave(cfg, st, fs.actions, fs.action_bytes, eb, kb, lane, sc);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -312,7 +398,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                     uint32_t* dst = reinterpret_cast<uint32_t*>(st.grid + (size_t)(eb + j) * cfg.cells_stride);
                     for (int i = lane; i < gdw; i += kWave) dst[i] = src[i];
                 }
-            } else {
+            } else if (!first) {
                 double pv0 = 0., pv1 = 0.;
                 if constexpr (kPrestige) {
                     const double* psrc = st.prestige + (size_t)eb * n;
