@@ -401,8 +401,8 @@ class MultiGridEnv(object):
                               self.mt_head.data_ptr())
 
     @_on_device
-    def _place_obs_buffers(self, batch=16, max_candidates=192, min_bytes=64 << 20, iters=3, budget=192 << 30,
-                           gain=0.12, seconds=4.0):
+    def _place_obs_buffers(self, batch=16, min_candidates=48, max_candidates=192, min_bytes=64 << 20, iters=3,
+                           budget=192 << 30, gain=0.12, seconds=4.0):
         """Choose WHERE in HBM the observation buffers live.  Measured on MI355X (tools/microbench/
         store_patterns6.hip, tools/placement_probe*.py, profiles/r02): the rate at which the raster's write
         pattern — thousands of waves, each streaming its own env — is absorbed depends on the buffer it
@@ -412,7 +412,9 @@ class MultiGridEnv(object):
         are a minority on some boxes (1 in 25 over the whole HBM: placement_map_whole_hbm.txt) and the rule
         on others.  So candidate buffers are
         allocated a `batch` at a time and the raster itself is timed into each (HIP events, `iters`
-        launches), until the buffers that would be kept are `gain` faster than the median candidate (they
+        launches; under a millisecond per candidate), at least `min_candidates` of them — there are two
+        fast classes, 0.157 and 0.165 ms per launch at the bench workload — and then until the buffers that
+        would be kept are `gain` faster than the median candidate (they
         are in the fast class), or a full batch shows no spread worth searching (every candidate is in the
         same class), or `max_candidates` / `budget` bytes / `seconds` are spent; the fastest are kept and
         the rest go back to the driver (they are held until then: freed memory is what the next
@@ -444,6 +446,8 @@ class MultiGridEnv(object):
                     cost.append(cost_of(cands[-1]))
                 ranked = sorted(cost)
                 median = ranked[len(ranked) // 2]
+                if len(cands) < min(cap, keep + min_candidates):
+                    continue
                 if ranked[keep - 1] <= (1.0 - gain) * median:
                     why = "kept set %d%% under the median candidate" % round(100 * (1 - ranked[keep - 1] / median))
                     break
