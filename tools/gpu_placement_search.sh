@@ -1,6 +1,6 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/c26
+OUT=$R/gpurun_out/placement_search
 mkdir -p $OUT
 cd $R
 for k in 1 2 3; do
