@@ -41,6 +41,9 @@
  *   mt_head     uint32 [B][16]                the 16 outputs generated last and not consumed yet
  *                                            (tempered), contiguous per env: what a step draws from
  *   step_count  int32  [B];  done uint8 [B];  error int32 [B]
+ *   error_flag  int32  [1]  HOST-mapped (mg_host_flag_alloc) or device: becomes non-zero when any
+ *                                            error[b] is set — a host polls this one word instead of
+ *                                            scanning error[B] after every launch
  *   obs         uint8  [B][n_agents][P][P][3] with P = view_size*tile_size
  */
 #ifndef MARLGRID_HIP_H
@@ -52,7 +55,7 @@
 extern "C" {
 #endif
 
-#define MG_ABI_VERSION 2
+#define MG_ABI_VERSION 3
 #define MG_MAX_AGENTS 16
 #define MG_MAX_OBJ 64
 #define MG_MAX_GEN 16
@@ -162,6 +165,11 @@ typedef struct MgState {
     int32_t* error;
     double* prestige;     /* [B][n_agents] agent.prestige (agents.py:141-153); NULL unless prestige_mask != 0 */
     uint32_t* mt_head;    /* [B][MG_MT_HEAD] */
+    int32_t* error_flag;  /* [1] or NULL.  A kernel that records a per-env error in error[b] also ORs 1 into this word
+                           * with a system-scope atomic, so the word may live in host-mapped memory
+                           * (mg_host_flag_alloc) and be polled by the host without a stream synchronize: the
+                           * reference raises inside step() (base.py:619-620); a batched host learns of an error
+                           * without giving up its asynchronous launch queue.  Never cleared by the library. */
 } MgState;
 
 /* `_gen_grid` as data: a static template (walls / put_obj results) + ordered random placements */
@@ -177,6 +185,10 @@ typedef struct MgGenProgram {
 } MgGenProgram;
 
 int32_t mg_abi_version(void);
+/* sizeof of the five structs above as THIS build sees them: out[0..4] = MgConfig, MgState, MgObjDesc, MgGenOp,
+ * MgGenProgram.  A binding compares them with its own mirror of the structs at load time (the layouts have no
+ * other self-description; MG_ABI_VERSION changes whenever one of them does).  Returns 5. */
+int32_t mg_struct_sizes(int32_t out[5]);
 /* "<library> gfx950 abi<N> <source id>": which build answered (bench.py echoes it) */
 const char* mg_build_info(void);
 const char* mg_error_string(int32_t code);
@@ -249,6 +261,28 @@ int32_t mg_render_obs_lds_bytes(const MgConfig* cfg);
  * launches on `stream`, bracketed by HIP events recorded on that same stream. */
 int32_t mg_time_render_obs(const MgConfig* cfg, const MgState* st, uint8_t* obs, int32_t iters,
                            float* avg_ms, void* stream);
+
+/* ---- memory helpers (optional: callers may bring any device-accessible memory) -------------------------------
+ *
+ * mg_host_flag_alloc: one int32 in pinned, coherent host memory, mapped into the device's address space:
+ * *host is what the CPU reads, *dev is what goes into MgState.error_flag.  Zero-initialised. */
+int32_t mg_host_flag_alloc(int32_t** host, int32_t** dev);
+int32_t mg_host_flag_free(int32_t* host);
+
+/* mg_obs_alloc: an observation buffer (the obs argument of mg_render_obs / mg_step_render) whose physical backing
+ * the engine lays out itself with HIP virtual memory management: one virtual range, physical handles of
+ * `chunk_bytes` each (rounded up to the device's 2 MiB granule) mapped back to back.  chunk_bytes 0: a plain
+ * hipMalloc; < 0: one handle for the whole buffer.  The obs raster's write pattern — thousands of waves, each
+ * streaming its own env — is sensitive to how a buffer's backing is cut up (profiles/r03/README.md), which
+ * hipMalloc leaves to chance.  Returns an opaque handle (NULL on failure); mg_obs_ptr gives the device pointer.
+ * Nothing on the step path allocates: these are construction-time helpers, and any other device memory is as
+ * valid an `obs` argument. */
+typedef struct MgObsBuffer MgObsBuffer;
+MgObsBuffer* mg_obs_alloc(uint64_t bytes, int32_t device, int64_t chunk_bytes);
+void* mg_obs_ptr(const MgObsBuffer* buf);
+/* out[0] = bytes mapped, out[1] = bytes per physical handle (0: hipMalloc), out[2] = handles */
+int32_t mg_obs_info(const MgObsBuffer* buf, uint64_t out[3]);
+int32_t mg_obs_free(MgObsBuffer* buf);
 
 #ifdef __cplusplus
 }

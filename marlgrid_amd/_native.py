@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 MAX_AGENTS, MAX_OBJ, MAX_GEN, MAX_VIEW, KEY_WORDS, MT_N, MT_HEAD = 16, 64, 16, 15, 2, 624, 16
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 OK = 0
 ERR_VALUE, ERR_RECURSION, ERR_TYPE, ERR_ASSERT = 1, 2, 3, 4
@@ -54,7 +54,7 @@ class Config(C.Structure):
 class State(C.Structure):
     _fields_ = [("grid", C.c_void_p), ("agents", C.c_void_p), ("mt", C.c_void_p), ("mt_pos", C.c_void_p),
                 ("step_count", C.c_void_p), ("done", C.c_void_p), ("error", C.c_void_p), ("prestige", C.c_void_p),
-                ("mt_head", C.c_void_p)]
+                ("mt_head", C.c_void_p), ("error_flag", C.c_void_p)]
 
 
 class GenOp(C.Structure):
@@ -69,7 +69,8 @@ class GenProgram(C.Structure):
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmarlgrid_hip.so")
 
 # every symbol include/marlgrid_hip.h declares
-SYMBOLS = ["mg_abi_version", "mg_build_info", "mg_error_string", "mg_mt_seed", "mg_reset", "mg_step", "mg_step_render",
+SYMBOLS = ["mg_abi_version", "mg_struct_sizes", "mg_host_flag_alloc", "mg_host_flag_free", "mg_obs_alloc", "mg_obs_ptr", "mg_obs_info",
+           "mg_obs_free", "mg_build_info", "mg_error_string", "mg_mt_seed", "mg_reset", "mg_step", "mg_step_render",
            "mg_render_obs",
            "mg_encode", "mg_put_obj", "mg_place", "mg_render_frame", "mg_time_render_obs",
            "mg_render_obs_lds_bytes"]
@@ -102,6 +103,25 @@ def lib():
     if L.mg_abi_version() != ABI_VERSION:
         raise ImportError("marlgrid_amd: %s has ABI version %d, this package needs %d — rebuild it"
                           % (path, L.mg_abi_version(), ABI_VERSION))
+    # the struct mirrors above against the library's own sizeof: a layout change that forgot this file (or
+    # the ABI version) fails here, at load time, instead of shifting every later field of a launch config
+    sizes = (i32 * 5)()
+    L.mg_struct_sizes.argtypes = [C.POINTER(i32)]
+    L.mg_struct_sizes.restype = i32
+    if L.mg_struct_sizes(sizes) != 5:
+        raise ImportError("marlgrid_amd: %s: mg_struct_sizes failed" % path)
+    mine = [C.sizeof(t) for t in (Config, State, ObjDesc, GenOp, GenProgram)]
+    if list(sizes) != mine:
+        raise ImportError("marlgrid_amd: struct layouts differ between %s %r and marlgrid_amd/_native.py %r "
+                          "(MgConfig, MgState, MgObjDesc, MgGenOp, MgGenProgram)" % (path, list(sizes), mine))
+    L.mg_host_flag_alloc.argtypes = [C.POINTER(C.POINTER(i32)), C.POINTER(C.POINTER(i32))]
+    L.mg_host_flag_free.argtypes = [C.POINTER(i32)]
+    L.mg_obs_alloc.argtypes = [C.c_uint64, i32, C.c_int64]
+    L.mg_obs_alloc.restype = vp
+    L.mg_obs_ptr.argtypes = [vp]
+    L.mg_obs_ptr.restype = vp
+    L.mg_obs_info.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.mg_obs_free.argtypes = [vp]
     L.mg_error_string.restype = C.c_char_p
     L.mg_error_string.argtypes = [i32]
     L.mg_build_info.restype = C.c_char_p
@@ -117,7 +137,7 @@ def lib():
     L.mg_time_render_obs.argtypes = [C.POINTER(Config), C.POINTER(State), vp, i32, C.POINTER(C.c_float), vp]
     for f in SYMBOLS:
         getattr(L, f)
-        if f not in ("mg_error_string", "mg_build_info"):
+        if f not in ("mg_error_string", "mg_build_info", "mg_obs_alloc", "mg_obs_ptr"):
             getattr(L, f).restype = i32
     _lib = L
     return L

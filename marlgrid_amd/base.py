@@ -36,6 +36,9 @@ from .agents import GridAgentInterface
 from .objects import COLOR_TO_IDX, OBJECT_TYPES, BonusTile, Box, Door, Goal, Key, Wall, WorldObj
 
 TILE_PIXELS = 32
+DEFAULT_PLACE_OBS = "vmm"
+OBS_CHUNK_BYTES = 2 << 20           # physical handle size of library-built observation buffers
+STATE_DICT_VERSION = 3              # = the C ABI whose MgState layout / RNG form the tensors follow
 
 _trace = threading.local()
 
@@ -230,6 +233,62 @@ class MultiGrid(object):
         raise NotImplementedError      # as upstream (base.py:216-218)
 
 
+class _HostFlag(object):
+    """MgState.error_flag: one int32 in pinned host memory that the device can write (mg_host_flag_alloc)"""
+
+    def __init__(self, lib):
+        self._lib = lib
+        h, d = C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)()
+        N.check(lib.mg_host_flag_alloc(C.byref(h), C.byref(d)))
+        self._host = h
+        self.dev = C.cast(d, C.c_void_p).value
+
+    def raised(self):
+        return self._host[0] != 0
+
+    def clear(self):
+        self._host[0] = 0
+
+    def __del__(self):
+        try:
+            self._lib.mg_host_flag_free(self._host)
+        except Exception:       # interpreter shutdown
+            pass
+
+
+class _LibBuffer(object):
+    """Device memory laid out by the library (mg_obs_alloc), handed to torch through the CUDA array interface:
+    the tensor keeps this object alive, and the memory goes back to the driver when the last view of it dies."""
+
+    def __init__(self, lib, nbytes, device, chunk_bytes):
+        self._lib, self.device, self.nbytes = lib, device, int(nbytes)
+        self._h = lib.mg_obs_alloc(self.nbytes, device.index, int(chunk_bytes))
+        self.ok = bool(self._h)
+        if self.ok:
+            self.ptr = lib.mg_obs_ptr(self._h)
+            self.__cuda_array_interface__ = {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False),
+                                             "version": 2, "strides": None}
+
+    def tensor(self, shape):
+        import torch
+        return torch.as_tensor(self, device=self.device).view(shape)
+
+    def info(self):
+        out = (C.c_uint64 * 3)()
+        N.check(self._lib.mg_obs_info(self._h, out))
+        return dict(mapped=int(out[0]), chunk=int(out[1]), handles=int(out[2]))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            try:
+                import torch
+                torch.cuda.synchronize(self.device)      # no launch may still be writing it
+                self._lib.mg_obs_free(self._h)
+            except Exception:   # interpreter shutdown
+                pass
+            self._h = None
+
+
 class _ViewGroup(object):
     """agents that share one view geometry: their launch config, atlas and observation buffers"""
 
@@ -264,10 +323,24 @@ class MultiGridEnv(object):
         self.ghost_mode = ghost_mode
         self.batch_size = int(batch_size)
         self.auto_reset = bool(auto_reset)
-        self.strict = bool(strict)
+        # Per-env runtime errors (the reference's exceptions).  strict=True: raised without giving up the
+        # asynchronous launch queue — the kernels raise a one-word flag in host-mapped memory that every
+        # step()/reset() polls (no stream synchronize), so the exception surfaces at the next call into the env
+        # after the GPU got there, at the latest at check_errors().  strict="sync": raised by the very step() that
+        # caused it, as upstream does (one host synchronize per step).  strict=False: only check_errors() raises.
+        if strict not in (True, False, "sync"):
+            raise ValueError("strict must be True, False or 'sync'")
+        self.strict = strict
         self.obs_buffers = max(1, int(obs_buffers))
         self.fused_step = bool(fused_step)     # step() = one launch (mg_step_render) instead of mg_step + mg_render_obs
-        self.place_obs = bool(place_obs)       # pick well-placed HBM buffers for the observations (see _place_obs_buffers)
+        # where the observation buffers live (see _new_obs_buffer / _place_obs_buffers): "vmm" = built by the
+        # library from 2 MiB physical handles behind one virtual range; "search" = the fastest of a bounded set
+        # of candidate allocations, timed with the raster itself; False = plain torch allocations
+        if place_obs is True:
+            place_obs = DEFAULT_PLACE_OBS
+        if place_obs not in ("vmm", "search", False):
+            raise ValueError("place_obs must be 'vmm', 'search', True (= %r) or False" % DEFAULT_PLACE_OBS)
+        self.place_obs = place_obs
         self._dry = bool(_dry)
         if self.batch_size < 1:
             raise ValueError("batch_size must be >= 1")
@@ -284,6 +357,7 @@ class MultiGridEnv(object):
 
         self.obj_reg = ObjectRegistry()
         self._tables_version = -1
+        self._settings_seen = None
         self._tracing = False
         self._prog_cache = {}
         self._spec_ctor = None
@@ -305,7 +379,7 @@ class MultiGridEnv(object):
         self._seeds_arg = seeds
         self.seed(seed=seed)
         self.reset()
-        if not self._dry and self.place_obs:
+        if not self._dry and self.place_obs == "search":
             self._place_obs_buffers()
         self._spec_ctor = self._spec_last     # the constructor-time `_gen_grid` (base.py:369)
         self._retrace = True
@@ -384,8 +458,8 @@ class MultiGridEnv(object):
             # returned stays intact while the next step is computed — the README loop
             # `save_step(obs, act, next_obs, rew, done)` sees two different observations.
             for g in self._groups:
-                g.ring = [torch.zeros((B, len(g.members), g.pixels, g.pixels, 3), dtype=torch.uint8, device=dev)
-                          for _ in range(self.obs_buffers)]
+                g.shape = (B, len(g.members), g.pixels, g.pixels, 3)
+                g.ring = [self._new_obs_buffer(g.shape, vmm=self.place_obs == "vmm") for _ in range(self.obs_buffers)]
                 g.obs = g.ring[0]
             self._ring = [dict(obs=self._groups[0].ring[i],
                                rewards=torch.zeros((B, n), dtype=torch.float32, device=dev),
@@ -394,31 +468,40 @@ class MultiGridEnv(object):
             self._ring_i = 0
             self.obs, self.rewards, self.done_t = (self._ring[0][k] for k in ("obs", "rewards", "done"))
             self.done_b = self.done_t.view(torch.bool)      # the same bytes, as the bool tensor step() returns
+        # one word of pinned host memory the kernels raise when they record an error in error_t: polled by
+        # step()/reset() instead of a nonzero() + .item() round trip through the stream
+        self._flag = _HostFlag(self._lib)
         self._state = N.State(self.grid_state.data_ptr(), self.agent_state.data_ptr(), self.mt_state.data_ptr(),
                               self.mt_pos.data_ptr(), self.step_count_t.data_ptr(), self.done_t.data_ptr(),
                               self.error_t.data_ptr(),
                               self.prestige_t.data_ptr() if self.prestige_t is not None else None,
-                              self.mt_head.data_ptr())
+                              self.mt_head.data_ptr(), self._flag.dev)
+
+    def _new_obs_buffer(self, shape, vmm, min_bytes=64 << 20):
+        """One observation buffer.  Large ones can be built by the library (mg_obs_alloc: one virtual range
+        backed by 2 MiB physical handles, see csrc/mg_mem.h) and wrapped as a torch tensor that owns them;
+        small ones — and vmm=False — are plain torch allocations."""
+        import torch
+        nbytes = int(np.prod(shape))
+        if vmm and nbytes >= min_bytes:
+            mem = _LibBuffer(self._lib, nbytes, self.device, OBS_CHUNK_BYTES)
+            if mem.ok:
+                t = mem.tensor(shape)
+                t.zero_()
+                return t
+        return torch.zeros(shape, dtype=torch.uint8, device=self.device)
 
     @_on_device
-    def _place_obs_buffers(self, batch=16, min_candidates=48, max_candidates=192, min_bytes=64 << 20, iters=3,
-                           budget=192 << 30, gain=0.12, seconds=4.0):
-        """Choose WHERE in HBM the observation buffers live.  Measured on MI355X (tools/microbench/
-        store_patterns6.hip, tools/placement_probe*.py, profiles/r02): the rate at which the raster's write
-        pattern — thousands of waves, each streaming its own env — is absorbed depends on the buffer it
-        writes, reproducibly per buffer and by up to 25 % (5.3 vs 6.6-6.8 TB/s), while a dense fill or a
-        dense write front over the same buffers is flat at 6.6-6.9 TB/s: a property of the allocation's
-        physical placement, not of the kernel, the size or the virtual address.  Well-placed allocations
-        are a minority on some boxes (1 in 25 over the whole HBM: placement_map_whole_hbm.txt) and the rule
-        on others.  So candidate buffers are
-        allocated a `batch` at a time and the raster itself is timed into each (HIP events, `iters`
-        launches; under a millisecond per candidate), at least `min_candidates` of them — there are two
-        fast classes, 0.157 and 0.165 ms per launch at the bench workload — and then until the buffers that
-        would be kept are `gain` faster than the median candidate (they
-        are in the fast class), or a full batch shows no spread worth searching (every candidate is in the
-        same class), or `max_candidates` / `budget` bytes / `seconds` are spent; the fastest are kept and
-        the rest go back to the driver (they are held until then: freed memory is what the next
-        allocation would get)."""
+    def _place_obs_buffers(self, batch=8, max_candidates=64, min_bytes=64 << 20, iters=3, budget=16 << 30, gain=0.10,
+                           seconds=2.0):
+        """place_obs="search": choose the observation buffers among candidate allocations by timing the raster
+        itself into each (HIP events, `iters` launches; under a millisecond per candidate) and keeping the
+        fastest.  Why an allocation matters at all: csrc/mg_mem.h and profiles/r02/README.md section 3.  The
+        candidates are raw hipMalloc allocations made and freed through the library (never torch's caching
+        allocator: nothing is cached, nothing else is flushed), at most `batch` of them alive at a time next to
+        the best `keep` so far, the whole search capped at `max_candidates`, `budget` bytes alive, a quarter of
+        the memory that is free when a batch starts, and `seconds`.  Running out of memory ends the search with
+        what it has."""
         import time
         import torch
         t_begin = time.perf_counter()
@@ -435,38 +518,51 @@ class MultiGridEnv(object):
                 return ms.value
 
             keep = len(g.ring)
-            cands = list(g.ring)
-            cost = [cost_of(c) for c in cands]
-            free, _total = torch.cuda.mem_get_info(self.device)
-            cap = keep + int(max(0, min(max_candidates, min(free // 2, budget) // nbytes)))   # candidates are transient
+            best = [(cost_of(t), t) for t in g.ring]          # (ms, tensor), the `keep` fastest so far
+            seen = [c for c, _ in best]
             why = "cap"
-            while len(cands) < cap:
-                for _ in range(min(batch, cap - len(cands))):
-                    cands.append(torch.empty_like(g.ring[0]))
-                    cost.append(cost_of(cands[-1]))
-                ranked = sorted(cost)
-                median = ranked[len(ranked) // 2]
-                if len(cands) < min(cap, keep + min_candidates):
-                    continue
-                if ranked[keep - 1] <= (1.0 - gain) * median:
-                    why = "kept set %d%% under the median candidate" % round(100 * (1 - ranked[keep - 1] / median))
-                    break
-                if ranked[-1] <= 1.05 * ranked[0]:
-                    why = "no spread among %d candidates" % len(cands)
-                    break
+            while len(seen) < keep + max_candidates:
                 if time.perf_counter() > t_end:
                     why = "time"
                     break
-            order = sorted(range(len(cands)), key=lambda i: cost[i])
-            g.ring = [cands[i] for i in order[:keep]]
+                free, _total = torch.cuda.mem_get_info(self.device)
+                room = int(min(free // 4, budget) // nbytes)
+                nb = min(batch, room, keep + max_candidates - len(seen))
+                if nb < 1:
+                    why = "memory"
+                    break
+                cands = []
+                for _ in range(nb):
+                    mem = _LibBuffer(self._lib, nbytes, self.device, 0)
+                    if not mem.ok:
+                        why = "out of memory"
+                        break
+                    cands.append(mem.tensor(g.shape))
+                for t in cands:
+                    c = cost_of(t)
+                    seen.append(c)
+                    best.append((c, t))
+                best.sort(key=lambda ct: ct[0])
+                del best[keep:], cands                  # the rejected ones go back to the driver here
+                if why == "out of memory":
+                    break
+                ranked = sorted(seen)
+                median = ranked[len(ranked) // 2]
+                if len(seen) >= keep + 2 * batch and best[keep - 1][0] <= (1.0 - gain) * median:
+                    why = "kept set %d%% under the median candidate" % round(100 * (1 - best[keep - 1][0] / median))
+                    break
+                if len(seen) >= keep + 2 * batch and ranked[-1] <= 1.05 * ranked[0]:
+                    why = "no spread among %d candidates" % len(seen)
+                    break
+            g.ring = [t for _, t in best]
+            for t in g.ring:
+                t.zero_()
             g.obs = g.ring[self._ring_i]
-            g.placement_ms = {"kept": [cost[i] for i in order[:keep]], "candidates": len(cands), "stopped": why,
-                              "seconds": time.perf_counter() - t_begin, "all": cost}
-            del cands
+            g.placement_ms = {"kept": [c for c, _ in best], "candidates": len(seen), "stopped": why,
+                              "seconds": time.perf_counter() - t_begin, "all": seen}
         for i, r in enumerate(self._ring):
             r["obs"] = self._groups[0].ring[i]
         self.obs = self._ring[self._ring_i]["obs"]
-        torch.cuda.empty_cache()            # the rejected candidates go back to the driver
         self._render()                      # the current observation, into the buffer that is current now
 
     def _stream(self):
@@ -729,14 +825,25 @@ class MultiGridEnv(object):
             cfg.prestige_beta[k], cfg.prestige_scale[k] = float(a.prestige_beta), float(a.prestige_scale)
         cfg.any_spawn_delay = int(any(a.spawn_delay != 0 for a in self.agents))
 
+    def _settings_key(self):
+        """the attributes _refresh_cfg reads, as one comparable value (what step() checks instead of re-deriving
+        every launch config on every step)"""
+        kw = self.agent_spawn_kwargs
+        return (self.max_steps, self.reward_decay, self.ghost_mode, self.respawn, self.auto_reset,
+                tuple(sorted((k, tuple(v) if isinstance(v, (list, tuple)) else v) for k, v in kw.items())) if kw else (),
+                tuple((a.spawn_delay, a.prestige_beta, a.prestige_scale) for a in self.agents))
+
     def _sync_tables(self):
         """Make the launch configs current: rebuild and upload the object table / atlas of every view group
         when a new object kind was registered since the last launch, refresh the scalar settings always."""
         if self._dry:
             return
         if self._tables_version == self.obj_reg.version:
-            for g in self._groups:
-                self._refresh_cfg(g.cfg)
+            key = self._settings_key()
+            if key != self._settings_seen:
+                for g in self._groups:
+                    self._refresh_cfg(g.cfg)
+                self._settings_seen = key
             return
         import torch
         for g in self._groups:
@@ -756,6 +863,7 @@ class MultiGridEnv(object):
         g0 = self._groups[0]
         self._cfg, self.atlas, self._obj_dev, self._atlas_dev = g0.cfg, g0.atlas, g0.obj_dev, g0.atlas_dev
         self._tables_version = self.obj_reg.version
+        self._settings_seen = self._settings_key()
 
     def _program(self, template, ops):
         import torch
@@ -821,7 +929,9 @@ class MultiGridEnv(object):
             actions = actions.to(torch.int64)
         if actions.device != self.device or not actions.is_contiguous():
             actions = actions.to(self.device).contiguous()
-        self._sync_tables()       # no-op unless a new object kind was registered since the last launch
+        if self.strict and self._flag.raised():
+            self.check_errors()   # an earlier launch recorded an error: raise it now (this is the only host sync)
+        self._sync_tables()       # re-derives the launch configs only if a setting or the object registry changed
         if self.obs_buffers > 1:
             self._ring_i = (self._ring_i + 1) % self.obs_buffers
             r = self._ring[self._ring_i]
@@ -866,7 +976,7 @@ class MultiGridEnv(object):
                                                 None, None, stream))
         if probe is not None:
             probe(2)
-        if self.strict:
+        if self.strict == "sync":
             self.check_errors()
         return self._package_obs(), self.rewards, done, {}
 
@@ -960,8 +1070,14 @@ class MultiGridEnv(object):
 
     @_on_device
     def check_errors(self):
-        """Raise the reference's exception for the first env that hit one (host sync)."""
+        """Raise the reference's exception for the first env that hit one.  Host sync: waits for the launches
+        queued so far, then reads ONE word (the error flag the kernels raise); the per-env codes are only
+        fetched when it is set."""
         import torch
+        torch.cuda.current_stream(self.device).synchronize()
+        if not self._flag.raised():
+            return
+        self._flag.clear()
         bad = torch.nonzero(self.error_t)
         if bad.numel():
             b = int(bad[0].item())
@@ -1072,16 +1188,36 @@ class MultiGridEnv(object):
         G = int(self.mt_pos[b].item())
         return seeding.numpy_form(mt, G, N.MT_HEAD)
 
+    _STATE_KEYS = ("grid_state", "agent_state", "mt_state", "mt_pos", "mt_head", "step_count_t", "done_t", "error_t")
+
     def state_dict(self):
-        keys = ("grid_state", "agent_state", "mt_state", "mt_pos", "mt_head", "step_count_t", "done_t", "error_t")
-        sd = {k: getattr(self, k).clone() for k in keys}
+        """The env batch's whole state as tensors (a checkpoint).  `version` names the layout: the packed agent
+        records and the RNG in its lazy form with the look-ahead head (mt_pos counts the words generated INTO the
+        head, not the words consumed) — an older checkpoint is a different RNG stream position, not this one."""
+        import torch
+        sd = {k: getattr(self, k).clone() for k in self._STATE_KEYS}
         if self.prestige_t is not None:
             sd["prestige_t"] = self.prestige_t.clone()
+        sd["version"] = torch.tensor(STATE_DICT_VERSION)
         return sd
 
     def load_state_dict(self, sd):
-        for k, v in sd.items():
-            getattr(self, k).copy_(v)
+        want = set(self._STATE_KEYS) | {"version"} | ({"prestige_t"} if self.prestige_t is not None else set())
+        if set(sd.keys()) != want:
+            raise KeyError("load_state_dict: expected exactly the keys %s, got %s (a checkpoint without "
+                           "'version' / 'mt_head' predates the look-ahead RNG form and cannot be resumed)"
+                           % (sorted(want), sorted(sd.keys())))
+        if int(sd["version"]) != STATE_DICT_VERSION:
+            raise ValueError("load_state_dict: checkpoint version %d, this engine reads %d"
+                             % (int(sd["version"]), STATE_DICT_VERSION))
+        for k in want - {"version"}:
+            if tuple(sd[k].shape) != tuple(getattr(self, k).shape):
+                raise ValueError("load_state_dict: %s has shape %s, expected %s" % (k, tuple(sd[k].shape),
+                                                                                    tuple(getattr(self, k).shape)))
+        for k in want - {"version"}:
+            getattr(self, k).copy_(sd[k])
+        if self.strict is not False and bool((self.error_t != 0).any()):
+            self._flag._host[0] = 1          # the restored batch carries recorded errors
 
     # ---- plain-data description (parity tests hand this to the oracle) -----------------------------------
     def scenario_spec(self):

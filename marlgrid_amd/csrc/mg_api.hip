@@ -3,6 +3,7 @@
 // caller's stream.
 #include "mg_device.h"
 #include "mg_launch.h"
+#include "mg_mem.h"
 
 namespace {
 
@@ -19,6 +20,10 @@ int check_cfg(const MgConfig* c) {
     if (c->prestige_mask && (c->prestige_sprite_tile < 0 || c->prestige_sprite_tile + 4 > c->n_tiles)) return MG_E_ARG;
     if (!c->obj || !c->atlas) return MG_E_ARG;
     if (c->max_steps < 1) return MG_E_ARG;
+    // the viewer subset of a launch (agents that differ in view geometry are rendered group by group)
+    if (c->n_view < 0 || c->n_view > c->n_agents) return MG_E_ARG;
+    for (int i = 0; i < c->n_view; i++)
+        if (c->view_agent[i] >= c->n_agents) return MG_E_ARG;
     if (c->spawn_x0 < 0 || c->spawn_y0 < 0 || c->spawn_x1 > c->W || c->spawn_y1 > c->H || c->spawn_x1 <= c->spawn_x0 ||
         c->spawn_y1 <= c->spawn_y0 || c->spawn_max_tries < 1 || c->spawn_max_tries > 100000)
         return MG_E_ARG;
@@ -58,14 +63,26 @@ extern "C" {
 
 int32_t mg_abi_version(void) { return MG_ABI_VERSION; }
 
+int32_t mg_struct_sizes(int32_t out[5]) {
+    if (!out) return MG_E_ARG;
+    out[0] = (int32_t)sizeof(MgConfig);
+    out[1] = (int32_t)sizeof(MgState);
+    out[2] = (int32_t)sizeof(MgObjDesc);
+    out[3] = (int32_t)sizeof(MgGenOp);
+    out[4] = (int32_t)sizeof(MgGenProgram);
+    return 5;
+}
+
+#define MG_STR2(x) #x
+#define MG_STR(x) MG_STR2(x)
 #ifndef MG_BUILD_ID
 #define MG_BUILD_ID "unknown"
 #endif
 const char* mg_build_info(void) {
 #if defined(MG_AB_VARIANTS)
-    return "libmarlgrid_hip_ab gfx950 abi2 " MG_BUILD_ID " (measurement variants: tools/ only)";
+    return "libmarlgrid_hip_ab gfx950 abi" MG_STR(MG_ABI_VERSION) " " MG_BUILD_ID " (measurement variants: tools/ only)";
 #else
-    return "libmarlgrid_hip gfx950 abi2 " MG_BUILD_ID;
+    return "libmarlgrid_hip gfx950 abi" MG_STR(MG_ABI_VERSION) " " MG_BUILD_ID;
 #endif
 }
 
@@ -122,6 +139,7 @@ int32_t mg_step_render(const MgConfig* cfg, const MgState* st, const void* actio
     if (e) return e;
     if (!actions || !rewards || !obs) return MG_E_ARG;
     if (action_bytes != 1 && action_bytes != 4 && action_bytes != 8) return MG_E_ARG;
+    if (cfg->n_view != 0) return MG_E_ARG;   // one launch steps AND renders every agent: view groups take mg_step + mg_render_obs
     if (auto_reset && (e = check_prog(cfg, auto_reset))) return e;
     mg::FusedStep fs;
     fs.actions = actions;
@@ -209,6 +227,43 @@ int32_t mg_time_render_obs(const MgConfig* cfg, const MgState* st, uint8_t* obs,
     (void)hipEventDestroy(t0);
     (void)hipEventDestroy(t1);
     return rc(err);
+}
+
+int32_t mg_host_flag_alloc(int32_t** host, int32_t** dev) {
+    if (!host || !dev) return MG_E_ARG;
+    void* h = nullptr;
+    void* d = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return MG_E_LAUNCH;
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipHostFree(h); return MG_E_LAUNCH; }
+    *static_cast<volatile int32_t*>(h) = 0;
+    *host = static_cast<int32_t*>(h);
+    *dev = static_cast<int32_t*>(d);
+    return MG_OK;
+}
+
+int32_t mg_host_flag_free(int32_t* host) {
+    if (!host) return MG_OK;
+    return rc(hipHostFree(host));
+}
+
+MgObsBuffer* mg_obs_alloc(uint64_t bytes, int32_t device, int64_t chunk_bytes) {
+    return reinterpret_cast<MgObsBuffer*>(mg::obs_alloc((size_t)bytes, device, (long long)chunk_bytes));
+}
+
+void* mg_obs_ptr(const MgObsBuffer* buf) { return buf ? reinterpret_cast<const mg::ObsBuffer*>(buf)->ptr : nullptr; }
+
+int32_t mg_obs_info(const MgObsBuffer* buf, uint64_t out[3]) {
+    if (!buf || !out) return MG_E_ARG;
+    const mg::ObsBuffer* b = reinterpret_cast<const mg::ObsBuffer*>(buf);
+    out[0] = b->mapped;
+    out[1] = b->chunk;
+    out[2] = b->handles.size();
+    return MG_OK;
+}
+
+int32_t mg_obs_free(MgObsBuffer* buf) {
+    mg::obs_free(reinterpret_cast<mg::ObsBuffer*>(buf));
+    return MG_OK;
 }
 
 }  // extern "C"

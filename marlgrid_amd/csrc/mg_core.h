@@ -29,6 +29,21 @@ MG_HD uint64_t rec_set(uint64_t r, int i, uint32_t v) {
 }
 MG_HD uint32_t rec_xy(uint64_t r) { return (uint32_t)r & 0xFFFFu; }  // x | y<<8
 
+// A per-env runtime error (the reference's exception): the first one sticks in error[b]; the one-word summary
+// MgState.error_flag — usually host-mapped memory a host polls without synchronising — is raised with a
+// system-scope atomic (error path only: nothing on the normal path touches it).
+MG_HD void record_error(const MgState& st, int b, int err) {
+    if (!err) return;
+    if (st.error[b] == 0) st.error[b] = err;
+    if (st.error_flag) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        __hip_atomic_fetch_or(st.error_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#else
+        *st.error_flag |= 1;
+#endif
+    }
+}
+
 // forward vector per dir: agents.py:183  [(1,0),(0,1),(-1,0),(0,-1)]
 MG_HD int dir_dx(int d) { return d == 0 ? 1 : (d == 2 ? -1 : 0); }
 MG_HD int dir_dy(int d) { return d == 1 ? 1 : (d == 3 ? -1 : 0); }
@@ -508,7 +523,7 @@ MG_HD bool step_run(const MgConfig& cfg, const MgState& st, const MgGenProgram& 
     mt_finish(mt, st.mt_head + (size_t)b * MG_MT_HEAD);
     st.mt_pos[b] = mt.pos;
     st.done[b] = (uint8_t)done;
-    if (err && st.error[b] == 0) st.error[b] = err;
+    record_error(st, b, err);
     return grid_dirty;
 }
 
@@ -526,7 +541,7 @@ MG_HD void reset_run(const MgConfig& cfg, const MgState& st, const MgGenProgram&
     st.mt_pos[b] = mt.pos;
     st.step_count[b] = 0;
     if (clear_done) st.done[b] = 0;
-    if (err && st.error[b] == 0) st.error[b] = err;
+    record_error(st, b, err);
 }
 
 // ---- MultiGridEnv.place_obj / try_place_obj on a live grid (base.py:664-708) for one env -------------
@@ -573,7 +588,7 @@ MG_HD void place_run(const MgConfig& cfg, const MgState& st, const uint8_t* ofla
     st.mt_pos[b] = mt.pos;
     if (out_pos) { out_pos[2 * b] = ok ? x : -1; out_pos[2 * b + 1] = ok ? y : -1; }
     if (out_ok) out_ok[b] = ok ? 1 : 0;
-    if (!ok && !fixed_pos && st.error[b] == 0) st.error[b] = MG_ERR_RECURSION;
+    if (!ok && !fixed_pos) record_error(st, b, MG_ERR_RECURSION);
 }
 
 }  // namespace mg

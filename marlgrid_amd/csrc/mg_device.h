@@ -84,7 +84,8 @@ struct RenderScratch {
     int cell_stride;   // bytes per slot of first / second
     int trow_stride;   // dwords per slot of trow
 };
-__host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride, int n, int vs, int stage_envs = 1,
+// n: the env's agents (records, who stands where); nv: the viewers this launch renders (view-sized arrays)
+__host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride, int n, int nv, int vs, int stage_envs = 1,
                                                                int dyn_bytes = 0, int out_bytes = 0, int piece_rows = 0,
                                                                bool batch_views = false, bool any_hide = true) {
     RenderScratch s;
@@ -100,15 +101,16 @@ __host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride,
     // (object, agent) pair waits in the env's tmap slot and visibility replaces transparency in place.
     s.view_slots = batch_views ? stage_envs : 1;
     s.cell_stride = round_up(cells_stride, 16);
-    s.trow_stride = round_up(n * vs * 4, 16) / 4;
+    // (trow doubles as the per-agent colour words of the 'prestige' recolouring: at least n dwords)
+    s.trow_stride = round_up((nv * vs > n ? nv * vs : n) * 4, 16) / 4;
     s.first = o; o += s.view_slots * s.cell_stride;
     s.second = o; o += (batch_views && !any_hide) ? 0 : s.view_slots * s.cell_stride;
-    s.vbase = o; o += batch_views ? 0 : round_up(n * vs * vs, 16);
-    s.vshow = o; o += batch_views ? 0 : round_up(n * vs * vs, 16);
+    s.vbase = o; o += batch_views ? 0 : round_up(nv * vs * vs, 16);
+    s.vshow = o; o += batch_views ? 0 : round_up(nv * vs * vs, 16);
     s.trow = o;  o += s.view_slots * s.trow_stride * 4;
     s.vis = batch_views ? s.trow : o; o += batch_views ? 0 : s.trow_stride * 4;
     s.tmap_slots = stage_envs;
-    s.tmap_stride = round_up(n * vs * vs * 2, 16);
+    s.tmap_stride = round_up(nv * vs * vs * 2, 16);
     s.tmap = o;  o += s.tmap_slots * s.tmap_stride;
     s.dyn = o;   o += round_up(dyn_bytes, 16);   // per-env recoloured ('prestige') agent tiles
     s.out = o;   o += round_up(out_bytes, 16);   // assemble-and-stream raster: the piece being assembled
@@ -131,6 +133,7 @@ __host__ __device__ inline bool render_chunk_raster(const MgConfig& cfg, int mod
 // and as many staged envs per batch (8, 4, 2 or 1) as `wpb` waves of scratch leave room for.
 __host__ __device__ inline RenderScratch render_scratch_for(const MgConfig& cfg, int wpb, int mode = 0) {
     const int n = cfg.n_agents, vs = cfg.view_size, ts = cfg.tile_size;
+    const int nv = cfg.n_view ? cfg.n_view : n;
     const int dyn = cfg.prestige_mask ? (cfg.any_hide ? 2 : 1) * n * 4 * ts * ts * 3 : 0;
     const int atlas_b = round_up(4 * cfg.n_tiles * ts * ts * 3, 16), misc = 1024;
     int rows = 0, out = 0;
@@ -138,17 +141,17 @@ __host__ __device__ inline RenderScratch render_scratch_for(const MgConfig& cfg,
         const int rb = 3 * vs * ts;
         rows = 4096 / rb;
         if (rows < 1) rows = 1;
-        if (rows > n * vs * ts) rows = n * vs * ts;
+        if (rows > nv * vs * ts) rows = nv * vs * ts;
         out = 32 + rows * rb;
     }
     // assemble-and-stream raster without recoloured tiles: the views of a whole batch are derived together,
     // one slot of view scratch per staged env (see the kernel's pass 0)
     const bool batch_views = out > 0 && dyn == 0;
-    const RenderScratch b = render_scratch_layout(cfg.cells_stride, n, vs, 1, dyn, out, rows);
+    const RenderScratch b = render_scratch_layout(cfg.cells_stride, n, nv, vs, 1, dyn, out, rows);
     const int resident = (atlas_b + 4 * b.total + misc <= 160 * 1024) ? atlas_b : 0;   // else the atlas is read in place
     int k = 8;
-    while (k > 1 && resident + wpb * render_scratch_layout(cfg.cells_stride, n, vs, k, dyn, out, rows, batch_views, cfg.any_hide != 0).total + misc > 160 * 1024) k >>= 1;
-    return render_scratch_layout(cfg.cells_stride, n, vs, k, dyn, out, rows, batch_views, cfg.any_hide != 0);
+    while (k > 1 && resident + wpb * render_scratch_layout(cfg.cells_stride, n, nv, vs, k, dyn, out, rows, batch_views, cfg.any_hide != 0).total + misc > 160 * 1024) k >>= 1;
+    return render_scratch_layout(cfg.cells_stride, n, nv, vs, k, dyn, out, rows, batch_views, cfg.any_hide != 0);
 }
 
 }  // namespace mg

@@ -1,0 +1,148 @@
+"""GPU tests of the host contract around the kernels (C ABI version 3): how per-env errors reach the caller
+without a host sync per step, where the observation buffers come from, checkpoints."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import product_envs
+
+pytestmark = pytest.mark.gpu
+
+
+def _bad_actions(B, n, env_b):
+    import torch
+    a = torch.zeros((B, n), dtype=torch.int64)
+    a[env_b, 0] = 9                                   # ValueError upstream (base.py:619-620)
+    return a
+
+
+def test_strict_modes():
+    """strict='sync' raises inside the step that caused the error (as upstream); strict=True (default) raises at
+    the next call into the env once the GPU got there — without a synchronize on the step path —; strict=False
+    only on check_errors().  All three leave the same state behind."""
+    import torch
+    B = 64
+    envs = {m: product_envs.build("MarlGrid-3AgentCluttered11x11-v0", batch_size=B, strict=m) for m in ("sync", True, False)}
+    good = torch.zeros((B, 3), dtype=torch.int64)
+    for env in envs.values():
+        env.reset()
+        env.step(good)
+    with pytest.raises(ValueError, match="env 17"):
+        envs["sync"].step(_bad_actions(B, 3, 17))
+    e = envs[True]
+    e.step(_bad_actions(B, 3, 17))                    # does not raise: nothing waited for the launch
+    torch.cuda.synchronize()
+    assert e._flag.raised()
+    with pytest.raises(ValueError, match="env 17"):
+        e.step(good)                                  # raised before anything is launched
+    assert not e._flag.raised() and int(e.error_t.abs().sum()) == 0
+    e.step(good)                                      # and the env keeps going
+    f = envs[False]
+    f.step(_bad_actions(B, 3, 17))
+    f.step(good)
+    with pytest.raises(ValueError, match="env 17"):
+        f.check_errors()
+    f.check_errors()                                  # cleared
+
+
+def test_default_strict_step_does_not_synchronize():
+    """env.step() with the defaults must not wait for the GPU: a step queued behind a long-running kernel
+    returns while that kernel is still running."""
+    import time
+    import torch
+    env = product_envs.build("MarlGrid-3AgentCluttered15x15-v0", batch_size=4096)
+    env.reset()
+    a = torch.zeros((4096, 3), dtype=torch.int64, device=env.device)
+    env.step(a)
+    torch.cuda.synchronize()
+    big = torch.empty(1 << 30, dtype=torch.uint8, device=env.device)
+    t0 = time.perf_counter()
+    for _ in range(40):
+        big.fill_(1)                                  # ~6 ms of queued GPU work
+    env.step(a)
+    t_host = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    t_all = time.perf_counter() - t0
+    assert t_host < 0.5 * t_all, (t_host, t_all)
+
+
+def test_obs_buffers_from_the_library():
+    """place_obs='vmm': the observation ring is built by mg_obs_alloc (one virtual range, 2 MiB physical
+    handles) and wrapped as torch tensors; 'search' picks among raw candidate allocations; False = torch.
+    Same observations either way, and the memory goes back when the env dies."""
+    import gc
+    import torch
+    from marlgrid_amd import _native as N
+    from marlgrid_amd.base import _LibBuffer
+    B = 4096                                           # 115 MB of observations: above the 64 MiB threshold
+    free0 = torch.cuda.mem_get_info()[0]
+    outs = {}
+    for mode in ("vmm", "search", False):
+        env = product_envs.build("MarlGrid-3AgentCluttered15x15-v0", batch_size=B, place_obs=mode)
+        env.reset()
+        g = torch.Generator().manual_seed(3)
+        for _ in range(5):
+            o, r, d, _ = env.step(torch.randint(0, 7, (B, 3), generator=g))
+        outs[mode] = (o.cpu(), r.cpu(), d.cpu())
+        if mode == "search":
+            assert env._groups[0].placement_ms["candidates"] >= 2
+        del env, o, r, d
+        gc.collect()
+    for mode in ("search", False):
+        for x, y in zip(outs["vmm"], outs[mode]):
+            assert torch.equal(x, y), mode
+    # a library buffer by itself: layout as asked, usable by torch, freed with its last view
+    mem = _LibBuffer(N.lib(), 100 << 20, torch.device("cuda", torch.cuda.current_device()), 2 << 20)
+    assert mem.ok and mem.info() == dict(mapped=100 << 20, chunk=2 << 20, handles=50)
+    t = mem.tensor((100 << 20,))
+    t.fill_(7)
+    assert int(t[::4097].sum()) == 7 * len(t[::4097])
+    del mem, t
+    gc.collect()
+    torch.cuda.empty_cache()
+    assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)
+
+
+def test_state_dict_round_trip_and_versioning():
+    import torch
+    env = product_envs.build("MarlGrid-3AgentCluttered11x11-v0", batch_size=32, auto_reset=True)
+    env.reset()
+    g = torch.Generator().manual_seed(5)
+    acts = [torch.randint(0, 7, (32, 3), generator=g) for _ in range(30)]
+    for a in acts[:10]:
+        env.step(a)
+    sd = env.state_dict()
+    assert int(sd["version"]) == 3
+    ref = [tuple(x.clone() for x in env.step(a)[:3]) for a in acts[10:]]
+    env2 = product_envs.build("MarlGrid-3AgentCluttered11x11-v0", batch_size=32, auto_reset=True)
+    env2.load_state_dict(sd)
+    for a, (o, r, d) in zip(acts[10:], ref):
+        o2, r2, d2, _ = env2.step(a)
+        assert torch.equal(o, o2) and torch.equal(r, r2) and torch.equal(d, d2)
+    old = {k: v for k, v in sd.items() if k not in ("version", "mt_head")}       # a round-1 checkpoint
+    with pytest.raises(KeyError, match="mt_head"):
+        env2.load_state_dict(old)
+    with pytest.raises(ValueError, match="version"):
+        env2.load_state_dict(dict(sd, version=torch.tensor(2)))
+
+
+def test_c_abi_rejects_bad_viewer_subsets():
+    """check_cfg: n_view / view_agent out of range are argument errors (they would index LDS out of range);
+    mg_step_render takes no viewer subset."""
+    from marlgrid_amd import _native as N
+    env = product_envs.build("MarlGrid-3AgentCluttered11x11-v0", batch_size=8)
+    env.reset()
+    L = N.lib()
+    cfg = N.Config.from_buffer_copy(env._cfg)
+    cfg.n_view = 4                                     # > n_agents
+    assert L.mg_render_obs(C.byref(cfg), C.byref(env._state), env.obs.data_ptr(), None, None, None, env._stream()) == -100
+    cfg.n_view = 1
+    cfg.view_agent[0] = 3                              # >= n_agents
+    assert L.mg_render_obs(C.byref(cfg), C.byref(env._state), env.obs.data_ptr(), None, None, None, env._stream()) == -100
+    cfg.view_agent[0] = 2
+    import torch
+    a = torch.zeros((8, 3), dtype=torch.int64, device=env.device)
+    assert L.mg_step_render(C.byref(cfg), C.byref(env._state), a.data_ptr(), 8, env.rewards.data_ptr(), None,
+                            env.obs.data_ptr(), env._stream()) == -100
+    torch.cuda.synchronize()

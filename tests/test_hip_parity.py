@@ -349,7 +349,8 @@ def test_interact_golden(sname):
         a = torch.tensor([act] * 3)
         if err in exc:
             with pytest.raises(exc[err]):
-                env.step(a)
+                env.step(a)             # (strict=True polls for recorded errors: the next call into the env raises)
+                env.check_errors()
             break
         o, r, dn, _ = env.step(a)
         st = product_envs.canonical(env)
@@ -571,7 +572,8 @@ def test_error_paths_raise_like_the_reference():
     env.reset()
     with pytest.raises(AssertionError):
         for _ in range(200):
-            env.step(torch.randint(0, 3, (8, 1)))
+            env.step(torch.randint(0, 3, (8, 1)))    # raised by a later step(): the error flag is polled
+        env.check_errors()
 
 
 def test_live_place_obj_and_try_place_obj_vs_oracle():
@@ -872,3 +874,49 @@ def test_agents_with_their_own_views_vs_oracle(shared):
     assert tuple(cells.shape) == (B, 7, 7) and bool(vis[env.agent_active[:, 1]].all())   # agent 1 sees through walls
     img = env.render(env_ids=[0, 5])
     assert img.shape[0] == 2 and img.shape[1] == 9 * 32
+
+
+def _full_size_properties(name, B, n, vs, ts, steps, **kw):
+    """size-independent properties at a BASELINE batch: shard invariance against a 7-env twin holding the same
+    global env ids, no runtime errors, every tile-sized block of the last envs' images is an atlas tile"""
+    import torch
+    env = product_envs.build(name, batch_size=B, strict=False, obs_buffers=1, auto_reset=True, **kw)
+    ids = np.array([0, 1, B // 4 - 1, B // 4, B // 2 + 5, B - 2, B - 1])
+    small = product_envs.build(name, batch_size=len(ids), seeds=1337 + ids, auto_reset=True)
+    assert env.view_size == vs and env.tile_size == ts and env.num_agents == n
+    o, o2 = env.reset(), small.reset()
+    assert torch.equal(o[ids].cpu(), o2.cpu())
+    g = torch.Generator().manual_seed(1)
+    for t in range(steps):
+        a = torch.randint(0, 7, (B, n), generator=g)
+        o, r, d, _ = env.step(a)
+        o2, r2, d2, _ = small.step(a[ids])
+        assert torch.equal(o[ids].cpu(), o2.cpu()) and torch.equal(r[ids].cpu(), r2.cpu()), (name, t)
+        assert torch.equal(d[ids].cpu(), d2.cpu())
+    env.check_errors()
+    tb = ts * ts * 3
+    tiles = env.obs[-32:].reshape(32, n, vs, ts, vs, ts, 3).permute(0, 1, 2, 4, 3, 5, 6).reshape(-1, tb).cpu().numpy()
+    known = {bytes(x) for x in env.atlas.reshape(-1, tb)}
+    assert all(bytes(x) in known for x in np.unique(tiles, axis=0))
+    return env
+
+
+def test_full_size_config2_4agent_empty9x9():
+    """BASELINE.json configs[2]: MarlGrid-4AgentEmpty9x9-v0 at B = 65 536 (6.2 GB of observations), library-built
+    observation buffers, episodes ending and restarting inside the launch (max_steps 100 is not reached in 12
+    steps; agents reaching the goal end episodes)"""
+    _full_size_properties("MarlGrid-4AgentEmpty9x9-v0", 65536, 4, 7, 8, 12)
+
+
+def test_full_size_config4_8agent_cluttered30x30():
+    """BASELINE.json configs[4] per GPU: 8 agents, 30x30, view 9, B = 131 072 — the <9, 8, 4>-wave instantiation,
+    16.3 GB of observations per buffer"""
+    env = _full_size_properties("Custom-8AgentCluttered30x30", 131072, 8, 9, 8, 6)
+    assert env.obs.numel() == 131072 * 8 * 72 * 72 * 3
+
+
+def test_full_size_config1_3agent_cluttered11x11():
+    """BASELINE.json configs[1]: MarlGrid-3AgentCluttered11x11-v0 at B = 4 096 with auto_reset, past max_steps
+    (every env resets in-launch at least once)"""
+    env = _full_size_properties("MarlGrid-3AgentCluttered11x11-v0", 4096, 3, 7, 8, 110)
+    assert int(env.step_count.max()) < 100

@@ -24,9 +24,46 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), name
     L.mg_abi_version.restype = ctypes.c_int32
-    assert L.mg_abi_version() == 2
     from marlgrid_amd import _native
+    assert L.mg_abi_version() == _native.ABI_VERSION == int(re.search(r"#define MG_ABI_VERSION (\d+)", hdr).group(1))
     assert sorted(_native.SYMBOLS) == declared
+
+
+def test_struct_sizes_match_the_binding():
+    """mg_struct_sizes() = the library's own sizeof of the five ABI structs; _native.lib() refuses to load a
+    library whose layouts differ from its ctypes mirrors (what a forgotten field would otherwise turn into
+    silently misread launch configs)."""
+    from marlgrid_amd import _native as N
+    L = N.lib()
+    out = (ctypes.c_int32 * 5)()
+    assert L.mg_struct_sizes(out) == 5
+    assert list(out) == [ctypes.sizeof(t) for t in (N.Config, N.State, N.ObjDesc, N.GenOp, N.GenProgram)]
+    assert L.mg_struct_sizes(None) == -100
+
+
+def test_integration_stub_executes(monkeypatch):
+    """The binding INTEGRATION.md shows a maintainer is code, not prose: extract the marked block, execute it
+    against the built library — it asserts the ABI version and every struct size itself — and cross-check its
+    structs field by field with the product binding."""
+    from marlgrid_amd import _native as N
+    N.lib()                                     # (loads libamdhip64 through torch first, as the product does)
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"<!-- binding-stub[^>]*-->\s*```python\n(.*?)```", md, re.S)
+    assert m, "INTEGRATION.md: the binding-stub block is gone"
+    monkeypatch.setenv("MARLGRID_HIP_LIB", N.LIB_PATH)
+    ns = {}
+    exec(compile(m.group(1), "INTEGRATION.md:binding-stub", "exec"), ns)
+    for mine, theirs in ((N.Config, ns["MgConfig"]), (N.State, ns["MgState"]), (N.ObjDesc, ns["MgObjDesc"]),
+                         (N.GenOp, ns["MgGenOp"]), (N.GenProgram, ns["MgGenProgram"])):
+        assert ctypes.sizeof(mine) == ctypes.sizeof(theirs)
+        a = [(n, getattr(mine, n).offset, getattr(mine, n).size) for n, *_ in mine._fields_]
+        b = [(n, getattr(theirs, n).offset, getattr(theirs, n).size) for n, *_ in theirs._fields_]
+        assert a == b, theirs.__name__
+    # every entry point on the reference's path is bound by the stub
+    bound = set(re.findall(r"_L\.(mg_[a-z_0-9]+)\.argtypes", m.group(1))) | {"mg_abi_version", "mg_struct_sizes"}
+    for need in ("mg_mt_seed", "mg_reset", "mg_step", "mg_step_render", "mg_render_obs", "mg_encode", "mg_put_obj",
+                 "mg_place", "mg_render_frame"):
+        assert need in bound, need
 
 
 def test_production_library_has_no_measurement_switches():
@@ -39,7 +76,7 @@ def test_production_library_has_no_measurement_switches():
     L = ctypes.CDLL(so)
     L.mg_build_info.restype = ctypes.c_char_p
     info = L.mg_build_info().decode()
-    assert info.startswith("libmarlgrid_hip gfx950 abi2 src-") and "variants" not in info
+    assert info.startswith("libmarlgrid_hip gfx950 abi3 src-") and "variants" not in info
 
 
 def test_product_never_imports_the_oracle():
@@ -260,3 +297,40 @@ def test_render_lds_query():
     assert need(2, 3, 32, 96, 24) < 4 * 24 * 32 * 32 * 3                  # atlas (288 KiB) stays in HBM / L2
     assert need(1, 7, 8, 200 * 200, 12) > 160 * 1024                      # rejected by MultiGridEnv
     assert need(0, 7, 8, 240, 28) < 0 and L.mg_render_obs_lds_bytes(None) < 0
+
+
+def test_export_video_frame_function(tmp_path, monkeypatch):
+    """utils/video.py:export_video against marlgrid/utils/video.py:8-36 with a stand-in for the optional moviepy:
+    the clip is asked for frames at arbitrary times; frame(t) = X[min(int(t * fps), T - 1)], every pixel blown up
+    rescale_factor times (np.kron with ones upstream), duration T / fps, written to the expanded path."""
+    import sys
+    import types
+    import numpy as np
+    calls = {}
+
+    class VideoClip(object):
+        def __init__(self, make_frame, duration=None):
+            calls["make_frame"], calls["duration"] = make_frame, duration
+
+        def write_videofile(self, path, fps=None):
+            calls["path"], calls["fps"] = path, fps
+
+    editor = types.ModuleType("moviepy.editor")
+    editor.VideoClip = VideoClip
+    pkg = types.ModuleType("moviepy")
+    pkg.editor = editor
+    monkeypatch.setitem(sys.modules, "moviepy", pkg)
+    monkeypatch.setitem(sys.modules, "moviepy.editor", editor)
+    from marlgrid_amd.utils.video import export_video
+    rng = np.random.RandomState(0)
+    X = [rng.randint(0, 256, size=(6, 5, 3)).astype(np.uint8) for _ in range(7)]
+    out = tmp_path / "sub" / "clip.mp4"
+    export_video(X, str(out), fps=10, rescale_factor=3)
+    assert calls["path"] == str(out) and calls["fps"] == 10 and abs(calls["duration"] - 0.7) < 1e-12
+    assert (tmp_path / "sub").is_dir()
+    want = np.kron(np.stack(X), np.ones((1, 3, 3, 1)))              # upstream's rescale
+    for t in (0.0, 0.05, 0.1, 0.35, 0.69, 0.7, 5.0):
+        f = calls["make_frame"](t)
+        assert f.shape == (18, 15, 3) and np.array_equal(f, want[min(int(t * 10), 6)])
+    export_video(np.stack(X), str(out), fps=20, rescale_factor=1)   # an array, no rescale
+    assert np.array_equal(calls["make_frame"](0.26), X[5])

@@ -89,6 +89,30 @@ def test_bench_skeleton_two_ranks_gloo():
     assert out["ms_per_step"] >= 2.0 and out["blocks"]["count"] >= 4
 
 
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must start 2 ranks itself (the driver's SCALE run
+    may invoke it exactly so) — here through the CPU self-test, which takes the same self-launch path — and a
+    launcher whose WORLD_SIZE disagrees with --gpus must be refused, not silently measured as something else."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if not (k.startswith("MG_") or k.startswith("MARLGRID_") or k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"))}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1",
+                        "--selftest-cpu", "--min-seconds", "0.05"], capture_output=True, text=True, timeout=300,
+                       env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and "bench.py --gpus 2" in out["launched_by"]
+    assert len(out["per_rank_ms_per_step"]) == 2
+    # WORLD_SIZE 1 (as a launcher would set it) but --gpus 2: refused with rc 2
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--selftest-cpu"],
+                       capture_output=True, text=True, timeout=120, env=dict(env, WORLD_SIZE="1", RANK="0"), cwd=root)
+    assert r.returncode == 2 and "WORLD_SIZE" in r.stderr
+
+
 def test_bench_refuses_measurement_switches():
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
