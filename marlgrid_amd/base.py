@@ -274,9 +274,31 @@ class _LibBuffer(object):
         return torch.as_tensor(self, device=self.device).view(shape)
 
     def info(self):
-        out = (C.c_uint64 * 3)()
+        out = (C.c_uint64 * 4)()
         N.check(self._lib.mg_obs_info(self._h, out))
-        return dict(mapped=int(out[0]), chunk=int(out[1]), handles=int(out[2]))
+        return dict(mapped=int(out[0]), chunk=int(out[1]), handles=int(out[2]), ranges=int(out[3]))
+
+    # the same physical memory behind another virtual range (csrc/mg_mem.h).  Tensors made before a move point
+    # at an unmapped range: make them afterwards.
+    def _moved(self):
+        self.ptr = self._lib.mg_obs_ptr(self._h)
+        self.__cuda_array_interface__ = dict(self.__cuda_array_interface__, data=(self.ptr, False))
+
+    def rebase(self):
+        import torch
+        torch.cuda.synchronize(self.device)
+        ok = bool(self._lib.mg_obs_rebase(self._h))
+        self._moved()
+        return ok
+
+    def select(self, i):
+        import torch
+        torch.cuda.synchronize(self.device)
+        N.check(self._lib.mg_obs_select(self._h, int(i)))
+        self._moved()
+
+    def trim(self):
+        N.check(self._lib.mg_obs_trim(self._h))
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -381,6 +403,8 @@ class MultiGridEnv(object):
         self.reset()
         if not self._dry and self.place_obs == "search":
             self._place_obs_buffers()
+        elif not self._dry and self.place_obs == "vmm":
+            self._place_obs_ranges()
         self._spec_ctor = self._spec_last     # the constructor-time `_gen_grid` (base.py:369)
         self._retrace = True
 
@@ -460,6 +484,7 @@ class MultiGridEnv(object):
             for g in self._groups:
                 g.shape = (B, len(g.members), g.pixels, g.pixels, 3)
                 g.ring = [self._new_obs_buffer(g.shape, vmm=self.place_obs == "vmm") for _ in range(self.obs_buffers)]
+                g.ring_mem = [getattr(t, "_mg_owner", None) for t in g.ring]
                 g.obs = g.ring[0]
             self._ring = [dict(obs=self._groups[0].ring[i],
                                rewards=torch.zeros((B, n), dtype=torch.float32, device=dev),
@@ -484,9 +509,13 @@ class MultiGridEnv(object):
         import torch
         nbytes = int(np.prod(shape))
         if vmm and nbytes >= min_bytes:
-            mem = _LibBuffer(self._lib, nbytes, self.device, OBS_CHUNK_BYTES)
+            chunk = OBS_CHUNK_BYTES                     # <= 512 physical handles per buffer
+            while nbytes > 512 * chunk:
+                chunk *= 2
+            mem = _LibBuffer(self._lib, nbytes, self.device, chunk)
             if mem.ok:
                 t = mem.tensor(shape)
+                t._mg_owner = mem
                 t.zero_()
                 return t
         return torch.zeros(shape, dtype=torch.uint8, device=self.device)
@@ -560,6 +589,64 @@ class MultiGridEnv(object):
             g.obs = g.ring[self._ring_i]
             g.placement_ms = {"kept": [c for c, _ in best], "candidates": len(seen), "stopped": why,
                               "seconds": time.perf_counter() - t_begin, "all": seen}
+        for i, r in enumerate(self._ring):
+            r["obs"] = self._groups[0].ring[i]
+        self.obs = self._ring[self._ring_i]["obs"]
+        self._render()                      # the current observation, into the buffer that is current now
+
+    @_on_device
+    def _place_obs_ranges(self, min_ranges=12, max_ranges=48, gain=0.10, seconds=1.0, iters=3):
+        """place_obs="vmm": choose the VIRTUAL range each library-built observation buffer is mapped behind.  The
+        rate at which HBM absorbs the raster's write pattern depends on the buffer by up to 25 % — and when a
+        buffer is taken apart (csrc/mg_mem.h; profiles/r03/README.md section 2) that class stays with its virtual
+        range when the physical handles behind it are permuted or traded with another buffer's.  So candidate
+        ranges are tried with the SAME physical memory (mg_obs_rebase: a remap, a few ms; no memory beyond the
+        buffer itself), the raster is timed into each (HIP events, `iters` launches), and the mapping goes back to
+        the fastest (mg_obs_select), the others are released (mg_obs_trim).  At least `min_ranges`, then until
+        the best is `gain` under the median, at most `max_ranges` / `seconds` (all buffers together)."""
+        import time
+        t_begin = time.perf_counter()
+        ms = C.c_float(0)
+        for g in self._groups:
+            if not any(m is not None for m in g.ring_mem):
+                continue
+            g.placement_ms = {"kept": [], "ranges_tried": [], "stopped": [], "all": []}
+            for i, mem in enumerate(g.ring_mem):
+                if mem is None:
+                    continue
+                g.ring[i] = None                       # (the tensor is re-made on the range that is kept)
+
+                def cost():
+                    N.check(self._lib.mg_time_render_obs(C.byref(g.cfg), C.byref(self._state), C.c_void_p(mem.ptr), iters,
+                                                         C.byref(ms), self._stream()))
+                    return ms.value
+
+                costs = [cost()]
+                why = "cap"
+                while len(costs) < max_ranges:
+                    if time.perf_counter() - t_begin > seconds * (i + 1) / len(g.ring_mem):
+                        why = "time"
+                        break
+                    if not mem.rebase():
+                        why = "no more address space"
+                        break
+                    costs.append(cost())
+                    ranked = sorted(costs)
+                    if len(costs) >= min_ranges and ranked[0] <= (1.0 - gain) * ranked[len(ranked) // 2]:
+                        why = "best %d%% under the median range" % round(100 * (1 - ranked[0] / ranked[len(ranked) // 2]))
+                        break
+                best = min(range(len(costs)), key=costs.__getitem__)
+                mem.select(best)
+                mem.trim()
+                t = mem.tensor(g.shape)
+                t._mg_owner = mem
+                g.ring[i] = t
+                g.placement_ms["kept"].append(costs[best])
+                g.placement_ms["ranges_tried"].append(len(costs))
+                g.placement_ms["stopped"].append(why)
+                g.placement_ms["all"].append(costs)
+            g.obs = g.ring[self._ring_i]
+            g.placement_ms["seconds"] = time.perf_counter() - t_begin
         for i, r in enumerate(self._ring):
             r["obs"] = self._groups[0].ring[i]
         self.obs = self._ring[self._ring_i]["obs"]

@@ -252,12 +252,25 @@ MgObsBuffer* mg_obs_alloc(uint64_t bytes, int32_t device, int64_t chunk_bytes) {
 
 void* mg_obs_ptr(const MgObsBuffer* buf) { return buf ? reinterpret_cast<const mg::ObsBuffer*>(buf)->ptr : nullptr; }
 
-int32_t mg_obs_info(const MgObsBuffer* buf, uint64_t out[3]) {
+int32_t mg_obs_info(const MgObsBuffer* buf, uint64_t out[4]) {
     if (!buf || !out) return MG_E_ARG;
     const mg::ObsBuffer* b = reinterpret_cast<const mg::ObsBuffer*>(buf);
     out[0] = b->mapped;
     out[1] = b->chunk;
     out[2] = b->handles.size();
+    out[3] = b->ranges.size();
+    return MG_OK;
+}
+
+void* mg_obs_rebase(MgObsBuffer* buf) { return mg::obs_rebase(reinterpret_cast<mg::ObsBuffer*>(buf)); }
+
+int32_t mg_obs_select(MgObsBuffer* buf, int32_t i) {
+    return mg::obs_select(reinterpret_cast<mg::ObsBuffer*>(buf), i) ? MG_OK : MG_E_ARG;
+}
+
+int32_t mg_obs_trim(MgObsBuffer* buf) {
+    if (!buf) return MG_E_ARG;
+    mg::obs_trim(reinterpret_cast<mg::ObsBuffer*>(buf));
     return MG_OK;
 }
 
@@ -265,5 +278,14 @@ int32_t mg_obs_free(MgObsBuffer* buf) {
     mg::obs_free(reinterpret_cast<mg::ObsBuffer*>(buf));
     return MG_OK;
 }
+
+#if defined(MG_AB_VARIANTS)
+int32_t mg_ab_obs_permute(MgObsBuffer* buf, const int32_t* order) {
+    return mg::obs_permute(reinterpret_cast<mg::ObsBuffer*>(buf), order) ? MG_OK : MG_E_LAUNCH;
+}
+int32_t mg_ab_obs_exchange(MgObsBuffer* a, MgObsBuffer* b, const int32_t* slots, int32_t n) {
+    return mg::obs_exchange(reinterpret_cast<mg::ObsBuffer*>(a), reinterpret_cast<mg::ObsBuffer*>(b), slots, n) ? MG_OK : MG_E_LAUNCH;
+}
+#endif
 
 }  // extern "C"

@@ -1,18 +1,22 @@
 // mg_mem.h — where the observation buffers live (host code; HIP virtual memory management).
 //
-// Measured on MI355X (profiles/r02/README.md section 3, profiles/r03): the rate at which HBM absorbs the obs
-// raster's write pattern — thousands of waves, each streaming its own env — depends on the ALLOCATION it
-// writes into (5.3 vs 6.6-6.8 TB/s), while a dense fill of the same buffers is flat.  A buffer that comes out
-// of hipMalloc is backed by whatever physical blocks the VRAM manager had at hand; what the raster is
-// sensitive to is how that backing is cut up.  So the engine builds its observation buffers itself: one
-// virtual range (hipMemAddressReserve), backed by physical handles of a chosen size (hipMemCreate, 2 MiB
-// granules), mapped back to back (hipMemMap) — a CONSTRUCTION with a known layout instead of a search among
-// allocations of unknown layout.  `chunk_bytes` = 0 falls back to a plain hipMalloc.
+// Measured on MI355X (profiles/r02/README.md section 3, profiles/r03/README.md section 2): the rate at which HBM
+// absorbs the obs raster's write pattern — thousands of waves, each streaming its own env — depends on the
+// BUFFER it writes into (0.160 vs 0.205 ms for the same 925 MB), reproducibly per buffer, while a dense fill of
+// the same buffers is flat.  Round 3 took the buffers apart with the virtual-memory API: a buffer built from
+// 2 MiB physical handles keeps its class when its handles are permuted, and when half of them are traded with
+// a buffer of the other class — the class belongs to the VIRTUAL RANGE, not to the physical memory behind it.
+// So the engine builds its observation buffers itself: physical handles (hipMemCreate, 2 MiB granules) that are
+// created ONCE, and a virtual range (hipMemAddressReserve) that can be exchanged for another at the cost of a
+// remap — a placement search that needs no memory beyond the buffer itself (obs_rebase / obs_select /
+// obs_trim; MultiGridEnv._place_obs_buffers times the raster into each candidate range).
+// `chunk_bytes` = 0 falls back to a plain hipMalloc.
 #pragma once
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <utility>
 #include <vector>
 
 namespace mg {
@@ -24,6 +28,7 @@ struct ObsBuffer {
     size_t chunk = 0;        // bytes per physical handle; 0: plain hipMalloc
     int device = 0;
     std::vector<hipMemGenericAllocationHandle_t> handles;
+    std::vector<void*> ranges;   // every virtual range reserved for this buffer; `ptr` is the one the handles are mapped in
 };
 
 inline size_t obs_granularity(int device, bool recommended) {
@@ -43,10 +48,9 @@ inline void obs_free(ObsBuffer* b) {
     if (b->chunk == 0) {
         if (b->ptr) (void)hipFree(b->ptr);
     } else {
-        if (b->ptr) {   // mapping by mapping, as they were made
+        if (b->ptr)   // mapping by mapping, as they were made
             for (size_t i = 0; i < b->handles.size(); i++) (void)hipMemUnmap(static_cast<char*>(b->ptr) + i * b->chunk, b->chunk);
-            (void)hipMemAddressFree(b->ptr, b->mapped);
-        }
+        for (void* r : b->ranges) (void)hipMemAddressFree(r, b->mapped);
         for (auto h : b->handles) (void)hipMemRelease(h);
     }
     delete b;
@@ -87,6 +91,7 @@ inline ObsBuffer* obs_alloc(size_t bytes, int device, long long chunk_bytes) {
         delete b;
         return nullptr;
     }
+    b->ranges.push_back(b->ptr);
     hipMemAccessDesc acc = {};
     acc.location.type = hipMemLocationTypeDevice;
     acc.location.id = device;
@@ -112,5 +117,79 @@ inline ObsBuffer* obs_alloc(size_t bytes, int device, long long chunk_bytes) {
     }
     return b;
 }
+
+inline bool obs_map_all(ObsBuffer* b, void* base) {
+    hipMemAccessDesc acc = {};
+    acc.location.type = hipMemLocationTypeDevice;
+    acc.location.id = b->device;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    for (size_t i = 0; i < b->handles.size(); i++) {
+        char* va = static_cast<char*>(base) + i * b->chunk;
+        if (hipMemMap(va, b->chunk, 0, b->handles[i], 0) != hipSuccess) return false;
+        if (hipMemSetAccess(va, b->chunk, &acc, 1) != hipSuccess) return false;
+    }
+    return true;
+}
+inline void obs_unmap_all(ObsBuffer* b) {
+    for (size_t i = 0; i < b->handles.size(); i++) (void)hipMemUnmap(static_cast<char*>(b->ptr) + i * b->chunk, b->chunk);
+}
+
+// The same physical memory behind another virtual range.  The caller must have drained every stream that uses
+// the buffer.  obs_rebase reserves a NEW range (the ones tried before stay reserved, so every call explores a
+// different one) and moves the mapping there; obs_select moves it back to the i-th range tried (0 = the one the
+// buffer was built with); obs_trim gives every range but the current one back.  Contents survive (same memory).
+inline bool obs_move_to(ObsBuffer* b, void* range) {
+    if (range == b->ptr) return true;
+    obs_unmap_all(b);
+    if (!obs_map_all(b, range)) return false;
+    b->ptr = range;
+    return true;
+}
+inline void* obs_rebase(ObsBuffer* b) {
+    if (!b || b->chunk == 0) return nullptr;
+    void* range = nullptr;
+    if (hipMemAddressReserve(&range, b->mapped, b->chunk < (1u << 30) ? b->chunk : (1u << 30), nullptr, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    b->ranges.push_back(range);
+    return obs_move_to(b, range) ? range : nullptr;
+}
+inline bool obs_select(ObsBuffer* b, int i) {
+    if (!b || b->chunk == 0 || i < 0 || (size_t)i >= b->ranges.size()) return false;
+    return obs_move_to(b, b->ranges[(size_t)i]);
+}
+inline void obs_trim(ObsBuffer* b) {
+    if (!b || b->chunk == 0) return;
+    for (void* r : b->ranges)
+        if (r != b->ptr) (void)hipMemAddressFree(r, b->mapped);
+    b->ranges.assign(1, b->ptr);
+}
+
+#if defined(MG_AB_VARIANTS)
+// Measurement build (tools/placement_vmm2.py): the same physical handles behind the same virtual range in
+// another ORDER, and handles traded between two buffers — is a buffer's class a property of its handles
+// (additive), or of how the raster's streams fall onto them?  (Answer: neither moves it; profiles/r03.)
+inline bool obs_permute(ObsBuffer* b, const int32_t* order) {
+    if (!b || b->chunk == 0) return false;
+    (void)hipDeviceSynchronize();
+    obs_unmap_all(b);
+    std::vector<hipMemGenericAllocationHandle_t> h(b->handles.size());
+    for (size_t i = 0; i < h.size(); i++) h[i] = b->handles[(size_t)order[i]];
+    b->handles = h;
+    return obs_map_all(b, b->ptr);
+}
+inline bool obs_exchange(ObsBuffer* a, ObsBuffer* b, const int32_t* slots, int n) {
+    if (!a || !b || a->chunk == 0 || a->chunk != b->chunk) return false;
+    (void)hipDeviceSynchronize();
+    obs_unmap_all(a);
+    obs_unmap_all(b);
+    for (int i = 0; i < n; i++) {
+        const size_t s = (size_t)slots[i];
+        if (s < a->handles.size() && s < b->handles.size()) std::swap(a->handles[s], b->handles[s]);
+    }
+    return obs_map_all(a, a->ptr) && obs_map_all(b, b->ptr);
+}
+#endif
 
 }  // namespace mg

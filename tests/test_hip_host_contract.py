@@ -87,6 +87,10 @@ def test_obs_buffers_from_the_library():
         outs[mode] = (o.cpu(), r.cpu(), d.cpu())
         if mode == "search":
             assert env._groups[0].placement_ms["candidates"] >= 2
+        if mode == "vmm":
+            pm = env._groups[0].placement_ms
+            assert len(pm["kept"]) == 2 and min(pm["ranges_tried"]) >= 2 and all(k == min(a) for k, a in zip(pm["kept"], pm["all"]))
+            assert all(m.info()["ranges"] == 1 for m in env._groups[0].ring_mem)
         del env, o, r, d
         gc.collect()
     for mode in ("search", False):
@@ -94,10 +98,23 @@ def test_obs_buffers_from_the_library():
             assert torch.equal(x, y), mode
     # a library buffer by itself: layout as asked, usable by torch, freed with its last view
     mem = _LibBuffer(N.lib(), 100 << 20, torch.device("cuda", torch.cuda.current_device()), 2 << 20)
-    assert mem.ok and mem.info() == dict(mapped=100 << 20, chunk=2 << 20, handles=50)
+    assert mem.ok and mem.info() == dict(mapped=100 << 20, chunk=2 << 20, handles=50, ranges=1)
     t = mem.tensor((100 << 20,))
-    t.fill_(7)
-    assert int(t[::4097].sum()) == 7 * len(t[::4097])
+    t.copy_(torch.arange(100 << 20, device=t.device) % 251)
+    want = t[::4097].clone()
+    p0 = mem.ptr
+    del t                                              # (a tensor made before a move points at an unmapped range)
+    # the same physical memory behind other virtual ranges: contents survive, the pointer changes, and back
+    assert mem.rebase() and mem.rebase() and mem.ptr != p0 and mem.info()["ranges"] == 3
+    t = mem.tensor((100 << 20,))
+    assert t.data_ptr() == mem.ptr and torch.equal(t[::4097], want)
+    del t
+    mem.select(0)
+    assert mem.ptr == p0
+    mem.trim()
+    assert mem.info()["ranges"] == 1
+    t = mem.tensor((100 << 20,))
+    assert torch.equal(t[::4097], want)
     del mem, t
     gc.collect()
     torch.cuda.empty_cache()

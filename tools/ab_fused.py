@@ -1,0 +1,76 @@
+#!/usr/bin/env python
+"""Interleaved A/B of the one-launch step (mg_step_render) between product-flavoured builds of the library that
+differ in the obs kernel's launch options (mg_device.h kRenderOpt*; `make -C marlgrid_amd/csrc variants OPTS=...`
+builds libmarlgrid_hip_v<opt>.so): bit 0 = RNG head refill deferred behind the raster, bits 8..11 = the wave's first
+N envs stepped and rendered ahead of the rest.  `ref` = libmarlgrid_hip_ref.so (a build of an earlier commit).
+First a parity check of every build against the first one (two envs, same seeds and actions, 130 steps:
+observations, rewards, done, records, grids and the whole RNG state must be equal), then 9 interleaved rounds of
+100 launches each, all into the SAME observation buffer.
+usage: ab_fused.py ref 0 1 257"""
+import ctypes as C
+import os
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from marlgrid_amd import _native as N  # noqa: E402
+from marlgrid_amd.envs import make  # noqa: E402
+
+names = sys.argv[1:] or ["ref", "0", "1", "257"]
+B = int(os.environ.get("B", "32768"))
+WL = os.environ.get("WL", "MarlGrid-3AgentCluttered15x15-v0")
+g = torch.Generator().manual_seed(0)
+env = make(WL, batch_size=B, auto_reset=True, strict=False, place_obs=False)
+n = env.num_agents
+acts = [torch.randint(0, 7, (B, n), generator=g).cuda() for _ in range(16)]
+vp, i32 = C.c_void_p, C.c_int32
+libs = {}
+for nm in names:
+    path = os.path.join(ROOT, "marlgrid_amd", "csrc", "libmarlgrid_hip_%s.so" % (nm if nm == "ref" else "v%d" % int(nm, 0)))
+    L = C.CDLL(path)
+    L.mg_step_render.argtypes = [C.POINTER(N.Config), C.POINTER(N.State), vp, i32, vp, C.POINTER(N.GenProgram), vp, vp]
+    L.mg_step_render.restype = i32
+    L.mg_build_info.restype = C.c_char_p
+    libs[nm] = L
+    print("%-6s %s" % (nm, L.mg_build_info().decode()))
+
+
+def launch(L, e, i):
+    rc = L.mg_step_render(C.byref(e._cfg), C.byref(e._state), acts[i % 16].data_ptr(), 8, e.rewards.data_ptr(),
+                          C.byref(e._reset_prog), e.obs.data_ptr(), e._stream())
+    assert rc == 0, rc
+
+
+env.reset()
+env.step(acts[0])          # (traces the reset program)
+if os.environ.get("CHECK", "1") != "0":
+    ref = make(WL, batch_size=B, auto_reset=True, strict=False, place_obs=False)
+    ref.reset()
+    ref.step(acts[0])
+    for nm in names[1:]:
+        for i in range(130):
+            launch(libs[names[0]], ref, i)
+            launch(libs[nm], env, i)
+            if i % 10 == 9 or i > 95:
+                for k in ("obs", "rewards", "done_t", "agent_state", "grid_state", "mt_state", "mt_pos", "mt_head", "step_count_t"):
+                    assert torch.equal(getattr(env, k), getattr(ref, k)), ("%s differs from %s in %s at step %d" % (nm, names[0], k, i))
+        env.check_errors()
+        print("%-6s identical to %s over 130 steps (obs, rewards, done, records, grids, RNG state)" % (nm, names[0]), flush=True)
+    del ref
+res = {nm: [] for nm in names}
+for rep in range(9):
+    for nm in names:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        launch(libs[nm], env, 0)
+        a.record()
+        for i in range(100):
+            launch(libs[nm], env, i)
+        b.record()
+        b.synchronize()
+        res[nm].append(a.elapsed_time(b) / 100)
+base = statistics.median(res[names[0]])
+for nm in names:
+    m = statistics.median(res[nm])
+    print("%-6s median %.4f ms (min %.4f max %.4f)  %+.2f%% vs %s" % (nm, m, min(res[nm]), max(res[nm]), 100 * (m / base - 1), names[0]))
