@@ -99,7 +99,6 @@ class Control(object):
 
 
 OBS_BUFFERS_NOTE = {
-    "vmm": "built by the library (mg_obs_alloc): one virtual range backed by 2 MiB physical handles",
     "search": "chosen among candidate HBM allocations by timing the raster into each at construction "
               "(MultiGridEnv._place_obs_buffers; ms per launch in obs_placement)",
     False: "plain torch allocations"}

@@ -269,31 +269,15 @@ int32_t mg_time_render_obs(const MgConfig* cfg, const MgState* st, uint8_t* obs,
 int32_t mg_host_flag_alloc(int32_t** host, int32_t** dev);
 int32_t mg_host_flag_free(int32_t* host);
 
-/* mg_obs_alloc: an observation buffer (the obs argument of mg_render_obs / mg_step_render) whose physical backing
- * the engine lays out itself with HIP virtual memory management: one virtual range, physical handles of
- * `chunk_bytes` each (rounded up to the device's 2 MiB granule) mapped back to back.  chunk_bytes 0: a plain
- * hipMalloc; < 0: one handle for the whole buffer.  The obs raster's write pattern — thousands of waves, each
- * streaming its own env — is sensitive to how a buffer's backing is cut up (profiles/r03/README.md), which
- * hipMalloc leaves to chance.  Returns an opaque handle (NULL on failure); mg_obs_ptr gives the device pointer.
+/* mg_obs_alloc / mg_obs_free: an observation buffer (the obs argument of mg_render_obs / mg_step_render) straight
+ * from the driver (hipMalloc on `device`), outside any caching allocator: the rate at which HBM absorbs the obs
+ * raster's write pattern depends on the allocation it writes into by up to 25 % (profiles/r03/README.md section
+ * 2), so hosts choose among candidate allocations by timing the raster into each (mg_time_render_obs) — and a
+ * rejected candidate must go back to the driver at once, which a caching allocator does not do.  NULL on failure.
  * Nothing on the step path allocates: these are construction-time helpers, and any other device memory is as
  * valid an `obs` argument. */
-typedef struct MgObsBuffer MgObsBuffer;
-MgObsBuffer* mg_obs_alloc(uint64_t bytes, int32_t device, int64_t chunk_bytes);
-void* mg_obs_ptr(const MgObsBuffer* buf);
-/* out[0] = bytes mapped, out[1] = bytes per physical handle (0: hipMalloc), out[2] = handles, out[3] = virtual
- * ranges currently reserved for it */
-int32_t mg_obs_info(const MgObsBuffer* buf, uint64_t out[4]);
-int32_t mg_obs_free(MgObsBuffer* buf);
-/* The class of a buffer (how fast the raster's pattern is absorbed) belongs to its VIRTUAL range, not to the
- * physical memory behind it (profiles/r03/README.md section 2) — so a placement search needs no memory: the same
- * physical handles are mapped behind another range.  The caller drains the streams that use the buffer first;
- * contents survive.  mg_obs_rebase: reserve a NEW range (the ones tried before stay reserved, so every call
- * explores a different one), move the mapping there, return the new device pointer (NULL on failure, or for a
- * hipMalloc buffer).  mg_obs_select: back to the i-th range tried (0 = the one the buffer was built with).
- * mg_obs_trim: give every range but the current one back. */
-void* mg_obs_rebase(MgObsBuffer* buf);
-int32_t mg_obs_select(MgObsBuffer* buf, int32_t i);
-int32_t mg_obs_trim(MgObsBuffer* buf);
+void* mg_obs_alloc(uint64_t bytes, int32_t device);
+int32_t mg_obs_free(void* ptr);
 
 #ifdef __cplusplus
 }

@@ -69,8 +69,7 @@ class GenProgram(C.Structure):
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmarlgrid_hip.so")
 
 # every symbol include/marlgrid_hip.h declares
-SYMBOLS = ["mg_abi_version", "mg_struct_sizes", "mg_host_flag_alloc", "mg_host_flag_free", "mg_obs_alloc", "mg_obs_ptr", "mg_obs_info",
-           "mg_obs_free", "mg_obs_rebase", "mg_obs_select", "mg_obs_trim", "mg_build_info", "mg_error_string", "mg_mt_seed", "mg_reset", "mg_step", "mg_step_render",
+SYMBOLS = ["mg_abi_version", "mg_struct_sizes", "mg_host_flag_alloc", "mg_host_flag_free", "mg_obs_alloc", "mg_obs_free", "mg_build_info", "mg_error_string", "mg_mt_seed", "mg_reset", "mg_step", "mg_step_render",
            "mg_render_obs",
            "mg_encode", "mg_put_obj", "mg_place", "mg_render_frame", "mg_time_render_obs",
            "mg_render_obs_lds_bytes"]
@@ -116,16 +115,9 @@ def lib():
                           "(MgConfig, MgState, MgObjDesc, MgGenOp, MgGenProgram)" % (path, list(sizes), mine))
     L.mg_host_flag_alloc.argtypes = [C.POINTER(C.POINTER(i32)), C.POINTER(C.POINTER(i32))]
     L.mg_host_flag_free.argtypes = [C.POINTER(i32)]
-    L.mg_obs_alloc.argtypes = [C.c_uint64, i32, C.c_int64]
+    L.mg_obs_alloc.argtypes = [C.c_uint64, i32]
     L.mg_obs_alloc.restype = vp
-    L.mg_obs_ptr.argtypes = [vp]
-    L.mg_obs_ptr.restype = vp
-    L.mg_obs_info.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.mg_obs_free.argtypes = [vp]
-    L.mg_obs_rebase.argtypes = [vp]
-    L.mg_obs_rebase.restype = vp
-    L.mg_obs_select.argtypes = [vp, i32]
-    L.mg_obs_trim.argtypes = [vp]
     L.mg_error_string.restype = C.c_char_p
     L.mg_error_string.argtypes = [i32]
     L.mg_build_info.restype = C.c_char_p
@@ -141,7 +133,7 @@ def lib():
     L.mg_time_render_obs.argtypes = [C.POINTER(Config), C.POINTER(State), vp, i32, C.POINTER(C.c_float), vp]
     for f in SYMBOLS:
         getattr(L, f)
-        if f not in ("mg_error_string", "mg_build_info", "mg_obs_alloc", "mg_obs_ptr", "mg_obs_rebase"):
+        if f not in ("mg_error_string", "mg_build_info", "mg_obs_alloc"):
             getattr(L, f).restype = i32
     _lib = L
     return L

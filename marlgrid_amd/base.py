@@ -36,8 +36,7 @@ from .agents import GridAgentInterface
 from .objects import COLOR_TO_IDX, OBJECT_TYPES, BonusTile, Box, Door, Goal, Key, Wall, WorldObj
 
 TILE_PIXELS = 32
-DEFAULT_PLACE_OBS = "vmm"
-OBS_CHUNK_BYTES = 2 << 20           # physical handle size of library-built observation buffers
+DEFAULT_PLACE_OBS = "search"
 STATE_DICT_VERSION = 3              # = the C ABI whose MgState layout / RNG form the tensors follow
 
 _trace = threading.local()
@@ -257,58 +256,33 @@ class _HostFlag(object):
 
 
 class _LibBuffer(object):
-    """Device memory laid out by the library (mg_obs_alloc), handed to torch through the CUDA array interface:
-    the tensor keeps this object alive, and the memory goes back to the driver when the last view of it dies."""
+    """Device memory straight from the driver (mg_obs_alloc: hipMalloc outside torch's caching allocator), handed
+    to torch through the CUDA array interface: the tensor keeps this object alive, and the memory goes back to
+    the driver — not into a cache — when the last view of it dies."""
 
-    def __init__(self, lib, nbytes, device, chunk_bytes):
+    def __init__(self, lib, nbytes, device):
         self._lib, self.device, self.nbytes = lib, device, int(nbytes)
-        self._h = lib.mg_obs_alloc(self.nbytes, device.index, int(chunk_bytes))
-        self.ok = bool(self._h)
+        self.ptr = lib.mg_obs_alloc(self.nbytes, device.index)
+        self.ok = bool(self.ptr)
         if self.ok:
-            self.ptr = lib.mg_obs_ptr(self._h)
             self.__cuda_array_interface__ = {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False),
                                              "version": 2, "strides": None}
 
     def tensor(self, shape):
         import torch
-        return torch.as_tensor(self, device=self.device).view(shape)
-
-    def info(self):
-        out = (C.c_uint64 * 4)()
-        N.check(self._lib.mg_obs_info(self._h, out))
-        return dict(mapped=int(out[0]), chunk=int(out[1]), handles=int(out[2]), ranges=int(out[3]))
-
-    # the same physical memory behind another virtual range (csrc/mg_mem.h).  Tensors made before a move point
-    # at an unmapped range: make them afterwards.
-    def _moved(self):
-        self.ptr = self._lib.mg_obs_ptr(self._h)
-        self.__cuda_array_interface__ = dict(self.__cuda_array_interface__, data=(self.ptr, False))
-
-    def rebase(self):
-        import torch
-        torch.cuda.synchronize(self.device)
-        ok = bool(self._lib.mg_obs_rebase(self._h))
-        self._moved()
-        return ok
-
-    def select(self, i):
-        import torch
-        torch.cuda.synchronize(self.device)
-        N.check(self._lib.mg_obs_select(self._h, int(i)))
-        self._moved()
-
-    def trim(self):
-        N.check(self._lib.mg_obs_trim(self._h))
+        t = torch.as_tensor(self, device=self.device).view(shape)
+        assert t.data_ptr() == self.ptr            # shares the memory (no copy)
+        return t
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "ptr", None):
             try:
                 import torch
                 torch.cuda.synchronize(self.device)      # no launch may still be writing it
-                self._lib.mg_obs_free(self._h)
+                self._lib.mg_obs_free(self.ptr)
             except Exception:   # interpreter shutdown
                 pass
-            self._h = None
+            self.ptr = None
 
 
 class _ViewGroup(object):
@@ -355,13 +329,12 @@ class MultiGridEnv(object):
         self.strict = strict
         self.obs_buffers = max(1, int(obs_buffers))
         self.fused_step = bool(fused_step)     # step() = one launch (mg_step_render) instead of mg_step + mg_render_obs
-        # where the observation buffers live (see _new_obs_buffer / _place_obs_buffers): "vmm" = built by the
-        # library from 2 MiB physical handles behind one virtual range; "search" = the fastest of a bounded set
-        # of candidate allocations, timed with the raster itself; False = plain torch allocations
+        # where the observation buffers live: "search" (= True) picks the fastest of a bounded set of candidate
+        # allocations by timing the raster itself into each (_place_obs_buffers); False = plain torch allocations
         if place_obs is True:
             place_obs = DEFAULT_PLACE_OBS
-        if place_obs not in ("vmm", "search", False):
-            raise ValueError("place_obs must be 'vmm', 'search', True (= %r) or False" % DEFAULT_PLACE_OBS)
+        if place_obs not in ("search", False):
+            raise ValueError("place_obs must be 'search' (= True) or False")
         self.place_obs = place_obs
         self._dry = bool(_dry)
         if self.batch_size < 1:
@@ -403,8 +376,6 @@ class MultiGridEnv(object):
         self.reset()
         if not self._dry and self.place_obs == "search":
             self._place_obs_buffers()
-        elif not self._dry and self.place_obs == "vmm":
-            self._place_obs_ranges()
         self._spec_ctor = self._spec_last     # the constructor-time `_gen_grid` (base.py:369)
         self._retrace = True
 
@@ -483,8 +454,7 @@ class MultiGridEnv(object):
             # `save_step(obs, act, next_obs, rew, done)` sees two different observations.
             for g in self._groups:
                 g.shape = (B, len(g.members), g.pixels, g.pixels, 3)
-                g.ring = [self._new_obs_buffer(g.shape, vmm=self.place_obs == "vmm") for _ in range(self.obs_buffers)]
-                g.ring_mem = [getattr(t, "_mg_owner", None) for t in g.ring]
+                g.ring = [torch.zeros(g.shape, dtype=torch.uint8, device=dev) for _ in range(self.obs_buffers)]
                 g.obs = g.ring[0]
             self._ring = [dict(obs=self._groups[0].ring[i],
                                rewards=torch.zeros((B, n), dtype=torch.float32, device=dev),
@@ -502,35 +472,25 @@ class MultiGridEnv(object):
                               self.prestige_t.data_ptr() if self.prestige_t is not None else None,
                               self.mt_head.data_ptr(), self._flag.dev)
 
-    def _new_obs_buffer(self, shape, vmm, min_bytes=64 << 20):
-        """One observation buffer.  Large ones can be built by the library (mg_obs_alloc: one virtual range
-        backed by 2 MiB physical handles, see csrc/mg_mem.h) and wrapped as a torch tensor that owns them;
-        small ones — and vmm=False — are plain torch allocations."""
-        import torch
-        nbytes = int(np.prod(shape))
-        if vmm and nbytes >= min_bytes:
-            chunk = OBS_CHUNK_BYTES                     # <= 512 physical handles per buffer
-            while nbytes > 512 * chunk:
-                chunk *= 2
-            mem = _LibBuffer(self._lib, nbytes, self.device, chunk)
-            if mem.ok:
-                t = mem.tensor(shape)
-                t._mg_owner = mem
-                t.zero_()
-                return t
-        return torch.zeros(shape, dtype=torch.uint8, device=self.device)
-
     @_on_device
-    def _place_obs_buffers(self, batch=8, max_candidates=64, min_bytes=64 << 20, iters=3, budget=16 << 30, gain=0.10,
+    def _place_obs_buffers(self, batch=8, max_candidates=64, min_bytes=256 << 20, iters=3, budget=32 << 30, gain=0.12,
                            seconds=2.0):
-        """place_obs="search": choose the observation buffers among candidate allocations by timing the raster
-        itself into each (HIP events, `iters` launches; under a millisecond per candidate) and keeping the
-        fastest.  Why an allocation matters at all: csrc/mg_mem.h and profiles/r02/README.md section 3.  The
-        candidates are raw hipMalloc allocations made and freed through the library (never torch's caching
-        allocator: nothing is cached, nothing else is flushed), at most `batch` of them alive at a time next to
-        the best `keep` so far, the whole search capped at `max_candidates`, `budget` bytes alive, a quarter of
-        the memory that is free when a batch starts, and `seconds`.  Running out of memory ends the search with
-        what it has."""
+        """place_obs="search" (default): choose WHERE in HBM the observation buffers live.  Measured on MI355X
+        (profiles/r02/README.md section 3, profiles/r03/README.md section 2): the rate at which the raster's
+        write pattern — thousands of waves, each streaming its own env — is absorbed depends on the ALLOCATION
+        it writes into, reproducibly per buffer and by up to 25 % (0.160 vs 0.205 ms for the bench workload's
+        925 MB), while a dense fill of the same buffers is flat; on one box 4 in 24 fresh allocations are in the
+        fast class, on another most are.  Round 3 took such buffers apart with the virtual-memory API — the class
+        does not travel with the physical pages, remapping the same memory never draws a fast one, and freed
+        virtual ranges come back with stale translations on ROCm 7.2 — so what remains is drawing new allocations
+        and measuring: candidates are raw hipMalloc allocations made and freed through the library (never torch's
+        caching allocator: nothing is cached, nothing else is flushed), the raster itself is timed into each (HIP
+        events, `iters` launches; under a millisecond per candidate), at most `batch` of them alive at a time
+        next to the best `keep` so far; the search stops when the buffers it would keep are `gain` faster than
+        the median candidate (they are in the fast class), when two batches show no spread worth searching, or
+        at `max_candidates` / `budget` bytes alive / a quarter of the memory that is free when a batch starts /
+        `seconds`.  Running out of memory ends the search with what it has.  Buffers under `min_bytes` (where no
+        classes are seen) are left alone."""
         import time
         import torch
         t_begin = time.perf_counter()
@@ -562,7 +522,7 @@ class MultiGridEnv(object):
                     break
                 cands = []
                 for _ in range(nb):
-                    mem = _LibBuffer(self._lib, nbytes, self.device, 0)
+                    mem = _LibBuffer(self._lib, nbytes, self.device)
                     if not mem.ok:
                         why = "out of memory"
                         break
@@ -589,64 +549,6 @@ class MultiGridEnv(object):
             g.obs = g.ring[self._ring_i]
             g.placement_ms = {"kept": [c for c, _ in best], "candidates": len(seen), "stopped": why,
                               "seconds": time.perf_counter() - t_begin, "all": seen}
-        for i, r in enumerate(self._ring):
-            r["obs"] = self._groups[0].ring[i]
-        self.obs = self._ring[self._ring_i]["obs"]
-        self._render()                      # the current observation, into the buffer that is current now
-
-    @_on_device
-    def _place_obs_ranges(self, min_ranges=12, max_ranges=48, gain=0.10, seconds=1.0, iters=3):
-        """place_obs="vmm": choose the VIRTUAL range each library-built observation buffer is mapped behind.  The
-        rate at which HBM absorbs the raster's write pattern depends on the buffer by up to 25 % — and when a
-        buffer is taken apart (csrc/mg_mem.h; profiles/r03/README.md section 2) that class stays with its virtual
-        range when the physical handles behind it are permuted or traded with another buffer's.  So candidate
-        ranges are tried with the SAME physical memory (mg_obs_rebase: a remap, a few ms; no memory beyond the
-        buffer itself), the raster is timed into each (HIP events, `iters` launches), and the mapping goes back to
-        the fastest (mg_obs_select), the others are released (mg_obs_trim).  At least `min_ranges`, then until
-        the best is `gain` under the median, at most `max_ranges` / `seconds` (all buffers together)."""
-        import time
-        t_begin = time.perf_counter()
-        ms = C.c_float(0)
-        for g in self._groups:
-            if not any(m is not None for m in g.ring_mem):
-                continue
-            g.placement_ms = {"kept": [], "ranges_tried": [], "stopped": [], "all": []}
-            for i, mem in enumerate(g.ring_mem):
-                if mem is None:
-                    continue
-                g.ring[i] = None                       # (the tensor is re-made on the range that is kept)
-
-                def cost():
-                    N.check(self._lib.mg_time_render_obs(C.byref(g.cfg), C.byref(self._state), C.c_void_p(mem.ptr), iters,
-                                                         C.byref(ms), self._stream()))
-                    return ms.value
-
-                costs = [cost()]
-                why = "cap"
-                while len(costs) < max_ranges:
-                    if time.perf_counter() - t_begin > seconds * (i + 1) / len(g.ring_mem):
-                        why = "time"
-                        break
-                    if not mem.rebase():
-                        why = "no more address space"
-                        break
-                    costs.append(cost())
-                    ranked = sorted(costs)
-                    if len(costs) >= min_ranges and ranked[0] <= (1.0 - gain) * ranked[len(ranked) // 2]:
-                        why = "best %d%% under the median range" % round(100 * (1 - ranked[0] / ranked[len(ranked) // 2]))
-                        break
-                best = min(range(len(costs)), key=costs.__getitem__)
-                mem.select(best)
-                mem.trim()
-                t = mem.tensor(g.shape)
-                t._mg_owner = mem
-                g.ring[i] = t
-                g.placement_ms["kept"].append(costs[best])
-                g.placement_ms["ranges_tried"].append(len(costs))
-                g.placement_ms["stopped"].append(why)
-                g.placement_ms["all"].append(costs)
-            g.obs = g.ring[self._ring_i]
-            g.placement_ms["seconds"] = time.perf_counter() - t_begin
         for i, r in enumerate(self._ring):
             r["obs"] = self._groups[0].ring[i]
         self.obs = self._ring[self._ring_i]["obs"]

@@ -3,7 +3,9 @@
 // caller's stream.
 #include "mg_device.h"
 #include "mg_launch.h"
+#if defined(MG_AB_VARIANTS)
 #include "mg_mem.h"
+#endif
 
 namespace {
 
@@ -246,13 +248,29 @@ int32_t mg_host_flag_free(int32_t* host) {
     return rc(hipHostFree(host));
 }
 
-MgObsBuffer* mg_obs_alloc(uint64_t bytes, int32_t device, int64_t chunk_bytes) {
-    return reinterpret_cast<MgObsBuffer*>(mg::obs_alloc((size_t)bytes, device, (long long)chunk_bytes));
+void* mg_obs_alloc(uint64_t bytes, int32_t device) {
+    if (bytes == 0) return nullptr;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    if (cur != device && hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    void* p = nullptr;
+    const hipError_t e = hipMalloc(&p, (size_t)bytes);
+    if (cur != device) (void)hipSetDevice(cur);
+    if (e != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
 }
 
-void* mg_obs_ptr(const MgObsBuffer* buf) { return buf ? reinterpret_cast<const mg::ObsBuffer*>(buf)->ptr : nullptr; }
+int32_t mg_obs_free(void* ptr) { return ptr ? rc(hipFree(ptr)) : MG_OK; }
 
-int32_t mg_obs_info(const MgObsBuffer* buf, uint64_t out[4]) {
+#if defined(MG_AB_VARIANTS)
+// measurement build: observation buffers built with HIP virtual memory management (mg_mem.h) — the experiments of
+// profiles/r03/README.md section 2 (tools/placement_vmm*.py, placement_va.py, vmm_reuse_check.py)
+typedef struct MgObsBuffer MgObsBuffer;
+MgObsBuffer* mg_ab_vmm_alloc(uint64_t bytes, int32_t device, int64_t chunk_bytes) {
+    return reinterpret_cast<MgObsBuffer*>(mg::obs_alloc((size_t)bytes, device, (long long)chunk_bytes));
+}
+void* mg_ab_vmm_ptr(const MgObsBuffer* buf) { return buf ? reinterpret_cast<const mg::ObsBuffer*>(buf)->ptr : nullptr; }
+int32_t mg_ab_vmm_info(const MgObsBuffer* buf, uint64_t out[4]) {
     if (!buf || !out) return MG_E_ARG;
     const mg::ObsBuffer* b = reinterpret_cast<const mg::ObsBuffer*>(buf);
     out[0] = b->mapped;
@@ -261,25 +279,19 @@ int32_t mg_obs_info(const MgObsBuffer* buf, uint64_t out[4]) {
     out[3] = b->ranges.size();
     return MG_OK;
 }
-
-void* mg_obs_rebase(MgObsBuffer* buf) { return mg::obs_rebase(reinterpret_cast<mg::ObsBuffer*>(buf)); }
-
-int32_t mg_obs_select(MgObsBuffer* buf, int32_t i) {
+int32_t mg_ab_vmm_free(MgObsBuffer* buf) {
+    mg::obs_free(reinterpret_cast<mg::ObsBuffer*>(buf));
+    return MG_OK;
+}
+void* mg_ab_vmm_rebase(MgObsBuffer* buf) { return mg::obs_rebase(reinterpret_cast<mg::ObsBuffer*>(buf)); }
+int32_t mg_ab_vmm_select(MgObsBuffer* buf, int32_t i) {
     return mg::obs_select(reinterpret_cast<mg::ObsBuffer*>(buf), i) ? MG_OK : MG_E_ARG;
 }
-
-int32_t mg_obs_trim(MgObsBuffer* buf) {
+int32_t mg_ab_vmm_trim(MgObsBuffer* buf) {
     if (!buf) return MG_E_ARG;
     mg::obs_trim(reinterpret_cast<mg::ObsBuffer*>(buf));
     return MG_OK;
 }
-
-int32_t mg_obs_free(MgObsBuffer* buf) {
-    mg::obs_free(reinterpret_cast<mg::ObsBuffer*>(buf));
-    return MG_OK;
-}
-
-#if defined(MG_AB_VARIANTS)
 int32_t mg_ab_obs_permute(MgObsBuffer* buf, const int32_t* order) {
     return mg::obs_permute(reinterpret_cast<mg::ObsBuffer*>(buf), order) ? MG_OK : MG_E_LAUNCH;
 }

@@ -73,7 +73,7 @@ struct SmallDiv {
 
 // per-wave LDS scratch of the obs-render kernel (bytes), shared by host launch code and kernel
 struct RenderScratch {
-    int grid, rec, pres, first, second, vbase, vshow, trow, vis, tmap, dyn, out, step, total;
+    int grid, rec, pres, pcol, first, second, vbase, vshow, trow, vis, tmap, dyn, out, step, total;
     int stage_envs;    // envs whose inputs (grid + agent records) are staged per batch: 1..8
     int tmap_slots;    // tmaps a wave can hold at once (= stage_envs): the look-ahead depth of its env loop
     int tmap_stride;   // bytes per tmap slot
@@ -95,6 +95,7 @@ __host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride,
     s.grid = o;  o += stage_envs * round_up(cells_stride, 16);
     s.rec = o;   o += stage_envs * s.rec_stride * 8;
     s.pres = o;  o += dyn_bytes ? stage_envs * s.rec_stride * 8 : 0;   // agent.prestige of the staged envs
+    s.pcol = o;  o += dyn_bytes ? stage_envs * s.rec_stride * 4 : 0;   // ... and the sprite colours it gives them (fused step)
     // Views one env at a time: first / second (agents of a cell), vbase / vshow (a view cell's object and
     // agent, phase 3 -> 5), trow / vis (transparency and visibility rows).  Views of the whole batch at once
     // (batch_views): a slot of first (second: only with hide_item_types) and trow per staged env; the

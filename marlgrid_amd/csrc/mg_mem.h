@@ -1,16 +1,21 @@
-// mg_mem.h — where the observation buffers live (host code; HIP virtual memory management).
+// mg_mem.h — MEASUREMENT BUILD ONLY (libmarlgrid_hip_ab.so; tools/placement_vmm*.py, placement_va.py,
+// vmm_reuse_check.py): observation buffers taken apart with HIP virtual memory management.
 //
-// Measured on MI355X (profiles/r02/README.md section 3, profiles/r03/README.md section 2): the rate at which HBM
-// absorbs the obs raster's write pattern — thousands of waves, each streaming its own env — depends on the
-// BUFFER it writes into (0.160 vs 0.205 ms for the same 925 MB), reproducibly per buffer, while a dense fill of
-// the same buffers is flat.  Round 3 took the buffers apart with the virtual-memory API: a buffer built from
-// 2 MiB physical handles keeps its class when its handles are permuted, and when half of them are traded with
-// a buffer of the other class — the class belongs to the VIRTUAL RANGE, not to the physical memory behind it.
-// So the engine builds its observation buffers itself: physical handles (hipMemCreate, 2 MiB granules) that are
-// created ONCE, and a virtual range (hipMemAddressReserve) that can be exchanged for another at the cost of a
-// remap — a placement search that needs no memory beyond the buffer itself (obs_rebase / obs_select /
-// obs_trim; MultiGridEnv._place_obs_buffers times the raster into each candidate range).
-// `chunk_bytes` = 0 falls back to a plain hipMalloc.
+// Why: the rate at which HBM absorbs the obs raster's write pattern — thousands of waves, each streaming its own
+// env — depends on the BUFFER it writes into (0.160 vs 0.205 ms for the same 925 MB), reproducibly per buffer,
+// while a dense fill of the same buffers is flat (profiles/r02/README.md section 3).  Round 3 built buffers from
+// 2 MiB physical handles (hipMemCreate) behind a reserved virtual range (hipMemAddressReserve / hipMemMap) to
+// find out what the class belongs to — profiles/r03/README.md section 2:
+//   * a buffer keeps its class when its handles are permuted, and when half of them are traded with a buffer of
+//     the other class: not the physical memory;
+//   * the same physical memory behind 40 fresh virtual ranges (obs_rebase) gives 40 times one and the same —
+//     slow — time: remapping does not draw a new class the way a new allocation does;
+//   * and the decisive one for the product: on ROCm 7.2 a virtual range that was freed and is handed out again
+//     ALIASES STALE TRANSLATIONS — writes through the reused range land in the previous owner's memory
+//     (tools/vmm_reuse_check.py: two buffers corrupt each other; an env built after another one was destroyed
+//     returned wrong observations).  A construction that is not safe to free cannot ship.
+// So the product allocates observation buffers with hipMalloc (mg_obs_alloc) and chooses among candidates by
+// timing the raster into each (MultiGridEnv._place_obs_buffers); this file stays as the record of the experiment.
 #pragma once
 
 #include <hip/hip_runtime.h>

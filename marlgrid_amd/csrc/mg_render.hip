@@ -213,6 +213,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     uint8_t* w_stage_g = ws + L.grid;                                      // [stage_envs][cells_stride] grids of a batch of envs
     uint64_t* w_stage_r = reinterpret_cast<uint64_t*>(ws + L.rec);        // [stage_envs][rec_stride] their agent records
     double* w_stage_p = reinterpret_cast<double*>(ws + L.pres);          // [stage_envs][rec_stride] agent.prestige ('prestige' agents only)
+    uint32_t* w_stage_c = reinterpret_cast<uint32_t*>(ws + L.pcol);      // [stage_envs][rec_stride] ... and their sprite colours (fused step)
     uint8_t* w_first = ws + L.first;
     uint8_t* w_second = ws + L.second;
     uint8_t* w_vbase = ws + L.vbase;
@@ -386,8 +387,19 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                     wrote = step_run(cfg, st, fs.prog, fs.has_prog != 0, fs.rewards, eb + lane, se, sc,
                                      w_stage_g + (size_t)lane * cfg.cells_stride);
                     for (int k = 0; k < n; k++) w_stage_r[lane * rec_stride + k] = sc.rec[k * 8 + lane];
-                    if constexpr (kPrestige)   // agent.prestige as this lane left it in HBM
-                        for (int k = 0; k < n; k++) w_stage_p[lane * rec_stride + k] = st.prestige[(size_t)(eb + lane) * n + k];
+                    if constexpr (kPrestige) {
+                        // agent.prestige as this lane left it in HBM, and — here, in the latency-bound step part where
+                        // the VALU is idle, one lane per ENV — the colour it gives the agent's sprite (the float64
+                        // tanh of render_post, agents.py:92-119): the raster's per-env phase only reads it
+                        for (int k = 0; k < n; k++) {
+                            const double p = st.prestige[(size_t)(eb + lane) * n + k];
+                            w_stage_p[lane * rec_stride + k] = p;
+                            if ((cfg.prestige_mask >> k) & 1u) {
+                                const PrestigeColor c = prestige_color(p, s_pscale[k]);
+                                w_stage_c[lane * rec_stride + k] = c.r | (c.g << 8) | (c.b << 16);
+                            }
+                        }
+                    }
                 }
                 uint64_t todo = __ballot(wrote);
                 wave_lds_sync();
@@ -538,8 +550,11 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             const uint64_t* w_rec = g_rec;
             uint32_t* w_col = w_trow;
             if (lane < n && ((cfg.prestige_mask >> lane) & 1u)) {
-                const PrestigeColor c = prestige_color(w_stage_p[(size_t)ej * rec_stride + lane], s_pscale[lane]);
-                w_col[lane] = c.r | (c.g << 8) | (c.b << 16);
+                if (fs.enabled) w_col[lane] = w_stage_c[(size_t)ej * rec_stride + lane];   // (computed by the env's stepping lane)
+                else {
+                    const PrestigeColor c = prestige_color(w_stage_p[(size_t)ej * rec_stride + lane], s_pscale[lane]);
+                    w_col[lane] = c.r | (c.g << 8) | (c.b << 16);
+                }
             }
             wave_lds_sync();
             for (int Xh = 0; Xh < (cfg.any_hide ? 2 * n : n); Xh++) {
@@ -665,15 +680,26 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             uint4* out = reinterpret_cast<uint4*>(obs + (size_t)e * nv * img_bytes);
             const int total = (int)(nv * (img_bytes / 16));
             uint32_t r = rast_r0, pr = rast_p0;
-            auto pair_addr = [&](uint32_t rr_, uint32_t pr_) -> uint32_t {
+            // pair (global pixel row rr_, pair-in-row pr_) -> its tmap index and its dword offset inside the tile
+            auto pair_coords = [&](uint32_t rr_, uint32_t pr_, uint32_t& ti, uint32_t& of) {
                 const uint32_t va = __umul24(pr_, M_PT) >> 16, kp = pr_ - __umul24(va, PT);
-                const uint32_t vb = __umul24(rr_, M_TS) >> 16, rr = rr_ - __umul24(vb, (uint32_t)TS_);
-                uint32_t t = (uint32_t)w_tmap[__umul24(vb, (uint32_t)VS) + va];
+                uint32_t vb, rr;
+                if constexpr ((TS_ & (TS_ - 1)) == 0) { vb = rr_ / (uint32_t)TS_; rr = rr_ & (uint32_t)(TS_ - 1); }   // (shifts)
+                else { vb = __umul24(rr_, M_TS) >> 16; rr = rr_ - __umul24(vb, (uint32_t)TS_); }
+                ti = __umul24(vb, (uint32_t)VS) + va;
+                of = __umul24(rr, TD) + kp * 2u;
+            };
+            auto tile_dword = [&](uint32_t t) -> uint32_t {      // tmap entry -> dword offset of the tile
                 if constexpr (kSplit)
-                    t = t < NT4 ? t * (uint32_t)(TS_ * TS_ * 3 / 4)
-                                : (kInLds | (dyn_off / 4 + (t - NT4) * (uint32_t)(TS_ * TS_ * 3 / 4)));
-                else if constexpr (kGlobalAtlas) t *= (uint32_t)(TS_ * TS_ * 3 / 4);   // tile index -> dword offset
-                return t + __umul24(rr, TD) + kp * 2u;
+                    return t < NT4 ? t * (uint32_t)(TS_ * TS_ * 3 / 4)
+                                   : (kInLds | (dyn_off / 4 + (t - NT4) * (uint32_t)(TS_ * TS_ * 3 / 4)));
+                else if constexpr (kGlobalAtlas) return t * (uint32_t)(TS_ * TS_ * 3 / 4);   // tile index -> dword offset
+                else return t;
+            };
+            auto pair_addr = [&](uint32_t rr_, uint32_t pr_) -> uint32_t {
+                uint32_t ti, of;
+                pair_coords(rr_, pr_, ti, of);
+                return tile_dword((uint32_t)w_tmap[ti]) + of;
             };
             auto fetch = [&](uint4& v) {
                 if constexpr (V_ == 4) {
@@ -697,12 +723,39 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             };
             int c = (int)c_first;
             constexpr int CS = (int)CH_STRIDE;
-            if constexpr (V_ != 6) {
-                // gather four chunks from LDS, then issue their four 1-KiB stores back to back
+            if constexpr (V_ == 4) {
                 for (; c + 3 * CS < total; c += 4 * CS) {
                     uint4 v0, v1, v2, v3;
                     fetch(v0); fetch(v1); fetch(v2); fetch(v3);
                     put(c, v0); put(c + CS, v1); put(c + 2 * CS, v2); put(c + 3 * CS, v3);
+                }
+            } else if constexpr (V_ != 6) {
+                // Four chunks per trip = eight pairs, in THREE phases with nothing scheduled across them: the eight
+                // tmap look-ups issued together (one LDS round trip), then the eight atlas reads (a second), then
+                // the four 1-KiB stores back to back.  Written pair by pair, the compiler — at the 128-VGPR limit
+                // of the 16-wave instantiations — serialises it into twelve dependent LDS round trips per trip.
+                for (; c + 3 * CS < total; c += 4 * CS) {
+                    uint32_t ti[8], of[8];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        uint32_t r1 = r, pr1 = pr + 1;
+                        if (pr1 == PR) { pr1 = 0; r1++; }
+                        pair_coords(r, pr, ti[2 * q], of[2 * q]);
+                        pair_coords(r1, pr1, ti[2 * q + 1], of[2 * q + 1]);
+                        pr += STEP_P; r += STEP_R;
+                        if (pr >= PR) { pr -= PR; r++; }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    uint32_t tt[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) tt[i] = (uint32_t)w_tmap[ti[i]];
+                    __builtin_amdgcn_sched_barrier(0);
+                    uint2 pp[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) pp[i] = ld_pair(tile_dword(tt[i]) + of[i]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) put(c + q * CS, make_uint4(pp[2 * q].x, pp[2 * q].y, pp[2 * q + 1].x, pp[2 * q + 1].y));
                 }
             }
             for (; c < total; c += CS) {
@@ -837,7 +890,7 @@ int render_min_lds_bytes(const MgConfig& cfg) {
 // still spread over all CUs.
 static int choose_wpb(const MgConfig& cfg) {
 #if defined(MG_AB_VARIANTS)
-    if (const char* f = getenv("MG_RENDER_WPB")) { int w = atoi(f); if (w == 4 || w == 8 || w == 16) return w; }
+    if (const char* f = getenv("MG_RENDER_WPB")) { int w = atoi(f); if (w == 4 || w == 8 || w == 12 || w == 16) return w; }
 #endif
     const int tile_bytes = cfg.tile_size * cfg.tile_size * 3;
     const RenderScratch L = render_scratch_for(cfg, 16);
@@ -853,6 +906,10 @@ static int choose_wpb(const MgConfig& cfg) {
 #define MG_RENDER_DISPATCH_RT(TS, V)                                                                       \
     (wpb == 16 ? launch_render_t<0, TS, 8, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo)             \
                : launch_render_t<0, TS, 4, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo))
+// 12-wave workgroups: 3 waves per SIMD, i.e. a 168-VGPR budget instead of the 128 of 16 waves — for the
+// instantiations that spill at 128 (the assemble-and-stream rasters) or need more anyway ('prestige')
+#define MG_RENDER_DISPATCH12(VS, TS, V)                                                                    \
+    (wpb == 12 ? launch_render_t<VS, TS, 12, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo) : MG_RENDER_DISPATCH(VS, TS, V))
 #define MG_RENDER_DISPATCH8(VS, TS, V)                                                                     \
     (wpb == 8 ? launch_render_t<VS, TS, 8, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo) : MG_RENDER_DISPATCH(VS, TS, V))
 
@@ -909,10 +966,12 @@ static hipError_t launch_render_one(const MgConfig& cfg, const MgState& st, uint
         // the shipped view: compile-time size; 8-wave workgroups when they fit (the recolouring code needs
         // more than the 128 VGPRs a 16-wave workgroup leaves per lane)
         if (vs == 7 && ts == 8)
-            return wpb == 16 ? launch_render_t<7, 8, 8, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo)
+            return wpb == 12 ? launch_render_t<7, 8, 12, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo)
+                 : wpb == 16 ? launch_render_t<7, 8, 8, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo)
                              : launch_render_t<7, 8, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
         if (vs == 7 && (ts % 8) != 0)
-            return wpb == 16 ? launch_render_t<7, 0, 8, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo)
+            return wpb == 12 ? launch_render_t<7, 0, 12, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo)
+                 : wpb == 16 ? launch_render_t<7, 0, 8, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo)
                              : launch_render_t<7, 0, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
         if (ts == 8) return launch_render_t<0, 8, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
         if (ts == 16) return launch_render_t<0, 16, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
@@ -954,8 +1013,8 @@ static hipError_t launch_render_one(const MgConfig& cfg, const MgState& st, uint
     if (ts == 32 && vs == 7) return MG_RENDER_DISPATCH(7, 32, 0);
     if (ts == 16) return MG_RENDER_DISPATCH_RT(16, 0);
     if (ts == 32) return MG_RENDER_DISPATCH_RT(32, 0);
-    if (vs == 7 && ts == 5) return MG_RENDER_DISPATCH(7, 5, 0);   // GridAgentInterface's defaults (agents.py:21-22)
-    if (vs == 7) return MG_RENDER_DISPATCH(7, 0, 0);      // the default view with any other tile size
+    if (vs == 7 && ts == 5) return MG_RENDER_DISPATCH12(7, 5, 0);   // GridAgentInterface's defaults (agents.py:21-22)
+    if (vs == 7) return MG_RENDER_DISPATCH12(7, 0, 0);      // the default view with any other tile size
     return MG_RENDER_DISPATCH_RT(0, 0);                   // anything else
 }
 

@@ -67,54 +67,42 @@ def test_default_strict_step_does_not_synchronize():
     assert t_host < 0.5 * t_all, (t_host, t_all)
 
 
-def test_obs_buffers_from_the_library():
-    """place_obs='vmm': the observation ring is built by mg_obs_alloc (one virtual range, 2 MiB physical
-    handles) and wrapped as torch tensors; 'search' picks among raw candidate allocations; False = torch.
-    Same observations either way, and the memory goes back when the env dies."""
+def test_obs_buffer_placement_search():
+    """place_obs='search' (default): the observation ring is chosen among raw candidate allocations (mg_obs_alloc:
+    hipMalloc outside torch's caching allocator) by timing the raster into each; False = torch allocations.  Same
+    observations either way; candidates are bounded and go back to the driver; so does the ring when the env dies."""
     import gc
     import torch
     from marlgrid_amd import _native as N
     from marlgrid_amd.base import _LibBuffer
-    B = 4096                                           # 115 MB of observations: above the 64 MiB threshold
+    B = 16384                                          # 462 MB of observations per buffer: above the 256 MiB threshold
+    torch.cuda.empty_cache()
     free0 = torch.cuda.mem_get_info()[0]
     outs = {}
-    for mode in ("vmm", "search", False):
+    for mode in ("search", False, "search"):
         env = product_envs.build("MarlGrid-3AgentCluttered15x15-v0", batch_size=B, place_obs=mode)
         env.reset()
         g = torch.Generator().manual_seed(3)
         for _ in range(5):
             o, r, d, _ = env.step(torch.randint(0, 7, (B, 3), generator=g))
-        outs[mode] = (o.cpu(), r.cpu(), d.cpu())
         if mode == "search":
-            assert env._groups[0].placement_ms["candidates"] >= 2
-        if mode == "vmm":
             pm = env._groups[0].placement_ms
-            assert len(pm["kept"]) == 2 and min(pm["ranges_tried"]) >= 2 and all(k == min(a) for k, a in zip(pm["kept"], pm["all"]))
-            assert all(m.info()["ranges"] == 1 for m in env._groups[0].ring_mem)
+            assert 2 <= pm["candidates"] <= 66 and pm["seconds"] < 4.0 and len(pm["kept"]) == 2
+            assert sorted(pm["all"])[:2] == sorted(pm["kept"])          # the fastest two were kept
+            assert torch.cuda.mem_get_info()[0] > free0 - (4 << 30)     # the rejected candidates are back
+        outs.setdefault(mode, []).append((o.cpu(), r.cpu(), d.cpu()))
         del env, o, r, d
         gc.collect()
-    for mode in ("search", False):
-        for x, y in zip(outs["vmm"], outs[mode]):
-            assert torch.equal(x, y), mode
-    # a library buffer by itself: layout as asked, usable by torch, freed with its last view
-    mem = _LibBuffer(N.lib(), 100 << 20, torch.device("cuda", torch.cuda.current_device()), 2 << 20)
-    assert mem.ok and mem.info() == dict(mapped=100 << 20, chunk=2 << 20, handles=50, ranges=1)
+    for got in outs["search"]:
+        for x, y in zip(got, outs[False][0]):
+            assert torch.equal(x, y)
+    # a library buffer by itself: usable by torch without a copy, freed with its last view
+    mem = _LibBuffer(N.lib(), 100 << 20, torch.device("cuda", torch.cuda.current_device()))
+    assert mem.ok
     t = mem.tensor((100 << 20,))
-    t.copy_(torch.arange(100 << 20, device=t.device) % 251)
-    want = t[::4097].clone()
-    p0 = mem.ptr
-    del t                                              # (a tensor made before a move points at an unmapped range)
-    # the same physical memory behind other virtual ranges: contents survive, the pointer changes, and back
-    assert mem.rebase() and mem.rebase() and mem.ptr != p0 and mem.info()["ranges"] == 3
-    t = mem.tensor((100 << 20,))
-    assert t.data_ptr() == mem.ptr and torch.equal(t[::4097], want)
-    del t
-    mem.select(0)
-    assert mem.ptr == p0
-    mem.trim()
-    assert mem.info()["ranges"] == 1
-    t = mem.tensor((100 << 20,))
-    assert torch.equal(t[::4097], want)
+    assert t.data_ptr() == mem.ptr
+    t.fill_(7)
+    assert int(t[::4097].sum()) == 7 * len(t[::4097])
     del mem, t
     gc.collect()
     torch.cuda.empty_cache()

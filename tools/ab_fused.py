@@ -1,12 +1,9 @@
 #!/usr/bin/env python
-"""Interleaved A/B of the one-launch step (mg_step_render) between product-flavoured builds of the library that
-differ in the obs kernel's launch options (mg_device.h kRenderOpt*; `make -C marlgrid_amd/csrc variants OPTS=...`
-builds libmarlgrid_hip_v<opt>.so): bit 0 = RNG head refill deferred behind the raster, bits 8..11 = the wave's first
-N envs stepped and rendered ahead of the rest.  `ref` = libmarlgrid_hip_ref.so (a build of an earlier commit).
-First a parity check of every build against the first one (two envs, same seeds and actions, 130 steps:
-observations, rewards, done, records, grids and the whole RNG state must be equal), then 9 interleaved rounds of
-100 launches each, all into the SAME observation buffer.
-usage: ab_fused.py ref 0 1 257"""
+"""Interleaved A/B of the one-launch step (mg_step_render) between builds of the library given as paths (e.g. a
+build of an earlier commit next to the current one).  First a parity check of every build against the first one
+(two envs, same seeds and actions, 130 steps: observations, rewards, done, records, grids and the whole RNG state
+must be equal), then 9 interleaved rounds of 100 launches each, all into the SAME observation buffer.
+usage: ab_fused.py path/to/ref.so path/to/new.so [...]"""
 import ctypes as C
 import os
 import statistics
@@ -18,7 +15,7 @@ import torch  # noqa: E402
 from marlgrid_amd import _native as N  # noqa: E402
 from marlgrid_amd.envs import make  # noqa: E402
 
-names = sys.argv[1:] or ["ref", "0", "1", "257"]
+names = sys.argv[1:]
 B = int(os.environ.get("B", "32768"))
 WL = os.environ.get("WL", "MarlGrid-3AgentCluttered15x15-v0")
 g = torch.Generator().manual_seed(0)
@@ -28,13 +25,12 @@ acts = [torch.randint(0, 7, (B, n), generator=g).cuda() for _ in range(16)]
 vp, i32 = C.c_void_p, C.c_int32
 libs = {}
 for nm in names:
-    path = os.path.join(ROOT, "marlgrid_amd", "csrc", "libmarlgrid_hip_%s.so" % (nm if nm == "ref" else "v%d" % int(nm, 0)))
-    L = C.CDLL(path)
+    L = C.CDLL(os.path.abspath(nm))
     L.mg_step_render.argtypes = [C.POINTER(N.Config), C.POINTER(N.State), vp, i32, vp, C.POINTER(N.GenProgram), vp, vp]
     L.mg_step_render.restype = i32
     L.mg_build_info.restype = C.c_char_p
     libs[nm] = L
-    print("%-6s %s" % (nm, L.mg_build_info().decode()))
+    print("%s: %s" % (nm, L.mg_build_info().decode()))
 
 
 def launch(L, e, i):
@@ -57,7 +53,7 @@ if os.environ.get("CHECK", "1") != "0":
                 for k in ("obs", "rewards", "done_t", "agent_state", "grid_state", "mt_state", "mt_pos", "mt_head", "step_count_t"):
                     assert torch.equal(getattr(env, k), getattr(ref, k)), ("%s differs from %s in %s at step %d" % (nm, names[0], k, i))
         env.check_errors()
-        print("%-6s identical to %s over 130 steps (obs, rewards, done, records, grids, RNG state)" % (nm, names[0]), flush=True)
+        print("%s identical to %s over 130 steps (obs, rewards, done, records, grids, RNG state)" % (nm, names[0]), flush=True)
     del ref
 res = {nm: [] for nm in names}
 for rep in range(9):
@@ -73,4 +69,4 @@ for rep in range(9):
 base = statistics.median(res[names[0]])
 for nm in names:
     m = statistics.median(res[nm])
-    print("%-6s median %.4f ms (min %.4f max %.4f)  %+.2f%% vs %s" % (nm, m, min(res[nm]), max(res[nm]), 100 * (m / base - 1), names[0]))
+    print("%s median %.4f ms (min %.4f max %.4f)  %+.2f%% vs %s" % (nm, m, min(res[nm]), max(res[nm]), 100 * (m / base - 1), names[0]))

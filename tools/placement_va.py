@@ -1,23 +1,24 @@
 #!/usr/bin/env python
 """The class of an observation buffer belongs to its virtual range (profiles/r03/README.md section 2): ONE set of
 physical handles (the bench workload's 925 MB) mapped behind N virtual ranges in turn, the real raster timed
-into each; then the first ranges again (is a range's class reproducible?), then what MultiGridEnv's own
-search (place_obs="vmm") does with it, three envs in a row."""
+into each; then the first ranges again (is a range's class reproducible?).  (Round 3 also ran MultiGridEnv's
+then-default range search three times here: 48 ranges tried per buffer, one fast range found in ~250.)"""
 import ctypes as C
 import os
 import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from vmm_buffer import VmmBuffer as _LibBuffer, ab_lib  # noqa: E402  (sets MARLGRID_HIP_LIB: measurement build)
 import torch  # noqa: E402
 from marlgrid_amd import _native as N  # noqa: E402
-from marlgrid_amd.base import _LibBuffer  # noqa: E402
 from marlgrid_amd.envs import make  # noqa: E402
 
 NR = int(os.environ.get("RANGES", "40"))
 env = make("MarlGrid-3AgentCluttered15x15-v0", batch_size=32768, auto_reset=True, strict=False, place_obs=False)
 env.reset()
-L, ms = N.lib(), C.c_float(0)
+L, ms = ab_lib(), C.c_float(0)
 
 
 def raster(ptr, iters=4):
@@ -42,12 +43,3 @@ for i in (0, 1, 2, 3, 4, 5, 6, 7):
 mem2 = _LibBuffer(L, env.obs.numel(), env.device, 2 << 20)     # other physical memory behind the ranges' neighbours
 print("a second buffer, as built: va %#014x raster %.4f ms" % (mem2.ptr, raster(mem2.ptr)))
 del mem, mem2, env
-for k in range(3):
-    t0 = time.perf_counter()
-    e = make("MarlGrid-3AgentCluttered15x15-v0", batch_size=32768, auto_reset=True)
-    torch.cuda.synchronize()
-    pm = e._groups[0].placement_ms
-    print("env %d: constructed in %.2f s; placement %.3f s, ranges tried %s, kept %s ms, stopped: %s" % (
-        k, time.perf_counter() - t0, pm["seconds"], pm["ranges_tried"], ["%.4f" % v for v in pm["kept"]], pm["stopped"]))
-    print("        all: %s" % " | ".join(" ".join("%.3f" % v for v in a) for a in pm["all"]))
-    del e

@@ -13,9 +13,10 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from vmm_buffer import VmmBuffer as _LibBuffer, ab_lib  # noqa: E402  (sets MARLGRID_HIP_LIB: measurement build)
 import torch  # noqa: E402
 from marlgrid_amd import _native as N  # noqa: E402
-from marlgrid_amd.base import _LibBuffer  # noqa: E402
 from marlgrid_amd.envs import make  # noqa: E402
 
 B = int(os.environ.get("BATCH", "32768"))
@@ -24,7 +25,7 @@ env.reset()
 dev = env.device
 nbytes = env.obs.numel()
 ms = C.c_float(0)
-L = N.lib()
+L = ab_lib()
 g = torch.Generator(device="cpu").manual_seed(1)
 idx = (torch.randint(0, nbytes // 4, (1 << 22,), generator=g)).to(dev)
 

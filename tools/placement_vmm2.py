@@ -13,19 +13,18 @@ import sys
 os.environ["MARLGRID_HIP_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                               "marlgrid_amd", "csrc", "libmarlgrid_hip_ab.so")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np  # noqa: E402
+from vmm_buffer import VmmBuffer as _LibBuffer, ab_lib  # noqa: E402  (sets MARLGRID_HIP_LIB: measurement build)
 import torch  # noqa: E402
 from marlgrid_amd import _native as N  # noqa: E402
-from marlgrid_amd.base import _LibBuffer  # noqa: E402
 from marlgrid_amd.envs import make  # noqa: E402
 
 env = make("MarlGrid-3AgentCluttered15x15-v0", batch_size=32768, auto_reset=True, strict=False, place_obs=False)
 env.reset()
-dev, nbytes, L = env.device, env.obs.numel(), N.lib()
+dev, nbytes, L = env.device, env.obs.numel(), ab_lib()
 ms = C.c_float(0)
 vp = C.c_void_p
-L.mg_ab_obs_permute.argtypes = [vp, vp]
-L.mg_ab_obs_exchange.argtypes = [vp, vp, vp, C.c_int32]
 
 
 def raster(mem, iters=6):
