@@ -19,12 +19,11 @@ How the line is measured (one self-consistent measurement, not a collage):
     max_steps together, so one step in 100 resets the whole batch inside the launch and costs twice the
     others.  The median block (which hides those steps) is `value_median_block`; min / max / first / last
     and the blocks beyond 3x the median (`outliers`) are listed.
-  * every other block is instrumented with HIP events on the launch stream: one before the block's first
-    launch and one after every few launches (an event costs ~2 us of stream time: one per launch would add
-    1 % to what it measures).  A block's event span / K is its per-launch interval (launch + dispatch gap);
-    `kernels` / `roofline.kernel_ms` report the mean over the instrumented blocks within 3x their median,
-    with median / min / max and the outliers beside it, and `closure` compares it with the same statistic
-    of the plain blocks' host-timed ms_per_step.
+  * EVERY block carries two HIP events on the launch stream — before its first launch and after its last (an
+    event costs ~2 us of stream time: 0.1 % of a 20-step block) — so a block's launch interval (GPU span / K:
+    launch + dispatch gap) and its host-timed ms per step describe the same K launches.  `kernels` /
+    `roofline.kernel_ms` report the MEDIAN block, with mean / min / max and the blocks beyond 3x the median
+    (`outliers`) beside it; `closure` = that median / the median host-timed ms per step.
   * `clocks` holds rocm-smi samples before the first and after the last block; `roofline.traffic`
     is measured in this run (tools/pmc.py: rocprofv3 --pmc passes in a child process, N = 1 only).
   * `extra.strong_n1`: the full headline batch (262 144 envs) on ONE GPU, same fields.
@@ -140,7 +139,7 @@ def timed_blocks(step_fn, sync_fn, ctl, K, min_seconds, max_blocks, probe_ctl=No
     of dicts (one per block)."""
     blocks, total, i = [], 0.0, 0
     while True:
-        instrumented = probe_ctl is not None and (i % 2 == 1)
+        instrumented = probe_ctl is not None and (probe_ctl.every_block or i % 2 == 1)
         if instrumented:
             probe_ctl.arm()
         sync_fn()
@@ -156,7 +155,8 @@ def timed_blocks(step_fn, sync_fn, ctl, K, min_seconds, max_blocks, probe_ctl=No
         mine = time.perf_counter() - t0
         both = ctl.gather((mine, own))
         elapsed = max(b[0] for b in both)             # the slowest rank defines the step time
-        b = {"elapsed_s": elapsed, "instrumented": instrumented, "per_rank_s": [x[1] for x in both]}
+        b = {"elapsed_s": elapsed, "instrumented": instrumented and not probe_ctl.every_block,
+             "per_rank_s": [x[1] for x in both]}
         if instrumented:
             b["kernels"] = probe_ctl.collect()
         blocks.append(b)
@@ -171,17 +171,19 @@ class Probes(object):
     """HIP events on the launch stream (torch's current stream IS the stream the C ABI launches on:
     MultiGridEnv passes torch.cuda.current_stream().cuda_stream to every call).  MultiGridEnv.step calls
     the probe before its first launch (tag 0), between mg_step and mg_render_obs when it runs as two
-    launches (tag 1), and after its last launch (tag 2).  One launch per step (mg_step_render): an event
-    before the block and one after every `stride`-th step — consecutive events are `stride` launch intervals
-    apart (an event costs ~2 us of stream time: one per launch would add 1 % to what it measures).  Two
-    launches per step (--unfused, A/B only): three events per step, for the breakdown."""
+    launches (tag 1), and after its last launch (tag 2).  One launch per step (mg_step_render): TWO events per
+    K-step block — before the block's first launch and after its last — in EVERY block (an event costs ~2 us of
+    stream time: 0.1 % of a 20-step block; one per launch would add 1 % to what it measures), so a block's
+    launch interval (GPU span / K: launch + dispatch gap) and its host-timed ms per step describe the same K
+    launches.  Two launches per step (--unfused, A/B only): three events per step in every other block, for the
+    breakdown."""
 
     def __init__(self, env, K):
         import torch
         self.env, self.K = env, K
         self.fused = bool(env.fused_step) and not env._hetero
-        self.stride = max(1, K // 4) if self.fused else 1
-        n = (K // self.stride + 2) if self.fused else 3 * K
+        self.every_block = self.fused
+        n = 2 if self.fused else 3 * K
         self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
         self.i = self.steps = 0
         self.on = False
@@ -190,27 +192,25 @@ class Probes(object):
         if not self.on:
             return
         if self.fused:
-            if tag == 2:
+            if tag == 0 and self.steps == 0:
+                self.ev[0].record()          # the block's first launch interval begins here
+            elif tag == 2:
                 self.steps += 1
-                if self.steps % self.stride == 0 or self.steps == self.K:
-                    self.ev[self.i].record()
-                    self.i += 1
+                if self.steps == self.K:
+                    self.ev[1].record()
         else:
             self.ev[self.i].record()
             self.i += 1
 
     def arm(self):
         self.i, self.steps, self.on = 0, 0, True
-        if self.fused:
-            self.ev[0].record()          # start of the block: the first launch interval begins here
-            self.i = 1
 
     def collect(self):
         self.on = False
         K, ev = self.K, self.ev
         if self.fused:
             assert self.steps == K
-            span = ev[0].elapsed_time(ev[self.i - 1]) / K
+            span = ev[0].elapsed_time(ev[1]) / K
             return {"step_render_interval_ms": span, "gpu_span_ms_per_step": span}
         assert self.i == 3 * K
         between = [ev[3 * j + 2].elapsed_time(ev[3 * j + 3]) for j in range(K - 1)]   # gap between steps
@@ -231,28 +231,31 @@ def robust(values, factor=3.0):
 
 
 def summarise(blocks, K):
+    """`plain` = the blocks the contract line is made of (all of them when every block carries its two events;
+    the un-instrumented ones in the --unfused A/B form), `kernels` = the event intervals of the blocks that have
+    them: MEDIAN block, with mean / min / max / outliers beside it."""
     plain = [b for b in blocks if not b["instrumented"]]
-    inst = [b for b in blocks if b["instrumented"]]
+    inst = [b for b in blocks if "kernels" in b]
     ms = lambda bs: [b["elapsed_s"] / K * 1e3 for b in bs]      # noqa: E731
     out = {"plain": robust(ms(plain)), "seconds_timed": sum(b["elapsed_s"] for b in blocks)}
     if inst:
-        out["instrumented"] = robust(ms(inst))
+        out["blocks_with_events"] = robust(ms(inst))
         ks = [b["kernels"] for b in inst]
         dom = "step_render_interval_ms" if "step_render_interval_ms" in ks[0] else "render_interval_ms"
         kern = {"dominant": dom}
         for key in ks[0]:
             r = robust([k[key] for k in ks])
-            kern[key] = r["mean_within_3x_median"]
+            kern[key] = r["median"]
             kern[key + "_stats"] = r
         out["kernels"] = kern
         launches = sum(kern[key] for key in ("step_render_interval_ms", "step_interval_ms", "render_interval_ms",
                                              "between_steps_ms") if key in kern)
         out["closure"] = {
             "event_intervals_ms": launches,
-            "vs_instrumented_ms_per_step": launches / out["instrumented"]["mean_within_3x_median"],
-            "vs_ms_per_step": launches / out["plain"]["mean_within_3x_median"],
-            "note": "per-launch event intervals of the instrumented blocks / host-timed ms per step of those "
-                    "blocks, and / that of the plain blocks — each the mean over the blocks within 3x their median"}
+            "vs_ms_per_step_of_the_same_blocks": launches / out["blocks_with_events"]["median"],
+            "vs_ms_per_step": launches / out["plain"]["median"],
+            "note": "median per-launch event interval (GPU span of a K-step block / K) / median host-timed ms per step "
+                    "of the blocks that carry the events, and / that of the contract line's blocks"}
     return out
 
 
@@ -313,11 +316,11 @@ def roofline_of(env, B, summary, traffic, raster_ms=None):
     return {"bound": "hbm", "kernel": kname + (" launched by mg_step_render (the env step fused in front of the raster)"
                                                   if fused else ""),
             "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-            "kernel_ms": ms, "kernel_ms_median": st["median"], "kernel_ms_mean_all_blocks": st["mean"],
+            "kernel_ms": ms, "kernel_ms_mean": st["mean"], "kernel_ms_mean_within_3x_median": st["mean_within_3x_median"],
             "kernel_ms_min": st["min"], "kernel_ms_max": st["max"], "kernel_ms_first": st["first"],
             "kernel_ms_last": st["last"], "kernel_ms_outliers": st["outliers"],
             "kernel_ms_source": "HIP events on the launch stream of the instrumented K-step blocks (event span / K: "
-                                "launch + dispatch gap); mean over the blocks within 3x their median",
+                                "launch + dispatch gap); the MEDIAN block (mean / min / max / outliers beside it)",
             "raster_only_ms": raster_ms,
             "raster_only_GBps": (B * n * alg / (raster_ms * 1e-3) / 1e9) if raster_ms else None,
             "algorithmic_bytes_per_agent_step": alg, "algorithmic_bytes_per_launch": B * n * alg,
@@ -444,7 +447,7 @@ def main():
                                "plain blocks' steps / their total time (every 100th step resets the whole batch "
                                "in-launch: the median block hides those)",
                        "blocks": pl, "seconds_timed": summary["seconds_timed"],
-                       "instrumented_blocks": summary.get("instrumented"),
+                       "blocks_with_events": summary.get("blocks_with_events"),
                        "per_rank": ranks_info,
                        "per_rank_ms_per_step_last_block": [x / K * 1e3 for x in blocks[-1]["per_rank_s"]],
                        "control_plane": ctl.backend, "ranks_share_a_gpu": bool(shared),

@@ -71,9 +71,26 @@ struct SmallDiv {
     __device__ uint32_t div(uint32_t x) const { return d > 1 ? __umulhi(x, m) : x; }
 };
 
+// x / d with ONE full-rate multiply: on CDNA a 32-bit v_mul_lo / v_mul_hi issues at a quarter of the rate of the
+// 24-bit v_mul_u32_u24 (and of every add, shift and compare), and the view / raster index arithmetic is made of
+// divisions — which is why the instantiations off the HBM-bound fast path were VALU-bound.  m = ceil(2^20 / d);
+// (x * m) >> 20 is x / d or x / d + 1 for every x < 2^20 whose quotient is < 2^11 (the product stays under 2^32,
+// both operands under 2^24), and the one compare-and-subtract makes it exact.  `exact`: the caller knows
+// x * (m * d - 2^20) < 2^20 for every x it passes (small compile-time divisors), so the fix-up is dropped.
+struct Div20 {
+    uint32_t d, m;
+    __host__ __device__ explicit Div20(uint32_t d_) : d(d_), m(((1u << 20) + d_ - 1u) / d_) {}
+    template <bool exact = false>
+    __device__ __forceinline__ uint32_t div(uint32_t x) const {
+        uint32_t q = __umul24(x, m) >> 20;
+        if constexpr (!exact) q -= (__umul24(q, d) > x) ? 1u : 0u;
+        return q;
+    }
+};
+
 // per-wave LDS scratch of the obs-render kernel (bytes), shared by host launch code and kernel
 struct RenderScratch {
-    int grid, rec, pres, pcol, first, second, vbase, vshow, trow, vis, tmap, dyn, out, step, total;
+    int grid, rec, pres, pcol, vaff, first, second, vbase, vshow, trow, vis, tmap, dyn, out, step, total;
     int stage_envs;    // envs whose inputs (grid + agent records) are staged per batch: 1..8
     int tmap_slots;    // tmaps a wave can hold at once (= stage_envs): the look-ahead depth of its env loop
     int tmap_stride;   // bytes per tmap slot
@@ -104,6 +121,7 @@ __host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride,
     s.cell_stride = round_up(cells_stride, 16);
     // (trow doubles as the per-agent colour words of the 'prestige' recolouring: at least n dwords)
     s.trow_stride = round_up((nv * vs > n ? nv * vs : n) * 4, 16) / 4;
+    s.vaff = o;  o += round_up(s.view_slots * nv * 8, 16);   // per viewer: its view's affine map and identity (phase 2b)
     s.first = o; o += s.view_slots * s.cell_stride;
     s.second = o; o += (batch_views && !any_hide) ? 0 : s.view_slots * s.cell_stride;
     s.vbase = o; o += batch_views ? 0 : round_up(nv * vs * vs, 16);

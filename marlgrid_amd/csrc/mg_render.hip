@@ -54,7 +54,7 @@ __device__ __forceinline__ void or_segment(const uint8_t* __restrict__ sb, uint3
     uint32_t* D = reinterpret_cast<uint32_t*>(lds0 + (dl & ~3u));
     const uint32_t end = (phi + SEG) & 3u;
     const uint32_t m_first = 0xFFFFFFFFu << (8u * phi), m_last = end ? 0xFFFFFFFFu >> (8u * (4u - end)) : 0xFFFFFFFFu;
-    constexpr int CH = SEGC ? ((SEGC + 6) / 4 < 8 ? (SEGC + 6) / 4 : 8) : 8;
+    constexpr int CH = SEGC ? ((SEGC + 6) / 4 < 10 ? (SEGC + 6) / 4 : 10) : 8;   // (a 33-byte segment — tile 11 — in one pass)
     uint32_t lo = a0 >= 0 ? A[a0] : 0u;
     for (uint32_t i0 = 0; i0 < nc; i0 += CH) {
         uint32_t w[CH + 1];
@@ -214,6 +214,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     uint64_t* w_stage_r = reinterpret_cast<uint64_t*>(ws + L.rec);        // [stage_envs][rec_stride] their agent records
     double* w_stage_p = reinterpret_cast<double*>(ws + L.pres);          // [stage_envs][rec_stride] agent.prestige ('prestige' agents only)
     uint32_t* w_stage_c = reinterpret_cast<uint32_t*>(ws + L.pcol);      // [stage_envs][rec_stride] ... and their sprite colours (fused step)
+    uint2* w_vaff = reinterpret_cast<uint2*>(ws + L.vaff);     // [view_slots][nv] (phase 2b)
     uint8_t* w_first = ws + L.first;
     uint8_t* w_second = ws + L.second;
     uint8_t* w_vbase = ws + L.vbase;
@@ -326,13 +327,15 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     // assemble-and-stream raster: the wave's run of envs is ONE contiguous output stream.  w_out[0] is
     // the byte at the 16-byte-aligned global address out_base; w_out[0 .. carry) are pending bytes of a
     // chunk that is not complete yet (at the start of the run: `head` bytes that belong to the wave before)
-    uintptr_t out_base = 0;
+    // (a POINTER derived from `obs`, not an integer: the compiler then knows the address space and emits
+    // global_store — through uintptr_t it emitted flat_store, which also counts in lgkmcnt, the LDS counter)
+    uint8_t* out_base = obs;
     uint32_t carry = 0, head = 0;
     if constexpr (!kChunkRaster) {
-        const uintptr_t a0 = reinterpret_cast<uintptr_t>(obs) + (size_t)e0 * nv * img_bytes;
-        head = (uint32_t)(a0 & 15);
+        const size_t a0 = (size_t)e0 * nv * img_bytes;
+        head = (uint32_t)((reinterpret_cast<uintptr_t>(obs) + a0) & 15);
         carry = head;
-        out_base = a0 - head;
+        out_base = obs + a0 - head;
         for (int i = lane; i < L.out_chunks; i += kWave) reinterpret_cast<uint4*>(w_out)[i] = make_uint4(0, 0, 0, 0);
         wave_lds_sync();
     }
@@ -343,7 +346,10 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     if (kBatchViews && TS < 8 && depth_mode <= 0) depth = L.tmap_slots;   // issue-bound: views of the whole batch at once
     if (depth > L.tmap_slots) depth = L.tmap_slots;
     if constexpr (kPrestige) depth = 1;
-    const SmallDiv by_n((uint32_t)n), by_nv((uint32_t)nv), by_nvVV((uint32_t)(nv * VV));   // item -> (slot, rest)
+    // item -> (slot, rest), view cell -> (viewer, row, column): 24-bit multiplies only (Div20)
+    const Div20 by_n((uint32_t)n), by_nv((uint32_t)nv), by_nvVV((uint32_t)(nv * VV)), by_VV((uint32_t)VV), by_VS((uint32_t)VS);
+    constexpr bool kExactVV = VS_ > 0 && VS_ <= 9;     // 16 viewers * VS^2 cells: x * (m*d - 2^20) < 2^20 holds (checked below)
+    static_assert(VS_ == 0 || VS_ > 9 || (16u * VS_ * VS_ * ((((1u << 20) + VS_ * VS_ - 1u) / (VS_ * VS_)) * (VS_ * VS_) - (1u << 20)) < (1u << 20)), "Div20 exactness");
 
     for (int eb = e0; eb < e_end; eb += K) {
         const int kb = min(K, e_end - eb);
@@ -474,44 +480,68 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             }
         };
         if constexpr (kBatchViews) {
-            for (int it = lane; it < G * n; it += kWave) { const int g = (int)by_n.div((uint32_t)it); first_of_cell(g, it - g * n); }
+            for (int it = lane; it < G * n; it += kWave) { const int g = (int)by_n.div((uint32_t)it); first_of_cell(g, it - __mul24(g, n)); }
         } else if (lane < n) first_of_cell(0, lane);
-        wave_lds_sync();
-        // 3. egocentric crop + rotate: view cell (a = column, b = row) -> world cell
-        for (int it = lane; it < G * nvVV; it += kWave) {
-            const int g = kBatchViews ? (int)by_nvVV.div((uint32_t)it) : 0, iv = it - g * nvVV;
-            const int v = iv / VV, c = iv - v * VV, k = s_vmap[v];      // viewer slot v is agent k
-            const int vb = c / VS, va = c - vb * VS;
-            const uint8_t* w_grid = g_grid + g * cfg.cells_stride;
-            const uint8_t* s_first = w_first + g * L.cell_stride;
-            const uint64_t r = g_rec[g * rec_stride + k];
+        // 2b. one lane per VIEWER: its view as an affine map of (column va, row vb) — SURVEY.md A.4's four cases
+        //     folded into an origin, a swap bit and two signs — and who it is, so that phase 3 does no per-cell
+        //     case analysis (as nested branches it ran every lane through all four headings):
+        //       p = swap ? vb : va, q = swap ? va : vb;  wx = x0 +- p;  wy = y0 +- q
+        //     word 0: x0 + 256 | (y0 + 256) << 10 | swap << 20 | negx << 21 | negy << 22
+        //     word 1: x | y << 8 | agent << 16 | orientation (3 - dir) & 3 << 24
+        auto view_affine = [&](const int g, const int v) {
+            const uint32_t k = s_vmap[v];
+            const uint64_t r = g_rec[__mul24(g, rec_stride) + (int)k];
             const int x = (int)rec_byte(r, MG_AG_X), y = (int)rec_byte(r, MG_AG_Y), dir = (int)rec_byte(r, MG_AG_DIR);
-            int wx, wy;
-            if (dir == 3)      { wx = x - h + va;                 wy = y - (VS - 1) + off + vb; }
-            else if (dir == 0) { wx = x - off + (VS - 1 - vb);    wy = y - h + va; }
-            else if (dir == 1) { wx = x - h + (VS - 1 - va);      wy = y - off + (VS - 1 - vb); }
-            else               { wx = x - VS + 1 + off + vb;      wy = y - h + (VS - 1 - va); }
+            int x0, y0;
+            uint32_t bits;
+            if (dir == 3)      { x0 = x - h;                 y0 = y - (VS - 1) + off;  bits = 0u; }
+            else if (dir == 0) { x0 = x - off + (VS - 1);    y0 = y - h;               bits = 1u | 2u; }
+            else if (dir == 1) { x0 = x - h + (VS - 1);      y0 = y - off + (VS - 1);  bits = 2u | 4u; }
+            else               { x0 = x - VS + 1 + off;      y0 = y - h + (VS - 1);    bits = 1u | 4u; }
+            w_vaff[__mul24(g, nv) + v] = make_uint2((uint32_t)(x0 + 256) | ((uint32_t)(y0 + 256) << 10) | (bits << 20),
+                                                    (uint32_t)x | ((uint32_t)y << 8) | (k << 16) | (((3u - (uint32_t)dir) & 3u) << 24));
+        };
+        if constexpr (kBatchViews) {
+            for (int it = lane; it < G * nv; it += kWave) { const int g = (int)by_nv.div((uint32_t)it); view_affine(g, it - __mul24(g, nv)); }
+        } else if (lane < nv) view_affine(0, lane);
+        wave_lds_sync();
+        // 3. egocentric crop + rotate: view cell (a = column, b = row) -> world cell.  All index
+        //    arithmetic in 24-bit multiplies (Div20; offsets of slot g are products of small numbers).
+        for (uint32_t it = (uint32_t)lane; it < (uint32_t)(G * nvVV); it += kWave) {
+            uint32_t g = 0, iv = it;
+            if constexpr (kBatchViews) { g = by_nvVV.div(it); iv = it - __umul24(g, (uint32_t)nvVV); }
+            const uint32_t v = by_VV.template div<kExactVV>(iv), c = iv - __umul24(v, (uint32_t)VV);
+            const uint32_t vb = by_VS.template div<(VS_ > 0)>(c), va = c - __umul24(vb, (uint32_t)VS);
+            const uint8_t* w_grid = g_grid + __umul24(g, (uint32_t)cfg.cells_stride);
+            const uint32_t gcell = __umul24(g, (uint32_t)L.cell_stride);
+            const uint2 aff = w_vaff[__umul24(g, (uint32_t)nv) + v];
+            const uint32_t k = (aff.y >> 16) & 0xFFu;
+            const int x = (int)(aff.y & 0xFFu), y = (int)((aff.y >> 8) & 0xFFu);
+            const bool swap = (aff.x >> 20) & 1u;
+            const int p = (int)(swap ? vb : va), q = (int)(swap ? va : vb);
+            const int wx = (int)(aff.x & 0x3FFu) - 256 + (((aff.x >> 21) & 1u) ? -p : p);
+            const int wy = (int)((aff.x >> 10) & 0x3FFu) - 256 + (((aff.x >> 22) & 1u) ? -q : q);
             const bool inb = wx >= 0 && wx < W && wy >= 0 && wy < H;
+            const int cell = __mul24(wx, H) + wy;
             uint32_t base = 0, show = 0xFF;
             if (inb) {
-                const int cell = wx * H + wy;
                 base = w_grid[cell];
-                show = s_first[cell];
-                if (show != 0xFF && wx == x && wy == y) show = (uint32_t)k;   // viewer in the stack: base.py:282-291
+                show = w_first[gcell + cell];
+                if (show != 0xFF && wx == x && wy == y) show = k;   // viewer in the stack: base.py:282-291
             }
-            if (s_oflags[base] & MG_OF_SEE_BEHIND) atomicOr(&w_trow[g * L.trow_stride + v * VS + vb], 1u << va);   // opacity first
+            if (s_oflags[base] & MG_OF_SEE_BEHIND)                     // opacity first
+                atomicOr(&w_trow[__umul24(g, (uint32_t)L.trow_stride) + __umul24(v, (uint32_t)VS) + vb], 1u << va);
             if (cfg.any_hide && inb) {
                 // hide_item_types (base.py:441-449), applied after visibility: a hidden cell object is
                 // replaced by the first agent standing on it (or nothing) and that agent is drawn as
                 // a plain cell object — the "viewer is in the stack" rule no longer applies to it
-                const int cell = wx * H + wy;
-                const uint32_t first = s_first[cell];
+                const uint32_t first = w_first[gcell + cell];
                 if (base && ((s_hide[k] >> base) & 1ull)) { base = 0; show = first; }
-                else if (base == 0 && first != 0xFF && first != (uint32_t)k && ((cfg.hide_agent_mask >> k) & 1u))
-                    show = w_second[g * L.cell_stride + cell];
+                else if (base == 0 && first != 0xFF && first != k && ((cfg.hide_agent_mask >> k) & 1u))
+                    show = w_second[gcell + cell];
             }
             if constexpr (kBatchViews) {   // the pair waits where phase 5 puts the tile it selects
-                w_tmap[(size_t)g * (L.tmap_stride / 2) + iv] = (uint16_t)(base | (show << 8));
+                w_tmap[__umul24(g, (uint32_t)(L.tmap_stride / 2)) + iv] = (uint16_t)(base | (show << 8));
             } else {
                 w_vbase[iv] = (uint8_t)base;
                 w_vshow[iv] = (uint8_t)show;
@@ -520,8 +550,8 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
         wave_lds_sync();
         // 4. visibility, one lane per viewer
         auto visibility = [&](const int g, const int v) {         // slot g, viewer v
-            const uint64_t r = g_rec[g * rec_stride + s_vmap[v]];
-            const int row0 = g * L.trow_stride + v * VS;
+            const uint64_t r = g_rec[__mul24(g, rec_stride) + s_vmap[v]];
+            const int row0 = __mul24(g, L.trow_stride) + __mul24(v, VS);
             uint32_t m[VS_ ? VS_ : MG_MAX_VIEW];
             if (!(rec_byte(r, MG_AG_FLAGS) & MG_AF_ACTIVE)) {           // base.py:420-425
                 for (int j = 0; j < VS; j++) m[j] = 0;
@@ -533,7 +563,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             for (int j = 0; j < VS; j++) w_vis[row0 + j] = m[j];
         };
         if constexpr (kBatchViews) {
-            for (int it = lane; it < G * nv; it += kWave) { const int g = (int)by_nv.div((uint32_t)it); visibility(g, it - g * nv); }
+            for (int it = lane; it < G * nv; it += kWave) { const int g = (int)by_nv.div((uint32_t)it); visibility(g, it - __mul24(g, nv)); }
         } else if (lane < nv) visibility(0, lane);
         wave_lds_sync();
         if constexpr (kPrestige) {
@@ -595,14 +625,16 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             wave_lds_sync();
         }
         // 5. tile selection (base.py:275-299) -> atlas byte offset / 4 per view cell
-        for (int it = lane; it < G * nvVV; it += kWave) {
-            const int g = kBatchViews ? (int)by_nvVV.div((uint32_t)it) : 0, iv = it - g * nvVV;
-            const int v = iv / VV, c = iv - v * VV, k = s_vmap[v];
-            const int vb = c / VS, va = c - vb * VS;
-            const uint8_t* w_grid = g_grid + g * cfg.cells_stride;
-            const uint64_t* w_rec = g_rec + g * rec_stride;
-            uint16_t* tmap = w_tmap + (size_t)g * (L.tmap_stride / 2);
-            const uint32_t visible = (w_vis[g * L.trow_stride + v * VS + vb] >> va) & 1u;
+        for (uint32_t it = (uint32_t)lane; it < (uint32_t)(G * nvVV); it += kWave) {
+            uint32_t g = 0, iv = it;
+            if constexpr (kBatchViews) { g = by_nvVV.div(it); iv = it - __umul24(g, (uint32_t)nvVV); }
+            const uint32_t v = by_VV.template div<kExactVV>(iv), c = iv - __umul24(v, (uint32_t)VV);
+            const uint32_t vb = by_VS.template div<(VS_ > 0)>(c), va = c - __umul24(vb, (uint32_t)VS);
+            const uint8_t* w_grid = g_grid + __umul24(g, (uint32_t)cfg.cells_stride);
+            const uint8_t* w_recb = reinterpret_cast<const uint8_t*>(g_rec + __umul24(g, (uint32_t)rec_stride));   // records, bytewise
+            uint16_t* tmap = w_tmap + __umul24(g, (uint32_t)(L.tmap_stride / 2));
+            const uint32_t visible = (w_vis[__umul24(g, (uint32_t)L.trow_stride) + __umul24(v, (uint32_t)VS) + vb] >> va) & 1u;
+            const uint32_t orient = (w_vaff[__umul24(g, (uint32_t)nv) + v].y >> 24) & 3u;   // -(dir+1) mod 4 of the viewer
             uint32_t base, show;
             if constexpr (kBatchViews) { const uint32_t pair = tmap[iv]; base = pair & 0xFFu; show = pair >> 8; }
             else { base = w_vbase[iv]; show = w_vshow[iv]; }
@@ -611,29 +643,28 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 const uint32_t slot = s_oslot[base];
                 if (show == 0xFF || slot == 0xFF) tile = 1 + base;
                 else {
-                    const uint32_t sdir = rec_byte(w_rec[show], MG_AG_DIR);
-                    tile = 1 + cfg.n_obj + (slot * n + show) * 4 + sdir;
+                    const uint32_t sdir = w_recb[show * 8 + MG_AG_DIR];
+                    tile = 1 + cfg.n_obj + (__umul24(slot, (uint32_t)n) + show) * 4 + sdir;
                 }
             }
-            const uint32_t orient = (3u - rec_byte(w_rec[k], MG_AG_DIR)) & 3u;   // -(dir+1) mod 4
-            uint32_t vt = orient * cfg.n_tiles + tile;                            // (virtual) tile index
+            uint32_t vt = __umul24(orient, (uint32_t)cfg.n_tiles) + tile;         // (virtual) tile index
             bool dyn = false;
             if constexpr (kPrestige) {
                 if (visible && show != 0xFF && s_oslot[base] != 0xFF && ((cfg.prestige_mask >> show) & 1u) &&
-                    (rec_byte(w_rec[show], MG_AG_FLAGS) & MG_AF_ACTIVE)) {
-                    const uint64_t rs = w_rec[show];   // hidden object under it: the plain-cell-object set
+                    (w_recb[show * 8 + MG_AG_FLAGS] & MG_AF_ACTIVE)) {
+                    // hidden object under it: the plain-cell-object set
                     const uint32_t hv = (cfg.any_hide && base == 0 &&
-                                         w_grid[rec_byte(rs, MG_AG_X) * H + rec_byte(rs, MG_AG_Y)] != 0) ? (uint32_t)n : 0u;
+                                         w_grid[__umul24(w_recb[show * 8 + MG_AG_X], (uint32_t)H) + w_recb[show * 8 + MG_AG_Y]] != 0) ? (uint32_t)n : 0u;
                     vt = NT4 + (hv + show) * 4 + orient;
                     dyn = true;
                 }
             }
             if constexpr (kChunkRaster && !kGlobalAtlas)                          // dword offset from the atlas base
-                tmap[iv] = (uint16_t)(dyn ? dyn_off / 4 + (vt - NT4) * (TS_ * TS_ * 3 / 4) : vt * (TS_ * TS_ * 3 / 4));
+                tmap[iv] = (uint16_t)(dyn ? dyn_off / 4 + __umul24(vt - NT4, (uint32_t)(TS_ * TS_ * 3 / 4)) : __umul24(vt, (uint32_t)(TS_ * TS_ * 3 / 4)));
             else
                 tmap[iv] = (uint16_t)vt;
             if (dbg_cells) {
-                const size_t o = ((size_t)(e + g) * nv + v) * VV + va * VS + vb;  // [i][j] like the reference
+                const size_t o = ((size_t)(e + (int)g) * nv + v) * VV + va * VS + vb;  // [i][j] like the reference
                 dbg_cells[o] = (uint8_t)base;
                 dbg_agent[o] = (uint8_t)show;
                 dbg_vis[o] = (uint8_t)visible;
@@ -773,31 +804,33 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             // the incomplete tail to the front, where the next piece — or the next env — continues.
             const uint32_t SEG = 3u * (uint32_t)TS, P = (uint32_t)(VS * TS), RB = P * 3u;
             const uint32_t NR = (uint32_t)nv * P;                          // pixel rows per env
-            const uint32_t mVS = 0xFFFFFFFFu / (uint32_t)VS + 1u, mTS = TS > 1 ? 0xFFFFFFFFu / (uint32_t)TS + 1u : 0u;
+            const Div20 by_TS((uint32_t)TS);
+            // (compile-time tile size: R < 16 viewers * 15 * 64 pixel rows, and R * (m * TS - 2^20) < 2^20 then)
+            constexpr bool kExactTS = TS_ > 0 && (16u * 15u * TS_ * (((((1u << 20) + (TS_ ? TS_ : 1) - 1u) / (TS_ ? TS_ : 1)) * (TS_ ? TS_ : 1)) - (1u << 20)) < (1u << 20));
             auto tile_off = [&](uint32_t vt) -> uint32_t {                 // virtual tile index -> byte offset
-                if constexpr (kSplit) return vt < NT4 ? vt * (uint32_t)tile_bytes : (kInLds | (dyn_off + (vt - NT4) * (uint32_t)tile_bytes));
-                else if constexpr (kPrestige) return vt < NT4 ? vt * (uint32_t)tile_bytes : dyn_off + (vt - NT4) * (uint32_t)tile_bytes;
-                else return vt * (uint32_t)tile_bytes;
+                if constexpr (kSplit) return vt < NT4 ? __umul24(vt, (uint32_t)tile_bytes) : (kInLds | (dyn_off + __umul24(vt - NT4, (uint32_t)tile_bytes)));
+                else if constexpr (kPrestige) return vt < NT4 ? __umul24(vt, (uint32_t)tile_bytes) : dyn_off + __umul24(vt - NT4, (uint32_t)tile_bytes);
+                else return __umul24(vt, (uint32_t)tile_bytes);
             };
             for (uint32_t R0 = 0; R0 < NR; R0 += (uint32_t)L.piece_rows) {
                 const uint32_t rows = min((uint32_t)L.piece_rows, NR - R0), nseg = rows * (uint32_t)VS;
                 for (uint32_t g = lane; g < nseg; g += kWave) {
-                    const uint32_t Rl = __umulhi(g, mVS), col = g - Rl * (uint32_t)VS, R = R0 + Rl;
-                    const uint32_t band = TS > 1 ? __umulhi(R, mTS) : R, rr = R - band * (uint32_t)TS;
-                    const uint32_t so = tile_off((uint32_t)w_tmap[band * (uint32_t)VS + col]) + rr * SEG;
+                    const uint32_t Rl = by_VS.div(g), col = g - __umul24(Rl, (uint32_t)VS), R = R0 + Rl;
+                    const uint32_t band = by_TS.template div<kExactTS>(R), rr = R - __umul24(band, (uint32_t)TS);
+                    const uint32_t so = tile_off((uint32_t)w_tmap[__umul24(band, (uint32_t)VS) + col]) + __umul24(rr, SEG);
                     const uint8_t* sb;       // source base the offset `sa` counts from
                     uint32_t sa = so;
                     if constexpr (kSplit) { sb = (so & kInLds) ? s_atlas : cfg.atlas; sa = so & ~kInLds; }
                     else if constexpr (kGlobalAtlas) sb = cfg.atlas;
                     else sb = s_atlas;
-                    or_segment<TS_ * 3>(sb, sa, w_out, carry + g * SEG, SEG);
+                    or_segment<TS_ * 3>(sb, sa, w_out, carry + __umul24(g, SEG), SEG);
                 }
                 wave_lds_sync();
                 const uint32_t total = carry + rows * RB, full = total >> 4;
                 if (full) {
                     uint32_t c0 = 0;
                     if (head) {   // chunk 0 is shared with the wave before this one: only our bytes of it
-                        if ((uint32_t)lane >= head && lane < 16) reinterpret_cast<uint8_t*>(out_base)[lane] = w_out[lane];
+                        if ((uint32_t)lane >= head && lane < 16) out_base[lane] = w_out[lane];
                         head = 0;
                         c0 = 1;
                     }
@@ -816,7 +849,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                     // zeroed for the next piece's ORs
                     if (lane < 16) w_out[lane] = tb;
                     for (int i = 1 + lane; i < L.out_chunks; i += kWave) reinterpret_cast<uint4*>(w_out)[i] = make_uint4(0, 0, 0, 0);
-                    out_base += (uintptr_t)full << 4;
+                    out_base += (size_t)full << 4;
                     carry = tail;
                 } else {
                     carry = total;
@@ -824,7 +857,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 wave_lds_sync();
             }
             if (e + 1 == e_end && carry > head) {   // end of the run: the bytes of the last, incomplete chunk
-                if ((uint32_t)lane >= head && (uint32_t)lane < carry) reinterpret_cast<uint8_t*>(out_base)[lane] = w_out[lane];
+                if ((uint32_t)lane >= head && (uint32_t)lane < carry) out_base[lane] = w_out[lane];
             }
         }
         }
@@ -882,6 +915,11 @@ int render_min_lds_bytes(const MgConfig& cfg) {
     const int atlas_b = round_up(4 * cfg.n_tiles * cfg.tile_size * cfg.tile_size * 3, 16);
     const int rest = kRenderShared + 4 * L.total;
     return atlas_b + rest <= 160 * 1024 ? atlas_b + rest : rest;   // else the atlas is read in place
+}
+
+static size_t render_lds_bytes(const MgConfig& cfg, int wpb) {
+    const RenderScratch L = render_scratch_for(cfg, wpb);
+    return (size_t)round_up(4 * cfg.n_tiles * cfg.tile_size * cfg.tile_size * 3, 16) + kRenderShared + (size_t)wpb * L.total;
 }
 
 // Workgroup shape.  16 waves per workgroup walk 16 *adjacent* envs at a time (a 450 KB contiguous
@@ -951,6 +989,10 @@ static hipError_t launch_render_one(const MgConfig& cfg, const MgState& st, uint
     none.prog.n_ops = 0;
     if (!fs) fs = &none;
     if ((view_cells || view_agent || vis_mask) && !(view_cells && view_agent && vis_mask)) return hipErrorInvalidValue;
+#if defined(MG_DEV_ONLY)   // development: compile ONE instantiation (register / ISA checks without the other sixty),
+    // e.g. -DMG_DEV_ONLY="7,5,16,0,0"
+    return launch_render_t<MG_DEV_ONLY>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
+#else
     const int vs = cfg.view_size, ts = cfg.tile_size;
     const int wpb = choose_wpb(cfg);
     if (cfg.prestige_mask) {   // per-env recoloured agent tiles (LDS), 4-wave workgroups
@@ -965,14 +1007,27 @@ static hipError_t launch_render_one(const MgConfig& cfg, const MgState& st, uint
         }
         // the shipped view: compile-time size; 8-wave workgroups when they fit (the recolouring code needs
         // more than the 128 VGPRs a 16-wave workgroup leaves per lane)
+        // 12-wave workgroups (3 waves per SIMD, 168 VGPRs: the recolouring code needs ~165) where their scratch
+        // fits next to the atlas: 0.52 -> 0.59 of 8 TB/s with three 'prestige' agents at tile 8, 0.24 -> 0.29 for the
+        // reference's example (one agent, tile 11) against 8-wave workgroups (profiles/r03/ab_offpath*.jsonl)
+        int pw = wpb;
+        if (pw == 16) pw = render_lds_bytes(cfg, 12) <= 160 * 1024 ? 12 : 8;
         if (vs == 7 && ts == 8)
-            return wpb == 12 ? launch_render_t<7, 8, 12, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo)
-                 : wpb == 16 ? launch_render_t<7, 8, 8, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo)
-                             : launch_render_t<7, 8, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
+            return pw == 12 ? launch_render_t<7, 8, 12, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo)
+                 : pw == 8 ? launch_render_t<7, 8, 8, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo)
+                           : launch_render_t<7, 8, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
+        bool rt_ts = false;
+#if defined(MG_AB_VARIANTS)
+        if (const char* f = getenv("MG_RENDER_RT_TS")) rt_ts = atoi(f) != 0;
+#endif
+        if (vs == 7 && ts == 11 && !rt_ts)     // examples/human_player.py's view_tile_size
+            return pw == 12 ? launch_render_t<7, 11, 12, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo)
+                 : pw == 8 ? launch_render_t<7, 11, 8, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo)
+                           : launch_render_t<7, 11, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
         if (vs == 7 && (ts % 8) != 0)
-            return wpb == 12 ? launch_render_t<7, 0, 12, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo)
-                 : wpb == 16 ? launch_render_t<7, 0, 8, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo)
-                             : launch_render_t<7, 0, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
+            return pw == 12 ? launch_render_t<7, 0, 12, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo)
+                 : pw == 8 ? launch_render_t<7, 0, 8, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo)
+                           : launch_render_t<7, 0, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
         if (ts == 8) return launch_render_t<0, 8, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
         if (ts == 16) return launch_render_t<0, 16, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
         if (ts == 32) return launch_render_t<0, 32, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
@@ -1013,9 +1068,16 @@ static hipError_t launch_render_one(const MgConfig& cfg, const MgState& st, uint
     if (ts == 32 && vs == 7) return MG_RENDER_DISPATCH(7, 32, 0);
     if (ts == 16) return MG_RENDER_DISPATCH_RT(16, 0);
     if (ts == 32) return MG_RENDER_DISPATCH_RT(32, 0);
-    if (vs == 7 && ts == 5) return MG_RENDER_DISPATCH12(7, 5, 0);   // GridAgentInterface's defaults (agents.py:21-22)
+    bool rt_ts = false;     // measurement build: MG_RENDER_RT_TS=1 takes the run-time-tile-size instantiation instead
+#if defined(MG_AB_VARIANTS)
+    if (const char* f = getenv("MG_RENDER_RT_TS")) rt_ts = atoi(f) != 0;
+#endif
+    if (vs == 7 && ts == 5 && !rt_ts) return MG_RENDER_DISPATCH12(7, 5, 0);   // GridAgentInterface's defaults (agents.py:21-22)
+    if (vs == 7 && ts == 6 && !rt_ts) return MG_RENDER_DISPATCH(7, 6, 0);
+    if (vs == 7 && ts == 11 && !rt_ts) return MG_RENDER_DISPATCH(7, 11, 0);
     if (vs == 7) return MG_RENDER_DISPATCH12(7, 0, 0);      // the default view with any other tile size
     return MG_RENDER_DISPATCH_RT(0, 0);                   // anything else
+#endif
 }
 
 }  // namespace mg

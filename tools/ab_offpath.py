@@ -39,11 +39,12 @@ def goalcycle(n, ts):
         initial_reward=True, penalty=-1.5, batch_size=B, strict=False, auto_reset=True, place_obs=False)
 
 
-cases = [("tile 5 (GridAgentInterface default)", cluttered(5), ["0", "12"]),
-         ("tile 6", cluttered(6), ["0", "12"]),
-         ("tile 11", cluttered(11), ["0", "12"]),
-         ("goal cycle, 3 'prestige' agents, tile 8", goalcycle(3, 8), ["0", "12", "4"]),
-         ("human_player: goal cycle, 1 'prestige' agent, tile 11", goalcycle(1, 11), ["0", "12", "4"])]
+# shapes: "<waves per workgroup>" (0 = the launcher's choice), "+rt" = the run-time-tile-size instantiation
+cases = [("tile 5 (GridAgentInterface default)", cluttered(5), ["0", "0+rt"]),
+         ("tile 6", cluttered(6), ["0", "0+rt"]),
+         ("tile 11", cluttered(11), ["0", "0+rt"]),
+         ("goal cycle, 3 'prestige' agents, tile 8", goalcycle(3, 8), ["0", "8"]),
+         ("human_player: goal cycle, 1 'prestige' agent, tile 11", goalcycle(1, 11), ["0", "0+rt", "8"])]
 only = sys.argv[1:]
 for label, mk, shapes in cases:
     if only and not any(o in label for o in only):
@@ -58,7 +59,8 @@ for label, mk, shapes in cases:
     res = {w: {"raster": [], "step": []} for w in shapes}
     for rep in range(5):
         for w in shapes:
-            os.environ["MG_RENDER_WPB"] = w
+            os.environ["MG_RENDER_WPB"] = w.split("+")[0]
+            os.environ["MG_RENDER_RT_TS"] = "1" if w.endswith("+rt") else "0"
             N.check(L.mg_time_render_obs(C.byref(env._cfg), C.byref(env._state), env.obs.data_ptr(), 20, C.byref(ms), env._stream()))
             res[w]["raster"].append(ms.value)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -70,11 +72,12 @@ for label, mk, shapes in cases:
             b.synchronize()
             res[w]["step"].append(a.elapsed_time(b) / 20)
     os.environ["MG_RENDER_WPB"] = "0"
+    os.environ["MG_RENDER_RT_TS"] = "0"
     env.check_errors()
     nb = env.obs.numel()
     for w in shapes:
         r, s = statistics.median(res[w]["raster"]), statistics.median(res[w]["step"])
-        print(json.dumps({"case": label, "waves_per_workgroup": "launcher's choice" if w == "0" else int(w), "B": B,
+        print(json.dumps({"case": label, "shape": {"0": "launcher's choice", "0+rt": "launcher's choice, run-time tile size"}.get(w, w + " waves per workgroup"), "B": B,
                           "n": env.num_agents, "tile": env.tile_size, "obs_bytes": nb, "raster_ms": r,
                           "raster_frac_of_8TBps": nb / r / 1e6 / 8000, "step_ms": s, "step_frac_of_8TBps": nb / s / 1e6 / 8000,
                           "agent_steps_per_s": B * env.num_agents / s * 1e3}), flush=True)
