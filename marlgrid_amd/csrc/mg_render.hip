@@ -713,7 +713,12 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             uint32_t r = rast_r0, pr = rast_p0;
             // pair (global pixel row rr_, pair-in-row pr_) -> its tmap index and its dword offset inside the tile
             auto pair_coords = [&](uint32_t rr_, uint32_t pr_, uint32_t& ti, uint32_t& of) {
-                const uint32_t va = __umul24(pr_, M_PT) >> 16, kp = pr_ - __umul24(va, PT);
+                // va = pr_ / PT and kp = pr_ % PT from ONE product: its high half is the quotient, its low half times PT
+                // the remainder.  (Written as pr_ - va * PT, the compiler fuses the multiply into a v_mad_u64_u32 on
+                // the (pr, r) register pair it keeps for the carry trick of the advance — a quarter-rate instruction,
+                // eight per trip.)
+                const uint32_t prod = __umul24(pr_, M_PT);
+                const uint32_t va = prod >> 16, kp = __umul24(prod & 0xFFFFu, PT) >> 16;
                 uint32_t vb, rr;
                 if constexpr ((TS_ & (TS_ - 1)) == 0) { vb = rr_ / (uint32_t)TS_; rr = rr_ & (uint32_t)(TS_ - 1); }   // (shifts)
                 else { vb = __umul24(rr_, M_TS) >> 16; rr = rr_ - __umul24(vb, (uint32_t)TS_); }

@@ -21,6 +21,9 @@ from marlgrid_amd.envs import ClutteredGoalCycleEnv, ClutteredMultiGrid  # noqa:
 
 COLS = ["red", "blue", "purple", "orange", "olive", "pink", "cyan", "yellow"]
 B = int(os.environ.get("B", "32768"))
+# observation buffers chosen by the product's placement search (default), or PLACE=0: plain torch allocations, whose
+# class varies from buffer to buffer by up to 25 % (what the tile >= 8 cases are sensitive to)
+PLACE = False if os.environ.get("PLACE", "1") == "0" else "search"
 
 
 def agents(n, vs, ts, **kw):
@@ -29,14 +32,14 @@ def agents(n, vs, ts, **kw):
 
 def cluttered(ts):
     return lambda: ClutteredMultiGrid(agents=agents(3, 7, ts), grid_size=15, clutter_density=0.15, batch_size=B,
-                                      strict=False, auto_reset=True, place_obs=False)
+                                      strict=False, auto_reset=True, place_obs=PLACE)
 
 
 def goalcycle(n, ts):
     return lambda: ClutteredGoalCycleEnv(
         agents=[GridAgentInterface(color="prestige", view_size=7, view_tile_size=ts, view_offset=1) for _ in range(n)],
         grid_size=13, clutter_density=0.15, n_bonus_tiles=3, max_steps=250, respawn=True, reward_decay=False,
-        initial_reward=True, penalty=-1.5, batch_size=B, strict=False, auto_reset=True, place_obs=False)
+        initial_reward=True, penalty=-1.5, batch_size=B, strict=False, auto_reset=True, place_obs=PLACE)
 
 
 # shapes: "<waves per workgroup>" (0 = the launcher's choice), "+rt" = the run-time-tile-size instantiation
