@@ -757,6 +757,84 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                     __builtin_nontemporal_store(nv, reinterpret_cast<u32x4*>(out + c));
                 } else out[c] = v;
             };
+            // FIXED-LANE mapping (compile-time view size, tile 8 / 16): the env's stream repeats every PRW pixel rows
+            // = PC 16-byte chunks (21 for view 7: two rows of 168 B at tile 8, one row of 336 B at tile 16), so a
+            // wave-instruction that covers a whole number of periods — 63 lanes = 3 periods, 1 008 contiguous bytes;
+            // lane 63 idles — gives every lane the SAME place in the period on every trip: which pixel row of the
+            // period, which view column, which pair of the tile row are per-lane constants, and a trip only
+            // advances the row by a constant.  Per pair and trip: shift, and, two 24-bit multiply-adds — where the
+            // general mapping (64 chunks per trip, the place in the period rotating) re-derives column and pair
+            // with a division each time: 157 VALU instructions per 4 KiB against ~70.  (The chunk raster is not
+            // purely HBM-bound: SQ counters show its VALU pipes 60 % busy, profiles/r03.)
+            constexpr uint32_t RBc = (uint32_t)(VS_ ? VS_ : 1) * TS_ * 3;                 // bytes per pixel row
+            constexpr uint32_t PRW = (RBc % 16u) ? 2u : 1u, PC = PRW * RBc / 16u;          // rows / chunks per period
+            constexpr uint32_t GPT = PC ? 64u / PC : 0u, LU = GPT * PC;                    // periods / lanes used per trip
+            constexpr bool kFixedLane = VS_ > 0 && LU >= 60 && V_ != 6;
+            if constexpr (kFixedLane) {
+                constexpr uint32_t PRc = RBc / 8u;                                          // pairs per pixel row
+                const uint32_t q = (uint32_t)lane % PC, grp = (uint32_t)lane / PC;
+                uint32_t rowpar[2], vaq[2], kp2[2];
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const uint32_t pj = 2u * q + (uint32_t)j;                               // pair within the period
+                    rowpar[j] = pj / PRc;
+                    const uint32_t prj = pj - rowpar[j] * PRc;
+                    vaq[j] = prj / PT;
+                    kp2[j] = (prj - vaq[j] * PT) * 2u;
+                }
+                const bool live = (uint32_t)lane < LU;
+                uint32_t rcur = PRW * grp;                                                  // first row of this lane's period
+                auto coords = [&](uint32_t rr_, int j, uint32_t& ti, uint32_t& of) {
+                    uint32_t vb, rr;
+                    if constexpr ((TS_ & (TS_ - 1)) == 0) { vb = rr_ / (uint32_t)TS_; rr = rr_ & (uint32_t)(TS_ - 1); }
+                    else { vb = __umul24(rr_, M_TS) >> 16; rr = rr_ - __umul24(vb, (uint32_t)TS_); }
+                    ti = __umul24(vb, (uint32_t)VS) + vaq[j];
+                    of = __umul24(rr, TD) + kp2[j];
+                };
+                constexpr int CSF = (int)LU;
+                int base = 0;                                                               // first chunk of the trip (uniform)
+                for (; base + 4 * CSF <= total; base += 4 * CSF) {                          // four WHOLE trips at a time
+                    if (live) {                                                             // (one exec mask for all of it)
+                        const int c = base + lane;
+                        uint32_t ti[8], of[8];
+#pragma unroll
+                        for (int t = 0; t < 4; t++) {
+                            coords(rcur + rowpar[0], 0, ti[2 * t], of[2 * t]);
+                            coords(rcur + rowpar[1], 1, ti[2 * t + 1], of[2 * t + 1]);
+                            rcur += PRW * GPT;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        uint2 pp[8];
+                        if constexpr (V_ != 4) {
+                            uint32_t tt[8];
+#pragma unroll
+                            for (int i = 0; i < 8; i++) tt[i] = (uint32_t)w_tmap[ti[i]];
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int i = 0; i < 8; i++) pp[i] = ld_pair(tile_dword(tt[i]) + of[i]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 8; i++) pp[i] = make_uint2(0x1e19231eu, 0x231e1923u);
+                        }
+#pragma unroll
+                        for (int t = 0; t < 4; t++) put(c + t * CSF, make_uint4(pp[2 * t].x, pp[2 * t].y, pp[2 * t + 1].x, pp[2 * t + 1].y));
+                    }
+                }
+                for (; base < total; base += CSF) {                                         // the remaining trips, one by one
+                    const int c = base + lane;
+                    uint32_t ti0, of0, ti1, of1;
+                    coords(rcur + rowpar[0], 0, ti0, of0);
+                    coords(rcur + rowpar[1], 1, ti1, of1);
+                    rcur += PRW * GPT;
+                    if (live && c < total) {
+                        uint2 p0, p1;
+                        if constexpr (V_ != 4) { p0 = ld_pair(tile_dword((uint32_t)w_tmap[ti0]) + of0); p1 = ld_pair(tile_dword((uint32_t)w_tmap[ti1]) + of1); }
+                        else { p0 = make_uint2(0x1e19231eu, 0x231e1923u); p1 = p0; }
+                        put(c, make_uint4(p0.x, p0.y, p1.x, p1.y));
+                    }
+                }
+            } else {
             int c = (int)c_first;
             constexpr int CS = (int)CH_STRIDE;
             if constexpr (V_ == 4) {
@@ -798,6 +876,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 uint4 v;
                 fetch(v);
                 put(c, v);
+            }
             }
         } else {
             // Any tile size: the env's n*P*P*3 output bytes are the next S bytes of the wave's stream;
