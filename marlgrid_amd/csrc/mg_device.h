@@ -117,7 +117,9 @@ __host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride,
     // agent, phase 3 -> 5), trow / vis (transparency and visibility rows).  Views of the whole batch at once
     // (batch_views): a slot of first (second: only with hide_item_types) and trow per staged env; the
     // (object, agent) pair waits in the env's tmap slot and visibility replaces transparency in place.
-    s.view_slots = batch_views ? stage_envs : 1;
+    // (chunk raster — out_bytes == 0 —: up to 4 envs of views at a time; it is HBM-bound and a wave's first store
+    // should not wait for eight envs of views; the assemble-and-stream rasters take the whole staged batch)
+    s.view_slots = batch_views ? (out_bytes == 0 && stage_envs > 4 ? 4 : stage_envs) : 1;
     s.cell_stride = round_up(cells_stride, 16);
     // (trow doubles as the per-agent colour words of the 'prestige' recolouring: at least n dwords)
     s.trow_stride = round_up((nv * vs > n ? nv * vs : n) * 4, 16) / 4;
@@ -163,9 +165,10 @@ __host__ __device__ inline RenderScratch render_scratch_for(const MgConfig& cfg,
         if (rows > nv * vs * ts) rows = nv * vs * ts;
         out = 32 + rows * rb;
     }
-    // assemble-and-stream raster without recoloured tiles: the views of a whole batch are derived together,
-    // one slot of view scratch per staged env (see the kernel's pass 0)
-    const bool batch_views = out > 0 && dyn == 0;
+    // without recoloured tiles the views of several envs are derived together — one lane per viewer in the shadow
+    // cast (its ~420 instructions run once per group instead of once per env), full trips in the per-cell phases —
+    // with one slot of view scratch per env of the group (see the kernel's pass 0)
+    const bool batch_views = dyn == 0;
     const RenderScratch b = render_scratch_layout(cfg.cells_stride, n, nv, vs, 1, dyn, out, rows);
     const int resident = (atlas_b + 4 * b.total + misc <= 160 * 1024) ? atlas_b : 0;   // else the atlas is read in place
     int k = 8;

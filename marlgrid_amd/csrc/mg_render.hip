@@ -207,7 +207,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     // env's agents differ in view size / tile size / offset and are rendered group by group (agents.py:19-35).
     const int nv = cfg.n_view ? cfg.n_view : n;
     constexpr bool kChunkRaster = TS_ > 0 && (TS_ % 8) == 0 && RM_ == 0;
-    constexpr bool kBatchViews = !kChunkRaster && !kPrestige;   // as render_scratch_for: view scratch per staged env
+    constexpr bool kBatchViews = !kPrestige;   // as render_scratch_for: views of a group of envs at once, a scratch slot each
     const RenderScratch L = render_scratch_for(cfg, WPB, RM_);
     uint8_t* ws = smem + atlas_bytes + kRenderShared + (size_t)wave * L.total;
     uint8_t* w_stage_g = ws + L.grid;                                      // [stage_envs][cells_stride] grids of a batch of envs
@@ -343,8 +343,9 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     // look-ahead depth of this wave (see the env loop): 1, 2, 4, 8 by wave; depth_mode > 0 (measurement
     // builds) forces one depth for all.  Per-env recoloured tiles ('prestige') have one slot only.
     int depth = depth_mode > 0 ? depth_mode : (1 << (wave & 3));
-    if (kBatchViews && TS < 8 && depth_mode <= 0) depth = L.tmap_slots;   // issue-bound: views of the whole batch at once
+    if (kBatchViews && !kChunkRaster && TS < 8 && depth_mode <= 0) depth = L.tmap_slots;   // issue-bound: views of the whole batch at once
     if (depth > L.tmap_slots) depth = L.tmap_slots;
+    if (kBatchViews && depth > L.view_slots) depth = L.view_slots;   // (a group's views need a scratch slot per env)
     if constexpr (kPrestige) depth = 1;
     // item -> (slot, rest), view cell -> (viewer, row, column): 24-bit multiplies only (Div20)
     const Div20 by_n((uint32_t)n), by_nv((uint32_t)nv), by_nvVV((uint32_t)(nv * VV)), by_VV((uint32_t)VV), by_VS((uint32_t)VS);
@@ -458,7 +459,8 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
         for (int i = lane; i < G * L.trow_stride; i += kWave) w_trow[i] = 0;
         wave_lds_sync();
         if constexpr (V_ == 3 || V_ == 4) {
-            for (int it = lane; it < nv * VV; it += kWave) w_tmap[it] = 0;
+            for (int g = 0; g < G; g++)
+                for (int it = lane; it < nv * VV; it += kWave) w_tmap[g * (L.tmap_stride / 2) + it] = 0;
         } else {
         for (int rep = 0; rep < (V_ == 11 ? 2 : 1); rep++) {   // V_ == 11 (measurement): phases 2-5 twice
         // 2. first (lowest-rank) agent of every occupied cell: the reference's "cell object" when
