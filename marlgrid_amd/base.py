@@ -473,8 +473,8 @@ class MultiGridEnv(object):
                               self.mt_head.data_ptr(), self._flag.dev)
 
     @_on_device
-    def _place_obs_buffers(self, batch=8, max_candidates=64, min_bytes=256 << 20, iters=3, budget=32 << 30, gain=0.12,
-                           seconds=2.0):
+    def _place_obs_buffers(self, batch=8, max_candidates=256, min_bytes=256 << 20, iters=3, budget=32 << 30, gain=0.12,
+                           seconds=1.5):
         """place_obs="search" (default): choose WHERE in HBM the observation buffers live.  Measured on MI355X
         (profiles/r02/README.md section 3, profiles/r03/README.md section 2): the rate at which the raster's
         write pattern — thousands of waves, each streaming its own env — is absorbed depends on the ALLOCATION

@@ -434,9 +434,14 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     // rasters.  Waves of a workgroup use different depths (1, 2, 4, 8): otherwise every wave of the chip —
     // they all start together and do identical work — would sit in the store-free phases 1-5 at the same
     // moments, env after env, and the HBM write stream would stall chip-wide each time.
-    for (int ej0 = 0; ej0 < kb; ej0 += depth)
+    // Chunk raster (HBM-bound: a launch's store-free head is pure loss): every wave RAMPS — its first env alone, so
+    // that its first store leaves as early as possible, then groups of 2, 4, ... up to its depth, where the shadow
+    // cast runs once per group and the per-cell phases fill their trips.
+    const bool ramp = kChunkRaster && kBatchViews && depth_mode <= 0 && eb == e0;
+    int gd = ramp ? 1 : depth;                  // size of the current group
+    for (int ej0 = 0; ej0 < kb; ej0 += gd, gd = ramp ? min(2 * gd, L.view_slots) : depth)
     for (int pass = 0; pass < 2; pass++)
-    for (int ej = ej0; ej < min(kb, ej0 + depth); ej++) {
+    for (int ej = ej0; ej < min(kb, ej0 + gd); ej++) {
         const int e = eb + ej;
         uint16_t* w_tmap = w_tmap0 + (size_t)(ej - ej0) * (L.tmap_stride / 2);
         if (pass == 0) {
@@ -446,7 +451,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
         // by instruction issue, phases 2 and 4 have one lane per AGENT — a lone env leaves 61 of 64 lanes
         // idle — and 3 x 49 view cells fill 2.3 trips of 64 lanes where 8 envs fill 18.4 of 19.
         if (kBatchViews && ej != ej0) continue;
-        const int G = kBatchViews ? min(kb, ej0 + depth) - ej0 : 1;
+        const int G = kBatchViews ? min(kb, ej0 + gd) - ej0 : 1;
         const int nvVV = nv * VV;
         const uint8_t* g_grid = w_stage_g + (size_t)ej * cfg.cells_stride;      // env ej + g: + g * cells_stride
         const uint64_t* g_rec = w_stage_r + (size_t)ej * rec_stride;            //            + g * rec_stride

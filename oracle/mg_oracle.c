@@ -356,19 +356,21 @@ static int try_place(MgoEnv* e, int val, int x, int y) {
     return 1;
 }
 
-/* MultiGridEnv.place_obj — base.py:690-708 (top=(0,0), size=None, reject_fn=None) */
-static int place_obj_in(MgoEnv* e, int val, double max_tries_in, int x0, int y0, int x1, int y1, int* ox, int* oy);
-static int place_obj(MgoEnv* e, int val, double max_tries_in) {
-    return place_obj_in(e, val, max_tries_in, 0, 0, e->sh->cfg.W, e->sh->cfg.H, 0, 0);
+/* MultiGridEnv.place_obj — base.py:690-708.  reject: reject_fn tabulated over the grid (x*H + y) or NULL */
+static int place_obj_in(MgoEnv* e, int val, double max_tries_in, int x0, int y0, int x1, int y1, const uint8_t* reject,
+                        int* ox, int* oy);
+static int place_obj(MgoEnv* e, int val, double max_tries_in, const uint8_t* reject) {
+    return place_obj_in(e, val, max_tries_in, 0, 0, e->sh->cfg.W, e->sh->cfg.H, reject, 0, 0);
 }
 /* self.place_obj(agent, **self.agent_spawn_kwargs) — base.py:411, 505, 643 */
 static int place_agent_spawn(MgoEnv* e, int k) {
     const MgoConfig* cfg = &e->sh->cfg;
     return place_obj_in(e, MGO_AGENT_BASE + k, (double)cfg->spawn_max_tries, cfg->spawn_x0, cfg->spawn_y0,
-                        cfg->spawn_x1, cfg->spawn_y1, 0, 0);
+                        cfg->spawn_x1, cfg->spawn_y1, cfg->spawn_reject, 0, 0);
 }
 /* top / size already clamped to [x0,x1) x [y0,y1) as base.py:692-695 does */
-static int place_obj_in(MgoEnv* e, int val, double max_tries_in, int x0, int y0, int x1, int y1, int* ox, int* oy) {
+static int place_obj_in(MgoEnv* e, int val, double max_tries_in, int x0, int y0, int x1, int y1, const uint8_t* reject,
+                        int* ox, int* oy) {
     double mt = max_tries_in < 1e5 ? max_tries_in : 1e5;
     if (mt < 1) mt = 1;
     long max_tries = (long)mt;
@@ -376,6 +378,7 @@ static int place_obj_in(MgoEnv* e, int val, double max_tries_in, int x0, int y0,
         /* np_random.randint(top, bottom): element 0 then element 1; low + bounded(high-low-1) */
         int x = x0 + (int)mgo_bounded(e->mt, &e->mt_pos, (uint32_t)(x1 - x0 - 1));
         int y = y0 + (int)mgo_bounded(e->mt, &e->mt_pos, (uint32_t)(y1 - y0 - 1));
+        if (reject && reject[x * e->sh->cfg.H + y]) continue;     /* reject_fn(pos): base.py:700-701 */
         if (try_place(e, val, x, y)) { if (ox) { *ox = x; *oy = y; } return MGO_OK; }
     }
     if (ox) { *ox = -1; *oy = -1; }
@@ -421,8 +424,8 @@ static int gen_grid(MgoEnv* e, int which) {
             break;
         case MGO_GEN_PLACE:
             for (int n = 0; n < op->count; n++) {
-                int rc = (op->w > 0) ? place_obj_in(e, op->obj, (double)op->max_tries, op->x, op->y, op->x + op->w, op->y + op->h, 0, 0)
-                                     : place_obj(e, op->obj, (double)op->max_tries);
+                int rc = (op->w > 0) ? place_obj_in(e, op->obj, (double)op->max_tries, op->x, op->y, op->x + op->w, op->y + op->h, op->reject, 0, 0)
+                                     : place_obj(e, op->obj, (double)op->max_tries, op->reject);
                 if (rc != MGO_OK) return rc;
             }
             break;
@@ -917,11 +920,11 @@ static void lift_agent(MgoEnv* e, int k);
 /* live place_obj / try_place_obj (base.py:664-708).  what >= 1: object id; what < 0: agent -(what+1),
  * lifted off the grid first (its stack re-seated like a move-out) and activated when it lands. */
 int32_t mgo_place_obj(MgoEnv* e, int32_t what, int32_t x0, int32_t y0, int32_t x1, int32_t y1, int32_t max_tries,
-                      int32_t* out_xy) {
+                      const uint8_t* reject, int32_t* out_xy) {
     int val = what > 0 ? what : MGO_AGENT_BASE + (-(what + 1));
     if (what < 0) { lift_agent(e, -(what + 1)); e->aactive[-(what + 1)] = 0; }
     int ox, oy;
-    int rc = place_obj_in(e, val, (double)max_tries, x0, y0, x1, y1, &ox, &oy);
+    int rc = place_obj_in(e, val, (double)max_tries, x0, y0, x1, y1, reject, &ox, &oy);
     if (rc == MGO_OK && what < 0) e->aactive[-(what + 1)] = 1;
     if (out_xy) { out_xy[0] = ox; out_xy[1] = oy; }
     return rc;

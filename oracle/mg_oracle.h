@@ -69,6 +69,9 @@ enum { MGO_GEN_WALL_RECT = 0, MGO_GEN_HORZ_WALL = 1, MGO_GEN_VERT_WALL = 2, MGO_
        MGO_GEN_PLACE = 4 };
 typedef struct {
     int32_t kind, obj, count, x, y, w, h, max_tries;
+    const uint8_t* reject;   /* place_obj(reject_fn=): the callback tabulated over the grid, index x*H + y, != 0 =
+                              * rejected (base.py:700-701: a rejected draw is a spent try); NULL: none.  The
+                              * caller keeps it alive. */
 } MgoGenOp;
 
 typedef struct {
@@ -92,6 +95,8 @@ typedef struct {
                                                                    * top / size clamped as base.py:692-695
                                                                    * (base.py:411, 505, 643) */
     int32_t spawn_max_tries;                                      /* agent_spawn_kwargs max_tries (<= 1e5) */
+    const uint8_t* spawn_reject;                                  /* agent_spawn_kwargs reject_fn, tabulated like
+                                                                   * MgoGenOp.reject; NULL: none */
 } MgoConfig;
 
 typedef struct MgoEnv MgoEnv;
@@ -134,7 +139,7 @@ int32_t mgo_put_obj(MgoEnv* e, int32_t obj, int32_t x, int32_t y);
 /* reward / position / orientation of agent k's 'rich' observation (base.py:461-471) */
 void mgo_rich_obs(const MgoEnv* e, int32_t k, double* reward, double* position2, int32_t* orientation);
 int32_t mgo_place_obj(MgoEnv* e, int32_t what, int32_t x0, int32_t y0, int32_t x1, int32_t y1, int32_t max_tries,
-                      int32_t* out_xy);
+                      const uint8_t* reject, int32_t* out_xy);
 int32_t mgo_try_place_obj(MgoEnv* e, int32_t what, int32_t x, int32_t y);
 int32_t mgo_regen_grid(MgoEnv* e, int32_t which_gen);
 int32_t mgo_place_agent_at(MgoEnv* e, int32_t k, int32_t x, int32_t y);

@@ -68,7 +68,7 @@ class ObjDesc(C.Structure):
 
 
 class GenOp(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("kind", "obj", "count", "x", "y", "w", "h", "max_tries")]
+    _fields_ = [(n, C.c_int32) for n in ("kind", "obj", "count", "x", "y", "w", "h", "max_tries")] + [("reject", C.c_void_p)]
 
 
 class Config(C.Structure):
@@ -84,7 +84,7 @@ class Config(C.Structure):
                 ("prestige_beta", C.c_double * MAX_AGENTS), ("prestige_scale", C.c_double * MAX_AGENTS),
                 ("hide_type_mask", C.c_uint32 * MAX_AGENTS),
                 ("spawn_x0", C.c_int32), ("spawn_y0", C.c_int32), ("spawn_x1", C.c_int32), ("spawn_y1", C.c_int32),
-                ("spawn_max_tries", C.c_int32)]
+                ("spawn_max_tries", C.c_int32), ("spawn_reject", C.c_void_p)]
 
 
 _lib = None
@@ -127,7 +127,7 @@ def lib():
         L.mgo_set_agent_dir.argtypes = [vp, C.c_int32, C.c_int32]
         L.mgo_set_carrying.argtypes = [vp, C.c_int32, C.c_int32]
         L.mgo_regen_grid.argtypes = [vp, C.c_int32]
-        L.mgo_place_obj.argtypes = [vp] + [C.c_int32] * 6 + [i32p]
+        L.mgo_place_obj.argtypes = [vp] + [C.c_int32] * 6 + [vp, i32p]
         L.mgo_try_place_obj.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
         L.mgo_put_obj.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
         L.mgo_place_agent_at.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
@@ -220,8 +220,17 @@ def _sprite(o):
 _GEN_KIND = {"wall_rect": 0, "horz_wall": 1, "vert_wall": 2, "put": 3, "place": 4}
 
 
+def reject_mask(cells, W, H):
+    """place_obj(reject_fn=) as data: the rejected cells ((x, y), ...) -> uint8 mask indexed x*H + y"""
+    m = np.zeros(W * H, np.uint8)
+    for (x, y) in cells:
+        m[x * H + y] = 1
+    return m
+
+
 def make_config(spec):
     cfg = Config()
+    cfg._keep = []                    # the reject masks the struct points at
     cfg.W, cfg.H = spec["W"], spec["H"]
     agents = spec["agents"]
     cfg.n_agents = len(agents)
@@ -241,6 +250,10 @@ def make_config(spec):
     cfg.spawn_x0, cfg.spawn_y0 = top
     cfg.spawn_x1, cfg.spawn_y1 = min(top[0] + size[0], cfg.W), min(top[1] + size[1], cfg.H)
     cfg.spawn_max_tries = int(max(1, min(sp.get("max_tries", 1e5), 1e5)))
+    if sp.get("reject"):              # agent_spawn_kwargs['reject_fn'], tabulated: the rejected cells
+        m = reject_mask(sp["reject"], cfg.W, cfg.H)
+        cfg._keep.append(m)
+        cfg.spawn_reject = m.ctypes.data
     cfg.agent_type_idx = TYPE_IDX["GridAgentInterface"]
     for k, a in enumerate(agents):
         cfg.agent_color_idx[k] = COLOR_TO_IDX[a["color"]]
@@ -314,8 +327,12 @@ def make_config(spec):
                 op.obj, op.x, op.y = g[1:4]
             elif g[0] == "place":
                 op.obj, op.count, op.max_tries = g[1:4]
-                if len(g) == 8:                      # sampling rectangle [x0,x1) x [y0,y1)
+                if len(g) >= 8:                      # sampling rectangle [x0,x1) x [y0,y1)
                     op.x, op.y, op.w, op.h = g[4], g[5], g[6] - g[4], g[7] - g[5]
+                if len(g) == 9 and g[8]:             # reject_fn, tabulated: the rejected cells ((x, y), ...)
+                    m = reject_mask(g[8], cfg.W, cfg.H)
+                    cfg._keep.append(m)
+                    op.reject = m.ctypes.data
     return cfg
 
 
@@ -433,11 +450,14 @@ class OracleEnv(object):
     def put_obj(self, obj, x, y):
         _raise(self.L.mgo_put_obj(self.h, obj, x, y))
 
-    def place_obj(self, what, region=None, max_tries=100000):
-        """live place_obj: what >= 1 object id, what < 0 agent -(what+1). Returns (x, y)."""
+    def place_obj(self, what, region=None, max_tries=100000, reject=None):
+        """live place_obj: what >= 1 object id, what < 0 agent -(what+1); reject: rejected cells ((x, y), ...).
+        Returns (x, y)."""
         x0, y0, x1, y1 = region or (0, 0, self.W, self.H)
         xy = np.zeros(2, np.int32)
-        _raise(self.L.mgo_place_obj(self.h, what, x0, y0, x1, y1, int(max_tries), _p(xy, C.c_int32)))
+        m = reject_mask(reject, self.W, self.H) if reject else None
+        _raise(self.L.mgo_place_obj(self.h, what, x0, y0, x1, y1, int(max_tries),
+                                    None if m is None else C.c_void_p(m.ctypes.data), _p(xy, C.c_int32)))
         return int(xy[0]), int(xy[1])
 
     def try_place_obj(self, what, x, y):

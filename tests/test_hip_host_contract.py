@@ -87,7 +87,7 @@ def test_obs_buffer_placement_search():
             o, r, d, _ = env.step(torch.randint(0, 7, (B, 3), generator=g))
         if mode == "search":
             pm = env._groups[0].placement_ms
-            assert 2 <= pm["candidates"] <= 66 and pm["seconds"] < 4.0 and len(pm["kept"]) == 2
+            assert 2 <= pm["candidates"] <= 258 and pm["seconds"] < 4.0 and len(pm["kept"]) == 2
             assert sorted(pm["all"])[:2] == sorted(pm["kept"])          # the fastest two were kept
             assert torch.cuda.mem_get_info()[0] > free0 - (4 << 30)     # the rejected candidates are back
         outs.setdefault(mode, []).append((o.cpu(), r.cpu(), d.cpu()))

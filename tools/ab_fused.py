@@ -19,7 +19,7 @@ names = sys.argv[1:]
 B = int(os.environ.get("B", "32768"))
 WL = os.environ.get("WL", "MarlGrid-3AgentCluttered15x15-v0")
 g = torch.Generator().manual_seed(0)
-env = make(WL, batch_size=B, auto_reset=True, strict=False, place_obs=False)
+env = make(WL, batch_size=B, auto_reset=True, strict=False, place_obs=("search" if os.environ.get("PLACE", "1") != "0" else False))
 n = env.num_agents
 acts = [torch.randint(0, 7, (B, n), generator=g).cuda() for _ in range(16)]
 vp, i32 = C.c_void_p, C.c_int32
@@ -42,7 +42,7 @@ def launch(L, e, i):
 env.reset()
 env.step(acts[0])          # (traces the reset program)
 if os.environ.get("CHECK", "1") != "0":
-    ref = make(WL, batch_size=B, auto_reset=True, strict=False, place_obs=False)
+    ref = make(WL, batch_size=B, auto_reset=True, strict=False, place_obs=("search" if os.environ.get("PLACE", "1") != "0" else False))
     ref.reset()
     ref.step(acts[0])
     for nm in names[1:]:

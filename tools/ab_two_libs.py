@@ -15,7 +15,7 @@ from marlgrid_amd.envs import make  # noqa: E402
 other = C.CDLL(os.path.abspath(sys.argv[1]))
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 9
 B = int(os.environ.get("B", "32768"))
-env = make(os.environ.get("WL", "MarlGrid-3AgentCluttered15x15-v0"), batch_size=B, auto_reset=True, strict=False, place_obs=False)
+env = make(os.environ.get("WL", "MarlGrid-3AgentCluttered15x15-v0"), batch_size=B, auto_reset=True, strict=False, place_obs=("search" if os.environ.get("PLACE", "1") != "0" else False))
 env.reset()
 g = torch.Generator().manual_seed(0)
 for i in range(30):
