@@ -153,6 +153,9 @@ typedef struct MgConfig {
     const uint8_t* atlas;   /* device, [4 orientations][n_tiles][tile_size*tile_size*3], pre-rotated.
                              * tile 0 = shadow; 1+o = object o alone (o=0: empty tile);
                              * 1+n_obj+(slot*n_agents+k)*4+d = slot's object with agent k facing d */
+    const uint8_t* spawn_reject; /* device [cells_stride] or NULL: agent_spawn_kwargs['reject_fn'] (base.py:411, 505,
+                             * 643 -> :700-701) tabulated over the grid, index x*H + y, != 0 = rejected: a rejected
+                             * draw is a spent try, exactly like a cell that does not accept the agent */
 } MgConfig;
 
 typedef struct MgState {
@@ -177,11 +180,17 @@ typedef struct MgGenOp {
     int32_t obj, count, max_tries;
     int32_t x0, y0, x1, y1;       /* sampling rectangle [x0,x1) x [y0,y1): place_obj(top=, size=) clamped
                                    * to the grid (base.py:692-695); the whole grid by default */
+    int32_t reject;               /* place_obj(reject_fn=) (base.py:690, 700-701): the callback tabulated once over the
+                                   * grid — row `reject` of MgGenProgram.reject, -1 = none.  A per-draw Python callback
+                                   * cannot run on the device; a function of the position alone is a table. */
 } MgGenOp;
 typedef struct MgGenProgram {
     const uint8_t* template_grid; /* device, [cells_stride] */
     int32_t n_ops;
     MgGenOp ops[MG_MAX_GEN];      /* place_obj(obj, max_tries) x count, in order */
+    const uint8_t* reject;        /* device, [n_reject][cells_stride], index x*H + y, != 0 = rejected; NULL if no op
+                                   * has a reject table */
+    int32_t n_reject;
 } MgGenProgram;
 
 int32_t mg_abi_version(void);
@@ -239,7 +248,8 @@ int32_t mg_put_obj(const MgConfig* cfg, const MgState* st, int32_t obj, int32_t 
  * at that cell (try_place_obj).  out_pos: device int32 [B][2] or NULL; out_ok: device uint8 [B] or NULL. */
 int32_t mg_place(const MgConfig* cfg, const MgState* st, int32_t what, int32_t x0, int32_t y0, int32_t x1,
                  int32_t y1, int32_t max_tries, const int32_t* fixed_pos, const uint8_t* env_mask,
-                 int32_t* out_pos, uint8_t* out_ok, void* stream);
+                 const uint8_t* reject, int32_t* out_pos, uint8_t* out_ok, void* stream);
+/* reject: device uint8 [cells_stride] or NULL — place_obj(reject_fn=) tabulated (see MgGenOp.reject). */
 
 /* Whole-grid human view of selected envs (caller-side format, not on the step path).
  * env_ids: device int32 [n_envs]; frame_atlas: device uint8 [n_tiles][ts][ts][3] (orientation 0,

@@ -48,7 +48,7 @@ class Config(C.Structure):
                 ("prestige_mask", C.c_uint32), ("prestige_amax", C.c_uint8 * 4), ("prestige_sprite_tile", C.c_int32),
                 ("prestige_beta", C.c_double * MAX_AGENTS), ("prestige_scale", C.c_double * MAX_AGENTS),
                 ("any_hide", C.c_int32), ("hide_agent_mask", C.c_uint32), ("hide_obj_mask", C.c_uint64 * MAX_AGENTS),
-                ("obj", C.c_void_p), ("atlas", C.c_void_p)]
+                ("obj", C.c_void_p), ("atlas", C.c_void_p), ("spawn_reject", C.c_void_p)]
 
 
 class State(C.Structure):
@@ -59,11 +59,12 @@ class State(C.Structure):
 
 class GenOp(C.Structure):
     _fields_ = [("obj", C.c_int32), ("count", C.c_int32), ("max_tries", C.c_int32),
-                ("x0", C.c_int32), ("y0", C.c_int32), ("x1", C.c_int32), ("y1", C.c_int32)]
+                ("x0", C.c_int32), ("y0", C.c_int32), ("x1", C.c_int32), ("y1", C.c_int32), ("reject", C.c_int32)]
 
 
 class GenProgram(C.Structure):
-    _fields_ = [("template_grid", C.c_void_p), ("n_ops", C.c_int32), ("ops", GenOp * MAX_GEN)]
+    _fields_ = [("template_grid", C.c_void_p), ("n_ops", C.c_int32), ("ops", GenOp * MAX_GEN),
+                ("reject", C.c_void_p), ("n_reject", C.c_int32)]
 
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmarlgrid_hip.so")
@@ -128,7 +129,7 @@ def lib():
     L.mg_render_obs.argtypes = [C.POINTER(Config), C.POINTER(State), vp, vp, vp, vp, vp]
     L.mg_encode.argtypes = [C.POINTER(Config), C.POINTER(State), vp, vp, vp]
     L.mg_put_obj.argtypes = [C.POINTER(Config), C.POINTER(State), i32, i32, i32, vp, vp]
-    L.mg_place.argtypes = [C.POINTER(Config), C.POINTER(State), i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]
+    L.mg_place.argtypes = [C.POINTER(Config), C.POINTER(State), i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]
     L.mg_render_frame.argtypes = [C.POINTER(Config), C.POINTER(State), vp, i32, vp, i32, i32, C.c_uint32, vp, vp]
     L.mg_time_render_obs.argtypes = [C.POINTER(Config), C.POINTER(State), vp, i32, C.POINTER(C.c_float), vp]
     for f in SYMBOLS:

@@ -630,6 +630,13 @@ class MultiGridEnv(object):
                                          self._mask_ptr(env_mask), self._stream()))
         return True
 
+    def _table_dev(self, table):
+        """a (W, H) uint8 table as the device layout the kernels index (x*H + y, cells_stride bytes)"""
+        import torch
+        t = np.zeros(self.cells_stride, np.uint8)
+        t[:self.width * self.height] = np.asarray(table, np.uint8).reshape(-1)
+        return torch.from_numpy(t).to(self.device)
+
     def _place_region(self, top, size):
         # sampling rectangle, clamped exactly like base.py:692-695
         top = (0, 0) if top is None else (max(int(top[0]), 0), max(int(top[1]), 0))
@@ -646,7 +653,7 @@ class MultiGridEnv(object):
         return self.obj_reg.get_key(obj)
 
     @_on_device
-    def _place_live(self, obj, top, size, max_tries, env_mask):
+    def _place_live(self, obj, top, size, max_tries, env_mask, reject_fn=None):
         """place_obj on the live grids: per-env rejection sampling on each env's RNG.  Returns the
         chosen positions (B, 2) int32 (-1, -1 where it failed: RecursionError on check_errors())."""
         import torch
@@ -654,25 +661,44 @@ class MultiGridEnv(object):
         self._sync_tables()
         x0, y0, x1, y1 = self._place_region(top, size)
         pos = torch.empty((self.batch_size, 2), dtype=torch.int32, device=self.device)
+        rej = self._reject_table(reject_fn, (x0, y0, x1, y1))
+        rej_dev = None if rej is None else self._table_dev(rej)
         N.check(self._lib.mg_place(C.byref(self._cfg), C.byref(self._state), what, x0, y0, x1, y1,
                                    int(max(1, min(max_tries, 1e5))), None, self._mask_ptr(env_mask),
+                                   None if rej_dev is None else C.c_void_p(rej_dev.data_ptr()),
                                    pos.data_ptr(), None, self._stream()))
         if self.strict:
             self.check_errors()
         return pos
 
+    def _reject_table(self, reject_fn, region):
+        """place_obj(reject_fn=) as data: the reference calls `reject_fn(pos)` with the drawn position and nothing
+        else (base.py:700-701) — a function of the position alone is a table.  Evaluated once over the sampling
+        rectangle (the only positions that can be drawn): (W, H) uint8, 1 = rejected; None without a callback.
+        (A callback that looks at anything else — per-env state, a counter — cannot be batched and is not
+        supported: it would see one call per cell here, not one per draw.)"""
+        if reject_fn is None:
+            return None
+        x0, y0, x1, y1 = region
+        t = np.zeros((self.width, self.height), np.uint8)
+        for x in range(x0, x1):
+            for y in range(y0, y1):
+                t[x, y] = 1 if reject_fn(np.array([x, y])) else 0
+        return t
+
     def place_obj(self, obj, top=None, size=None, reject_fn=None, max_tries=1e5, env_mask=None):
         """Rejection-sample a free cell for `obj` (base.py:690-708).  Inside `_gen_grid` this records
-        one placement; the draw happens on the device, per env."""
-        if reject_fn is not None:
-            raise NotImplementedError("place_obj(reject_fn=) is a Python callback per draw: not supported")
+        one placement; the draw happens on the device, per env.  `reject_fn(pos)` is tabulated over the
+        sampling rectangle once (see `_reject_table`)."""
         if not self._tracing:
-            return self._place_live(obj, top, size, max_tries, env_mask)
+            return self._place_live(obj, top, size, max_tries, env_mask, reject_fn)
         if isinstance(obj, GridAgentInterface):
             raise NotImplementedError("inside _gen_grid agents are placed by reset() itself")
         max_tries = int(max(1, min(max_tries, 1e5)))
         key = self.obj_reg.get_key(obj)
-        op = (key, 1, max_tries) + self._place_region(top, size)
+        region = self._place_region(top, size)
+        rej = self._reject_table(reject_fn, region)
+        op = (key, 1, max_tries) + region + (None if rej is None else rej.tobytes(),)
         if self._tr_ops and self._tr_ops[-1][0] == key and self._tr_ops[-1][2:] == op[2:]:
             self._tr_ops[-1] = (key, self._tr_ops[-1][1] + 1) + op[2:]
         else:
@@ -694,7 +720,7 @@ class MultiGridEnv(object):
         p = p.contiguous()
         ok = torch.zeros((self.batch_size,), dtype=torch.uint8, device=self.device)
         N.check(self._lib.mg_place(C.byref(self._cfg), C.byref(self._state), what, 0, 0, self.width, self.height, 1,
-                                   p.data_ptr(), self._mask_ptr(env_mask), None, ok.data_ptr(), self._stream()))
+                                   p.data_ptr(), self._mask_ptr(env_mask), None, None, ok.data_ptr(), self._stream()))
         return ok.bool()
 
     def place_agents(self, top=None, size=None, rand_dir=True, max_tries=1000):
@@ -800,12 +826,20 @@ class MultiGridEnv(object):
         cfg.auto_reset = int(self.auto_reset)
         # place_obj(agent, **agent_spawn_kwargs) (base.py:411, 505, 643)
         kw = dict(self.agent_spawn_kwargs or {})
-        if kw.pop("reject_fn", None) is not None:
-            raise NotImplementedError("agent_spawn_kwargs['reject_fn'] is a Python callback per draw: not supported")
+        reject_fn = kw.pop("reject_fn", None)
         top, size, max_tries = kw.pop("top", None), kw.pop("size", None), kw.pop("max_tries", 1e5)
         if kw:
             raise TypeError("place_obj() got an unexpected keyword argument %r" % sorted(kw)[0])
         cfg.spawn_x0, cfg.spawn_y0, cfg.spawn_x1, cfg.spawn_y1 = self._place_region(top, size)
+        # agent_spawn_kwargs['reject_fn'] (base.py:411, 505, 643 -> :700-701): tabulated like place_obj's
+        self._spawn_reject = self._reject_table(reject_fn, (cfg.spawn_x0, cfg.spawn_y0, cfg.spawn_x1, cfg.spawn_y1))
+        if self._spawn_reject is not None and not self._dry:
+            if getattr(self, "_spawn_reject_key", None) != self._spawn_reject.tobytes():
+                self._spawn_reject_dev = self._table_dev(self._spawn_reject)
+                self._spawn_reject_key = self._spawn_reject.tobytes()
+            cfg.spawn_reject = self._spawn_reject_dev.data_ptr()
+        else:
+            cfg.spawn_reject = None
         cfg.spawn_max_tries = int(max(1, min(max_tries, 1e5)))
         for k, a in enumerate(self.agents):
             if a.spawn_delay < 0:
@@ -868,9 +902,20 @@ class MultiGridEnv(object):
         prog._template_dev = torch.from_numpy(t).to(self.device)
         prog.template_grid = prog._template_dev.data_ptr()
         prog.n_ops = len(ops)
-        for i, (obj, count, max_tries, x0, y0, x1, y1) in enumerate(ops):
+        tables = []                   # place_obj(reject_fn=) tables, one row of cells_stride bytes each
+        for i, (obj, count, max_tries, x0, y0, x1, y1, rej) in enumerate(ops):
             o = prog.ops[i]
             o.obj, o.count, o.max_tries, o.x0, o.y0, o.x1, o.y1 = obj, count, max_tries, x0, y0, x1, y1
+            o.reject = -1
+            if rej is not None:
+                row = np.zeros(self.cells_stride, np.uint8)
+                row[:self.width * self.height] = np.frombuffer(rej, np.uint8)
+                o.reject = len(tables)
+                tables.append(row)
+        prog.n_reject = len(tables)
+        if tables:
+            prog._reject_dev = torch.from_numpy(np.stack(tables)).to(self.device)
+            prog.reject = prog._reject_dev.data_ptr()
         self._prog_cache[key] = prog
         return prog
 
@@ -1223,9 +1268,13 @@ class MultiGridEnv(object):
 
         def prog(p):
             out = list(p["sym"])
-            for (k, c, t, x0, y0, x1, y1) in p["ops"]:
+            for (k, c, t, x0, y0, x1, y1, rej) in p["ops"]:
                 full = (x0, y0, x1, y1) == (0, 0, self.width, self.height)
-                out.append(("place", k, c, t) if full else ("place", k, c, t, x0, y0, x1, y1))
+                if rej is not None:      # reject_fn, tabulated: the rejected cells of the sampling rectangle
+                    cells = np.argwhere(np.frombuffer(rej, np.uint8).reshape(self.width, self.height))
+                    out.append(("place", k, c, t, x0, y0, x1, y1, tuple((int(x), int(y)) for x, y in cells)))
+                else:
+                    out.append(("place", k, c, t) if full else ("place", k, c, t, x0, y0, x1, y1))
             return out
         def aspec(a):
             d = dict(color=a.color)
@@ -1245,7 +1294,11 @@ class MultiGridEnv(object):
         extra = {}
         if self.agent_spawn_kwargs:
             extra["agent_spawn"] = {k: (tuple(v) if k in ("top", "size") else v)
-                                    for k, v in self.agent_spawn_kwargs.items()}
+                                    for k, v in self.agent_spawn_kwargs.items() if k != "reject_fn"}
+            if self.agent_spawn_kwargs.get("reject_fn") is not None:
+                x0, y0, x1, y1 = self._place_region(self.agent_spawn_kwargs.get("top"), self.agent_spawn_kwargs.get("size"))
+                t = self._reject_table(self.agent_spawn_kwargs["reject_fn"], (x0, y0, x1, y1))
+                extra["agent_spawn"]["reject"] = tuple((int(x), int(y)) for x, y in np.argwhere(t))
         return dict(W=self.width, H=self.height, agents=[aspec(a) for a in self.agents], **extra,
                     view_size=self.view_size, tile_size=self.tile_size, view_offset=self.view_offset,
                     see_through_walls=self.see_through_walls, max_steps=self.max_steps,

@@ -38,6 +38,7 @@ int check_prog(const MgConfig* cfg, const MgGenProgram* prog) {
         const MgGenOp& op = prog->ops[i];
         if (op.obj <= 0 || op.obj >= cfg->n_obj || op.count < 0) return MG_E_ARG;
         if (op.x0 < 0 || op.y0 < 0 || op.x1 > cfg->W || op.y1 > cfg->H || op.x1 <= op.x0 || op.y1 <= op.y0) return MG_E_ARG;
+        if (op.reject < -1 || op.reject >= prog->n_reject || (op.reject >= 0 && !prog->reject)) return MG_E_ARG;
     }
     return MG_OK;
 }
@@ -150,7 +151,7 @@ int32_t mg_step_render(const MgConfig* cfg, const MgState* st, const void* actio
     fs.enabled = 1;
     fs.has_prog = auto_reset ? 1 : 0;
     if (auto_reset) fs.prog = *auto_reset;
-    else { fs.prog.template_grid = nullptr; fs.prog.n_ops = 0; }
+    else { fs.prog.template_grid = nullptr; fs.prog.n_ops = 0; fs.prog.reject = nullptr; fs.prog.n_reject = 0; }
     return rc(mg::launch_render(*cfg, *st, obs, nullptr, nullptr, nullptr, (hipStream_t)stream, &fs));
 }
 
@@ -174,8 +175,8 @@ int32_t mg_put_obj(const MgConfig* cfg, const MgState* st, int32_t obj, int32_t 
 }
 
 int32_t mg_place(const MgConfig* cfg, const MgState* st, int32_t what, int32_t x0, int32_t y0, int32_t x1, int32_t y1,
-                 int32_t max_tries, const int32_t* fixed_pos, const uint8_t* env_mask, int32_t* out_pos,
-                 uint8_t* out_ok, void* stream) {
+                 int32_t max_tries, const int32_t* fixed_pos, const uint8_t* env_mask, const uint8_t* reject,
+                 int32_t* out_pos, uint8_t* out_ok, void* stream) {
     int e = check_cfg(cfg);
     if (e) return e;
     e = check_state(st);
@@ -183,7 +184,7 @@ int32_t mg_place(const MgConfig* cfg, const MgState* st, int32_t what, int32_t x
     if (what == 0 || what >= cfg->n_obj || -(what + 1) >= cfg->n_agents) return MG_E_ARG;
     if (!fixed_pos && (x0 < 0 || y0 < 0 || x1 > cfg->W || y1 > cfg->H || x1 <= x0 || y1 <= y0 || max_tries < 1))
         return MG_E_ARG;
-    return rc(mg::launch_place(*cfg, *st, what, x0, y0, x1, y1, max_tries, fixed_pos, env_mask, out_pos, out_ok,
+    return rc(mg::launch_place(*cfg, *st, what, x0, y0, x1, y1, max_tries, fixed_pos, env_mask, reject, out_pos, out_ok,
                                (hipStream_t)stream));
 }
 

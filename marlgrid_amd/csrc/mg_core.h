@@ -229,6 +229,7 @@ MG_HD bool place_agent(const MgConfig& cfg, const uint8_t* oflags, uint8_t* g, M
         // np_random.randint(top, bottom): low + bounded(high - low - 1) per coordinate
         const int x = x0 + (int)mt.bounded(mx);
         const int y = y0 + (int)mt.bounded(my);
+        if (cfg.spawn_reject && cfg.spawn_reject[x * H + y]) continue;   // reject_fn(pos): a spent try (base.py:700-701)
         const uint32_t base = g[x * H + y];
         const uint32_t xy = (uint32_t)x | ((uint32_t)y << 8);
         const int cnt = agents_on(rec, S, col, n, xy);
@@ -270,6 +271,7 @@ MG_HD int reset_env(const MgConfig& cfg, const MgState& st, const MgGenProgram& 
                 const int x = op.x0 + (int)mt.bounded((uint32_t)(op.x1 - op.x0 - 1));
                 const int y = op.y0 + (int)mt.bounded((uint32_t)(op.y1 - op.y0 - 1));
                 const int cell = x * H + y;
+                if (op.reject >= 0 && prog.reject[(size_t)op.reject * cfg.cells_stride + cell]) continue;   // reject_fn(pos)
                 if (g[cell] == 0) { g[cell] = (uint8_t)op.obj; ok = true; break; }
             }
             if (!ok) err = MG_ERR_RECURSION;
@@ -546,8 +548,8 @@ MG_HD void reset_run(const MgConfig& cfg, const MgState& st, const MgGenProgram&
 
 // ---- MultiGridEnv.place_obj / try_place_obj on a live grid (base.py:664-708) for one env -------------
 MG_HD void place_run(const MgConfig& cfg, const MgState& st, const uint8_t* oflags, int b, int what, int x0, int y0,
-                     int x1, int y1, int max_tries, const int32_t* fixed_pos, int32_t* out_pos, uint8_t* out_ok,
-                     uint64_t* rec, int S, int col) {
+                     int x1, int y1, int max_tries, const int32_t* fixed_pos, const uint8_t* reject, int32_t* out_pos,
+                     uint8_t* out_ok, uint64_t* rec, int S, int col) {
     const int n = cfg.n_agents, H = cfg.H;
     uint8_t* g = st.grid + (size_t)b * cfg.cells_stride;
     uint32_t* head = st.mt_head + (size_t)b * MG_MT_HEAD;
@@ -567,6 +569,7 @@ MG_HD void place_run(const MgConfig& cfg, const MgState& st, const uint8_t* ofla
         else {
             x = x0 + (int)mt.bounded((uint32_t)(x1 - x0 - 1));
             y = y0 + (int)mt.bounded((uint32_t)(y1 - y0 - 1));
+            if (reject && reject[x * H + y]) continue;       // reject_fn(pos): a spent try (base.py:700-701)
         }
         const uint32_t base = g[x * H + y];
         const uint32_t xy = (uint32_t)x | ((uint32_t)y << 8);

@@ -22,7 +22,8 @@ hipError_t launch_encode(const MgConfig& cfg, const MgState& st, const uint8_t* 
 hipError_t launch_put_obj(const MgConfig& cfg, const MgState& st, int obj, int x, int y, const uint8_t* mask,
                           hipStream_t s);
 hipError_t launch_place(const MgConfig& cfg, const MgState& st, int what, int x0, int y0, int x1, int y1, int max_tries,
-                        const int32_t* fixed_pos, const uint8_t* mask, int32_t* out_pos, uint8_t* out_ok, hipStream_t s);
+                        const int32_t* fixed_pos, const uint8_t* mask, const uint8_t* reject, int32_t* out_pos,
+                        uint8_t* out_ok, hipStream_t s);
 hipError_t launch_frame(const MgConfig& cfg, const MgState& st, const int32_t* env_ids, int K, const uint8_t* atlas,
                         int ts, int highlight, uint32_t amax, uint8_t* out, hipStream_t s);
 }  // namespace mg

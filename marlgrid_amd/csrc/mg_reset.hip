@@ -43,25 +43,25 @@ __global__ __launch_bounds__(kBlock) void put_obj_kernel(MgConfig cfg, MgState s
 // MultiGridEnv.place_obj / try_place_obj on a live grid (base.py:664-708): lane per env.
 __global__ __launch_bounds__(kBlock) void place_kernel(MgConfig cfg, MgState st, int what, int x0, int y0, int x1,
                                                        int y1, int max_tries, const int32_t* __restrict__ fixed_pos,
-                                                       const uint8_t* __restrict__ mask, int32_t* __restrict__ out_pos,
-                                                       uint8_t* __restrict__ out_ok) {
+                                                       const uint8_t* __restrict__ mask, const uint8_t* __restrict__ reject,
+                                                       int32_t* __restrict__ out_pos, uint8_t* __restrict__ out_ok) {
     extern __shared__ __attribute__((aligned(16))) uint64_t s_rec[];  // [n][kBlock]
     uint8_t* s_oflags = reinterpret_cast<uint8_t*>(s_rec + (size_t)cfg.n_agents * kBlock);
     stage_oflags(cfg, s_oflags);
     const int b = blockIdx.x * kBlock + threadIdx.x;
     if (b >= cfg.B) return;
     if (mask && !mask[b]) return;
-    place_run(cfg, st, s_oflags, b, what, x0, y0, x1, y1, max_tries, fixed_pos, out_pos, out_ok, s_rec, kBlock,
+    place_run(cfg, st, s_oflags, b, what, x0, y0, x1, y1, max_tries, fixed_pos, reject, out_pos, out_ok, s_rec, kBlock,
               (int)threadIdx.x);
 }
 
 hipError_t launch_place(const MgConfig& cfg, const MgState& st, int what, int x0, int y0, int x1, int y1, int max_tries,
-                        const int32_t* fixed_pos, const uint8_t* mask, int32_t* out_pos, uint8_t* out_ok,
-                        hipStream_t s) {
+                        const int32_t* fixed_pos, const uint8_t* mask, const uint8_t* reject, int32_t* out_pos,
+                        uint8_t* out_ok, hipStream_t s) {
     if (cfg.B <= 0) return hipSuccess;
     const size_t lds = (size_t)cfg.n_agents * kBlock * sizeof(uint64_t) + MG_MAX_OBJ;
     hipLaunchKernelGGL(place_kernel, dim3((cfg.B + kBlock - 1) / kBlock), dim3(kBlock), lds, s, cfg, st, what, x0, y0,
-                       x1, y1, max_tries, fixed_pos, mask, out_pos, out_ok);
+                       x1, y1, max_tries, fixed_pos, mask, reject, out_pos, out_ok);
     return hipGetLastError();
 }
 

@@ -47,6 +47,7 @@ TRAJ = {  # scenario -> (n_seeds, n_steps, n_full_obs_seeds)
     "Test-3AgentCluttered9x9-hide": (6, 120, 2),
     "Test-2AgentRegion9x9": (6, 100, 1),
     "Test-3AgentSpawnRect9x9": (8, 150, 1),
+    "Test-2AgentReject9x9": (8, 150, 1),
     "Test-3AgentEmpty7x7-rich": (6, 90, 2),
     "Test-3AgentCluttered9x9-hetero-views": (6, 100, 2),
     "Test-2AgentGoalcycle9x9-prestige": (8, 120, 2),

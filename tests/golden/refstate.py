@@ -29,6 +29,8 @@ def make_ref_env(spec, recipe, seed=1337):
         return _region_env_class()(agents=agents, **kw)
     if cls_name == "SpawnRectTestEnv":
         return _spawn_rect_env_class()(agents=agents, **kw)
+    if cls_name == "RejectTestEnv":
+        return _reject_env_class()(agents=agents, **kw)
     return getattr(E, cls_name)(agents=agents, **kw)
 
 
@@ -50,6 +52,29 @@ def _spawn_rect_env_class():
             for _ in range(4):
                 self.place_obj(Wall(), max_tries=100)
     return SpawnRectTestEnv
+
+
+def _reject_env_class():
+    """A test-only scenario ON TOP OF the reference's classes exercising place_obj(reject_fn=) (base.py:690-708):
+    clutter on odd-parity cells only, a locked Door off the diagonal of a 4x4 corner; `agent_spawn_kwargs` (left
+    alone by `_gen_grid`) carries a reject_fn too.  The callbacks are the texts in tests/scenarios.py."""
+    from marlgrid.base import MultiGridEnv, MultiGrid
+    from marlgrid.objects import Goal, Wall, Door
+    import scenarios
+
+    class RejectTestEnv(MultiGridEnv):
+        mission = ""
+        metadata = {}
+
+        def _gen_grid(self, width, height):
+            self.grid = MultiGrid((width, height))
+            self.grid.wall_rect(0, 0, width, height)
+            self.put_obj(Goal(color="green", reward=1), width - 2, height - 2)
+            for _ in range(5):
+                self.place_obj(Wall(), reject_fn=eval(scenarios.REJECT_CLUTTER), max_tries=200)
+            self.place_obj(Door(color="yellow", state=3), top=(1, 1), size=(4, 4), reject_fn=eval(scenarios.REJECT_DOOR),
+                           max_tries=100)
+    return RejectTestEnv
 
 
 def _region_env_class():

@@ -68,6 +68,10 @@ class HostEmu(object):
             self._tables_version = env.obj_reg.version
         else:
             env._refresh_cfg(self.cfg)
+        if getattr(env, "_spawn_reject", None) is not None:     # agent_spawn_kwargs['reject_fn'], tabulated
+            self._spawn_rej = np.zeros(env.cells_stride, np.uint8)
+            self._spawn_rej[:env.width * env.height] = env._spawn_reject.reshape(-1)
+            self.cfg.spawn_reject = self._spawn_rej.ctypes.data
         return self.cfg
 
     def _prog(self, trace):
@@ -79,9 +83,20 @@ class HostEmu(object):
         prog._keep = t
         prog.template_grid = t.ctypes.data
         prog.n_ops = len(ops)
-        for i, (obj, count, max_tries, x0, y0, x1, y1) in enumerate(ops):
+        tables = []
+        for i, (obj, count, max_tries, x0, y0, x1, y1, rej) in enumerate(ops):
             o = prog.ops[i]
             o.obj, o.count, o.max_tries, o.x0, o.y0, o.x1, o.y1 = obj, count, max_tries, x0, y0, x1, y1
+            o.reject = -1
+            if rej is not None:                          # place_obj(reject_fn=), tabulated (base.py:_reject_table)
+                row = np.zeros(env.cells_stride, np.uint8)
+                row[:env.width * env.height] = np.frombuffer(rej, np.uint8)
+                o.reject = len(tables)
+                tables.append(row)
+        prog.n_reject = len(tables)
+        if tables:
+            prog._keep_reject = np.stack(tables)
+            prog.reject = prog._keep_reject.ctypes.data
         return prog
 
     def _reset_with(self, trace, mask):
@@ -104,14 +119,19 @@ class HostEmu(object):
         assert rc == 0
         return self.rewards.copy(), self.done.astype(bool)
 
-    def place(self, what, region, max_tries=100000, fixed_pos=None, mask=None):
+    def place(self, what, region, max_tries=100000, fixed_pos=None, mask=None, reject=None):
         x0, y0, x1, y1 = region
         pos = np.zeros((self.B, 2), np.int32)
         ok = np.zeros(self.B, np.uint8)
         fp = None if fixed_pos is None else np.ascontiguousarray(np.broadcast_to(fixed_pos, (self.B, 2)), np.int32)
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        rj = None
+        if reject is not None:                           # (W, H) table
+            rj = np.zeros(self.env.cells_stride, np.uint8)
+            rj[:self.env.width * self.env.height] = np.asarray(reject, np.uint8).reshape(-1)
         self.L.emu_place(C.byref(self._cfg()), C.byref(self.state), what, x0, y0, x1, y1, int(max_tries),
-                         None if fp is None else _ptr(fp), None if m is None else _ptr(m), _ptr(pos), _ptr(ok))
+                         None if fp is None else _ptr(fp), None if m is None else _ptr(m),
+                         None if rj is None else _ptr(rj), _ptr(pos), _ptr(ok))
         return pos, ok.astype(bool)
 
     def canonical(self):

@@ -65,11 +65,11 @@ int emu_step(const MgConfig* cfg, const MgState* st, const void* actions, int ac
 }
 
 int emu_place(const MgConfig* cfg, const MgState* st, int what, int x0, int y0, int x1, int y1, int max_tries,
-              const int32_t* fixed_pos, const uint8_t* mask, int32_t* out_pos, uint8_t* out_ok) {
+              const int32_t* fixed_pos, const uint8_t* mask, const uint8_t* reject, int32_t* out_pos, uint8_t* out_ok) {
     Scratch s(cfg);
     for (int b = 0; b < cfg->B; b++) {
         if (mask && !mask[b]) continue;
-        mg::place_run(*cfg, *st, s.oflags.data(), b, what, x0, y0, x1, y1, max_tries, fixed_pos, out_pos, out_ok,
+        mg::place_run(*cfg, *st, s.oflags.data(), b, what, x0, y0, x1, y1, max_tries, fixed_pos, reject, out_pos, out_ok,
                       s.rec.data(), 1, 0);
     }
     return 0;

@@ -25,6 +25,8 @@ def build(name, **kw):
         return _region_env_class()(agents=agents, **{**kwargs, **kw})
     if cls_name == "SpawnRectTestEnv":
         return _spawn_rect_env_class()(agents=agents, **{**kwargs, **kw})
+    if cls_name == "RejectTestEnv":
+        return _reject_env_class()(agents=agents, **{**kwargs, **kw})
     return getattr(E, cls_name)(agents=agents, **{**kwargs, **kw})
 
 
@@ -43,6 +45,24 @@ def _region_env_class():
             for _ in range(3):
                 self.place_obj(Wall(), top=(width // 2 + 1, 2), size=(width, height - 3), max_tries=50)
     return RegionTestEnv
+
+
+def _reject_env_class():
+    """the product-side twin of tests/golden/refstate.py:_reject_env_class (same _gen_grid text)"""
+    from marlgrid_amd.base import MultiGridEnv, MultiGrid
+    from marlgrid_amd.objects import Goal, Wall, Door
+    import scenarios
+
+    class RejectTestEnv(MultiGridEnv):
+        def _gen_grid(self, width, height):
+            self.grid = MultiGrid((width, height))
+            self.grid.wall_rect(0, 0, width, height)
+            self.put_obj(Goal(color="green", reward=1), width - 2, height - 2)
+            for _ in range(5):
+                self.place_obj(Wall(), reject_fn=eval(scenarios.REJECT_CLUTTER), max_tries=200)
+            self.place_obj(Door(color="yellow", state=3), top=(1, 1), size=(4, 4), reject_fn=eval(scenarios.REJECT_DOOR),
+                           max_tries=100)
+    return RejectTestEnv
 
 
 def _spawn_rect_env_class():

@@ -117,6 +117,8 @@ def ref_recipe(name):
         "Test-2AgentRegion9x9": ("RegionTestEnv", dict(grid_size=9)),
         "Test-3AgentSpawnRect9x9": ("SpawnRectTestEnv", dict(grid_size=9, respawn=True, max_steps=60,
                                                              agent_spawn_kwargs=dict(top=(1, 1), size=(3, 9), max_tries=500))),
+        "Test-2AgentReject9x9": ("RejectTestEnv", dict(grid_size=9, respawn=True, max_steps=60,
+                                                       agent_spawn_kwargs=dict(reject_fn=eval(REJECT_SPAWN), max_tries=1000))),
         "Test-3AgentEmpty7x7-rich": ("EmptyMultiGrid", dict(grid_size=7, max_steps=40)),
         "Test-3AgentCluttered9x9-hetero-views": ("ClutteredMultiGrid", dict(grid_size=9, n_clutter=6, max_steps=50)),
         "Test-2AgentGoalcycle9x9-prestige": ("ClutteredGoalCycleEnv", dict(grid_size=9, n_clutter=4, n_bonus_tiles=3,
@@ -183,6 +185,29 @@ def spawn_rect_spec():
     return s
 
 
+REJECT_CLUTTER = "lambda pos: (pos[0] + pos[1]) % 2 == 0"      # the callbacks of the reject scenario, as text: the
+REJECT_DOOR = "lambda pos: pos[0] == pos[1]"                     # reference-side and product-side twins eval() the same
+REJECT_SPAWN = "lambda pos: pos[1] < 4"
+
+
+def reject_spec():
+    """test-only scenario with place_obj(reject_fn=) inside `_gen_grid` and agent_spawn_kwargs['reject_fn']
+    (base.py:690-708, 411, 505, 643): clutter only on odd-parity cells, a locked Door off the diagonal of a 4x4
+    corner, agents (re)spawning in the lower part of the room only.  See tests/golden/refstate.py:_reject_env_class."""
+    s = _base(2, 9, 7, respawn=True, max_steps=60)
+    W = H = 9
+    s["objects"] = [None, WALL, GOAL, dict(type="Door", color="yellow", state=3),
+                    dict(type="Door", color="yellow", state=1), dict(type="Door", color="yellow", state=2)]
+    s["wall_obj"] = 1
+    even = tuple((x, y) for x in range(W) for y in range(H) if (x + y) % 2 == 0)
+    diag = tuple((x, x) for x in range(1, 5))
+    prog = [("wall_rect", 0, 0, W, H), ("put", 2, W - 2, H - 2), ("place", 1, 5, 200, 0, 0, W, H, even),
+            ("place", 3, 1, 100, 1, 1, 5, 5, diag)]
+    s["gen_ctor"], s["gen_reset"] = prog, prog
+    s["agent_spawn"] = dict(max_tries=1000, reject=tuple((x, y) for x in range(W) for y in range(H) if y < 4))
+    return s
+
+
 def _with_views(spec, views):
     """per-agent view geometry (agents.py:19-35); spec-level view_size / tile_size / ... stay the first agent's"""
     for a, v in zip(spec["agents"], views):
@@ -230,6 +255,7 @@ def registered(name):   # noqa: F811  (extends the table above with test-only sc
         "Test-3AgentCluttered9x9-hide": lambda: _with_hide(cluttered_spec(3, 9, 7, n_clutter=8), [["Wall"], ["Agent", "Goal"], []]),
         "Test-2AgentRegion9x9": lambda: region_spec(),
         "Test-3AgentSpawnRect9x9": lambda: spawn_rect_spec(),
+        "Test-2AgentReject9x9": lambda: reject_spec(),
         # every agent its own view (agents.py:19-35): a 5x5 view at 8 px, a 7x7 view at 5 px looking through walls,
         # a 5x5 view at 8 px again (same group as the first) with the agent one row up
         "Test-3AgentCluttered9x9-hetero-views": lambda: _with_views(
@@ -327,7 +353,7 @@ ALL_SCENARIOS = [
     "Test-2AgentRegion9x9", "Test-2AgentGoalcycle9x9-prestige", "Test-1AgentGoalcycle11x11-prestige-ts11",
     "Test-3AgentCluttered9x9-prestige-mixed", "Test-4AgentEmpty5x5-ghost0", "Test-3AgentEmpty7x11-nonsquare",
     "Test-3AgentCluttered12x6-nonsquare", "Test-3AgentSpawnRect9x9", "Test-3AgentEmpty7x7-rich",
-    "Test-3AgentCluttered9x9-hetero-views",
+    "Test-3AgentCluttered9x9-hetero-views", "Test-2AgentReject9x9",
 ]
 
 

@@ -64,6 +64,7 @@ def test_numpy_form_round_trip():
     ("Test-3AgentCluttered9x9-prestige-mixed", 32, 200, True),
     ("Test-2AgentRegion9x9", 32, 60, True),
     ("Test-3AgentSpawnRect9x9", 48, 200, True),      # agent_spawn_kwargs: reset, late spawn and respawn
+    ("Test-2AgentReject9x9", 48, 200, True),         # place_obj(reject_fn=) tables in _gen_grid and agent_spawn_kwargs
     ("Test-3AgentSpawnRect9x9", 16, 130, False),
 ])
 def test_core_bodies_vs_oracle(name, B, T, auto):

@@ -592,6 +592,14 @@ def test_live_place_obj_and_try_place_obj_vs_oracle():
         assert np.array_equal(pos, want)
     pos = env.place_obj(Goal(color="green", reward=1), top=(2, 3), size=(4, 20), max_tries=100).cpu().numpy()
     assert np.array_equal(pos, np.array([e.place_obj(2, region=(2, 3, 6, 11), max_tries=100) for e in orc.envs]))
+    # place_obj(reject_fn=) on the live grids: the callback is tabulated (a rejected draw is a spent try)
+    rej = tuple((x, y) for x in range(11) for y in range(11) if (x * 3 + y) % 4 != 1)
+    pos = env.place_obj(Wall(), reject_fn=lambda p: (p[0] * 3 + p[1]) % 4 != 1, max_tries=400).cpu().numpy()
+    assert np.array_equal(pos, np.array([e.place_obj(1, max_tries=400, reject=rej) for e in orc.envs]))
+    assert all((x * 3 + y) % 4 == 1 for x, y in pos)
+    pos = env.place_obj(env.agents[2], top=(1, 1), size=(6, 6), reject_fn=lambda p: p[0] > p[1]).cpu().numpy()
+    rej2 = tuple((x, y) for x in range(1, 7) for y in range(1, 7) if x > y)
+    assert np.array_equal(pos, np.array([e.place_obj(-3, region=(1, 1, 7, 7), reject=rej2) for e in orc.envs]))
     # re-seat agent 1 at random (lift + place, highest rank), and try fixed cells for objects / agent 0
     pos = env.place_obj(env.agents[1]).cpu().numpy()
     assert np.array_equal(pos, np.array([e.place_obj(-2) for e in orc.envs]))
@@ -796,6 +804,7 @@ def test_settings_are_read_every_step():
                                        ("Test-3AgentCluttered9x9-respawn", 300, 120),
                                        ("Test-3AgentEmpty7x7-spawn-delay", 64, 60),
                                        ("Test-3AgentSpawnRect9x9", 129, 90),
+                                       ("Test-2AgentReject9x9", 130, 90),
                                        ("Test-3AgentCluttered9x9-prestige-mixed", 5000, 60),
                                        ("Edge-3AgentCluttered15x15-default-tiles", 4099, 40),
                                        ("Custom-8AgentCluttered30x30", 64, 40),

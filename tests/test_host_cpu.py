@@ -105,6 +105,29 @@ def test_scenario_spec_matches_independent_restatement(name):
         assert a[k] == b[k], (k, a[k], b[k])
 
 
+def test_reject_fn_is_recorded_as_tables():
+    """place_obj(reject_fn=) inside `_gen_grid` and agent_spawn_kwargs['reject_fn'] (base.py:690-708): the product
+    tabulates the callbacks over their sampling rectangles; its plain-data spec equals the independent restatement
+    (rejected cells listed), ops that differ only in their table are not merged, and the launch structs carry them."""
+    import product_envs
+    env = product_envs.build("Test-2AgentReject9x9", _dry=True)
+    env.reset()
+    a, b = env.scenario_spec(), scenarios.registered("Test-2AgentReject9x9")
+    for k in b:
+        assert a[k] == b[k], (k, a[k], b[k])
+    template, ops = env._dry_trace
+    assert [(o[0], o[1]) for o in ops] == [(1, 5), (3, 1)] and all(o[7] is not None for o in ops)
+    t = np.frombuffer(ops[1][7], np.uint8).reshape(9, 9)
+    assert sorted(map(tuple, np.argwhere(t))) == [(1, 1), (2, 2), (3, 3), (4, 4)]
+    env._host_tables()             # (derives the launch config on the host: what a non-dry env does before a launch)
+    assert env._spawn_reject is not None and env._spawn_reject[:, :4].all() and not env._spawn_reject[:, 4:].any()
+    # a callback that rejects every cell of the rectangle is a RecursionError at run time, not here; an unknown
+    # keyword in agent_spawn_kwargs still is a TypeError, as place_obj(**kw) would raise upstream
+    env.agent_spawn_kwargs = dict(reject=lambda p: False)
+    with pytest.raises(TypeError):
+        env._refresh_cfg(env._host_tables()[0])
+
+
 def test_fuzz_specs_product_equals_restatement():
     """random constructor knobs (scenarios.fuzz_case): the product's host side derives the same
     plain-data spec (object table, generator program, agent options) as the independent restatement"""
