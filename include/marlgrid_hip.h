@@ -75,6 +75,8 @@ extern "C" {
 #define MG_ERR_RECURSION 2 /* RecursionError: rejection sampling failed base.py:705-706 */
 #define MG_ERR_TYPE 3      /* TypeError: Box.toggle arity               objects.py:381-382 */
 #define MG_ERR_ASSERT 4    /* AssertionError: grid.get out of bounds    base.py:154-156 */
+#define MG_ERR_ATTRIBUTE 5 /* AttributeError: None.can_overlap() — an agent whose cell put_obj(None) emptied moves on
+                            * (base.py:555-558; see MG_AF_EVICTED) */
 
 /* packed agent record (uint64, little endian bytes) */
 #define MG_AG_X 0      /* byte 0: x */
@@ -87,6 +89,11 @@ extern "C" {
 #define MG_AF_ACTIVE 1
 #define MG_AF_DONE 2
 #define MG_AF_PLACED 4
+#define MG_AF_EVICTED 8 /* put_obj replaced the cell the agent stood on (base.py:655-662: `grid.set` drops whatever was
+                         * there): the agent is in no cell any more — nobody sees it, nothing stands on it — but keeps
+                         * its position, turns and looks; its next successful forward move raises what upstream's
+                         * "remove agent from old cell" raises (base.py:555-559): AssertionError on a solid object,
+                         * ValueError (list.remove) on an overlappable one or another agent, AttributeError on None */
 
 /* object descriptor flags */
 #define MG_OF_CAN_OVERLAP 1
@@ -237,7 +244,8 @@ int32_t mg_render_obs(const MgConfig* cfg, const MgState* st, uint8_t* obs, uint
 int32_t mg_encode(const MgConfig* cfg, const MgState* st, const uint8_t* vis_mask, uint8_t* out,
                   void* stream);
 
-/* env_mask as in mg_reset. Replaces whatever is in the cell (base.py:655-662). */
+/* env_mask as in mg_reset. Replaces whatever is in the cell (base.py:655-662) — agents standing there included: they
+ * leave the grid (MG_AF_EVICTED). */
 int32_t mg_put_obj(const MgConfig* cfg, const MgState* st, int32_t obj, int32_t x, int32_t y,
                    const uint8_t* env_mask, void* stream);
 

@@ -11,12 +11,12 @@ MAX_AGENTS, MAX_OBJ, MAX_GEN, MAX_VIEW, KEY_WORDS, MT_N, MT_HEAD = 16, 64, 16, 1
 ABI_VERSION = 3
 
 OK = 0
-ERR_VALUE, ERR_RECURSION, ERR_TYPE, ERR_ASSERT = 1, 2, 3, 4
+ERR_VALUE, ERR_RECURSION, ERR_TYPE, ERR_ASSERT, ERR_ATTRIBUTE = 1, 2, 3, 4, 5
 ERR_EXC = {ERR_VALUE: ValueError, ERR_RECURSION: RecursionError, ERR_TYPE: TypeError,
-           ERR_ASSERT: AssertionError}
+           ERR_ASSERT: AssertionError, ERR_ATTRIBUTE: AttributeError}
 
 AG_X, AG_Y, AG_DIR, AG_FLAGS, AG_CARRY, AG_RANK, AG_BONUS = range(7)
-AF_ACTIVE, AF_DONE, AF_PLACED = 1, 2, 4
+AF_ACTIVE, AF_DONE, AF_PLACED, AF_EVICTED = 1, 2, 4, 8
 OF_CAN_OVERLAP, OF_CAN_PICKUP, OF_SEE_BEHIND, OF_ENDS_EPISODE = 1, 2, 4, 8
 OF_IS_KEY, OF_IS_DOOR, OF_IS_BOX, OF_DOOR_LOCKED = 16, 32, 64, 128
 

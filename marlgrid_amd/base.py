@@ -618,7 +618,9 @@ class MultiGridEnv(object):
 
     @_on_device
     def put_obj(self, obj, i, j, env_mask=None):
-        """Put an object at a specific position, replacing what is there (base.py:655-662)."""
+        """Put an object at a specific position, replacing what is there (base.py:655-662) — an agent standing
+        there included: as upstream it is in no cell afterwards (nobody sees it; it keeps its position, turns
+        and looks), and its next successful forward move raises what upstream raises (MG_AF_EVICTED)."""
         if self._tracing:
             self._tr_grid.set(i, j, obj)
             return True
@@ -1120,7 +1122,8 @@ class MultiGridEnv(object):
             msgs = {N.ERR_VALUE: "Environment can't handle action (env %d)." % b,
                     N.ERR_RECURSION: "Rejection sampling failed in place_obj (env %d)." % b,
                     N.ERR_TYPE: "toggle() takes 1 positional argument but 3 were given (Box, env %d)" % b,
-                    N.ERR_ASSERT: "grid access out of bounds (env %d)" % b}
+                    N.ERR_ASSERT: "grid access out of bounds, or an agent left a cell it is not in (env %d)" % b,
+                    N.ERR_ATTRIBUTE: "'NoneType' object has no attribute 'can_overlap' (env %d)" % b}
             raise N.ERR_EXC[code](msgs[code])
 
     def check_agent_position_integrity(self, title=""):

@@ -99,6 +99,7 @@ const char* mg_error_string(int32_t code) {
     case MG_ERR_RECURSION: return "RecursionError: rejection sampling failed in place_obj";
     case MG_ERR_TYPE: return "TypeError: toggle() arity (Box)";
     case MG_ERR_ASSERT: return "AssertionError: grid access out of bounds";
+    case MG_ERR_ATTRIBUTE: return "AttributeError: the cell under an agent was emptied by put_obj(None)";
     default: return "unknown";
     }
 }

@@ -412,7 +412,15 @@ MG_HD bool step_run(const MgConfig& cfg, const MgState& st, const MgGenProgram& 
                         // there is one, else the first agent standing there (agents overlap)
                         bool can_move = fbase ? (fflags & MG_OF_CAN_OVERLAP) != 0 : true;
                         if (!(cfg.ghost_mode & 1) && fbase == 0 && agents_there > 0) can_move = false;  // :541-542
-                        if (can_move) {
+                        if (can_move && (flags & MG_AF_EVICTED)) {
+                            // the agent is in no cell (put_obj replaced the one it stood on): "remove agent from old
+                            // cell" (base.py:555-559) fails — the assert on a solid object, list.remove -> ValueError
+                            // on an overlappable object or on another agent, AttributeError on None
+                            const uint32_t cb = g[cx * H + cy];
+                            const int e2 = cb ? ((sc.oflags[cb] & MG_OF_CAN_OVERLAP) ? MG_ERR_VALUE : MG_ERR_ASSERT)
+                                              : (agents_on(s_rec, S, col, n, (uint32_t)cx | ((uint32_t)cy << 8)) ? MG_ERR_VALUE : MG_ERR_ATTRIBUTE);
+                            err = err ? err : e2;
+                        } else if (can_move) {
                             r = arrive(s_rec, S, col, n, r);
                             r = rec_set(r, MG_AG_X, (uint32_t)fx);
                             r = rec_set(r, MG_AG_Y, (uint32_t)fy);

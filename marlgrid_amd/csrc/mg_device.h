@@ -90,7 +90,7 @@ struct Div20 {
 
 // per-wave LDS scratch of the obs-render kernel (bytes), shared by host launch code and kernel
 struct RenderScratch {
-    int grid, rec, pres, pcol, vaff, first, second, vbase, vshow, trow, vis, tmap, dyn, out, step, step_env, total;
+    int grid, rec, pres, pcol, vaff, first, second, vbase, vshow, trow, vis, tmap, dyn, out, step, total;
     int stage_envs;    // envs whose inputs (grid + agent records) are staged per batch: 1..8
     int tmap_slots;    // tmaps a wave can hold at once (= stage_envs): the look-ahead depth of its env loop
     int tmap_stride;   // bytes per tmap slot
@@ -138,8 +138,7 @@ __host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride,
     s.piece_rows = piece_rows;
     s.out_chunks = round_up(out_bytes, 16) / 16;
     // fused step (mg_step_render): lane j < stage_envs steps staged env j; its [item][8] columns
-    s.step_env = round_up(n * 8 * 8 + MG_MT_HEAD * 8 * 4 + 3 * n * 8, 16);   // ... then [8][2] ints: the lanes' (RNG position, step count)
-    s.step = o;  o += s.step_env + 8 * 2 * 4;
+    s.step = o;  o += round_up(n * 8 * 8 + MG_MT_HEAD * 8 * 4 + 3 * n * 8, 16);
     s.total = o;
     return s;
 }

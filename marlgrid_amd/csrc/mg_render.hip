@@ -247,7 +247,6 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     // batch a wave's run is one batch: it reads before its first store and never again.
     const int gdw = cfg.cells_stride / 4;
     const int K = L.stage_envs, rec_stride = L.rec_stride;
-    int* w_senv = reinterpret_cast<int*>(ws + L.step + L.step_env);    // [8][2]: what step_load_wave read per lane (fused step)
     const int per_wave = (cfg.B + gridDim.x * WPB - 1) / (gridDim.x * WPB);
     const int e0 = (blockIdx.x * WPB + wave) * per_wave;
     const int e_end = min(cfg.B, e0 + per_wave);
@@ -389,9 +388,39 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             }
             if (eb == e0) MG_STAMP(2);
             if (fs.enabled) {
-                // the envs are stepped group by group, right before each group's views (below): what step_load_wave
-                // read for lane j waits in the step's scratch meanwhile (registers across a raster would spill)
-                if (lane < kb) { w_senv[2 * lane] = se.pos0; w_senv[2 * lane + 1] = se.sc0; }
+                // (The whole batch is stepped here, before its first store.  Stepping group by group — each view
+                // group right before its views, so that the wave's first store waits for the step of ONE env — was
+                // measured 11 % SLOWER (profiles/r03/ab_fused_step_per_group*.txt): the step's RNG refill is a
+                // dependent HBM load, and a load issued after stores waits for the wave's whole store queue.)
+                wave_lds_sync();
+                bool wrote = false;
+                if (lane < kb) {
+                    wrote = step_run(cfg, st, fs.prog, fs.has_prog != 0, fs.rewards, eb + lane, se, sc,
+                                     w_stage_g + (size_t)lane * cfg.cells_stride);
+                    for (int k = 0; k < n; k++) w_stage_r[lane * rec_stride + k] = sc.rec[k * 8 + lane];
+                    if constexpr (kPrestige) {
+                        // agent.prestige as this lane left it in HBM, and — here, in the latency-bound step part where
+                        // the VALU is idle, one lane per ENV — the colour it gives the agent's sprite (the float64
+                        // tanh of render_post, agents.py:92-119): the raster's per-env phase only reads it
+                        for (int k = 0; k < n; k++) {
+                            const double p = st.prestige[(size_t)(eb + lane) * n + k];
+                            w_stage_p[lane * rec_stride + k] = p;
+                            if ((cfg.prestige_mask >> k) & 1u) {
+                                const PrestigeColor c = prestige_color(p, s_pscale[k]);
+                                w_stage_c[lane * rec_stride + k] = c.r | (c.g << 8) | (c.b << 16);
+                            }
+                        }
+                    }
+                }
+                uint64_t todo = __ballot(wrote);
+                wave_lds_sync();
+                while (todo) {      // grid slices the step wrote: back to HBM, the whole wave per slice
+                    const int j = __builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    const uint32_t* src = reinterpret_cast<const uint32_t*>(w_stage_g + (size_t)j * cfg.cells_stride);
+                    uint32_t* dst = reinterpret_cast<uint32_t*>(st.grid + (size_t)(eb + j) * cfg.cells_stride);
+                    for (int i = lane; i < gdw; i += kWave) dst[i] = src[i];
+                }
             } else if (!first) {
                 double pv0 = 0., pv1 = 0.;
                 if constexpr (kPrestige) {
@@ -404,7 +433,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             }
         }
         wave_lds_sync();
-        if (eb == e0 && !fs.enabled) MG_STAMP(3);
+        if (eb == e0) MG_STAMP(3);
     // `depth` envs at a time: first all their views (phases 1-5 -> one tmap slot each), then all their
     // rasters.  Waves of a workgroup use different depths (1, 2, 4, 8): otherwise every wave of the chip —
     // they all start together and do identical work — would sit in the store-free phases 1-5 at the same
@@ -414,47 +443,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     // cast runs once per group and the per-cell phases fill their trips.
     const bool ramp = kChunkRaster && kBatchViews && depth_mode <= 0 && eb == e0;
     int gd = ramp ? 1 : depth;                  // size of the current group
-    for (int ej0 = 0; ej0 < kb; ej0 += gd, gd = ramp ? min(2 * gd, L.view_slots) : depth) {
-    if (fs.enabled) {
-        // mg_step_render: the group is STEPPED here, lane j = env eb + j on its staged grid — not the whole batch up
-        // front: the wave's first store then waits for the step of one env (one lane's branches, not the union of
-        // eight lanes'), and the later groups are stepped while the earlier ones' stores drain.  (The step's one
-        // dependent HBM round trip — the RNG head refill at its end — then waits for those stores: a wave that has
-        // queued an env's 28 KiB has nothing better to do.)
-        const StepScratch sc = fused_step_scratch(cfg, lane, ws + L.step, s_obj, s_oflags);
-        const int j1 = min(kb, ej0 + gd);
-        bool wrote = false;
-        if (lane >= ej0 && lane < j1) {
-            const StepEnv se = {w_senv[2 * lane], w_senv[2 * lane + 1]};
-            wrote = step_run(cfg, st, fs.prog, fs.has_prog != 0, fs.rewards, eb + lane, se, sc,
-                             w_stage_g + (size_t)lane * cfg.cells_stride);
-            for (int k = 0; k < n; k++) w_stage_r[lane * rec_stride + k] = sc.rec[k * 8 + lane];
-            if constexpr (kPrestige) {
-                // agent.prestige as this lane left it in HBM, and — here, in the latency-bound step part where
-                // the VALU is idle, one lane per ENV — the colour it gives the agent's sprite (the float64
-                // tanh of render_post, agents.py:92-119): the raster's per-env phase only reads it
-                for (int k = 0; k < n; k++) {
-                    const double p = st.prestige[(size_t)(eb + lane) * n + k];
-                    w_stage_p[lane * rec_stride + k] = p;
-                    if ((cfg.prestige_mask >> k) & 1u) {
-                        const PrestigeColor c = prestige_color(p, s_pscale[k]);
-                        w_stage_c[lane * rec_stride + k] = c.r | (c.g << 8) | (c.b << 16);
-                    }
-                }
-            }
-        }
-        uint64_t todo = __ballot(wrote);
-        wave_lds_sync();
-        while (todo) {      // grid slices the step wrote: back to HBM, the whole wave per slice
-            const int j = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            const uint32_t* src = reinterpret_cast<const uint32_t*>(w_stage_g + (size_t)j * cfg.cells_stride);
-            uint32_t* dst = reinterpret_cast<uint32_t*>(st.grid + (size_t)(eb + j) * cfg.cells_stride);
-            for (int i = lane; i < gdw; i += kWave) dst[i] = src[i];
-        }
-        wave_lds_sync();
-        if (eb == e0 && ej0 == 0) MG_STAMP(3);
-    }
+    for (int ej0 = 0; ej0 < kb; ej0 += gd, gd = ramp ? min(2 * gd, L.view_slots) : depth)
     for (int pass = 0; pass < 2; pass++)
     for (int ej = ej0; ej < min(kb, ej0 + gd); ej++) {
         const int e = eb + ej;
@@ -509,7 +498,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
         //     case analysis (as nested branches it ran every lane through all four headings):
         //       p = swap ? vb : va, q = swap ? va : vb;  wx = x0 +- p;  wy = y0 +- q
         //     word 0: x0 + 256 | (y0 + 256) << 10 | swap << 20 | negx << 21 | negy << 22
-        //     word 1: x | y << 8 | agent << 16 | orientation (3 - dir) & 3 << 24
+        //     word 1: x | y << 8 | agent << 16 | orientation (3 - dir) & 3 << 24 | in the grid << 26
         auto view_affine = [&](const int g, const int v) {
             const uint32_t k = s_vmap[v];
             const uint64_t r = g_rec[__mul24(g, rec_stride) + (int)k];
@@ -520,8 +509,9 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             else if (dir == 0) { x0 = x - off + (VS - 1);    y0 = y - h;               bits = 1u | 2u; }
             else if (dir == 1) { x0 = x - h + (VS - 1);      y0 = y - off + (VS - 1);  bits = 2u | 4u; }
             else               { x0 = x - VS + 1 + off;      y0 = y - h + (VS - 1);    bits = 1u | 4u; }
+            const uint32_t placed = (rec_byte(r, MG_AG_FLAGS) & MG_AF_PLACED) ? 1u : 0u;   // (an evicted viewer is in no stack)
             w_vaff[__mul24(g, nv) + v] = make_uint2((uint32_t)(x0 + 256) | ((uint32_t)(y0 + 256) << 10) | (bits << 20),
-                                                    (uint32_t)x | ((uint32_t)y << 8) | (k << 16) | (((3u - (uint32_t)dir) & 3u) << 24));
+                                                    (uint32_t)x | ((uint32_t)y << 8) | (k << 16) | (((3u - (uint32_t)dir) & 3u) << 24) | (placed << 26));
         };
         if constexpr (kBatchViews) {
             for (int it = lane; it < G * nv; it += kWave) { const int g = (int)by_nv.div((uint32_t)it); view_affine(g, it - __mul24(g, nv)); }
@@ -549,7 +539,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             if (inb) {
                 base = w_grid[cell];
                 show = w_first[gcell + cell];
-                if (show != 0xFF && wx == x && wy == y) show = k;   // viewer in the stack: base.py:282-291
+                if (show != 0xFF && wx == x && wy == y && ((aff.y >> 26) & 1u)) show = k;   // viewer in the stack: base.py:282-291
             }
             if (s_oflags[base] & MG_OF_SEE_BEHIND)                     // opacity first
                 atomicOr(&w_trow[__umul24(g, (uint32_t)L.trow_stride) + __umul24(v, (uint32_t)VS) + vb], 1u << va);
@@ -969,7 +959,6 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
         }
         wave_lds_sync();   // scratch is reused by the next env
         if (e == e0) MG_STAMP(pass == 0 ? 4 : 5);
-    }
     }
     }
     MG_STAMP(6);

@@ -38,6 +38,14 @@ __global__ __launch_bounds__(kBlock) void put_obj_kernel(MgConfig cfg, MgState s
     if (b >= cfg.B) return;
     if (mask && !mask[b]) return;
     st.grid[(size_t)b * cfg.cells_stride + x * cfg.H + y] = (uint8_t)obj;
+    // `grid.set(i, j, obj)` replaces the cell's object: an agent that WAS the cell's object, or stood in the replaced
+    // object's `.agents`, is in no cell any more (base.py:655-662)
+    for (int k = 0; k < cfg.n_agents; k++) {
+        const uint64_t r = st.agents[(size_t)b * cfg.n_agents + k];
+        const uint32_t f = rec_byte(r, MG_AG_FLAGS);
+        if ((f & MG_AF_PLACED) && (int)rec_byte(r, MG_AG_X) == x && (int)rec_byte(r, MG_AG_Y) == y)
+            st.agents[(size_t)b * cfg.n_agents + k] = rec_set(r, MG_AG_FLAGS, (f & ~MG_AF_PLACED) | MG_AF_EVICTED);
+    }
 }
 
 // MultiGridEnv.place_obj / try_place_obj on a live grid (base.py:664-708): lane per env.

@@ -462,13 +462,15 @@ int32_t mgo_reset(MgoEnv* e, int32_t which_gen) {
 /* step — MultiGridEnv.step, base.py:501-649                                                   */
 /* ------------------------------------------------------------------------------------------ */
 
-static void list_remove(int32_t* lst, int32_t* n, int v) {
+/* list.remove(v): 0 if v is not in the list (Python raises ValueError) */
+static int list_remove(int32_t* lst, int32_t* n, int v) {
     for (int i = 0; i < *n; i++)
         if (lst[i] == v) {
             for (int j = i; j < *n - 1; j++) lst[j] = lst[j + 1];
             (*n)--;
-            return;
+            return 1;
         }
+    return 0;
 }
 
 /* BonusTile.get_reward — objects.py:180-206 */
@@ -542,12 +544,16 @@ int32_t mgo_step(MgoEnv* e, const int32_t* actions, double* rewards, int32_t* ep
                     e->ag_agents[f][e->ag_nagents[f]++] = k;
                 } else e->cell_agents[fc * MGO_MAX_AGENTS + e->cell_nagents[fc]++] = k;
                 e->ax[k] = fx; e->ay[k] = fy;
-                /* remove agent from old cell — :555-559 */
+                /* remove agent from old cell — :555-559.  After put_obj replaced the cell the agent stood on
+                 * (:655-662) the agent is in no list any more: `assert cur_cell.can_overlap()` fails on a solid
+                 * object, raises AttributeError on None, and `cur_cell.agents.remove(agent)` raises ValueError */
                 if (cur_cell == me) e->cell[cc] = 0;
+                else if (cur_cell == 0) { rc = MGO_ERR_ATTRIBUTE; continue; }
+                else if (!val_can_overlap(e, cur_cell)) { rc = MGO_ERR_ASSERT; continue; }
                 else if (is_agent_val(cur_cell)) {
                     int c = cur_cell - MGO_AGENT_BASE;
-                    list_remove(e->ag_agents[c], &e->ag_nagents[c], k);
-                } else list_remove(&e->cell_agents[cc * MGO_MAX_AGENTS], &e->cell_nagents[cc], k);
+                    if (!list_remove(e->ag_agents[c], &e->ag_nagents[c], k)) { rc = MGO_ERR_VALUE; continue; }
+                } else if (!list_remove(&e->cell_agents[cc * MGO_MAX_AGENTS], &e->cell_nagents[cc], k)) { rc = MGO_ERR_VALUE; continue; }
                 /* add agent's agents to old cell — :562-569 */
                 for (int li = 0; li < e->ag_nagents[k]; li++) {
                     int lb = e->ag_agents[k][li];

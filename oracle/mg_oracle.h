@@ -38,6 +38,8 @@ extern "C" {
 #define MGO_ERR_TYPE (-3)      /* TypeError: Box.toggle arity             objects.py:381-382 */
 #define MGO_ERR_ASSERT (-4)    /* AssertionError: grid.get out of bounds  base.py:154-156 */
 #define MGO_ERR_STACK (-5)     /* ValueError("?!?!?!")                    base.py:568-569 */
+#define MGO_ERR_ATTRIBUTE (-6) /* AttributeError: None.can_overlap() — an agent whose cell put_obj(None) emptied moves
+                                * on (base.py:555-558) */
 
 /* sprite fill op: restates one `fill_coords(img, fn, color)` call of objects.py render methods */
 enum { MGO_FILL_RECT = 0, MGO_FILL_TRI_ROT = 1, MGO_FILL_CIRCLE = 2 };

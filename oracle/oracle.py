@@ -336,7 +336,7 @@ def make_config(spec):
     return cfg
 
 
-_ERR = {0: None, -1: ValueError, -2: RecursionError, -3: TypeError, -4: AssertionError, -5: ValueError}
+_ERR = {0: None, -1: ValueError, -2: RecursionError, -3: TypeError, -4: AssertionError, -5: ValueError, -6: AttributeError}
 
 
 def _raise(rc):

@@ -331,7 +331,7 @@ def gen_interact(m, out):
         mk = {"Box": lambda c, s: Box(c), "Door": lambda c, s: Door(color=c, state=s), "Key": lambda c, s: Key(c)}
         for (oid, x, y) in sc["objects"]:
             o = spec["objects"][oid]
-            env.put_obj(mk[o["type"]](o["color"], o.get("state", 0)), x, y)
+            env.put_obj(None if o is None else mk[o["type"]](o["color"], o.get("state", 0)), x, y)
         for k, oid in sc.get("carrying", {}).items():
             o = spec["objects"][oid]
             env.agents[k].carrying = mk[o["type"]](o["color"], o.get("state", 0))

@@ -122,6 +122,8 @@ def canonical(env):
             o = env.grid.get(*a.pos)
             if o is a:
                 ordinal[k] = 0
+            elif o is None or a not in o.agents:
+                ordinal[k] = -1          # put_obj replaced the cell it stood on (base.py:655-662): in no cell any more
             elif o.is_agent:
                 ordinal[k] = 1 + o.agents.index(a)
             else:

@@ -97,7 +97,8 @@ def canonical_arrays(spec, base, rec, sc):
     placed = (fl & K.AF_PLACED) != 0
     out = []
     for bb in range(B):
-        pos = np.stack([np.where(placed[bb], x[bb], -1), np.where(placed[bb], y[bb], -1)], axis=1)
+        there = placed[bb] | ((fl[bb] & K.AF_EVICTED) != 0)     # (an evicted agent keeps its position; ordinal -1)
+        pos = np.stack([np.where(there, x[bb], -1), np.where(there, y[bb], -1)], axis=1)
         ordinal = np.full(n, -1)
         for k in range(n):
             if placed[bb, k]:

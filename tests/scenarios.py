@@ -411,4 +411,14 @@ def interact_scenes():
         "drop_blocked": dict(agents=[(2, 3, 0), (3, 3, 2)], objects=[], carrying={0: 3},
                              actions=[[DROP, DONE], [L, DONE], [DROP, DONE], [PICK, DONE]]),
         "bad_action": dict(agents=[(2, 3, 0), (1, 1, 0)], objects=[], actions=[[9, DONE]]),
+        # put_obj onto the cell an agent stands on (base.py:655-662) replaces the cell's object: the agent is in no
+        # cell any more (others do not see it, it still turns and looks) — and its next successful forward move
+        # raises where upstream does: the assert on a solid object, ValueError from list.remove on an overlappable
+        # one, AttributeError on None (:555-559)
+        "put_box_over_agent": dict(agents=[(2, 3, 0), (1, 1, 0)], objects=[(3, 2, 3)],
+                                   actions=[[L, DONE], [R, R], [F, DONE]]),
+        "put_open_door_over_agent": dict(agents=[(2, 3, 0), (1, 1, 0)], objects=[(4, 2, 3)],
+                                         actions=[[R, DONE], [L, R], [TOG, DONE], [F, DONE]]),
+        "put_none_over_agent": dict(agents=[(2, 3, 0), (1, 1, 0)], objects=[(0, 2, 3)],
+                                    actions=[[DONE, R], [F, DONE]]),
     }

@@ -326,7 +326,7 @@ def _setup_scene(env, sc, spec):
     for k, (x, y, d) in enumerate(sc["agents"]):
         env.set_agent(k, x=x, y=y, dir=d)
     for (oid, x, y) in sc["objects"]:
-        env.put_obj(mk[spec["objects"][oid]["type"]](spec["objects"][oid]), x, y)
+        env.put_obj(None if oid == 0 else mk[spec["objects"][oid]["type"]](spec["objects"][oid]), x, y)
     for k, oid in sc.get("carrying", {}).items():
         env.set_agent(k, carrying=mk[spec["objects"][oid]["type"]](spec["objects"][oid]))
 
@@ -342,7 +342,8 @@ def test_interact_golden(sname):
     env = EmptyMultiGrid(agents=[GridAgentInterface(color=c, view_size=7, view_tile_size=8) for c in ("red", "blue")],
                          grid_size=7, batch_size=3, seed=1337)
     _setup_scene(env, sc, spec)
-    exc = {"ValueError": ValueError, "TypeError": TypeError, "AssertionError": AssertionError}
+    exc = {"ValueError": ValueError, "TypeError": TypeError, "AssertionError": AssertionError,
+           "AttributeError": AttributeError}
     for t, act in enumerate(sc["actions"]):
         err = str(g["%s/error" % sname][t])
         what = "%s step %d" % (sname, t)

@@ -201,8 +201,9 @@ def test_interact(sname):
     for t, act in enumerate(sc["actions"]):
         err = str(g["%s/error" % sname][t])
         what = "%s step %d" % (sname, t)
-        if err in ("ValueError", "TypeError", "AssertionError"):
-            with pytest.raises({"ValueError": ValueError, "TypeError": TypeError, "AssertionError": AssertionError}[err]):
+        if err in ("ValueError", "TypeError", "AssertionError", "AttributeError"):
+            with pytest.raises({"ValueError": ValueError, "TypeError": TypeError, "AssertionError": AssertionError,
+                                "AttributeError": AttributeError}[err]):
                 orc.step(act)
             break      # state after a mid-loop exception depends on the shuffled order: not pinned
         o, r, dn, _ = orc.step(act)
