@@ -1,10 +1,10 @@
 #!/bin/bash
-# Round 3, visit 12: put_obj evicting agents (interact goldens), reject tables, the kernel back to the whole-batch
-# step — suite, then the evidence set of the final kernels.
+# Visit 12: the whole -m gpu suite on the final kernels (put_obj eviction, reject tables, whole-batch step), then
+# the final evidence set.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/${1:-v12}
 mkdir -p $OUT
-cd /tmp && export TMPDIR=/tmp
-(cd $R && timeout 1200 python -m pytest tests -m gpu -q -x > $OUT/pytest.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest.log)
+cd $R
+timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest.log
 tail -n 4 $OUT/pytest.log
-bash $R/tools/gpu_r3_final.sh ${1:-v12}/final
+bash tools/gpu_r3_final.sh ${1:-v12}/final
