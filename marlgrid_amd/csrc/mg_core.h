@@ -312,8 +312,16 @@ struct StepScratch {        // per-workgroup arrays, this env is column `col`, e
     const MgObjDesc* obj;   // [n_obj] object table (shared)
     const uint8_t* oflags;  // [MG_MAX_OBJ] object flags (shared)
     int S, col;
+#if defined(MG_AB_VARIANTS)
+    unsigned long long* stamp = nullptr;   // measurement build: 4 words, wall_clock64 at the section ends of step_run (or null)
+#endif
 };
 struct StepEnv { int pos0, sc0; };
+#if defined(MG_AB_VARIANTS) && defined(__HIP_DEVICE_COMPILE__)
+#define MG_STEP_STAMP(i) do { if (sc.stamp) sc.stamp[i] = wall_clock64(); } while (0)
+#else
+#define MG_STEP_STAMP(i) do {} while (0)
+#endif
 
 // round trip 1: everything whose address is known up front, all of it contiguous across the batch.
 // actions: [B][n] little-endian integers of `action_bytes` (1, 4 or 8) bytes each.
@@ -382,6 +390,7 @@ MG_HD bool step_run(const MgConfig& cfg, const MgState& st, const MgGenProgram& 
         sc.order[j * S + col] = t;
     }
 
+    MG_STEP_STAMP(0);
     for (int oi = 0; oi < n; oi++) {
         const int k = sc.order[oi * S + col];
         float rew = 0.0f;
@@ -500,6 +509,7 @@ MG_HD bool step_run(const MgConfig& cfg, const MgState& st, const MgGenProgram& 
         rewards[(size_t)b * n + k] = rew;
     }
 
+    MG_STEP_STAMP(1);
     // done agents (base.py:627-646), in index order: without respawn they are deactivated but stay
     // where they are; with respawn they leave their cell (an agent only ever becomes done on a Goal /
     // Lava, i.e. inside that object's stack, so nothing is left behind), drop what they carry
@@ -528,12 +538,14 @@ MG_HD bool step_run(const MgConfig& cfg, const MgState& st, const MgGenProgram& 
         step_count = 0;
         grid_dirty = true;
     }
+    MG_STEP_STAMP(2);
     for (int k = 0; k < n; k++) st.agents[(size_t)b * n + k] = s_rec[k * S + col];
     st.step_count[b] = step_count;
     mt_finish(mt, st.mt_head + (size_t)b * MG_MT_HEAD);
     st.mt_pos[b] = mt.pos;
     st.done[b] = (uint8_t)done;
     record_error(st, b, err);
+    MG_STEP_STAMP(3);
     return grid_dirty;
 }
 

@@ -143,10 +143,12 @@ __device__ __forceinline__ StepEnv step_load_wave(const MgConfig& cfg, const MgS
 #if defined(MG_AB_VARIANTS)
 // measurement build: wall_clock64 (100 MHz) of every wave's lane 0 at the phase boundaries of its FIRST batch —
 // 0 entry, 1 tables + atlas in LDS, 2 batch staged (and step_load done), 3 batch stepped, 4 first views, 5 first
-// env rastered, 6 wave done; 7: XCC_ID << 16 | HW_ID — read by tools/phase_stamps.py
+// env rastered, 6 wave done; 7: XCC_ID << 16 | HW_ID; 8..11 inside step_run of the first batch (StepScratch::stamp:
+// 8 spawns + front cells + shuffle done, 9 agent loop done, 10 done / respawn / reset done, 11 state written back)
+// — 16 words per wave, read by tools/phase_stamps.py
 __device__ unsigned long long* d_ab_stamps = nullptr;
 extern "C" int mg_ab_stamps(unsigned long long* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(d_ab_stamps), &p, sizeof(p)); }
-#define MG_STAMP(slot) do { if (d_ab_stamps && lane == 0) d_ab_stamps[(size_t)(blockIdx.x * WPB + wave) * 8 + (slot)] = wall_clock64(); } while (0)
+#define MG_STAMP(slot) do { if (d_ab_stamps && lane == 0) d_ab_stamps[(size_t)(blockIdx.x * WPB + wave) * 16 + (slot)] = wall_clock64(); } while (0)
 #else
 #define MG_STAMP(slot) do {} while (0)
 #endif
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     MG_STAMP(0);
 #if defined(MG_AB_VARIANTS)
     if (d_ab_stamps && lane == 0)      // where this wave runs: XCC_ID (hwreg 20) << 16 | HW_ID (hwreg 4) [15:0]
-        d_ab_stamps[(size_t)(blockIdx.x * WPB + wave) * 8 + 7] =
+        d_ab_stamps[(size_t)(blockIdx.x * WPB + wave) * 16 + 7] =
             ((unsigned long long)(__builtin_amdgcn_s_getreg((32 - 1) << 11 | 20) & 0xF) << 16) |
             (unsigned long long)(__builtin_amdgcn_s_getreg((16 - 1) << 11 | 4) & 0xFFFF);
 #endif
@@ -372,6 +374,9 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             if (!fs.enabled && !first) { rv0 = r0i < nr ? rsrc[r0i] : 0ull; rv1 = r1i < nr ? rsrc[r1i] : 0ull; }
             StepScratch sc = sc0;
             StepEnv se = se0;
+#if defined(MG_AB_VARIANTS)
+            sc.stamp = (d_ab_stamps && first && lane == 0) ? d_ab_stamps + (size_t)(blockIdx.x * WPB + wave) * 16 + 8 : nullptr;
+#endif
             for (int i0 = first ? kSR * kWave : 0; i0 < nd; i0 += kSR * kWave) {
                 uint32_t v[kSR];
 #pragma unroll

@@ -729,8 +729,8 @@ def test_objects_zoo_vs_oracle():
     board = [(5, 2, 2), (3, 4, 2), (4, 6, 2), (6, 2, 5), (7, 5, 2), (8, 3, 3), (9, 4, 4), (10, 5, 5), (4, 1, 6), (8, 6, 6)]
     for o in objs[3:]:
         env.obj_reg.get_key(o)
-    # agents to fixed free cells first: put_obj on an occupied cell evicts the agent upstream (the cell's
-    # object is replaced, base.py:655-662) while the engine keeps it — a documented difference
+    # agents to fixed free cells first: put_obj on an occupied cell evicts the agent (the cell's object is
+    # replaced, base.py:655-662) — test_interact_golden's put_*_over_agent scenes cover that
     for k, (x, y, d) in enumerate([(1, 1, 0), (7, 1, 2)]):
         env.set_agent(k, x=x, y=y, dir=d)
         for e in orc.envs:
@@ -770,8 +770,12 @@ def test_auto_reset_survives_a_table_rebuild():
     for t in range(150):
         if t in (3, 40):       # a kind the registry has not seen: tables + atlas are rebuilt and re-uploaded
             obj = Key("blue") if t == 3 else Ball("red")
+            cx, cy = 4, 4 + (t == 40)
+            # (only where no agent stands on the cell: put_obj over an agent evicts it, as upstream, and its
+            # next forward move raises — test_interact_golden covers that)
+            free = ~((e1.agent_pos[..., 0] == cx) & (e1.agent_pos[..., 1] == cy)).any(dim=1)
             for e in (e1, e2):
-                e.put_obj(obj, 4, 4 + (t == 40))
+                e.put_obj(obj, cx, cy, env_mask=free)
             junk = [torch.full((e1.cells_stride,), 0xEE, dtype=torch.uint8, device=e1.device) for _ in range(64)]
         a = torch.from_numpy(rng.randint(0, 3, size=(B, 3)))
         o1, r1, d1, _ = e1.step(a)

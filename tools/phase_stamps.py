@@ -21,14 +21,14 @@ acts = [torch.randint(0, 7, (B, env.num_agents), generator=g).cuda() for _ in ra
 for i in range(40):
     env.step(acts[i % 16])
 L, cfg, st = env._lib, C.byref(env._cfg), C.byref(env._state)
-stamps = torch.zeros(65536 * 8, dtype=torch.int64, device="cuda")
+stamps = torch.zeros(65536 * 16, dtype=torch.int64, device="cuda")
 names = ["tables + atlas -> LDS, barrier", "stage grids (+ step_load)", "step_run (+ records, write-back)",
          "views of the first group", "raster of the first env", "rest of the run"]
 
 
 def report(title):
     torch.cuda.synchronize()
-    t = stamps.view(-1, 8).cpu()
+    t = stamps.view(-1, 16).cpu()
     if os.environ.get("STAMPS_OUT"):
         import numpy as np
         np.save(os.path.join(os.environ["STAMPS_OUT"], "stamps_%s_%d.npy" % (title, report.n)), t[t[:, 6] != 0].numpy())
@@ -50,6 +50,16 @@ def report(title):
     print("   mean exit time by XCD (workgroup %% 8): %s" % " ".join("%.1f" % v for v in by_xcd))
     by_wave = [ex[torch.arange(len(ex)) % 4 == w].mean().item() for w in range(4)]
     print("   mean exit time by look-ahead depth 1/2/4/8 (wave %% 4): %s" % " ".join("%.1f" % v for v in by_wave))
+    if (t[:, 8] != 0).any():        # inside step_run of the first batch (lane 0's env)
+        inner = ["spawns, front cells, shuffle", "agent loop", "done / respawn / fused reset", "write-back + RNG head refill"]
+        prev = t[:, 2]
+        for k in range(4):
+            d = t[:, 8 + k] - prev
+            prev = t[:, 8 + k]
+            print("      step_run: %-30s mean %7.2f  min %7.2f  p50 %7.2f  p90 %7.2f  max %7.2f us" %
+                  (inner[k], d.mean().item(), d.min().item(), d.median().item(), torch.quantile(d, 0.9).item(), d.max().item()))
+        d = t[:, 3] - t[:, 11]
+        print("      step_run: %-30s mean %7.2f  min %7.2f  max %7.2f us" % ("records to the views, grid write-back", d.mean().item(), d.min().item(), d.max().item()))
     d = t[:, 4] - t[:, 0]
     print("   entry -> first views done            mean %7.2f  min %7.2f  max %7.2f us" % (d.mean().item(), d.min().item(), d.max().item()))
     stamps.zero_()
