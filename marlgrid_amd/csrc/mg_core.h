@@ -313,7 +313,7 @@ struct StepScratch {        // per-workgroup arrays, this env is column `col`, e
     const uint8_t* oflags;  // [MG_MAX_OBJ] object flags (shared)
     int S, col;
 #if defined(MG_AB_VARIANTS)
-    unsigned long long* stamp = nullptr;   // measurement build: 4 words, wall_clock64 at the section ends of step_run (or null)
+    unsigned long long* stamp = nullptr;   // measurement build: 5 words, wall_clock64 at the section ends of step_run (or null)
 #endif
 };
 struct StepEnv { int pos0, sc0; };
@@ -354,6 +354,7 @@ MG_HD bool step_run(const MgConfig& cfg, const MgState& st, const MgGenProgram& 
     uint64_t* s_rec = sc.rec;
     Mt mt{st.mt + (size_t)b * MG_MT_N, env.pos0, sc.head + col, S, 0};
     int err = 0;
+    MG_STEP_STAMP(0);
 
     // late spawns (base.py:503-506), before step_count is incremented and before the shuffle: any agent
     // that is neither active nor done (spawn_delay not reached at reset, or lifted off the grid by a
@@ -390,7 +391,7 @@ MG_HD bool step_run(const MgConfig& cfg, const MgState& st, const MgGenProgram& 
         sc.order[j * S + col] = t;
     }
 
-    MG_STEP_STAMP(0);
+    MG_STEP_STAMP(1);
     for (int oi = 0; oi < n; oi++) {
         const int k = sc.order[oi * S + col];
         float rew = 0.0f;
@@ -509,7 +510,7 @@ MG_HD bool step_run(const MgConfig& cfg, const MgState& st, const MgGenProgram& 
         rewards[(size_t)b * n + k] = rew;
     }
 
-    MG_STEP_STAMP(1);
+    MG_STEP_STAMP(2);
     // done agents (base.py:627-646), in index order: without respawn they are deactivated but stay
     // where they are; with respawn they leave their cell (an agent only ever becomes done on a Goal /
     // Lava, i.e. inside that object's stack, so nothing is left behind), drop what they carry
@@ -538,14 +539,14 @@ MG_HD bool step_run(const MgConfig& cfg, const MgState& st, const MgGenProgram& 
         step_count = 0;
         grid_dirty = true;
     }
-    MG_STEP_STAMP(2);
+    MG_STEP_STAMP(3);
     for (int k = 0; k < n; k++) st.agents[(size_t)b * n + k] = s_rec[k * S + col];
     st.step_count[b] = step_count;
     mt_finish(mt, st.mt_head + (size_t)b * MG_MT_HEAD);
     st.mt_pos[b] = mt.pos;
     st.done[b] = (uint8_t)done;
     record_error(st, b, err);
-    MG_STEP_STAMP(3);
+    MG_STEP_STAMP(4);
     return grid_dirty;
 }
 

@@ -80,6 +80,7 @@ struct SmallDiv {
 struct Div20 {
     uint32_t d, m;
     __host__ __device__ explicit Div20(uint32_t d_) : d(d_), m(((1u << 20) + d_ - 1u) / d_) {}
+    __host__ __device__ Div20(uint32_t d_, uint32_t m_) : d(d_), m(m_) {}      // (m worked out by the launcher)
     template <bool exact = false>
     __device__ __forceinline__ uint32_t div(uint32_t x) const {
         uint32_t q = __umul24(x, m) >> 20;
@@ -100,6 +101,15 @@ struct RenderScratch {
     int view_slots;    // envs whose views are derived together: slots of first / second / trow (1, or stage_envs)
     int cell_stride;   // bytes per slot of first / second
     int trow_stride;   // dwords per slot of trow
+};
+// What a launch of the obs kernel would otherwise work out in every wave before it requests its first byte — the
+// LDS layout (render_scratch_for: four candidate layouts), the envs per wave, the dividers' multipliers: ~600
+// instructions, 1.5 us of the launch's store-free head (tools/phase_stamps.py) — worked out by the launcher instead.
+struct RenderLaunch {
+    RenderScratch L;
+    int per_wave;                               // envs per wave of the persistent grid
+    uint32_t m_n, m_nv, m_nvVV, m_VV, m_VS;     // Div20 multipliers of n, nv, nv * VS^2, VS^2, VS
+    int depth_mode;                             // measurement builds: look-ahead depth forced for all waves (0: by wave)
 };
 // n: the env's agents (records, who stands where); nv: the viewers this launch renders (view-sized arrays)
 __host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride, int n, int nv, int vs, int stage_envs = 1,

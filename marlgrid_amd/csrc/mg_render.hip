@@ -105,50 +105,67 @@ __device__ __forceinline__ StepScratch fused_step_scratch(const MgConfig& cfg, i
 // different cache lines, ~25 instructions: 3 us of the launch's store-free head.  The batch's records, actions
 // and look-ahead words are each one CONTIGUOUS run in HBM, so the wave reads them as such (lane l: element l,
 // l + 64) and transposes into the step's [item][8] LDS columns.  Same result as step_load on lanes 0 .. kb-1.
-__device__ __forceinline__ StepEnv step_load_wave(const MgConfig& cfg, const MgState& st, const void* actions, int action_bytes,
-                                                  int eb, int kb, int lane, const StepScratch& sc) {
+// In two halves — the loads (step_load_issue) and, after whatever the caller has to do in between, the wait and
+// the LDS columns (step_load_commit; its `kb` may be smaller than the one the loads were issued for).
+struct StepLoadRegs { uint64_t rv[2]; uint64_t a8[2]; uint32_t a4[2]; uint32_t a1[2]; uint32_t hv[2]; int pos0, sc0; };   // (a8 / a4 / a1: the action's raw bytes, by width)
+__device__ __forceinline__ StepLoadRegs step_load_issue(const MgConfig& cfg, const MgState& st, const void* actions, int action_bytes,
+                                                        int eb, int kb, int lane) {
     const int n = cfg.n_agents, nr = kb * n, nh = kb * MG_MT_HEAD;
     const uint64_t* rsrc = st.agents + (size_t)eb * n;
     const uint32_t* hsrc = st.mt_head + (size_t)eb * MG_MT_HEAD;
-    uint64_t rv[2] = {0ull, 0ull};
-    long long av[2] = {0, 0};
-    uint32_t hv[2] = {0u, 0u};
+    StepLoadRegs r = {{0ull, 0ull}, {0ull, 0ull}, {0u, 0u}, {0u, 0u}, {0u, 0u}, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int i = lane + q * kWave;
+        if (i < nr) r.rv[q] = rsrc[i];
+        if (i < nh) r.hv[q] = hsrc[i];
+    }
+    if (lane < kb) { r.pos0 = st.mt_pos[eb + lane]; r.sc0 = st.step_count[eb + lane]; }
+    // The actions LAST, raw, a register per width: anything done to a loaded value — a sign extension, even the
+    // move that merges two widths into one variable — is a wait for everything requested so far, and hipcc waits
+    // where the three widths' branches meet in any case: at the end of the requests that wait is the round trip's own.
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int i = lane + q * kWave;
+        // (per-lane conditions — `lane` is opaque here —: as uniform branches the three widths are a diamond whose arms
+        // zero the other widths' registers, and hipcc waits for every outstanding load before such a write)
+        const size_t a = (size_t)eb * n + i;
+        const bool live = i < nr && lane >= 0;
+        if (live && action_bytes == 8) r.a8[q] = static_cast<const uint64_t*>(actions)[a];
+        if (live && action_bytes == 4) r.a4[q] = static_cast<const uint32_t*>(actions)[a];
+        if (live && action_bytes == 1) r.a1[q] = static_cast<const uint8_t*>(actions)[a];
+    }
+    return r;
+}
+__device__ __forceinline__ StepEnv step_load_commit(const MgConfig& cfg, const StepLoadRegs& r, int kb, int lane, const StepScratch& sc,
+                                                    const Div20& by_n) {
+    const int n = cfg.n_agents, nr = kb * n, nh = kb * MG_MT_HEAD;
 #pragma unroll
     for (int q = 0; q < 2; q++) {
         const int i = lane + q * kWave;
         if (i < nr) {
-            const size_t a = (size_t)eb * n + i;
-            rv[q] = rsrc[i];
-            av[q] = action_bytes == 8 ? (long long)static_cast<const int64_t*>(actions)[a]
-                  : action_bytes == 4 ? (long long)static_cast<const int32_t*>(actions)[a]
-                                      : (long long)static_cast<const uint8_t*>(actions)[a];
+            const int j = (int)by_n.div((uint32_t)i), k = i - __mul24(j, n);
+            sc.rec[k * 8 + j] = r.rv[q];
+            // valid actions are 0..6 (step_load): as unsigned raw bytes of any width, exactly the values <= 6
+            const uint64_t av = r.a8[q] | (uint64_t)(r.a4[q] | r.a1[q]);     // (only the launch's width was loaded; the others are 0)
+            sc.act[k * 8 + j] = av <= 6ull ? (uint8_t)av : (uint8_t)0xFF;
         }
-        if (i < nh) hv[q] = hsrc[i];
+        if (i < nh) sc.head[(i % MG_MT_HEAD) * 8 + i / MG_MT_HEAD] = r.hv[q];
     }
-    StepEnv e = {0, 0};
-    if (lane < kb) { e.pos0 = st.mt_pos[eb + lane]; e.sc0 = st.step_count[eb + lane]; }
-#pragma unroll
-    for (int q = 0; q < 2; q++) {
-        const int i = lane + q * kWave;
-        if (i < nr) {
-            const int j = i / n, k = i - j * n;
-            sc.rec[k * 8 + j] = rv[q];
-            sc.act[k * 8 + j] = (av[q] >= 0 && av[q] <= 6) ? (uint8_t)av[q] : (uint8_t)0xFF;
-        }
-        if (i < nh) sc.head[(i % MG_MT_HEAD) * 8 + i / MG_MT_HEAD] = hv[q];
-    }
+    StepEnv e = {r.pos0, r.sc0};
     return e;
 }
 
 #if defined(MG_AB_VARIANTS)
 // measurement build: wall_clock64 (100 MHz) of every wave's lane 0 at the phase boundaries of its FIRST batch —
 // 0 entry, 1 tables + atlas in LDS, 2 batch staged (and step_load done), 3 batch stepped, 4 first views, 5 first
-// env rastered, 6 wave done; 7: XCC_ID << 16 | HW_ID; 8..11 inside step_run of the first batch (StepScratch::stamp:
-// 8 spawns + front cells + shuffle done, 9 agent loop done, 10 done / respawn / reset done, 11 state written back)
-// — 16 words per wave, read by tools/phase_stamps.py
+// env rastered, 6 wave done; 7: XCC_ID << 16 | HW_ID; 8..12 inside step_run of the first batch (StepScratch::stamp:
+// 8 entry, 9 spawns + front cells + shuffle done, 10 agent loop done, 11 done / respawn / reset done, 12 state written
+// back), 16..20 the same of the wave's LAST batch; 13 the launch's constants set up, 14 env loop entered, 15 the
+// prologue's data is there — 24 words per wave, read by tools/phase_stamps.py
 __device__ unsigned long long* d_ab_stamps = nullptr;
 extern "C" int mg_ab_stamps(unsigned long long* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(d_ab_stamps), &p, sizeof(p)); }
-#define MG_STAMP(slot) do { if (d_ab_stamps && lane == 0) d_ab_stamps[(size_t)(blockIdx.x * WPB + wave) * 16 + (slot)] = wall_clock64(); } while (0)
+#define MG_STAMP(slot) do { if (d_ab_stamps && lane == 0) d_ab_stamps[(size_t)(blockIdx.x * WPB + wave) * 24 + (slot)] = wall_clock64(); } while (0)
 #else
 #define MG_STAMP(slot) do {} while (0)
 #endif
@@ -167,7 +184,7 @@ template <int VS_, int TS_, int WPB, int V_ = 0, int RM_ = 0>
 __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState st, uint8_t* __restrict__ obs,
                                                         uint8_t* __restrict__ dbg_cells,
                                                         uint8_t* __restrict__ dbg_agent,
-                                                        uint8_t* __restrict__ dbg_vis, int depth_mode, FusedStep fs
+                                                        uint8_t* __restrict__ dbg_vis, RenderLaunch lc, FusedStep fs
 #if defined(MG_AB_VARIANTS)
                                                         , uint16_t* __restrict__ view_out   // measurement build: views only
 #endif
@@ -184,19 +201,27 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     MG_STAMP(0);
 #if defined(MG_AB_VARIANTS)
     if (d_ab_stamps && lane == 0)      // where this wave runs: XCC_ID (hwreg 20) << 16 | HW_ID (hwreg 4) [15:0]
-        d_ab_stamps[(size_t)(blockIdx.x * WPB + wave) * 16 + 7] =
+        d_ab_stamps[(size_t)(blockIdx.x * WPB + wave) * 24 + 7] =
             ((unsigned long long)(__builtin_amdgcn_s_getreg((32 - 1) << 11 | 20) & 0xF) << 16) |
             (unsigned long long)(__builtin_amdgcn_s_getreg((16 - 1) << 11 | 4) & 0xFFFF);
 #endif
 
+    // Each wave walks its own CONTIGUOUS run of envs, i.e. one long sequential output stream per wave
+    // (measured +5 % HBM write throughput over a grid-strided walk).
+    constexpr bool kGlobalAtlas = (V_ == 8 || V_ == 12);
+    const int atlas_bytes = kGlobalAtlas ? 0 : round_up(4 * cfg.n_tiles * tile_bytes, 16);
+    const int gdw = cfg.cells_stride / 4;
+    const int per_wave = lc.per_wave, depth_mode = lc.depth_mode;
+    const int e0 = (blockIdx.x * WPB + wave) * per_wave;
+    const int e_end = min(cfg.B, e0 + per_wave);
+    constexpr int kSR = 8;                                              // grid dwords per lane and round trip
+
     // ---- block-shared: atlas + object flags ----
     // V_ == 8: the atlas does not fit the 160 KiB of LDS next to the per-env scratch (large tiles);
     // it is then read in place (global memory, L2-resident: it is a few hundred KB).
-    constexpr bool kGlobalAtlas = (V_ == 8 || V_ == 12);
     constexpr bool kPrestige = (V_ == 9 || V_ == 12);   // some agent is 'prestige'-coloured: per-env recoloured tiles
     constexpr bool kSplit = (V_ == 12);        // static tiles in global memory, recoloured ones in LDS
     constexpr uint32_t kInLds = 0x80000000u;   // kSplit: marks a source offset as relative to the LDS base
-    const int atlas_bytes = kGlobalAtlas ? 0 : round_up(4 * cfg.n_tiles * tile_bytes, 16);
     uint8_t* s_atlas = smem;
     uint8_t* s_oflags = smem + atlas_bytes;             // [MG_MAX_OBJ]
     uint8_t* s_oslot = s_oflags + MG_MAX_OBJ;           // [MG_MAX_OBJ]
@@ -210,7 +235,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     const int nv = cfg.n_view ? cfg.n_view : n;
     constexpr bool kChunkRaster = TS_ > 0 && (TS_ % 8) == 0 && RM_ == 0;
     constexpr bool kBatchViews = !kPrestige;   // as render_scratch_for: views of a group of envs at once, a scratch slot each
-    const RenderScratch L = render_scratch_for(cfg, WPB, RM_);
+    const RenderScratch& L = lc.L;      // (= render_scratch_for(cfg, WPB, RM_), worked out by the launcher)
     uint8_t* ws = smem + atlas_bytes + kRenderShared + (size_t)wave * L.total;
     uint8_t* w_stage_g = ws + L.grid;                                      // [stage_envs][cells_stride] grids of a batch of envs
     uint64_t* w_stage_r = reinterpret_cast<uint64_t*>(ws + L.rec);        // [stage_envs][rec_stride] their agent records
@@ -240,91 +265,15 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     const uint32_t STEP_R = PR ? (2u * CH_STRIDE) / PR : 0u, STEP_P = PR ? (2u * CH_STRIDE) - STEP_R * PR : 0u;
     const uint32_t rast_r0 = PR ? (2u * c_first) / PR : 0u, rast_p0 = PR ? 2u * c_first - rast_r0 * PR : 0u;
 
-    // Each wave walks its own CONTIGUOUS run of envs, i.e. one long sequential output stream per wave
-    // (measured +5 % HBM write throughput over a grid-strided walk).  The inputs of the run — 240 B of
-    // grid and a few agent records per env — are staged in LDS a BATCH of envs at a time: on gfx950 the
-    // wait for a load's data is a vmcnt wait, vmcnt is in-order and also counts this wave's stores, so
-    // every load consumed in the middle of the run drains the wave's whole store queue first (the
-    // pure-store microbenchmark loses 25 % of its throughput to one such load per env).  At the bench
-    // batch a wave's run is one batch: it reads before its first store and never again.
-    const int gdw = cfg.cells_stride / 4;
+    // The inputs of a wave's run — 240 B of grid and a few agent records per env — are staged in LDS a BATCH of
+    // envs at a time: on gfx950 the wait for a load's data is a vmcnt wait, vmcnt is in-order and also counts this
+    // wave's stores, so every load consumed in the middle of the run drains the wave's whole store queue first
+    // (the pure-store microbenchmark loses 25 % of its throughput to one such load per env).  At the bench batch
+    // a wave's run is one batch: it reads before its first store and never again.
     const int K = L.stage_envs, rec_stride = L.rec_stride;
-    const int per_wave = (cfg.B + gridDim.x * WPB - 1) / (gridDim.x * WPB);
-    const int e0 = (blockIdx.x * WPB + wave) * per_wave;
-    const int e_end = min(cfg.B, e0 + per_wave);
-
-    // ---- prologue: tables + atlas -> LDS and the wave's FIRST batch staged, in ONE HBM round trip ----
-    // (tools/phase_stamps.py: with the atlas copied first and the batch staged after the barrier, the median
-    // wave waited 2 us + 5.5 us — 8.8 us with the env step's loads — before it could begin.)  Everything
-    // whose address is known now is loaded first: the first two atlas chunks of this thread, the object
-    // table, the first batch's grids and records — or, in mg_step_render, the step's own loads (step_load) —;
-    // then the LDS stores, then the barrier.
-    constexpr int kSR = 8;                                              // grid dwords per lane and round trip
-    const int kb0 = max(0, min(K, e_end - e0));
     StepScratch sc0;
-    StepEnv se0 = {0, 0};
-    {
-        const int T = WPB * 64;
-        const uint32_t* gsrc = reinterpret_cast<const uint32_t*>(st.grid + (size_t)e0 * cfg.cells_stride);
-        const int nd0 = kb0 * gdw, nr0 = kb0 * n;
-        uint32_t v0[kSR];
-#pragma unroll
-        for (int q = 0; q < kSR; q++) { const int i = q * kWave + lane; v0[q] = i < nd0 ? gsrc[i] : 0u; }
-        const int r0i = lane, r1i = lane + kWave;
-        uint64_t rv0 = 0ull, rv1 = 0ull;
-        double pv0 = 0., pv1 = 0.;
-        if (!fs.enabled) {
-            const uint64_t* rsrc = st.agents + (size_t)e0 * n;
-            if (r0i < nr0) rv0 = rsrc[r0i];
-            if (r1i < nr0) rv1 = rsrc[r1i];
-            if constexpr (kPrestige) {
-                const double* psrc = st.prestige + (size_t)e0 * n;
-                if (r0i < nr0) pv0 = psrc[r0i];
-                if (r1i < nr0) pv1 = psrc[r1i];
-            }
-        }
-        const uint4* asrc = reinterpret_cast<const uint4*>(cfg.atlas);
-        uint4* adst = reinterpret_cast<uint4*>(s_atlas);
-        const int na = atlas_bytes / 16;                                // (0 when the atlas is read in place)
-        uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0, o0 = a0;
-        if (tid < na) a0 = asrc[tid];
-        if (tid + T < na) a1 = asrc[tid + T];
-        const int no = fs.enabled ? cfg.n_obj * 2 : 0;                  // object table (fused step): <= 128 chunks
-        if (tid < no) o0 = reinterpret_cast<const uint4*>(cfg.obj)[tid];
-        uint8_t f = 0, sl = 0xFF, f2 = 0;
-        if (tid < cfg.n_obj) { f = cfg.obj[tid].flags; sl = cfg.obj[tid].ovl_slot; f2 = cfg.obj[tid].flags2; }
-        if (tid == 0) { f = MG_OF_SEE_BEHIND | MG_OF_CAN_OVERLAP; sl = 0; f2 = 1; }   // empty cell
-        if (fs.enabled) {
-            sc0 = fused_step_scratch(cfg, lane, ws + L.step, s_obj, s_oflags);
-            se0 = step_load_wave(cfg, st, fs.actions, fs.action_bytes, e0, kb0, lane, sc0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (tid < na) adst[tid] = a0;
-        if (tid + T < na) adst[tid + T] = a1;
-        for (int i = tid + 2 * T; i < na; i += T) adst[i] = asrc[i];    // (larger atlases: the rest, a second trip)
-        if (tid < no) reinterpret_cast<uint4*>(s_obj)[tid] = o0;
-        if (tid < MG_MAX_OBJ) {
-            s_oflags[tid] = f;
-            s_oslot[tid] = sl;
-            s_oflags2[tid] = f2;
-        }
-        if (tid < MG_MAX_AGENTS) {
-            s_hide[tid] = cfg.hide_obj_mask[tid];
-            s_pscale[tid] = cfg.prestige_scale[tid];
-            s_vmap[tid] = cfg.n_view ? cfg.view_agent[tid] : (uint8_t)tid;
-        }
-#pragma unroll
-        for (int q = 0; q < kSR; q++) {
-            const int i = q * kWave + lane;
-            if (i < nd0) reinterpret_cast<uint32_t*>(w_stage_g)[i] = v0[q];
-        }
-        if (!fs.enabled) {
-            if (r0i < nr0) { const int j = r0i / n; w_stage_r[j * rec_stride + (r0i - j * n)] = rv0; if constexpr (kPrestige) w_stage_p[j * rec_stride + (r0i - j * n)] = pv0; }
-            if (r1i < nr0) { const int j = r1i / n; w_stage_r[j * rec_stride + (r1i - j * n)] = rv1; if constexpr (kPrestige) w_stage_p[j * rec_stride + (r1i - j * n)] = pv1; }
-        }
-    }
-    __syncthreads();
-    MG_STAMP(1);
+    if (fs.enabled) sc0 = fused_step_scratch(cfg, lane, ws + L.step, s_obj, s_oflags);
+    MG_STAMP(13);
 
     // assemble-and-stream raster: the wave's run of envs is ONE contiguous output stream.  w_out[0] is
     // the byte at the 16-byte-aligned global address out_base; w_out[0 .. carry) are pending bytes of a
@@ -350,47 +299,127 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     if (kBatchViews && depth > L.view_slots) depth = L.view_slots;   // (a group's views need a scratch slot per env)
     if constexpr (kPrestige) depth = 1;
     // item -> (slot, rest), view cell -> (viewer, row, column): 24-bit multiplies only (Div20)
-    const Div20 by_n((uint32_t)n), by_nv((uint32_t)nv), by_nvVV((uint32_t)(nv * VV)), by_VV((uint32_t)VV), by_VS((uint32_t)VS);
+    const Div20 by_n((uint32_t)n, lc.m_n), by_nv((uint32_t)nv, lc.m_nv), by_nvVV((uint32_t)(nv * VV), lc.m_nvVV);
+    const Div20 by_VV = VS_ ? Div20((uint32_t)VV) : Div20((uint32_t)VV, lc.m_VV), by_VS = VS_ ? Div20((uint32_t)VS) : Div20((uint32_t)VS, lc.m_VS);
     constexpr bool kExactVV = VS_ > 0 && VS_ <= 9;     // 16 viewers * VS^2 cells: x * (m*d - 2^20) < 2^20 holds (checked below)
     static_assert(VS_ == 0 || VS_ > 9 || (16u * VS_ * VS_ * ((((1u << 20) + VS_ * VS_ - 1u) / (VS_ * VS_)) * (VS_ * VS_) - (1u << 20)) < (1u << 20)), "Div20 exactness");
 
-    for (int eb = e0; eb < e_end; eb += K) {
-        const int kb = min(K, e_end - eb);
+    for (int eb = e0; ; eb += K) {
+        const bool first = (eb == e0);
+        if (eb >= e_end && !first) break;
+        const int kb = max(0, min(K, e_end - eb));
         // 0. stage the batch (contiguous in HBM): loads first, all in flight, then one wait.  mg_step_render:
         //    the step's own up-front loads ride the same round trip, the envs are stepped on the staged grids
-        //    (lane j: env eb + j) and their records are staged from the step's scratch.  The wave's first
-        //    batch was staged by the prologue (all but the grid dwords beyond its kSR per lane).
+        //    (lane j: env eb + j) and their records are staged from the step's scratch.
+        //    The wave's FIRST pass is also the launch's PROLOGUE: tables + atlas -> LDS ride the same round trip,
+        //    and the workgroup's one barrier follows — every wave of the workgroup passes here exactly once, with
+        //    or without envs of its own.  (tools/phase_stamps.py: with the atlas copied first and the batch staged
+        //    after the barrier, the median wave waited 2 us + 5.5 us — 8.8 us with the env step's loads — before
+        //    it could begin.)  ONE round trip has to be defended against the compiler: nothing may be computed on
+        //    a loaded value before the last request is out (a select, a sign extension, the merge of two widths
+        //    into one variable: each was a vmcnt(0) in the middle — round 2's prologue was five round trips).
+        //    Tried on top of this and measured in the product build (profiles/r03/ab_head_variants_v18.txt):
+        //    the inputs TOUCHED ahead (two LDS-DMA loads per wave, before the launch's constants are set up, so that
+        //    this round trip ends in the L2): +0.7 %; the operands of the RNG head's top-up (mt_finish) requested
+        //    here and handed to the step through LDS: +2 % — what they save at the end of step_run they cost in
+        //    front of it; both removed.
         //    (A workgroup-wide variant — the 128 envs of a batch stepped by two full waves between two
         //    barriers instead of 8 lanes in each of 16 waves — was measured 4 us SLOWER per launch: the step is
         //    bound by the latency of one wave's dependent chain, not by issue slots, and a 64-lane wave runs
         //    the union of its lanes' branches — nearly always including a reset.)
+        //    (LDS-DMA for the grids, the atlas and the object table — no staging registers — was tried here: hipcc
+        //    then waits vmcnt(0) at every use of an ordinary load's result and before the barrier, which turns the
+        //    one round trip into eight.)
         {
-            const bool first = (eb == e0);
+            // (`tidl`, `lanel`: the thread and lane index, opaque to the compiler — everything derived from them in here
+            // is an invariant of the env loop to it, computed ahead of the loop, spilled at the 128-VGPR limit and
+            // reloaded with a full wait in the middle of this round trip)
+            int tidl = tid, lanel = lane;
+            asm volatile("" : "+v"(tidl), "+v"(lanel));
+            if (first) MG_STAMP(14);
+            const int T = WPB * 64;
             const uint32_t* gsrc = reinterpret_cast<const uint32_t*>(st.grid + (size_t)eb * cfg.cells_stride);
             const uint64_t* rsrc = st.agents + (size_t)eb * n;
             const int nd = kb * gdw, nr = kb * n;
-            const int r0i = lane, r1i = lane + kWave;                       // kb * n <= 8 * 16 = 2 * kWave records
+            uint32_t v[kSR];
+#pragma unroll
+            for (int q = 0; q < kSR; q++) { const int i = q * kWave + lanel; v[q] = i < nd ? gsrc[i] : 0u; }
+            const int r0i = lanel, r1i = lanel + kWave;                     // kb * n <= 8 * 16 = 2 * kWave records
             uint64_t rv0 = 0ull, rv1 = 0ull;
-            if (!fs.enabled && !first) { rv0 = r0i < nr ? rsrc[r0i] : 0ull; rv1 = r1i < nr ? rsrc[r1i] : 0ull; }
-            StepScratch sc = sc0;
-            StepEnv se = se0;
-#if defined(MG_AB_VARIANTS)
-            sc.stamp = (d_ab_stamps && first && lane == 0) ? d_ab_stamps + (size_t)(blockIdx.x * WPB + wave) * 16 + 8 : nullptr;
-#endif
-            for (int i0 = first ? kSR * kWave : 0; i0 < nd; i0 += kSR * kWave) {
-                uint32_t v[kSR];
-#pragma unroll
-                for (int q = 0; q < kSR; q++) { const int i = i0 + q * kWave + lane; v[q] = i < nd ? gsrc[i] : 0u; }
-                if (i0 == 0 && fs.enabled) {
-                    se = step_load_wave(cfg, st, fs.actions, fs.action_bytes, eb, kb, lane, sc);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int q = 0; q < kSR; q++) {
-                    const int i = i0 + q * kWave + lane;
-                    if (i < nd) reinterpret_cast<uint32_t*>(w_stage_g)[i] = v[q];
+            double pv0 = 0., pv1 = 0.;
+            if (!fs.enabled) {
+                rv0 = r0i < nr ? rsrc[r0i] : 0ull; rv1 = r1i < nr ? rsrc[r1i] : 0ull;
+                if constexpr (kPrestige) {
+                    const double* psrc = st.prestige + (size_t)eb * n;
+                    if (r0i < nr) pv0 = psrc[r0i];
+                    if (r1i < nr) pv1 = psrc[r1i];
                 }
             }
+            const uint4* asrc = reinterpret_cast<const uint4*>(cfg.atlas);
+            const int na = atlas_bytes / 16;                                // (0 when the atlas is read in place)
+            const int no = fs.enabled ? cfg.n_obj * 2 : 0;                  // object table (fused step): <= 128 chunks
+            uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0, o0 = a0;
+            uint8_t f = 0, sl = 0xFF, f2 = 0, vmap0 = 0;
+            uint64_t hide0 = 0;
+            double pscale0 = 0.;
+            if (first) {
+                if (tidl < na) a0 = asrc[tidl];
+                if (tidl + T < na) a1 = asrc[tidl + T];
+                if (tidl < no) o0 = reinterpret_cast<const uint4*>(cfg.obj)[tidl];
+                if (tidl < cfg.n_obj) { f = cfg.obj[tidl].flags; sl = cfg.obj[tidl].ovl_slot; f2 = cfg.obj[tidl].flags2; }
+                if (tidl < MG_MAX_AGENTS) {     // the per-agent tables of the launch struct, requested with the rest
+                    hide0 = cfg.hide_obj_mask[tidl];
+                    pscale0 = cfg.prestige_scale[tidl];
+                    vmap0 = cfg.view_agent[tidl];
+                }
+            }
+            StepScratch sc = sc0;
+            StepEnv se = {0, 0};
+#if defined(MG_AB_VARIANTS)
+            sc.stamp = (d_ab_stamps && lane == 0) ? d_ab_stamps + (size_t)(blockIdx.x * WPB + wave) * 24 + (first ? 8 : 16) : nullptr;
+#endif
+            if (fs.enabled) {
+                const StepLoadRegs r = step_load_issue(cfg, st, fs.actions, fs.action_bytes, eb, kb, lanel);
+                __builtin_amdgcn_sched_barrier(0);
+                se = step_load_commit(cfg, r, kb, lanel, sc, by_n);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (first) MG_STAMP(15);
+#pragma unroll
+            for (int q = 0; q < kSR; q++) {
+                const int i = q * kWave + lanel;
+                if (i < nd) reinterpret_cast<uint32_t*>(w_stage_g)[i] = v[q];
+            }
+            for (int i = kSR * kWave + lanel; i < nd; i += kWave) reinterpret_cast<uint32_t*>(w_stage_g)[i] = gsrc[i];   // (grids beyond 2 KiB per batch: a second trip)
+            if (!fs.enabled) {
+                if (r0i < nr) { const int j = (int)by_n.div((uint32_t)r0i); w_stage_r[j * rec_stride + (r0i - j * n)] = rv0; if constexpr (kPrestige) w_stage_p[j * rec_stride + (r0i - j * n)] = pv0; }
+                if (r1i < nr) { const int j = (int)by_n.div((uint32_t)r1i); w_stage_r[j * rec_stride + (r1i - j * n)] = rv1; if constexpr (kPrestige) w_stage_p[j * rec_stride + (r1i - j * n)] = pv1; }
+            }
+            if (first) {
+                uint4* adst = reinterpret_cast<uint4*>(s_atlas);
+                if (tidl < na) adst[tidl] = a0;
+                if (tidl + T < na) adst[tidl + T] = a1;
+                for (int i = tidl + 2 * T; i < na; i += T) adst[i] = asrc[i];    // (larger atlases: the rest, a second trip)
+                if (tidl < no) reinterpret_cast<uint4*>(s_obj)[tidl] = o0;
+                // (anything computed on a loaded value goes here, behind the round trip: in front of the step's loads
+                // it was a wait for the first half of the requests before the second half was issued)
+                if (tidl == 0) { f = MG_OF_SEE_BEHIND | MG_OF_CAN_OVERLAP; sl = 0; f2 = 1; }   // empty cell
+                if (tidl < MG_MAX_OBJ) {
+                    s_oflags[tidl] = f;
+                    s_oslot[tidl] = sl;
+                    s_oflags2[tidl] = f2;
+                }
+                if (tidl < MG_MAX_AGENTS) {
+                    s_hide[tidl] = hide0;
+                    s_pscale[tidl] = pscale0;
+                    s_vmap[tidl] = cfg.n_view ? vmap0 : (uint8_t)tidl;
+                }
+            }
+            if (first) {
+                __syncthreads();
+                MG_STAMP(1);
+            }
+            if (eb >= e_end) break;
             if (eb == e0) MG_STAMP(2);
             if (fs.enabled) {
                 // (The whole batch is stepped here, before its first store.  Stepping group by group — each view
@@ -426,15 +455,6 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                     uint32_t* dst = reinterpret_cast<uint32_t*>(st.grid + (size_t)(eb + j) * cfg.cells_stride);
                     for (int i = lane; i < gdw; i += kWave) dst[i] = src[i];
                 }
-            } else if (!first) {
-                double pv0 = 0., pv1 = 0.;
-                if constexpr (kPrestige) {
-                    const double* psrc = st.prestige + (size_t)eb * n;
-                    if (r0i < nr) pv0 = psrc[r0i];
-                    if (r1i < nr) pv1 = psrc[r1i];
-                }
-                if (r0i < nr) { const int j = r0i / n; w_stage_r[j * rec_stride + (r0i - j * n)] = rv0; if constexpr (kPrestige) w_stage_p[j * rec_stride + (r0i - j * n)] = pv0; }
-                if (r1i < nr) { const int j = r1i / n; w_stage_r[j * rec_stride + (r1i - j * n)] = rv1; if constexpr (kPrestige) w_stage_p[j * rec_stride + (r1i - j * n)] = pv1; }
             }
         }
         wave_lds_sync();
@@ -996,17 +1016,26 @@ static hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_
     const int need = (cfg.B + WPB - 1) / WPB;   // workgroups if every wave took one env
     const int rounds = (need + max_blocks - 1) / max_blocks;
     const int blocks = (need + rounds - 1) / rounds;
-    int depth_mode = 0;
+    RenderLaunch lc;
+    lc.L = L;
+    lc.per_wave = (cfg.B + blocks * WPB - 1) / (blocks * WPB);
+    const uint32_t nv = (uint32_t)(cfg.n_view ? cfg.n_view : cfg.n_agents), vs = (uint32_t)cfg.view_size;
+    lc.m_n = Div20((uint32_t)cfg.n_agents).m;
+    lc.m_nv = Div20(nv).m;
+    lc.m_nvVV = Div20(nv * vs * vs).m;
+    lc.m_VV = Div20(vs * vs).m;
+    lc.m_VS = Div20(vs).m;
+    lc.depth_mode = 0;
 #if defined(MG_AB_VARIANTS)
-    if (const char* f = getenv("MG_RENDER_DEPTH")) depth_mode = atoi(f);   // 1: every wave view -> raster env by env
+    if (const char* f = getenv("MG_RENDER_DEPTH")) lc.depth_mode = atoi(f);   // 1: every wave view -> raster env by env
 #endif
 #if defined(MG_AB_VARIANTS)
     hipLaunchKernelGGL((render_kernel<VS_, TS_, WPB, V_, RM_>), dim3(blocks), dim3(WPB * 64), lds, s, cfg, st, obs, c, a, v,
-                       depth_mode, *fs, view_out);
+                       lc, *fs, view_out);
 #else
     (void)view_out;
     hipLaunchKernelGGL((render_kernel<VS_, TS_, WPB, V_, RM_>), dim3(blocks), dim3(WPB * 64), lds, s, cfg, st, obs, c, a, v,
-                       depth_mode, *fs);
+                       lc, *fs);
 #endif
     return hipGetLastError();
 }

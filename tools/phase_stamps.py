@@ -7,7 +7,7 @@ import os
 import sys
 
 os.environ["MARLGRID_HIP_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                              "marlgrid_amd", "csrc", "libmarlgrid_hip_ab.so")
+                                              "marlgrid_amd", "csrc", os.environ.get("AB_LIB", "libmarlgrid_hip_ab.so"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 from marlgrid_amd import _native as N  # noqa: E402
@@ -21,14 +21,14 @@ acts = [torch.randint(0, 7, (B, env.num_agents), generator=g).cuda() for _ in ra
 for i in range(40):
     env.step(acts[i % 16])
 L, cfg, st = env._lib, C.byref(env._cfg), C.byref(env._state)
-stamps = torch.zeros(65536 * 16, dtype=torch.int64, device="cuda")
+stamps = torch.zeros(65536 * 24, dtype=torch.int64, device="cuda")
 names = ["tables + atlas -> LDS, barrier", "stage grids (+ step_load)", "step_run (+ records, write-back)",
          "views of the first group", "raster of the first env", "rest of the run"]
 
 
 def report(title):
     torch.cuda.synchronize()
-    t = stamps.view(-1, 16).cpu()
+    t = stamps.view(-1, 24).cpu()
     if os.environ.get("STAMPS_OUT"):
         import numpy as np
         np.save(os.path.join(os.environ["STAMPS_OUT"], "stamps_%s_%d.npy" % (title, report.n)), t[t[:, 6] != 0].numpy())
@@ -50,16 +50,22 @@ def report(title):
     print("   mean exit time by XCD (workgroup %% 8): %s" % " ".join("%.1f" % v for v in by_xcd))
     by_wave = [ex[torch.arange(len(ex)) % 4 == w].mean().item() for w in range(4)]
     print("   mean exit time by look-ahead depth 1/2/4/8 (wave %% 4): %s" % " ".join("%.1f" % v for v in by_wave))
-    if (t[:, 8] != 0).any():        # inside step_run of the first batch (lane 0's env)
-        inner = ["spawns, front cells, shuffle", "agent loop", "done / respawn / fused reset", "write-back + RNG head refill"]
-        prev = t[:, 2]
+    if (t[:, 13] != 0).any():
+        for nm, x, y in (("entry -> launch constants set up", 0, 13), ("-> env loop entered (hoisted invariants)", 13, 14),
+                         ("prologue's loads issued and back", 14, 15), ("LDS stores + barrier", 15, 1)):
+            d = t[:, y] - t[:, x]
+            print("      head: %-40s mean %7.2f  min %7.2f  p50 %7.2f  p90 %7.2f  max %7.2f us" %
+                  (nm, d.mean().item(), d.min().item(), d.median().item(), torch.quantile(d, 0.9).item(), d.max().item()))
+    inner = ["spawns, front cells, shuffle", "agent loop", "done / respawn / fused reset", "write-back + RNG head refill"]
+    for base, which in ((8, "first batch"), (16, "last batch")):
+        if not (t[:, base] != 0).any():        # inside step_run (lane 0's env)
+            continue
+        print("      step_run of the wave's %s: stage/step_load -> entry mean %.2f us" % (which, (t[:, base] - t[:, 2]).mean().item()) if base == 8
+              else "      step_run of the wave's %s (entered %.1f us after the wave's entry, mean):" % (which, (t[:, base] - t[:, 0]).mean().item()))
         for k in range(4):
-            d = t[:, 8 + k] - prev
-            prev = t[:, 8 + k]
-            print("      step_run: %-30s mean %7.2f  min %7.2f  p50 %7.2f  p90 %7.2f  max %7.2f us" %
+            d = t[:, base + 1 + k] - t[:, base + k]
+            print("         %-30s mean %7.2f  min %7.2f  p50 %7.2f  p90 %7.2f  max %7.2f us" %
                   (inner[k], d.mean().item(), d.min().item(), d.median().item(), torch.quantile(d, 0.9).item(), d.max().item()))
-        d = t[:, 3] - t[:, 11]
-        print("      step_run: %-30s mean %7.2f  min %7.2f  max %7.2f us" % ("records to the views, grid write-back", d.mean().item(), d.min().item(), d.max().item()))
     d = t[:, 4] - t[:, 0]
     print("   entry -> first views done            mean %7.2f  min %7.2f  max %7.2f us" % (d.mean().item(), d.min().item(), d.max().item()))
     stamps.zero_()
