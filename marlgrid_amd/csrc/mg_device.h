@@ -102,6 +102,24 @@ struct RenderScratch {
     int cell_stride;   // bytes per slot of first / second
     int trow_stride;   // dwords per slot of trow
 };
+// The atlas in LDS.  As it is in HBM ([4 orientations][n_tiles][ts][ts][3], rounded up to 16 bytes) — except for
+// the assemble-and-stream raster at the reference's default view with 5- or 6-pixel tiles (render_pad_rows), where
+// every tile ROW gets 4 zero bytes in front and at least 4 behind (render_row_bytes: 24 bytes for a 15-byte row):
+// a row segment copied to an arbitrary byte phase is then whole aligned dwords read around the row — no edge
+// masks, no conditional reads (or_segment_padded in mg_render.hip): 62 -> 42 instructions per segment, the whole step
+// -5.7 % at tile 5, -2.0 % at tile 6 against the same build without (profiles/r03/ab_fused_padded_rows_tile*_v21.txt).
+__host__ __device__ inline bool render_pad_rows(const MgConfig& cfg) {
+    return cfg.view_size == 7 && (cfg.tile_size == 5 || cfg.tile_size == 6) && cfg.prestige_mask == 0;
+}
+__host__ __device__ inline int render_row_bytes(int ts) { return (3 * ts + 8 + 7) / 8 * 8; }
+__host__ __device__ inline int render_atlas_raw_bytes(const MgConfig& cfg) {
+    return (4 * cfg.n_tiles * cfg.tile_size * cfg.tile_size * 3 + 15) / 16 * 16;
+}
+__host__ __device__ inline int render_atlas_lds_bytes(const MgConfig& cfg) {
+    if (!render_pad_rows(cfg)) return render_atlas_raw_bytes(cfg);
+    return (4 * cfg.n_tiles * cfg.tile_size * render_row_bytes(cfg.tile_size) + 8 + 15) / 16 * 16;   // (+ 8 zero bytes behind the last row)
+}
+
 // What a launch of the obs kernel would otherwise work out in every wave before it requests its first byte — the
 // LDS layout (render_scratch_for: four candidate layouts), the envs per wave, the dividers' multipliers: ~600
 // instructions, 1.5 us of the launch's store-free head (tools/phase_stamps.py) — worked out by the launcher instead.
@@ -110,6 +128,7 @@ struct RenderLaunch {
     int per_wave;                               // envs per wave of the persistent grid
     uint32_t m_n, m_nv, m_nvVV, m_VV, m_VS;     // Div20 multipliers of n, nv, nv * VS^2, VS^2, VS
     int depth_mode;                             // measurement builds: look-ahead depth forced for all waves (0: by wave)
+    int atlas_lds;                              // bytes the atlas takes in LDS (render_atlas_lds_bytes; 0: read in place)
 };
 // n: the env's agents (records, who stands where); nv: the viewers this launch renders (view-sized arrays)
 __host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride, int n, int nv, int vs, int stage_envs = 1,
@@ -166,7 +185,7 @@ __host__ __device__ inline RenderScratch render_scratch_for(const MgConfig& cfg,
     const int n = cfg.n_agents, vs = cfg.view_size, ts = cfg.tile_size;
     const int nv = cfg.n_view ? cfg.n_view : n;
     const int dyn = cfg.prestige_mask ? (cfg.any_hide ? 2 : 1) * n * 4 * ts * ts * 3 : 0;
-    const int atlas_b = round_up(4 * cfg.n_tiles * ts * ts * 3, 16), misc = 1024;
+    const int atlas_b = render_atlas_lds_bytes(cfg), misc = 1024;
     int rows = 0, out = 0;
     if (!render_chunk_raster(cfg, mode)) {
         const int rb = 3 * vs * ts;

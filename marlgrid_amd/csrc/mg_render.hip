@@ -74,6 +74,26 @@ __device__ __forceinline__ void or_segment(const uint8_t* __restrict__ sb, uint3
     }
 }
 
+// The same for tile rows that sit in LDS PADDED with zeros (render_pad_rows: 4 zero bytes, the SEG bytes of the row,
+// >= 4 zero bytes; ROWB bytes per row, 8-byte aligned): the NC destination dwords are whole aligned dwords read
+// around the row and cut to the destination's phase — what lies outside the segment reads as zero, so there is
+// nothing to mask and nothing conditional.  `row`: the padded row.  Destination dword i holds padded bytes
+// [4 i + 4 - phi, 4 i + 8 - phi): for phi = 1..3 that is v_alignbyte(w[i + 1], w[i], 4 - phi); for phi = 0 it is
+// w[i + 1] — the same expression with the reads one dword further and a shift of 0.
+template <int SEG, int ROWB>
+__device__ __forceinline__ void or_segment_padded(const uint8_t* __restrict__ row, uint8_t* __restrict__ lds0, uint32_t dl) {
+    constexpr int NC = (SEG + 6) / 4;                    // destination dwords a segment can touch
+    static_assert(NC + 2 <= ROWB / 4 + 1, "padded row: NC + 1 source dwords from dword 0 or 1 (the last one may be the next row's zeros)");
+    const uint32_t phi = dl & 3u, sh = (4u - phi) & 3u;
+    const uint32_t* A = reinterpret_cast<const uint32_t*>(row) + (phi == 0u ? 1 : 0);
+    uint32_t* D = reinterpret_cast<uint32_t*>(lds0 + (dl & ~3u));
+    uint32_t w[NC + 1];
+#pragma unroll
+    for (int i = 0; i <= NC; i++) w[i] = A[i];
+#pragma unroll
+    for (int i = 0; i < NC; i++) atomicOr(&D[i], __builtin_amdgcn_alignbyte(w[i + 1], w[i], sh));
+}
+
 // ---- mg_step_render: the step of a batch of staged envs, lane j < kb steps env eb + j (mg_core.h) ----
 // The wave steps the envs it is about to render ON THEIR STAGED COPIES: the loads whose addresses are known up
 // front (records, actions, RNG look-ahead, counters: step_load) are issued together with the batch's grid loads
@@ -209,7 +229,11 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     // Each wave walks its own CONTIGUOUS run of envs, i.e. one long sequential output stream per wave
     // (measured +5 % HBM write throughput over a grid-strided walk).
     constexpr bool kGlobalAtlas = (V_ == 8 || V_ == 12);
-    const int atlas_bytes = kGlobalAtlas ? 0 : round_up(4 * cfg.n_tiles * tile_bytes, 16);
+    const int atlas_bytes = kGlobalAtlas ? 0 : lc.atlas_lds;       // in LDS (render_atlas_lds_bytes)
+    // tile rows padded with zeros in LDS (mg_device.h: render_pad_rows — the launcher takes this instantiation for
+    // exactly those configs)
+    constexpr bool kPadRows = VS_ == 7 && (TS_ == 5 || TS_ == 6) && V_ == 0 && RM_ == 0;
+    constexpr int kRowB = kPadRows ? (3 * TS_ + 8 + 7) / 8 * 8 : 0, kRowW = kRowB / 4;
     const int gdw = cfg.cells_stride / 4;
     const int per_wave = lc.per_wave, depth_mode = lc.depth_mode;
     const int e0 = (blockIdx.x * WPB + wave) * per_wave;
@@ -356,15 +380,37 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 }
             }
             const uint4* asrc = reinterpret_cast<const uint4*>(cfg.atlas);
-            const int na = atlas_bytes / 16;                                // (0 when the atlas is read in place)
+            const int na = kGlobalAtlas ? 0 : render_atlas_raw_bytes(cfg) / 16;   // (0 when the atlas is read in place)
             const int no = fs.enabled ? cfg.n_obj * 2 : 0;                  // object table (fused step): <= 128 chunks
             uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0, o0 = a0;
             uint8_t f = 0, sl = 0xFF, f2 = 0, vmap0 = 0;
             uint64_t hide0 = 0;
             double pscale0 = 0.;
+            // padded tile rows (kPadRows): LDS dword d is 4 bytes of row d / kRowW, read as the 8 aligned bytes of the
+            // atlas around them (pad_window) and cut out when they are stored
+            const int raw16 = render_atlas_raw_bytes(cfg), npd = kPadRows ? 4 * cfg.n_tiles * TS * kRowW + 2 : 0;
+            auto pad_window = [&](int d, uint32_t& cut, uint32_t& keep) -> int {     // byte offset of the window, -1: zeros
+                const int row = d / (kRowW ? kRowW : 1), k = d - row * kRowW, j0 = 4 * k - 4;    // row bytes [j0, j0 + 4)
+                const int nvb = min(4, 3 * TS - j0);
+                if (k == 0 || nvb <= 0 || row >= 4 * cfg.n_tiles * TS) return -1;
+                const int sb = row * 3 * TS + j0, a = min(sb & ~3, raw16 - 8);
+                cut = (uint32_t)(sb - a) * 8u;                                        // (0 .. 56 bits)
+                keep = nvb >= 4 ? 0xFFFFFFFFu : (1u << (8 * nvb)) - 1u;
+                return a;
+            };
+            uint2 pw[4] = {make_uint2(0, 0), make_uint2(0, 0), make_uint2(0, 0), make_uint2(0, 0)};
             if (first) {
-                if (tidl < na) a0 = asrc[tidl];
-                if (tidl + T < na) a1 = asrc[tidl + T];
+                if constexpr (kPadRows) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        uint32_t cut, keep;
+                        const int a = tidl + q * T < npd ? pad_window(tidl + q * T, cut, keep) : -1;
+                        if (a >= 0) pw[q] = *reinterpret_cast<const uint2*>(cfg.atlas + a);
+                    }
+                } else {
+                    if (tidl < na) a0 = asrc[tidl];
+                    if (tidl + T < na) a1 = asrc[tidl + T];
+                }
                 if (tidl < no) o0 = reinterpret_cast<const uint4*>(cfg.obj)[tidl];
                 if (tidl < cfg.n_obj) { f = cfg.obj[tidl].flags; sl = cfg.obj[tidl].ovl_slot; f2 = cfg.obj[tidl].flags2; }
                 if (tidl < MG_MAX_AGENTS) {     // the per-agent tables of the launch struct, requested with the rest
@@ -396,10 +442,28 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 if (r1i < nr) { const int j = (int)by_n.div((uint32_t)r1i); w_stage_r[j * rec_stride + (r1i - j * n)] = rv1; if constexpr (kPrestige) w_stage_p[j * rec_stride + (r1i - j * n)] = pv1; }
             }
             if (first) {
+                if constexpr (kPadRows) {
+                    uint32_t* adst = reinterpret_cast<uint32_t*>(s_atlas);
+                    auto cut_out = [&](uint2 w, uint32_t cut, uint32_t keep) -> uint32_t {
+                        return (uint32_t)((((uint64_t)w.y << 32) | w.x) >> cut) & keep;
+                    };
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int d = tidl + q * T;
+                        uint32_t cut = 0, keep = 0;
+                        if (d < npd) adst[d] = pad_window(d, cut, keep) >= 0 ? cut_out(pw[q], cut, keep) : 0u;
+                    }
+                    for (int d = tidl + 4 * T; d < npd; d += T) {                 // (larger atlases: the rest, a second trip)
+                        uint32_t cut = 0, keep = 0;
+                        const int a = pad_window(d, cut, keep);
+                        adst[d] = a >= 0 ? cut_out(*reinterpret_cast<const uint2*>(cfg.atlas + a), cut, keep) : 0u;
+                    }
+                } else {
                 uint4* adst = reinterpret_cast<uint4*>(s_atlas);
                 if (tidl < na) adst[tidl] = a0;
                 if (tidl + T < na) adst[tidl + T] = a1;
                 for (int i = tidl + 2 * T; i < na; i += T) adst[i] = asrc[i];    // (larger atlases: the rest, a second trip)
+                }
                 if (tidl < no) reinterpret_cast<uint4*>(s_obj)[tidl] = o0;
                 // (anything computed on a loaded value goes here, behind the round trip: in front of the step's loads
                 // it was a wait for the first half of the requests before the second half was issued)
@@ -937,7 +1001,23 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 const uint32_t rows = min((uint32_t)L.piece_rows, NR - R0), nseg = rows * (uint32_t)VS;
                 for (uint32_t g = lane; g < nseg; g += kWave) {
                     const uint32_t Rl = by_VS.div(g), col = g - __umul24(Rl, (uint32_t)VS), R = R0 + Rl;
-                    const uint32_t band = by_TS.template div<kExactTS>(R), rr = R - __umul24(band, (uint32_t)TS);
+                    // band = R / TS and rr = R % TS from ONE 24-bit product when the quotient is exact (R - band * TS
+                    // is fused into a quarter-rate v_mad_u64_u32 otherwise): the fraction times TS, rounded down
+                    uint32_t band, rr;
+                    if constexpr (kExactTS) {
+                        const uint32_t prod = __umul24(R, by_TS.m);
+                        band = prod >> 20;
+                        rr = __umul24(prod & 0xFFFFFu, (uint32_t)TS) >> 20;
+                    } else {
+                        band = by_TS.template div<false>(R);
+                        rr = R - __umul24(band, (uint32_t)TS);
+                    }
+                    if constexpr (kPadRows) {
+                        const uint32_t vt = (uint32_t)w_tmap[__umul24(band, (uint32_t)VS) + col];
+                        or_segment_padded<3 * TS_, kRowB>(s_atlas + __umul24(__umul24(vt, (uint32_t)TS) + rr, (uint32_t)kRowB), w_out,
+                                                          carry + __umul24(g, SEG));
+                        continue;
+                    }
                     const uint32_t so = tile_off((uint32_t)w_tmap[__umul24(band, (uint32_t)VS) + col]) + __umul24(rr, SEG);
                     const uint8_t* sb;       // source base the offset `sa` counts from
                     uint32_t sa = so;
@@ -995,8 +1075,8 @@ static hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_
     const int tile_bytes = cfg.tile_size * cfg.tile_size * 3;
     static_assert(RM_ == 1 || TS_ == 0 || (TS_ % 8) != 0 || TS_ == 8 || TS_ == 16 || TS_ == 32, "see render_chunk_raster");
     const RenderScratch L = render_scratch_for(cfg, WPB, RM_);
-    size_t lds = ((V_ == 8 || V_ == 12) ? 0 : (size_t)round_up(4 * cfg.n_tiles * tile_bytes, 16)) + kRenderShared +
-                 WPB * (size_t)L.total;
+    const size_t atlas_lds = (V_ == 8 || V_ == 12) ? 0 : (size_t)render_atlas_lds_bytes(cfg);
+    size_t lds = atlas_lds + kRenderShared + WPB * (size_t)L.total;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<VS_, TS_, WPB, V_, RM_>),
@@ -1026,6 +1106,7 @@ static hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_
     lc.m_VV = Div20(vs * vs).m;
     lc.m_VS = Div20(vs).m;
     lc.depth_mode = 0;
+    lc.atlas_lds = (int)atlas_lds;
 #if defined(MG_AB_VARIANTS)
     if (const char* f = getenv("MG_RENDER_DEPTH")) lc.depth_mode = atoi(f);   // 1: every wave view -> raster env by env
 #endif
@@ -1042,14 +1123,14 @@ static hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_
 
 int render_min_lds_bytes(const MgConfig& cfg) {
     const RenderScratch L = render_scratch_for(cfg, 4);
-    const int atlas_b = round_up(4 * cfg.n_tiles * cfg.tile_size * cfg.tile_size * 3, 16);
+    const int atlas_b = render_atlas_lds_bytes(cfg);
     const int rest = kRenderShared + 4 * L.total;
     return atlas_b + rest <= 160 * 1024 ? atlas_b + rest : rest;   // else the atlas is read in place
 }
 
 static size_t render_lds_bytes(const MgConfig& cfg, int wpb) {
     const RenderScratch L = render_scratch_for(cfg, wpb);
-    return (size_t)round_up(4 * cfg.n_tiles * cfg.tile_size * cfg.tile_size * 3, 16) + kRenderShared + (size_t)wpb * L.total;
+    return (size_t)render_atlas_lds_bytes(cfg) + kRenderShared + (size_t)wpb * L.total;
 }
 
 // Workgroup shape.  16 waves per workgroup walk 16 *adjacent* envs at a time (a 450 KB contiguous
@@ -1062,7 +1143,7 @@ static int choose_wpb(const MgConfig& cfg) {
 #endif
     const int tile_bytes = cfg.tile_size * cfg.tile_size * 3;
     const RenderScratch L = render_scratch_for(cfg, 16);
-    size_t lds16 = (size_t)round_up(4 * cfg.n_tiles * tile_bytes, 16) + kRenderShared + 16 * (size_t)L.total;
+    size_t lds16 = (size_t)render_atlas_lds_bytes(cfg) + kRenderShared + 16 * (size_t)L.total;
     return (cfg.B >= 4096 && lds16 <= 160 * 1024) ? 16 : 4;
 }
 
@@ -1127,7 +1208,7 @@ static hipError_t launch_render_one(const MgConfig& cfg, const MgState& st, uint
     const int wpb = choose_wpb(cfg);
     if (cfg.prestige_mask) {   // per-env recoloured agent tiles (LDS), 4-wave workgroups
         const RenderScratch L = render_scratch_for(cfg, 4);
-        const size_t lds4 = (size_t)round_up(4 * cfg.n_tiles * ts * ts * 3, 16) + kRenderShared +
+        const size_t lds4 = (size_t)render_atlas_lds_bytes(cfg) + kRenderShared +
                             4 * (size_t)L.total;
         if (lds4 > 160 * 1024) {   // the static atlas stays in global memory
             if (ts == 8) return launch_render_t<0, 8, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
@@ -1165,7 +1246,7 @@ static hipError_t launch_render_one(const MgConfig& cfg, const MgState& st, uint
     }
     {   // atlas too large for LDS (next to 4 waves of scratch): read it from global memory instead
         const RenderScratch L = render_scratch_for(cfg, 4);
-        const size_t lds4 = (size_t)round_up(4 * cfg.n_tiles * ts * ts * 3, 16) + kRenderShared +
+        const size_t lds4 = (size_t)render_atlas_lds_bytes(cfg) + kRenderShared +
                             4 * (size_t)L.total;
         if (lds4 > 160 * 1024) {
             if (ts == 8) return launch_render_t<0, 8, 4, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);

@@ -3,7 +3,7 @@
 build of an earlier commit next to the current one).  First a parity check of every build against the first one
 (two envs, same seeds and actions, 130 steps: observations, rewards, done, records, grids and the whole RNG state
 must be equal), then 9 interleaved rounds of 100 launches each, all into the SAME observation buffer.
-usage: ab_fused.py path/to/ref.so path/to/new.so [...]"""
+usage: [TILE=5] [B=...] ab_fused.py path/to/ref.so path/to/new.so [...]"""
 import ctypes as C
 import os
 import statistics
@@ -19,7 +19,19 @@ names = sys.argv[1:]
 B = int(os.environ.get("B", "32768"))
 WL = os.environ.get("WL", "MarlGrid-3AgentCluttered15x15-v0")
 g = torch.Generator().manual_seed(0)
-env = make(WL, batch_size=B, auto_reset=True, strict=False, place_obs=("search" if os.environ.get("PLACE", "1") != "0" else False))
+PLACE = "search" if os.environ.get("PLACE", "1") != "0" else False
+
+
+def build():
+    if os.environ.get("TILE"):      # the bench scenario's shape with another view_tile_size (the instantiations off the fast path)
+        from marlgrid_amd.agents import GridAgentInterface
+        from marlgrid_amd.envs import ClutteredMultiGrid
+        return ClutteredMultiGrid(agents=[GridAgentInterface(color=c, view_size=7, view_tile_size=int(os.environ["TILE"])) for c in ("red", "blue", "purple")],
+                                  grid_size=15, clutter_density=0.15, batch_size=B, strict=False, auto_reset=True, place_obs=PLACE)
+    return make(WL, batch_size=B, auto_reset=True, strict=False, place_obs=PLACE)
+
+
+env = build()
 n = env.num_agents
 acts = [torch.randint(0, 7, (B, n), generator=g).cuda() for _ in range(16)]
 vp, i32 = C.c_void_p, C.c_int32
@@ -42,7 +54,7 @@ def launch(L, e, i):
 env.reset()
 env.step(acts[0])          # (traces the reset program)
 if os.environ.get("CHECK", "1") != "0":
-    ref = make(WL, batch_size=B, auto_reset=True, strict=False, place_obs=("search" if os.environ.get("PLACE", "1") != "0" else False))
+    ref = build()
     ref.reset()
     ref.step(acts[0])
     for nm in names[1:]:
