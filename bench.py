@@ -27,6 +27,9 @@ How the line is measured (one self-consistent measurement, not a collage):
   * `clocks` holds rocm-smi samples before the first and after the last block; `roofline.traffic`
     is measured in this run (tools/pmc.py: rocprofv3 --pmc passes in a child process, N = 1 only).
   * `extra.strong_n1`: the full headline batch (262 144 envs) on ONE GPU, same fields.
+  * `extra.pipelined_shards`: the per-GPU batch (and twice it) as TWO envs on two streams, stepped without a join
+    (marlgrid_amd.sharding.ShardPipeline): what overlapping launches of independent shards are worth, next to the
+    same number of envs as one env.  The contract line itself is ONE env on one stream.
 The run refuses to start if an MG_* / MARLGRID_* environment variable is set, and echoes the
 library's build id.
 """
@@ -290,6 +293,33 @@ def measure(wl, B, dev, ctl, seeds, K, Wm, min_seconds, max_blocks, action_seed,
     return env, summarise(blocks, K), blocks
 
 
+_PIPE_STREAMS = {}
+
+
+def measure_pipeline(wl, B, parts, dev, ctl, K, Wm, min_seconds, max_blocks, action_seed, fused=True):
+    """The same batch as `parts` envs on as many streams (marlgrid_amd.sharding.ShardPipeline: overlapping launches
+    of independent shards), timed like the contract line: K-step blocks, barrier + synchronize on both sides."""
+    import torch
+    from marlgrid_amd.sharding import ShardPipeline
+    if parts not in _PIPE_STREAMS:      # the same streams for every pipeline of this process (hardware queues are few)
+        _PIPE_STREAMS[parts] = [torch.cuda.Stream(device=dev) for _ in range(parts)]
+    pipe = ShardPipeline(lambda batch_size, seeds, device: build_env(wl, batch_size, device, seeds, fused), B, parts=parts,
+                         seed=1337, device=dev, streams=_PIPE_STREAMS[parts])
+    pipe.reset()
+    n = pipe.envs[0].num_agents
+    g = torch.Generator(device="cpu").manual_seed(action_seed)
+    pool = [torch.randint(0, 7, (B, n), generator=g).to(dev) for _ in range(64)]
+    pool = [[pipe.part(k, a).contiguous() for k in range(parts)] for a in pool]
+    torch.cuda.synchronize(dev)
+    for i in range(Wm):
+        pipe.step(pool[i % 64])
+    blocks = timed_blocks(lambda i: pipe.step(pool[(Wm + i) % 64]), lambda: torch.cuda.synchronize(dev), ctl, K,
+                          min_seconds, max_blocks, None)
+    pipe.check_errors()
+    placement = [{k: v for k, v in (getattr(e._groups[0], "placement_ms", None) or {}).items() if k != "all"} for e in pipe.envs]
+    return n, summarise(blocks, K), placement
+
+
 def raster_only_ms(env, iters=50):
     """the obs raster alone (mg_render_obs launched back to back on the launch stream, HIP events): what the
     fused launch's raster part costs without the step in front of it"""
@@ -340,6 +370,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic = null)")
     ap.add_argument("--no-strong", action="store_true", help="skip the 262 144-env single-GPU point")
+    ap.add_argument("--no-pipeline", action="store_true", help="skip extra.pipelined_shards (two envs on two streams)")
     ap.add_argument("--unfused", action="store_true",
                     help="env.step() as two launches (mg_step, mg_render_obs) instead of one (mg_step_render): A/B only")
     ap.add_argument("--oversubscribe", action="store_true",
@@ -488,6 +519,30 @@ def main():
             "closure": sum_s.get("closure"), "roofline": roofline_of(env_s, Bs, sum_s, None, raster_s)}
         del env_s
         torch.cuda.empty_cache()
+
+    # overlapping launches — the same batch as two envs on two streams, and twice the batch
+    if n_gpus == 1 and not args.no_pipeline and wl == WORKLOAD:
+        pts = []
+        for Bp in (B, 2 * B):
+            ms_one = ms
+            if Bp != B:
+                seeds_o = sharding.shard_seeds(1337, Bp, 0, 1)
+                env_o, sum_o, _ = measure(wl, Bp, dev, ctl, seeds_o, K, min(Wm, 5), min(args.min_seconds, 1.0), 400, 0, fused)
+                ms_one = sum_o["plain"]["mean"]
+                del env_o
+                torch.cuda.empty_cache()
+            n_p, sum_p, place_p = measure_pipeline(wl, Bp, 2, dev, ctl, K, min(Wm, 5), min(args.min_seconds, 1.0), 400, 0, fused)
+            ms_p = sum_p["plain"]["mean"]
+            pts.append({"envs": Bp, "parts": 2, "envs_per_part": Bp // 2, "ms_per_step": ms_p,
+                        "value": Bp * n_p / (ms_p * 1e-3), "unit": "agent-steps/s", "timing": sum_p["plain"],
+                        "one_env_ms_per_step": ms_one, "one_env_value": Bp * n_p / (ms_one * 1e-3),
+                        "vs_one_env": ms_one / ms_p, "obs_placement": place_p})
+            torch.cuda.empty_cache()
+        out.setdefault("extra", {})["pipelined_shards"] = {
+            "what": "the per-GPU batch as TWO envs on two streams (marlgrid_amd.sharding.ShardPipeline), stepped without "
+                    "a join in between: launches of independent shards overlap (the store-free head of one under the "
+                    "stores of the other); same trajectories env by env; the contract line above is ONE env, one stream",
+            "points": pts}
 
     if rank == 0:
         if n_gpus == 1 and not args.no_cpu_baseline:

@@ -474,7 +474,7 @@ class MultiGridEnv(object):
 
     @_on_device
     def _place_obs_buffers(self, batch=8, max_candidates=256, min_bytes=256 << 20, iters=3, budget=32 << 30, gain=0.12,
-                           seconds=1.5):
+                           seconds=1.5, flat_after=128):
         """place_obs="search" (default): choose WHERE in HBM the observation buffers live.  Measured on MI355X
         (profiles/r02/README.md section 3, profiles/r03/README.md section 2): the rate at which the raster's
         write pattern — thousands of waves, each streaming its own env — is absorbed depends on the ALLOCATION
@@ -485,11 +485,12 @@ class MultiGridEnv(object):
         virtual ranges come back with stale translations on ROCm 7.2 — so what remains is drawing new allocations
         and measuring: candidates are raw hipMalloc allocations made and freed through the library (never torch's
         caching allocator: nothing is cached, nothing else is flushed), the raster itself is timed into each (HIP
-        events, `iters` launches; under a millisecond per candidate), at most `batch` of them alive at a time
+        events, `iters` launches; about a millisecond per candidate), at most `batch` of them alive at a time
         next to the best `keep` so far; the search stops when the buffers it would keep are `gain` faster than
-        the median candidate (they are in the fast class), when two batches show no spread worth searching, or
-        at `max_candidates` / `budget` bytes alive / a quarter of the memory that is free when a batch starts /
-        `seconds`.  Running out of memory ends the search with what it has.  Buffers under `min_bytes` (where no
+        the median candidate (they are in the fast class), when `flat_after` candidates show no spread (only then:
+        on a box where one allocation in thirty is fast the first eighteen all came out slow, within 5 % of each
+        other — profiles/r03: 469 M instead of 576 M agent-steps/s), or at `max_candidates` / `budget` bytes alive
+        / a quarter of the memory that is free when a batch starts / `seconds`.  Running out of memory ends the search with what it has.  Buffers under `min_bytes` (where no
         classes are seen) are left alone."""
         import time
         import torch
@@ -540,7 +541,7 @@ class MultiGridEnv(object):
                 if len(seen) >= keep + 2 * batch and best[keep - 1][0] <= (1.0 - gain) * median:
                     why = "kept set %d%% under the median candidate" % round(100 * (1 - best[keep - 1][0] / median))
                     break
-                if len(seen) >= keep + 2 * batch and ranked[-1] <= 1.05 * ranked[0]:
+                if len(seen) >= keep + flat_after and ranked[-1] <= 1.05 * ranked[0]:
                     why = "no spread among %d candidates" % len(seen)
                     break
             g.ring = [t for _, t in best]

@@ -1095,7 +1095,12 @@ static hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_
     const int max_blocks = 256 * per_cu;
     const int need = (cfg.B + WPB - 1) / WPB;   // workgroups if every wave took one env
     const int rounds = (need + max_blocks - 1) / max_blocks;
-    const int blocks = (need + rounds - 1) / rounds;
+    int blocks = (need + rounds - 1) / rounds;
+#if defined(MG_AB_VARIANTS)
+    // measurement build (tools/ab_rounds.py): more workgroups than are resident at a time — the later ones start as the
+    // first ones exit, their store-free heads under the others' stores (VERDICT r02 item 4a within ONE launch)
+    if (const char* f = getenv("MG_RENDER_OVERSUB")) { const int v = atoi(f); if (v > 1) blocks = min(need, blocks * v); }
+#endif
     RenderLaunch lc;
     lc.L = L;
     lc.per_wave = (cfg.B + blocks * WPB - 1) / (blocks * WPB);

@@ -151,3 +151,33 @@ def test_c_abi_rejects_bad_viewer_subsets():
     assert L.mg_step_render(C.byref(cfg), C.byref(env._state), a.data_ptr(), 8, env.rewards.data_ptr(), None,
                             env.obs.data_ptr(), env._stream()) == -100
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_shard_pipeline_equals_one_env():
+    """ShardPipeline: the batch as two envs on two streams (overlapping launches) — the same trajectories as ONE env
+    of the whole batch, env by env, and the parts really run on their own streams"""
+    import torch
+    from marlgrid_amd.envs import make
+    from marlgrid_amd.sharding import ShardPipeline
+    name, B = "MarlGrid-3AgentCluttered11x11-v0", 512
+    one = make(name, batch_size=B, seeds=[1337 + g for g in range(B)], auto_reset=True)
+    pipe = ShardPipeline(lambda **kw: make(name, auto_reset=True, **kw), B, parts=2, seed=1337)
+    assert pipe.streams[0].cuda_stream != pipe.streams[1].cuda_stream and pipe.part_size == 256
+    o = one.reset()
+    parts = pipe.reset()
+    pipe.synchronize()
+    for k in range(2):
+        assert torch.equal(pipe.part(k, o), parts[k])
+    rng = np.random.RandomState(5)
+    for t in range(120):            # past max_steps: every env resets inside a launch at least once
+        a = torch.from_numpy(rng.randint(0, 7, size=(B, 3))).cuda()
+        o, r, d, _ = one.step(a)
+        res = pipe.step(a)
+        pipe.synchronize()
+        for k in range(2):
+            o2, r2, d2, _ = res[k]
+            assert torch.equal(pipe.part(k, o), o2) and torch.equal(pipe.part(k, r), r2) and torch.equal(pipe.part(k, d), d2), (t, k)
+    pipe.check_errors()
+    with pytest.raises(ValueError):
+        ShardPipeline(lambda **kw: None, 7, parts=2)

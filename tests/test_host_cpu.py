@@ -357,3 +357,14 @@ def test_export_video_frame_function(tmp_path, monkeypatch):
         assert f.shape == (18, 15, 3) and np.array_equal(f, want[min(int(t * 10), 6)])
     export_video(np.stack(X), str(out), fps=20, rescale_factor=1)   # an array, no rescale
     assert np.array_equal(calls["make_frame"](0.26), X[5])
+
+
+def test_shard_pipeline_arguments():
+    """ShardPipeline refuses a batch that does not split evenly — before it touches a device"""
+    from marlgrid_amd.sharding import ShardPipeline, shard_seeds
+    with pytest.raises(ValueError):
+        ShardPipeline(lambda **kw: None, 7, parts=2)
+    with pytest.raises(ValueError):
+        ShardPipeline(lambda **kw: None, 8, parts=0)
+    # the seeds a part gets are those of its slice of the one big env
+    assert shard_seeds(1337, 8, 1, 2) == [1341, 1342, 1343, 1344]
