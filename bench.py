@@ -543,6 +543,7 @@ def main():
                     "a join in between: launches of independent shards overlap (the store-free head of one under the "
                     "stores of the other); same trajectories env by env; the contract line above is ONE env, one stream",
             "points": pts}
+        out["value_pipelined_shards"] = pts[0]["value"]       # the same batch as two envs on two streams (extra.pipelined_shards)
 
     if rank == 0:
         if n_gpus == 1 and not args.no_cpu_baseline:
