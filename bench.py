@@ -30,6 +30,8 @@ How the line is measured (one self-consistent measurement, not a collage):
   * `extra.pipelined_shards`: the per-GPU batch (and twice it) as TWO envs on two streams, stepped without a join
     (marlgrid_amd.sharding.ShardPipeline): what overlapping launches of independent shards are worth, next to the
     same number of envs as one env.  The contract line itself is ONE env on one stream.
+  * the interpreter's garbage is collected (and the survivors frozen) before every timed region: a full collection in
+    the middle of a 20-step block is a 50 ms host stall (settle_interpreter).
 The run refuses to start if an MG_* / MARLGRID_* environment variable is set, and echoes the
 library's build id.
 """
@@ -170,6 +172,17 @@ def timed_blocks(step_fn, sync_fn, ctl, K, min_seconds, max_blocks, probe_ctl=No
             return blocks
 
 
+def settle_interpreter():
+    """Before a timed region: one full garbage collection now, and what survives it moved out of the collector's way
+    (gc.freeze).  A generation-2 collection walks every torch / ctypes / numpy object of the process: one 40-55 ms host
+    stall some hundred steps into the run (profiles/r03/stall_probe_python_gc.txt) — hidden when the host runs ahead
+    of the GPU, fully exposed in a K = 20 block that synchronises on both sides (it was the one `outliers` block of
+    every driver-flags run).  The collector stays enabled."""
+    import gc
+    gc.collect()
+    gc.freeze()
+
+
 class Probes(object):
     """HIP events on the launch stream (torch's current stream IS the stream the C ABI launches on:
     MultiGridEnv passes torch.cuda.current_stream().cuda_stream to every call).  MultiGridEnv.step calls
@@ -286,6 +299,7 @@ def measure(wl, B, dev, ctl, seeds, K, Wm, min_seconds, max_blocks, action_seed,
     env._probe = probes
     for i in range(Wm):
         env.step(pool[i % 64])
+    settle_interpreter()
     blocks = timed_blocks(lambda i: env.step(pool[(Wm + i) % 64]), lambda: torch.cuda.synchronize(dev), ctl, K,
                           min_seconds, max_blocks, probes)
     env._probe = None
@@ -313,6 +327,7 @@ def measure_pipeline(wl, B, parts, dev, ctl, K, Wm, min_seconds, max_blocks, act
     torch.cuda.synchronize(dev)
     for i in range(Wm):
         pipe.step(pool[i % 64])
+    settle_interpreter()
     blocks = timed_blocks(lambda i: pipe.step(pool[(Wm + i) % 64]), lambda: torch.cuda.synchronize(dev), ctl, K,
                           min_seconds, max_blocks, None)
     pipe.check_errors()

@@ -511,6 +511,7 @@ class MultiGridEnv(object):
             best = [(cost_of(t), t) for t in g.ring]          # (ms, tensor), the `keep` fastest so far
             seen = [c for c, _ in best]
             why = "cap"
+            polish = 0
             while len(seen) < keep + max_candidates:
                 if time.perf_counter() > t_end:
                     why = "time"
@@ -539,8 +540,12 @@ class MultiGridEnv(object):
                 ranked = sorted(seen)
                 median = ranked[len(ranked) // 2]
                 if len(seen) >= keep + 2 * batch and best[keep - 1][0] <= (1.0 - gain) * median:
-                    why = "kept set %d%% under the median candidate" % round(100 * (1 - best[keep - 1][0] / median))
-                    break
+                    # in the fast class; a few more batches while the kept buffers are not equally good (the fast
+                    # class has a spread of its own: 0.153 .. 0.160 ms for the bench workload's 925 MB)
+                    polish += 1
+                    if best[keep - 1][0] <= 1.02 * best[0][0] or polish > 6:
+                        why = "kept set %d%% under the median candidate" % round(100 * (1 - best[keep - 1][0] / median))
+                        break
                 if len(seen) >= keep + flat_after and ranked[-1] <= 1.05 * ranked[0]:
                     why = "no spread among %d candidates" % len(seen)
                     break

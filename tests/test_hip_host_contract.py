@@ -76,6 +76,14 @@ def test_obs_buffer_placement_search():
     from marlgrid_amd import _native as N
     from marlgrid_amd.base import _LibBuffer
     B = 16384                                          # 462 MB of observations per buffer: above the 256 MiB threshold
+    # (what the process allocates once — code objects, the runtime's pools, a first env's launch — is not this test's
+    # business: it has happened before `free0` is read, also when the test runs alone)
+    warm = product_envs.build("MarlGrid-3AgentCluttered15x15-v0", batch_size=64)
+    warm.reset()
+    warm.step(torch.zeros((64, 3), dtype=torch.int64))
+    torch.cuda.synchronize()
+    del warm
+    gc.collect()
     torch.cuda.empty_cache()
     free0 = torch.cuda.mem_get_info()[0]
     outs = {}
