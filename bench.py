@@ -69,7 +69,18 @@ class Control(object):
             if backend == "nccl":
                 dist.init_process_group(backend="nccl", device_id=device)
             else:
-                dist.init_process_group(backend="gloo")
+                # gloo announces its connections on stdout ("[Gloo] Rank 0 is connected to ..."): stdout is for the ONE
+                # JSON line, so the descriptor points at stderr while the group forms
+                sys.stdout.flush()
+                saved = os.dup(1)
+                os.dup2(2, 1)
+                try:
+                    dist.init_process_group(backend="gloo")
+                    dist.barrier()
+                finally:
+                    sys.stdout.flush()
+                    os.dup2(saved, 1)
+                    os.close(saved)
 
     def barrier(self):
         if self.world > 1:
