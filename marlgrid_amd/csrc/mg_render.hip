@@ -9,18 +9,20 @@
 // grid; every wave walks its own contiguous run of envs.
 //   * the whole pre-rotated sprite atlas ([4 orientations][n_tiles][ts*ts*3] bytes, ~21 KB for the
 //     3-agent configs) is staged once per workgroup in LDS (read in place from L2 if it cannot fit);
-//   * per env, the wave stages the env's grid (W*H bytes) and agent records in LDS (prefetched into
-//     registers during the previous env's raster), derives the n view_size x view_size egocentric
-//     neighbourhoods (base object, shown agent, transparency) cooperatively, lanes 0..n-1 run the
-//     shadow-casting pass as row bit-masks (log-step floods), and the wave writes a per-view-cell
-//     atlas offset map (tmap) to LDS;
+//   * a BATCH of up to 8 envs at a time, the wave stages the envs' grids (W*H bytes each) and agent records in
+//     LDS — in mg_step_render together with the env step's own inputs, and lanes 0..7 then STEP the staged envs
+//     (mg_core.h step_run, auto-reset included) before anything is drawn —, derives the view_size x view_size
+//     egocentric neighbourhoods (base object, shown agent, transparency) of a group of envs cooperatively, one
+//     lane per viewer runs the shadow-casting pass as row bit-masks (log-step floods), and the wave writes a
+//     per-view-cell atlas offset map (tmap) per env to LDS;
 //   * the raster then emits the env's n*P*P*3 contiguous output bytes as 16-byte
 //     (global_store_dwordx4) chunks, consecutive lanes -> consecutive chunks.  Tile sizes that are a
 //     multiple of 8: each chunk is assembled in registers from two 8-byte LDS look-ups
 //     atlas[tmap[cell] + row*TD + k].  Any other tile size: a few KiB of whole pixel rows at a time are
 //     first ASSEMBLED in an LDS piece buffer — one lane per (row, view column) segment ORs its 3*TS bytes
 //     from the atlas tile row into the zeroed buffer (aligned dwords cut with v_alignbyte and ds_or_b32:
-//     unaligned DS accesses are serialised on gfx950) — and then STREAMED out as linear
+//     unaligned DS accesses are serialised on gfx950; at tile 5 / 6 the atlas rows sit in LDS padded with zeros, so
+//     that a segment is whole dwords read around the row: no edge masks) — and then STREAMED out as linear
 //     ds_read_b128 -> aligned dwordx4 stores; the bytes of a chunk that straddles two pieces (or two
 //     envs of the wave's run) are carried over in the buffer, so everything but the first and last
 //     <16 bytes of a wave's whole run leaves as aligned 16-byte stores.
