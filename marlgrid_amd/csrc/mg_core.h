@@ -19,6 +19,14 @@
 #else
 #define MG_HD inline
 #endif
+// A 32-bit value made opaque to the compiler AT THIS POINT (device code; nothing on the host): what is computed from it
+// stays behind this point — the compiler otherwise hoists a float64 division out of the rarely taken branch that needs
+// it, and starts on loaded values (with the wait that takes) the moment they are requested.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MG_OPAQUE32(x) asm volatile("" : "+v"(x))
+#else
+#define MG_OPAQUE32(x) do {} while (0)
+#endif
 
 namespace mg {
 
@@ -137,15 +145,61 @@ struct Mt {
     }
 };
 
+// The operands of the head's top-up, requested AHEAD: a step that only shuffles has drawn all it will draw long
+// before it ends (2-3 words for three agents), and the top-up at its end is three dependent HBM loads per word —
+// 2 us that every wave of the launch spent waiting in mt_finish.  Right after the shuffle the step asks for the
+// operands of the `used` (<= kMtAhead) words it has consumed — w[pos + i], w[pos + i + 1], w[pos + i + 397] —; they
+// travel while the agents act, and mt_finish takes them if nothing has been drawn or regenerated since (no
+// placement, no reset: the state's pos and the draw count are what they were).
+constexpr int kMtAhead = 4;     // (mt_ahead's loads are written for exactly 4)
+struct MtAhead {
+    uint32_t a[kMtAhead + 1], c[kMtAhead];
+    int pos, used;          // the state these operands belong to (used == 0: nothing requested)
+};
+MG_HD MtAhead mt_ahead(const Mt& mt) {
+    // (three loads — 16 + 4 + 16 bytes — and nothing else: the step is a chain of dependent instructions in which
+    // every instruction counts; as nine conditional loads with their own wrap-around arithmetic the request cost
+    // what it saved.  A `pos` whose operands wrap around the end of the state is left to mt_finish's own loads.)
+    MtAhead ah;
+    const int p = mt.pos;
+    int pm = p + 397;
+    if (pm >= MG_MT_N) pm -= MG_MT_N;
+    ah.pos = p;
+    ah.used = (mt.used >= 1 && mt.used <= kMtAhead && p + kMtAhead < MG_MT_N && pm + kMtAhead <= MG_MT_N) ? mt.used : 0;
+    if (ah.used) {
+        __builtin_memcpy(&ah.a[0], mt.w + p, 16);
+        ah.a[4] = mt.w[p + 4];
+        __builtin_memcpy(&ah.c[0], mt.w + pm, 16);
+    }
+    return ah;
+}
+
 // After the env's last draw of the kernel: what is left of the current head slides down to the front,
 // the rest is generated, so that the head again holds the next 16 outputs.  `head_out`: the env's 16
 // head words in HBM (may be the array `mt.head` points at: the copy runs upwards, dst < src).
-MG_HD void mt_finish(Mt& mt, uint32_t* head_out) {
+MG_HD void mt_finish(Mt& mt, uint32_t* head_out, const MtAhead* ah = nullptr) {
     if (mt.used == 0) return;
     const int r = mt.used & (MG_MT_HEAD - 1);
     const int k = r ? r : MG_MT_HEAD;           // words consumed from the current head
     const int keep = MG_MT_HEAD - k;
     for (int j = 0; j < keep; j++) head_out[j] = mt.head[(j + k) * mt.hstride];
+    if (ah && ah->used && ah->used == mt.used && ah->pos == mt.pos) {      // (k == used <= kMtAhead)
+        int p = mt.pos;
+#pragma unroll
+        for (int i = 0; i < kMtAhead; i++) {
+            if (i < k) {
+                uint32_t a0 = ah->a[i], a1 = ah->a[i + 1], c0 = ah->c[i];
+                MG_OPAQUE32(a0); MG_OPAQUE32(a1); MG_OPAQUE32(c0);      // (used HERE, not where they were requested)
+                const uint32_t x = mt_twist(a0, a1, c0);
+                mt.w[p] = x;
+                head_out[keep + i] = mt_temper(x);
+                if (++p == MG_MT_N) p = 0;
+            }
+        }
+        mt.pos = p;
+        mt.used = 0;
+        return;
+    }
     for (int j = keep; j < MG_MT_HEAD; j += 8) {
         const int cnt = (MG_MT_HEAD - j) < 8 ? (MG_MT_HEAD - j) : 8;
         uint32_t t[8];
@@ -306,9 +360,8 @@ MG_HD int reset_env(const MgConfig& cfg, const MgState& st, const MgGenProgram& 
 struct StepScratch {        // per-workgroup arrays, this env is column `col`, element stride S
     uint64_t* rec;          // [n][S] agent records
     uint32_t* head;         // [MG_MT_HEAD][S] look-ahead RNG words
-    uint8_t* order;         // [n][S] shuffled agent order
     uint8_t* act;           // [n][S] action (0xFF: invalid)
-    uint8_t* fb;            // [n][S] front-cell base id
+    uint8_t* fb;            // [n][S] front-cell base id, pre-loaded (null: `g` is cheap to read, no pre-load)
     const MgObjDesc* obj;   // [n_obj] object table (shared)
     const uint8_t* oflags;  // [MG_MAX_OBJ] object flags (shared)
     int S, col;
@@ -368,32 +421,43 @@ MG_HD bool step_run(const MgConfig& cfg, const MgState& st, const MgGenProgram& 
     // round trip 2: every agent's front cell.  An agent's position and heading are only ever changed
     // by its own action, so its front cell is known before the loop; the cell's *content* can only be
     // changed by a pickup / drop / toggle earlier in this step (grid_dirty), in which case it is re-read.
-    for (int k = 0; k < n; k++) {
-        const uint64_t r = s_rec[k * S + col];
-        const int dir = (int)rec_byte(r, MG_AG_DIR);
-        const int fx = (int)rec_byte(r, MG_AG_X) + dir_dx(dir), fy = (int)rec_byte(r, MG_AG_Y) + dir_dy(dir);
-        const bool ok = (rec_byte(r, MG_AG_FLAGS) & MG_AF_ACTIVE) && fx >= 0 && fx < W && fy >= 0 && fy < H;
-        sc.fb[k * S + col] = ok ? g[fx * H + fy] : (uint8_t)0;
-    }
+    // (sc.fb == nullptr: `g` is a staged copy in LDS — the obs kernel's fused step —, every look-up is as cheap as
+    // one into `fb` and the pre-load would only be three more LDS round trips per agent)
+    if (sc.fb)
+        for (int k = 0; k < n; k++) {
+            const uint64_t r = s_rec[k * S + col];
+            const int dir = (int)rec_byte(r, MG_AG_DIR);
+            const int fx = (int)rec_byte(r, MG_AG_X) + dir_dx(dir), fy = (int)rec_byte(r, MG_AG_Y) + dir_dy(dir);
+            const bool ok = (rec_byte(r, MG_AG_FLAGS) & MG_AF_ACTIVE) && fx >= 0 && fx < W && fy >= 0 && fy < H;
+            sc.fb[k * S + col] = ok ? g[fx * H + fy] : (uint8_t)0;
+        }
+    const bool direct = !sc.fb;     // (no pre-loaded front cells: the action loop reads `g`)
     bool grid_dirty = false;
 
     int step_count = env.sc0 + 1;   // base.py:512
-    // reward decay factor, float64 like the reference (base.py:579)
-    const double decay = cfg.reward_decay ? (1.0 - 0.9 * ((double)step_count / (double)cfg.max_steps)) : 1.0;
+    // reward decay factor, float64 like the reference (base.py:579) — worked out where a reward is paid (a float64
+    // division: a hundred dependent cycles that most steps of most envs do not need)
+    auto decay_now = [&]() -> double {
+        int t = step_count;
+        MG_OPAQUE32(t);
+        return cfg.reward_decay ? (1.0 - 0.9 * ((double)t / (double)cfg.max_steps)) : 1.0;
+    };
 
     // iter_order = arange(n); np_random.shuffle(iter_order)  (base.py:514-516): legacy Fisher-Yates
     // over numpy's masked-rejection bounded draws — served from the look-ahead head
-    for (int k = 0; k < n; k++) sc.order[k * S + col] = (uint8_t)k;
+    // (the permutation as sixteen nibbles of one register: a swap is four shifts instead of four LDS round trips)
+    static_assert(MG_MAX_AGENTS <= 16, "iter_order: one nibble per agent");
+    uint64_t order = 0xFEDCBA9876543210ull;
     for (int i = n - 1; i >= 1; i--) {
         const int j = (int)mt.bounded((uint32_t)i);
-        const uint8_t t = sc.order[i * S + col];
-        sc.order[i * S + col] = sc.order[j * S + col];
-        sc.order[j * S + col] = t;
+        const uint64_t oi_ = (order >> (4 * i)) & 0xFull, oj_ = (order >> (4 * j)) & 0xFull;
+        order = (order & ~((0xFull << (4 * i)) | (0xFull << (4 * j)))) | (oj_ << (4 * i)) | (oi_ << (4 * j));
     }
 
+    const MtAhead ahead = mt_ahead(mt);
     MG_STEP_STAMP(1);
     for (int oi = 0; oi < n; oi++) {
-        const int k = sc.order[oi * S + col];
+        const int k = (int)((order >> (4 * oi)) & 0xFull);
         float rew = 0.0f;
         bool rewarded = false;      // agent.reward(rwd) was called (prestige bookkeeping)
         double rwd_applied = 0.0;
@@ -408,7 +472,7 @@ MG_HD bool step_run(const MgConfig& cfg, const MgState& st, const MgGenProgram& 
                 err = err ? err : MG_ERR_ASSERT;   // grid.get asserts (base.py:154-156)
             } else {
                 const int fcell = fx * H + fy;
-                const uint32_t fbase = grid_dirty ? (uint32_t)g[fcell] : (uint32_t)sc.fb[k * S + col];
+                const uint32_t fbase = (direct || grid_dirty) ? (uint32_t)g[fcell] : (uint32_t)sc.fb[k * S + col];
                 const uint32_t fxy = (uint32_t)fx | ((uint32_t)fy << 8);
                 const uint32_t fflags = sc.oflags[fbase];
                 if (action == 0) {                                   // left  base.py:530-531
@@ -452,7 +516,7 @@ MG_HD bool step_run(const MgConfig& cfg, const MgState& st, const MgGenProgram& 
                                         if (first_bonus && !(od.bonus_flags & 1)) rwd = 0.0;
                                         r = rec_set(r, MG_AG_BONUS, (uint32_t)bs);
                                     }
-                                    rwd_applied = rwd * decay;
+                                    rwd_applied = rwd * decay_now();
                                     rewarded = true;
                                     rew = (float)rwd_applied;
                                 }
@@ -542,7 +606,7 @@ MG_HD bool step_run(const MgConfig& cfg, const MgState& st, const MgGenProgram& 
     MG_STEP_STAMP(3);
     for (int k = 0; k < n; k++) st.agents[(size_t)b * n + k] = s_rec[k * S + col];
     st.step_count[b] = step_count;
-    mt_finish(mt, st.mt_head + (size_t)b * MG_MT_HEAD);
+    mt_finish(mt, st.mt_head + (size_t)b * MG_MT_HEAD, &ahead);
     st.mt_pos[b] = mt.pos;
     st.done[b] = (uint8_t)done;
     record_error(st, b, err);

@@ -112,9 +112,8 @@ __device__ __forceinline__ StepScratch fused_step_scratch(const MgConfig& cfg, i
     StepScratch sc;
     sc.rec = reinterpret_cast<uint64_t*>(sp);                                   // [n][8]
     sc.head = reinterpret_cast<uint32_t*>(sp + n * 8 * 8);                      // [MG_MT_HEAD][8]
-    sc.order = sp + n * 8 * 8 + MG_MT_HEAD * 8 * 4;                             // [n][8]
-    sc.act = sc.order + n * 8;
-    sc.fb = sc.act + n * 8;
+    sc.act = sp + n * 8 * 8 + MG_MT_HEAD * 8 * 4;                               // [n][8]
+    sc.fb = nullptr;                                                            // (the grid is a staged LDS copy: no pre-load)
     sc.obj = s_obj;
     sc.oflags = s_oflags;
     sc.S = 8;

@@ -33,8 +33,7 @@ __global__ __launch_bounds__(BS) void step_kernel(MgConfig cfg, MgState st, MgGe
     sc.rec = s_mem;                                                          // [n][BS] u64
     MgObjDesc* s_obj = reinterpret_cast<MgObjDesc*>(s_mem + (size_t)n * BS);   // [MG_MAX_OBJ] 32 B each
     sc.head = reinterpret_cast<uint32_t*>(s_obj + MG_MAX_OBJ);               // [MG_MT_HEAD][BS] u32
-    sc.order = reinterpret_cast<uint8_t*>(sc.head + MG_MT_HEAD * BS);        // [n][BS]
-    sc.act = sc.order + (size_t)n * BS;                                      // [n][BS]
+    sc.act = reinterpret_cast<uint8_t*>(sc.head + MG_MT_HEAD * BS);          // [n][BS]
     sc.fb = sc.act + (size_t)n * BS;                                         // [n][BS]
     uint8_t* s_oflags = sc.fb + (size_t)n * BS;                              // [MG_MAX_OBJ]
     sc.obj = s_obj;

@@ -15,12 +15,12 @@ namespace {
 struct Scratch {
     std::vector<uint64_t> rec;
     std::vector<uint32_t> head;
-    std::vector<uint8_t> order, act, fb, oflags;
+    std::vector<uint8_t> act, fb, oflags;
     mg::StepScratch sc;
-    Scratch(const MgConfig* cfg) : rec(MG_MAX_AGENTS), head(MG_MT_HEAD), order(MG_MAX_AGENTS), act(MG_MAX_AGENTS),
+    Scratch(const MgConfig* cfg) : rec(MG_MAX_AGENTS), head(MG_MT_HEAD), act(MG_MAX_AGENTS),
                                    fb(MG_MAX_AGENTS), oflags(MG_MAX_OBJ, 0) {
         for (int i = 1; i < cfg->n_obj; i++) oflags[i] = cfg->obj[i].flags;
-        sc.rec = rec.data(); sc.head = head.data(); sc.order = order.data(); sc.act = act.data(); sc.fb = fb.data();
+        sc.rec = rec.data(); sc.head = head.data(); sc.act = act.data(); sc.fb = fb.data();
         sc.obj = cfg->obj; sc.oflags = oflags.data(); sc.S = 1; sc.col = 0;
     }
 };
@@ -52,6 +52,9 @@ int emu_step(const MgConfig* cfg, const MgState* st, const void* actions, int ac
     const MgGenProgram& prog = auto_reset ? *auto_reset : none;
     for (int b = 0; b < cfg->B; b++) {
         if (action_bytes != 1 && action_bytes != 4 && action_bytes != 8) return -100;
+        // odd envs without the pre-loaded front cells (StepScratch::fb == nullptr: the obs kernel's fused step reads its
+        // staged grid directly), even envs with them (mg_step's kernel): the oracle comparison covers both
+        s.sc.fb = (b & 1) ? nullptr : s.fb.data();
         const mg::StepEnv e = mg::step_load(*cfg, *st, actions, action_bytes, b, s.sc);
         // stepped on a staged copy of the grid slice, as the obs kernel does (mg_render.hip): the copy goes
         // back only when step_run reports it written — and must be unchanged when it does not
