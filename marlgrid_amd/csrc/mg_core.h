@@ -211,6 +211,42 @@ MG_HD void mt_finish(Mt& mt, uint32_t* head_out, const MtAhead* ah = nullptr) {
     mt.used = 0;
 }
 
+// The same for a caller that writes the head back ITSELF (the obs kernel: the whole wave copies its batch's heads to
+// HBM as contiguous runs, instead of sixteen scattered stores per stepping lane): the new outputs go into the slots of
+// the consumed ones, mt.head becomes a ring, and the returned k is where it starts — the head in order is
+// mt.head[((j + k) & 15) * hstride], j = 0 .. 15.  The state words and `pos` are written as in mt_finish.
+MG_HD int mt_finish_ring(Mt& mt, const MtAhead* ah = nullptr) {
+    if (mt.used == 0) return 0;
+    const int r = mt.used & (MG_MT_HEAD - 1);
+    const int k = r ? r : MG_MT_HEAD;           // words consumed from the current head: slots 0 .. k-1
+    if (ah && ah->used && ah->used == mt.used && ah->pos == mt.pos) {      // (k == used <= kMtAhead)
+        int p = mt.pos;
+#pragma unroll
+        for (int i = 0; i < kMtAhead; i++) {
+            if (i < k) {
+                uint32_t a0 = ah->a[i], a1 = ah->a[i + 1], c0 = ah->c[i];
+                MG_OPAQUE32(a0); MG_OPAQUE32(a1); MG_OPAQUE32(c0);
+                const uint32_t x = mt_twist(a0, a1, c0);
+                mt.w[p] = x;
+                mt.head[i * mt.hstride] = mt_temper(x);
+                if (++p == MG_MT_N) p = 0;
+            }
+        }
+        mt.pos = p;
+    } else {
+        for (int j = 0; j < k; j += 8) {
+            const int cnt = (k - j) < 8 ? (k - j) : 8;
+            uint32_t t[8];
+            mt_generate(mt.w, mt.pos, cnt, t);
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (i < cnt) mt.head[(j + i) * mt.hstride] = t[i];
+        }
+    }
+    mt.used = 0;
+    return k & (MG_MT_HEAD - 1);
+}
+
 // MultiGridEnv.seed -> gym seeding.np_random -> RandomState.seed([k0(, k1)]) = init_by_array
 // (base.py:371-374), then the first head.
 MG_HD void mt_seed_env(const uint32_t* key, int klen, uint32_t* mt, int32_t* mt_pos, uint32_t* head) {
@@ -365,11 +401,15 @@ struct StepScratch {        // per-workgroup arrays, this env is column `col`, e
     const MgObjDesc* obj;   // [n_obj] object table (shared)
     const uint8_t* oflags;  // [MG_MAX_OBJ] object flags (shared)
     int S, col;
+    bool defer_writeback = false;   // the caller writes records and RNG head back itself (StepOut::head_k; the obs kernel)
 #if defined(MG_AB_VARIANTS)
     unsigned long long* stamp = nullptr;   // measurement build: 5 words, wall_clock64 at the section ends of step_run (or null)
 #endif
 };
 struct StepEnv { int pos0, sc0; };
+// what step_run reports: whether it wrote the grid slice; with StepScratch::defer_writeback also where the RNG head
+// ring starts (mt_finish_ring) — the stepped records are in StepScratch::rec, the head in StepScratch::head
+struct StepOut { bool wrote; int head_k; };
 #if defined(MG_AB_VARIANTS) && defined(__HIP_DEVICE_COMPILE__)
 #define MG_STEP_STAMP(i) do { if (sc.stamp) sc.stamp[i] = wall_clock64(); } while (0)
 #else
@@ -401,8 +441,8 @@ MG_HD StepEnv step_load(const MgConfig& cfg, const MgState& st, const void* acti
 // `g`: the env's grid slice — its home in HBM (st.grid + b * cells_stride), or a staged copy of it (the obs
 // kernel steps the envs it is about to render on their LDS copies: no dependent HBM round trip per grid
 // look-up); returns whether the slice was written (the owner of a staged copy then writes it back).
-MG_HD bool step_run(const MgConfig& cfg, const MgState& st, const MgGenProgram& prog, bool auto_reset, float* rewards,
-                    int b, const StepEnv& env, const StepScratch& sc, uint8_t* g) {
+MG_HD StepOut step_run(const MgConfig& cfg, const MgState& st, const MgGenProgram& prog, bool auto_reset, float* rewards,
+                       int b, const StepEnv& env, const StepScratch& sc, uint8_t* g) {
     const int n = cfg.n_agents, W = cfg.W, H = cfg.H, S = sc.S, col = sc.col;
     uint64_t* s_rec = sc.rec;
     Mt mt{st.mt + (size_t)b * MG_MT_N, env.pos0, sc.head + col, S, 0};
@@ -604,14 +644,20 @@ MG_HD bool step_run(const MgConfig& cfg, const MgState& st, const MgGenProgram& 
         grid_dirty = true;
     }
     MG_STEP_STAMP(3);
-    for (int k = 0; k < n; k++) st.agents[(size_t)b * n + k] = s_rec[k * S + col];
+    int head_k = -1;
+    if (sc.defer_writeback) {
+        head_k = mt_finish_ring(mt, &ahead);
+    } else {
+        for (int k = 0; k < n; k++) st.agents[(size_t)b * n + k] = s_rec[k * S + col];
+        mt_finish(mt, st.mt_head + (size_t)b * MG_MT_HEAD, &ahead);
+    }
     st.step_count[b] = step_count;
-    mt_finish(mt, st.mt_head + (size_t)b * MG_MT_HEAD, &ahead);
     st.mt_pos[b] = mt.pos;
     st.done[b] = (uint8_t)done;
     record_error(st, b, err);
     MG_STEP_STAMP(4);
-    return grid_dirty;
+    StepOut out = {grid_dirty, head_k};
+    return out;
 }
 
 // ---- MultiGridEnv.reset for one env (explicit reset; the auto-reset runs inside step_run) ---------

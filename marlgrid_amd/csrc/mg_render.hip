@@ -493,10 +493,13 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 // dependent HBM load, and a load issued after stores waits for the wave's whole store queue.)
                 wave_lds_sync();
                 bool wrote = false;
+                int head_k = 0;
+                sc.defer_writeback = true;      // records and RNG heads go back to HBM from the whole wave, below
                 if (lane < kb) {
-                    wrote = step_run(cfg, st, fs.prog, fs.has_prog != 0, fs.rewards, eb + lane, se, sc,
-                                     w_stage_g + (size_t)lane * cfg.cells_stride);
-                    for (int k = 0; k < n; k++) w_stage_r[lane * rec_stride + k] = sc.rec[k * 8 + lane];
+                    const StepOut so = step_run(cfg, st, fs.prog, fs.has_prog != 0, fs.rewards, eb + lane, se, sc,
+                                                w_stage_g + (size_t)lane * cfg.cells_stride);
+                    wrote = so.wrote;
+                    head_k = so.head_k;
                     if constexpr (kPrestige) {
                         // agent.prestige as this lane left it in HBM, and — here, in the latency-bound step part where
                         // the VALU is idle, one lane per ENV — the colour it gives the agent's sprite (the float64
@@ -513,6 +516,26 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 }
                 uint64_t todo = __ballot(wrote);
                 wave_lds_sync();
+                // The stepped records (to HBM, and to where the views read them) and the RNG heads (a ring per env that
+                // starts at head_k: mt_finish_ring), by the whole wave as the contiguous runs they are: two coalesced
+                // stores per lane instead of sixteen scattered ones — and as many LDS reads — in every stepping lane.
+                {
+                    uint64_t* rdst = st.agents + (size_t)eb * n;
+                    uint32_t* hdst = st.mt_head + (size_t)eb * MG_MT_HEAD;
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        const int i = lane + q * kWave;
+                        const int e = i >> 4, j = i & (MG_MT_HEAD - 1);             // head word j of env e
+                        const int ke = __shfl(head_k, e & 7);
+                        if (i < kb * MG_MT_HEAD) hdst[i] = sc.head[((j + ke) & (MG_MT_HEAD - 1)) * 8 + e];
+                        if (i < kb * n) {
+                            const int er = (int)by_n.div((uint32_t)i), k = i - __mul24(er, n);
+                            const uint64_t r = sc.rec[k * 8 + er];
+                            rdst[i] = r;
+                            w_stage_r[er * rec_stride + k] = r;
+                        }
+                    }
+                }
                 while (todo) {      // grid slices the step wrote: back to HBM, the whole wave per slice
                     const int j = __builtin_ctzll(todo);
                     todo &= todo - 1;

@@ -60,7 +60,14 @@ int emu_step(const MgConfig* cfg, const MgState* st, const void* actions, int ac
         // back only when step_run reports it written — and must be unchanged when it does not
         uint8_t* home = st->grid + (size_t)b * cfg->cells_stride;
         std::vector<uint8_t> staged(home, home + cfg->cells_stride);
-        const bool wrote = mg::step_run(*cfg, *st, prog, auto_reset != nullptr, rewards, b, e, s.sc, staged.data());
+        // ... and every third env with the write-back left to the caller, as the obs kernel does it for its whole batch
+        s.sc.defer_writeback = (b % 3) == 2;
+        const mg::StepOut out = mg::step_run(*cfg, *st, prog, auto_reset != nullptr, rewards, b, e, s.sc, staged.data());
+        if (s.sc.defer_writeback) {
+            for (int k = 0; k < cfg->n_agents; k++) st->agents[(size_t)b * cfg->n_agents + k] = s.rec[k];
+            for (int j = 0; j < MG_MT_HEAD; j++) st->mt_head[(size_t)b * MG_MT_HEAD + j] = s.head[(j + out.head_k) & (MG_MT_HEAD - 1)];
+        }
+        const bool wrote = out.wrote;
         if (wrote) memcpy(home, staged.data(), cfg->cells_stride);
         else if (memcmp(home, staged.data(), cfg->cells_stride) != 0) return -101;
     }
