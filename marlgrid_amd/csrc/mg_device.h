@@ -141,7 +141,7 @@ __host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride,
     s.grid = o;  o += stage_envs * round_up(cells_stride, 16);
     s.rec = o;   o += stage_envs * s.rec_stride * 8;
     s.pres = o;  o += dyn_bytes ? stage_envs * s.rec_stride * 8 : 0;   // agent.prestige of the staged envs
-    s.pcol = o;  o += dyn_bytes ? stage_envs * s.rec_stride * 4 : 0;   // ... and the sprite colours it gives them (fused step)
+    s.pcol = o;  o += dyn_bytes ? round_up(stage_envs * s.rec_stride * 4, 16) : 0;   // ... and the sprite colours it gives them (fused step)
     // Views one env at a time: first / second (agents of a cell), vbase / vshow (a view cell's object and
     // agent, phase 3 -> 5), trow / vis (transparency and visibility rows).  Views of the whole batch at once
     // (batch_views): a slot of first (second: only with hide_item_types) and trow per staged env; the

@@ -366,9 +366,15 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             const uint32_t* gsrc = reinterpret_cast<const uint32_t*>(st.grid + (size_t)eb * cfg.cells_stride);
             const uint64_t* rsrc = st.agents + (size_t)eb * n;
             const int nd = kb * gdw, nr = kb * n;
-            uint32_t v[kSR];
+            // (16 bytes per lane and request: a batch's grids are whole 16-byte chunks — cells_stride is a multiple of 16 —,
+            // and every request costs its address, its bounds check and its exec mask: 2 instead of 8)
+            static_assert(kSR % 4 == 0, "grid dwords per lane: whole uint4s");
+            uint4 v[kSR / 4];
 #pragma unroll
-            for (int q = 0; q < kSR; q++) { const int i = q * kWave + lanel; v[q] = i < nd ? gsrc[i] : 0u; }
+            for (int q = 0; q < kSR / 4; q++) {
+                const int i = q * kWave + lanel;
+                v[q] = 4 * i < nd ? reinterpret_cast<const uint4*>(gsrc)[i] : make_uint4(0, 0, 0, 0);
+            }
             const int r0i = lanel, r1i = lanel + kWave;                     // kb * n <= 8 * 16 = 2 * kWave records
             uint64_t rv0 = 0ull, rv1 = 0ull;
             double pv0 = 0., pv1 = 0.;
@@ -433,9 +439,9 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             __builtin_amdgcn_sched_barrier(0);
             if (first) MG_STAMP(15);
 #pragma unroll
-            for (int q = 0; q < kSR; q++) {
+            for (int q = 0; q < kSR / 4; q++) {
                 const int i = q * kWave + lanel;
-                if (i < nd) reinterpret_cast<uint32_t*>(w_stage_g)[i] = v[q];
+                if (4 * i < nd) reinterpret_cast<uint4*>(w_stage_g)[i] = v[q];
             }
             for (int i = kSR * kWave + lanel; i < nd; i += kWave) reinterpret_cast<uint32_t*>(w_stage_g)[i] = gsrc[i];   // (grids beyond 2 KiB per batch: a second trip)
             if (!fs.enabled) {
