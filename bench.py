@@ -520,10 +520,28 @@ def main():
 
     # the dominant kernel's HBM traffic from the PMC counters, measured now (child processes under
     # rocprofv3 on this GPU; N = 1 only: the counters are per process and the workload is per GPU)
+    # (every leg from here on is optional: whatever goes wrong in one of them is recorded under `errors` and the
+    # contract line is printed all the same)
+    errors = {}
+
+    def leg(name, fn):
+        try:
+            return fn()
+        except Exception as e:      # noqa: BLE001 — an optional leg must not cost the line
+            import traceback
+            errors[name] = "%s: %s | %s" % (type(e).__name__, e, traceback.format_exc().strip().splitlines()[-3:])
+            try:
+                torch.cuda.empty_cache()
+            except Exception:       # noqa: BLE001
+                pass
+            return None
+
     traffic = None
     if rank == 0 and n_gpus == 1 and not args.no_pmc:
-        import pmc
-        traffic = pmc.measure(wl, B)
+        def _pmc():
+            import pmc
+            return pmc.measure(wl, B)
+        traffic = leg("pmc", _pmc)
     if rank == 0:
         # roofline needs the env's geometry only
         class _Geo(object):
@@ -532,22 +550,28 @@ def main():
         out["pmc"] = traffic
 
     # strong-scaling N = 1 point: BASELINE.json's whole headline batch on one GPU
-    if n_gpus == 1 and not args.no_strong and wl == WORKLOAD:
+    def _strong():
         Bs = 262144
         seeds_s = sharding.shard_seeds(1337, Bs, 0, 1)
         env_s, sum_s, _ = measure(wl, Bs, dev, ctl, seeds_s, K, min(Wm, 5), min(args.min_seconds, 1.0), 400, 0, fused)
         raster_s = raster_only_ms(env_s, 10)
         ms_s = sum_s["plain"]["mean"]
-        out.setdefault("extra", {})["strong_n1"] = {
+        res = {
             "what": "the full headline batch (262 144 envs) on ONE GPU: the N = 1 point of a strong-scaling curve",
             "value": Bs * n / (ms_s * 1e-3), "unit": "agent-steps/s", "ms_per_step": ms_s,
             "global_batch": Bs, "timing": sum_s["plain"], "kernels": sum_s.get("kernels"),
             "closure": sum_s.get("closure"), "roofline": roofline_of(env_s, Bs, sum_s, None, raster_s)}
         del env_s
         torch.cuda.empty_cache()
+        return res
+
+    if n_gpus == 1 and not args.no_strong and wl == WORKLOAD:
+        res = leg("strong_n1", _strong)
+        if res is not None:
+            out.setdefault("extra", {})["strong_n1"] = res
 
     # overlapping launches — the same batch as two envs on two streams, and twice the batch
-    if n_gpus == 1 and not args.no_pipeline and wl == WORKLOAD:
+    def _pipeline():
         pts = []
         for Bp in (B, 2 * B):
             ms_one = ms
@@ -564,6 +588,10 @@ def main():
                         "one_env_ms_per_step": ms_one, "one_env_value": Bp * n_p / (ms_one * 1e-3),
                         "vs_one_env": ms_one / ms_p, "obs_placement": place_p})
             torch.cuda.empty_cache()
+        return pts
+
+    pts = leg("pipelined_shards", _pipeline) if (n_gpus == 1 and not args.no_pipeline and wl == WORKLOAD) else None
+    if pts:
         out.setdefault("extra", {})["pipelined_shards"] = {
             "what": "the per-GPU batch as TWO envs on two streams (marlgrid_amd.sharding.ShardPipeline), stepped without "
                     "a join in between: launches of independent shards overlap (the store-free head of one under the "
@@ -573,7 +601,9 @@ def main():
 
     if rank == 0:
         if n_gpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, wl)
+            out["cpu_baseline"] = leg("cpu_baseline", lambda: cpu_baseline(args.cpu_seconds, wl))
+        if errors:
+            out["errors"] = errors
         print(json.dumps(out), flush=True)
     ctl.close()
 
