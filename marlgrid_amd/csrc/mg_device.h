@@ -190,6 +190,7 @@ __host__ __device__ inline RenderScratch render_scratch_for(const MgConfig& cfg,
     if (!render_chunk_raster(cfg, mode)) {
         const int rb = 3 * vs * ts;
         rows = 4096 / rb;
+        if (render_pad_rows(cfg)) rows = rows / (64 / vs) * (64 / vs);      // whole trips of 64 / vs pixel rows (mg_render.hip)
         if (rows < 1) rows = 1;
         if (rows > nv * vs * ts) rows = nv * vs * ts;
         out = 32 + rows * rb;

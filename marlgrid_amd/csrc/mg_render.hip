@@ -1029,6 +1029,23 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             };
             for (uint32_t R0 = 0; R0 < NR; R0 += (uint32_t)L.piece_rows) {
                 const uint32_t rows = min((uint32_t)L.piece_rows, NR - R0), nseg = rows * (uint32_t)VS;
+                if constexpr (kPadRows) {
+                    // A lane keeps its view column: a trip is RT = 64 / VS whole pixel rows (63 lanes = 9 rows of 7 at the
+                    // default view), so the (row, column) of a lane's segment is a constant plus RT rows per trip — no
+                    // division by VS per segment —, and the layout makes a piece a whole number of trips
+                    // (render_scratch_for: piece_rows a multiple of RT).
+                    constexpr uint32_t RT = kWave / VS_;
+                    const uint32_t rl = (uint32_t)lane / (uint32_t)VS_, col = (uint32_t)lane - rl * VS_;
+                    if (rl < RT) {
+                        for (uint32_t Rl = rl; Rl < rows; Rl += RT) {
+                            const uint32_t prod = __umul24(R0 + Rl, by_TS.m);       // (kExactTS holds for these tile sizes)
+                            const uint32_t band = prod >> 20, rr = __umul24(prod & 0xFFFFFu, (uint32_t)TS) >> 20;
+                            const uint32_t vt = (uint32_t)w_tmap[__umul24(band, (uint32_t)VS) + col];
+                            or_segment_padded<3 * TS_, kRowB>(s_atlas + __umul24(__umul24(vt, (uint32_t)TS) + rr, (uint32_t)kRowB), w_out,
+                                                              carry + __umul24(__umul24(Rl, (uint32_t)VS) + col, SEG));
+                        }
+                    }
+                } else
                 for (uint32_t g = lane; g < nseg; g += kWave) {
                     const uint32_t Rl = by_VS.div(g), col = g - __umul24(Rl, (uint32_t)VS), R = R0 + Rl;
                     // band = R / TS and rr = R % TS from ONE 24-bit product when the quotient is exact (R - band * TS
@@ -1041,12 +1058,6 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                     } else {
                         band = by_TS.template div<false>(R);
                         rr = R - __umul24(band, (uint32_t)TS);
-                    }
-                    if constexpr (kPadRows) {
-                        const uint32_t vt = (uint32_t)w_tmap[__umul24(band, (uint32_t)VS) + col];
-                        or_segment_padded<3 * TS_, kRowB>(s_atlas + __umul24(__umul24(vt, (uint32_t)TS) + rr, (uint32_t)kRowB), w_out,
-                                                          carry + __umul24(g, SEG));
-                        continue;
                     }
                     const uint32_t so = tile_off((uint32_t)w_tmap[__umul24(band, (uint32_t)VS) + col]) + __umul24(rr, SEG);
                     const uint8_t* sb;       // source base the offset `sa` counts from
