@@ -22,6 +22,6 @@ for f in sorted(glob.glob(out + "/sc[AB]/**/*counter_collection.csv", recursive=
     print(f.split("/")[-3] if "/sc" in f else f)
     for k in sorted(acc["fused"]):
         a, b = acc["fused"][k], acc["raster"].get(k, 0.0)
-        print("   %-22s fused %13.0f  raster %13.0f  step = %12.0f per launch = %9.1f per wave batch (8 192 of them)" % (k, a, b, a - b, (a - b) / 8192))
+        print("   %-22s fused %13.0f  raster %13.0f  step = %12.0f per launch = %9.1f per wave (4 096 waves, one batch of 8 envs each)" % (k, a, b, a - b, (a - b) / 4096))
 PY
 cat $OUT/step_counters.txt
