@@ -53,47 +53,95 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
 class Control(object):
-    """The benchmark's control plane: barriers and scalar reductions over ranks.  Nothing on the data
-    path goes through it.  backend 'nccl' (= RCCL, one rank per GPU) or 'gloo' (ranks that share a
-    GPU: --oversubscribe, and the CPU self-test)."""
+    """The benchmark's control plane: barriers and small gathers over ranks.  Nothing on the data path goes
+    through it (one RNG per env, nothing shared: marlgrid/base.py:371-374).
 
-    def __init__(self, backend, device=None):
-        import torch.distributed as dist
+    The default process group is ALWAYS gloo (TCP on 127.0.0.1: it comes up wherever torch.distributed does) and
+    carries the gathers and every agreement between ranks.  With prefer="nccl" (one rank per GPU) an RCCL group is
+    formed on top of it for the barriers and PROBED with one all-reduce under a timeout; the ranks then agree over
+    gloo whether it worked for ALL of them.  If it did not — an exception at init, at the first collective, or a
+    timeout on any rank — the barriers run over gloo too, `fallback` holds the exception text of every rank that
+    failed, and the run goes on: a control plane that cannot come up must not cost the scaling curve."""
+
+    PROBE_TIMEOUT_S = 90
+
+    def __init__(self, prefer, device=None):
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        self.device = device if backend == "nccl" else None
-        self.backend = backend if self.world > 1 else None
-        if self.world > 1:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            if backend == "nccl":
-                dist.init_process_group(backend="nccl", device_id=device)
+        self.device = device
+        self.backend = None          # what the barriers run on: "nccl" | "gloo" | None (one rank)
+        self.fallback = None         # why not RCCL, when RCCL was asked for
+        self._pg = None
+        if self.world == 1:
+            return
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # gloo announces its connections on stdout ("[Gloo] Rank 0 is connected to ..."): stdout is for the ONE
+        # JSON line, so the descriptor points at stderr while the group forms
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend="gloo")
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
+        self.backend = "gloo"
+        if prefer == "nccl":
+            err = self._try_rccl()
+            errs = self.gather_objects(err)
+            if all(e is None for e in errs):
+                self.backend = "nccl"
             else:
-                # gloo announces its connections on stdout ("[Gloo] Rank 0 is connected to ..."): stdout is for the ONE
-                # JSON line, so the descriptor points at stderr while the group forms
-                sys.stdout.flush()
-                saved = os.dup(1)
-                os.dup2(2, 1)
-                try:
-                    dist.init_process_group(backend="gloo")
-                    dist.barrier()
-                finally:
-                    sys.stdout.flush()
-                    os.dup2(saved, 1)
-                    os.close(saved)
+                self._pg = None
+                self.fallback = {"asked_for": "nccl", "using": "gloo",
+                                 "errors_by_rank": {str(r): e for r, e in enumerate(errs) if e is not None}}
+
+    def _try_rccl(self):
+        """form the RCCL group and run one all-reduce through it; None, or the text of what went wrong"""
+        import datetime
+        import torch
+        import torch.distributed as dist
+        # a collective that cannot complete must raise HERE (after the timeout), not abort the process from
+        # the watchdog thread: blocking wait turns the timeout into an exception on this thread
+        os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "1")
+        os.environ.setdefault("NCCL_BLOCKING_WAIT", "1")
+        try:
+            hook = os.environ.get("BENCH_TEST_FAIL_NCCL")      # tests: the failure path without breaking RCCL
+            if hook and (hook == "all" or int(hook) == self.rank):
+                raise RuntimeError("forced by BENCH_TEST_FAIL_NCCL=%s" % hook)
+            pg = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=self.PROBE_TIMEOUT_S))
+            t = torch.ones(1, device=self.device)
+            work = dist.all_reduce(t, group=pg, async_op=True)
+            work.wait(timeout=datetime.timedelta(seconds=self.PROBE_TIMEOUT_S))
+            torch.cuda.synchronize(self.device)
+            if int(t.item()) != self.world:
+                raise RuntimeError("RCCL all-reduce returned %r, expected %d" % (t.item(), self.world))
+            self._pg = pg
+            return None
+        except BaseException as e:     # noqa: BLE001 — whatever it is, the line must still be printed
+            if isinstance(e, (KeyboardInterrupt, SystemExit)):
+                raise
+            return ("%s: %s" % (type(e).__name__, e))[:600]
 
     def barrier(self):
         if self.world > 1:
             import torch.distributed as dist
-            dist.barrier()
+            if self._pg is not None:
+                dist.barrier(group=self._pg, device_ids=[self.device.index])
+            else:
+                dist.barrier()
 
     def gather(self, values):
-        """every rank's tuple of floats, on every rank (list of `world` lists)"""
+        """every rank's tuple of floats, on every rank (list of `world` lists); over gloo, host memory"""
         if self.world == 1:
             return [[float(v) for v in values]]
         import torch
         import torch.distributed as dist
-        t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=self.device)
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64)
         out = [torch.zeros_like(t) for _ in range(self.world)]
         dist.all_gather(out, t)
         return [[float(x) for x in o.tolist()] for o in out]
@@ -106,11 +154,56 @@ class Control(object):
         dist.all_gather_object(out, obj)
         return out
 
+    def describe(self):
+        if self.world == 1:
+            return None
+        return {"barriers": self.backend, "gathers": "gloo", "fallback": self.fallback}
+
     def close(self):
         if self.world > 1:
             import torch.distributed as dist
-            dist.barrier()
-            dist.destroy_process_group()
+            try:
+                dist.barrier()
+                dist.destroy_process_group()
+            except Exception:       # noqa: BLE001 — the line is out; a teardown hiccup must not turn rc != 0
+                pass
+
+
+def pin_to_gpu_numa(dev_index):
+    """Pin this rank's launch thread to the CPUs of its GPU's NUMA node (sysfs: the PCI device's local_cpulist).
+    Eight Python launch loops at 6 k launches/s each should not migrate across sockets or share whatever the
+    scheduler gives them.  Returns what was done (reported per rank); never raises."""
+    info = {"pinned": False}
+    try:
+        import torch
+        before = sorted(os.sched_getaffinity(0))
+        info["cpus_before"] = len(before)
+        p = torch.cuda.get_device_properties(dev_index)
+        dom, bus, devn = (getattr(p, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+        if bus is None:
+            info["why"] = "torch reports no PCI ids for the device"
+            return info, before
+        bdf = "%04x:%02x:%02x.0" % (int(dom or 0), int(bus), int(devn or 0))
+        info["pci"] = bdf
+        base = "/sys/bus/pci/devices/%s/" % bdf
+        node = int(open(base + "numa_node").read().strip())
+        info["numa_node"] = node
+        cpulist = open(base + "local_cpulist").read().strip()
+        cpus = set()
+        for part in cpulist.split(","):
+            if part:
+                lo, _, hi = part.partition("-")
+                cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= set(before)
+        if node < 0 or not cpus or len(cpus) == len(before):
+            info["why"] = "no NUMA locality to pin to (numa_node %d, %d local of %d allowed CPUs)" % (node, len(cpus), len(before))
+            return info, before
+        os.sched_setaffinity(0, cpus)
+        info.update(pinned=True, cpus=cpulist, n_cpus=len(cpus))
+        return info, before
+    except Exception as e:      # noqa: BLE001
+        info["why"] = "%s: %s" % (type(e).__name__, e)
+        return info, None
 
 
 OBS_BUFFERS_NOTE = {
@@ -151,8 +244,8 @@ def self_launch(args):
 
 def timed_blocks(step_fn, sync_fn, ctl, K, min_seconds, max_blocks, probe_ctl=None):
     """Blocks of exactly K steps, each bracketed by sync + barrier + sync on both sides; the block
-    time is the MAX over ranks.  Odd blocks are instrumented when `probe_ctl` is given.  Returns a list
-    of dicts (one per block)."""
+    time is the MAX over ranks of each rank's own K steps (opening barrier -> its own synchronize).  Odd blocks
+    are instrumented when `probe_ctl` is given.  Returns a list of dicts (one per block)."""
     blocks, total, i = [], 0.0, 0
     while True:
         instrumented = probe_ctl is not None and (probe_ctl.every_block or i % 2 == 1)
@@ -170,8 +263,13 @@ def timed_blocks(step_fn, sync_fn, ctl, K, min_seconds, max_blocks, probe_ctl=No
         sync_fn()
         mine = time.perf_counter() - t0
         both = ctl.gather((mine, own))
-        elapsed = max(b[0] for b in both)             # the slowest rank defines the step time
-        b = {"elapsed_s": elapsed, "instrumented": instrumented and not probe_ctl.every_block,
+        # The slowest rank's OWN K steps define the step time: from the opening barrier to this rank's own
+        # synchronize.  `mine` also holds the closing barrier — a kernel launch and an all-reduce over RCCL, 30-80 us,
+        # 1-2 % of a 20-step block, and nothing at N = 1 (no-op): as the block time it would bend the scaling curve
+        # by something that is not the engine.  It rides along as `with_barrier_s`.
+        elapsed = max(b[1] for b in both)
+        b = {"elapsed_s": elapsed, "with_barrier_s": max(b[0] for b in both),
+             "instrumented": instrumented and not probe_ctl.every_block,
              "per_rank_s": [x[1] for x in both]}
         if instrumented:
             b["kernels"] = probe_ctl.collect()
@@ -264,7 +362,9 @@ def summarise(blocks, K):
     plain = [b for b in blocks if not b["instrumented"]]
     inst = [b for b in blocks if "kernels" in b]
     ms = lambda bs: [b["elapsed_s"] / K * 1e3 for b in bs]      # noqa: E731
-    out = {"plain": robust(ms(plain)), "seconds_timed": sum(b["elapsed_s"] for b in blocks)}
+    out = {"plain": robust(ms(plain)), "seconds_timed": sum(b["elapsed_s"] for b in blocks),
+           # the same blocks timed up to the end of the closing barrier (what round 3 reported as the block time)
+           "with_barrier": robust([b.get("with_barrier_s", b["elapsed_s"]) / K * 1e3 for b in plain])}
     if inst:
         out["blocks_with_events"] = robust(ms(inst))
         ks = [b["kernels"] for b in inst]
@@ -390,7 +490,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch-per-gpu", type=int, default=32768)
-    ap.add_argument("--min-seconds", type=float, default=3.0, help="keep timing K-step blocks until this much is timed")
+    ap.add_argument("--min-seconds", type=float, default=10.0, help="keep timing K-step blocks until this much is timed "
+                    "(10 s of back-to-back blocks: long enough for clocks and any utilisation sampler to see the card busy)")
     ap.add_argument("--max-blocks", type=int, default=2000)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -402,6 +503,11 @@ def main():
     ap.add_argument("--oversubscribe", action="store_true",
                     help="ranks map to local_rank %% device_count and the control plane runs on gloo: the N > 1 code "
                          "path on a box with fewer GPUs than ranks (plumbing check, not a scaling number)")
+    ap.add_argument("--control-plane", choices=("auto", "nccl", "gloo"), default="auto",
+                    help="barriers over RCCL (one rank per GPU: the default) or gloo (--oversubscribe's default); either "
+                         "way the gathers run over gloo, and a RCCL group that does not come up on every rank falls "
+                         "back to gloo (timing.control_plane.fallback says why)")
+    ap.add_argument("--no-pin", action="store_true", help="do not pin the rank to the CPUs of its GPU's NUMA node")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="run the distributed measurement skeleton with a sleep() in place of the engine (gloo, no GPU)")
     ap.add_argument("--workload", default=WORKLOAD, help="exploration only; the contract line uses the default")
@@ -429,17 +535,7 @@ def main():
         sys.exit(2)
 
     if args.selftest_cpu:
-        ctl = Control("gloo")
-        blocks = timed_blocks(lambda i: time.sleep(0.001 * (1 + rank)), lambda: None, ctl, K, args.min_seconds,
-                              args.max_blocks)
-        s = summarise(blocks, K)
-        if rank == 0:
-            print(json.dumps({"metric": "selftest (sleep in place of the engine)", "value": None, "n_gpus": world,
-                              "steps": K, "warmup": Wm, "ms_per_step": s["plain"]["mean"], "data": "selftest",
-                              "blocks": s["plain"], "launched_by": os.environ.get("BENCH_SELF_LAUNCHED", "external launcher"),
-                              "per_rank_ms_per_step": [x / K * 1e3 for x in blocks[-1]["per_rank_s"]]}), flush=True)
-        ctl.close()
-        return
+        return selftest_cpu(args, rank, local_rank, world, K, Wm)
 
     import torch
     from marlgrid_amd import _native as N
@@ -455,7 +551,9 @@ def main():
     dev_index = local_rank % ndev if args.oversubscribe else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    ctl = Control("gloo" if args.oversubscribe else "nccl", dev)
+    affinity, cpus_all = ({"pinned": False, "why": "--no-pin"}, None) if args.no_pin else pin_to_gpu_numa(dev_index)
+    prefer = args.control_plane if args.control_plane != "auto" else ("gloo" if args.oversubscribe else "nccl")
+    ctl = Control(prefer, dev)
     n_gpus = world
     B = args.batch_per_gpu
     wl = args.workload
@@ -471,9 +569,13 @@ def main():
     raster_ms = raster_only_ms(env) if rank == 0 else None
     # who ran what: every rank's device and its own K-step times (a straggler, or two ranks on one GPU, shows)
     own = robust([b["per_rank_s"][rank] / K * 1e3 for b in blocks if not b["instrumented"]])
+    place = getattr(env._groups[0], "placement_ms", None) or {}
     ranks_info = ctl.gather_objects({"rank": rank, "local_rank": local_rank, "device_index": dev_index,
-                                     "device": device_identity(dev_index),
-                                     "ms_per_step_own": own["mean"], "ms_per_step_own_median": own["median"]})
+                                     "device": device_identity(dev_index), "affinity": affinity,
+                                     "ms_per_step_own": own["mean"], "ms_per_step_own_median": own["median"],
+                                     # which observation buffers this rank drew (ms per raster launch into each kept
+                                     # buffer): the MAX over ranks is the unluckiest rank's
+                                     "obs_placement": {k: place.get(k) for k in ("kept", "candidates", "stopped", "seconds")}})
     n, vs, ts = env.num_agents, env.view_size, env.tile_size
     P = vs * ts
 
@@ -500,14 +602,17 @@ def main():
                                                             "mg_render_obs"]),
                        "sharding": "env batch split contiguously, no collectives",
                        "obs_buffers": OBS_BUFFERS_NOTE.get(env.place_obs, str(env.place_obs))},
-            "timing": {"what": "K-step blocks, each bracketed by barrier + synchronize, MAX over ranks; value = all "
-                               "plain blocks' steps / their total time (every 100th step resets the whole batch "
-                               "in-launch: the median block hides those)",
-                       "blocks": pl, "seconds_timed": summary["seconds_timed"],
+            "timing": {"what": "K-step blocks, each bracketed by barrier + synchronize; a block's time = MAX over ranks of "
+                               "the rank's own K steps (opening barrier -> its own synchronize; `with_barrier` = up to the "
+                               "end of the closing barrier); value = all plain blocks' steps / their total time (every "
+                               "100th step resets the whole batch in-launch: the median block hides those)",
+                       "blocks": pl, "with_barrier": summary["with_barrier"],
+                       "value_with_barrier": n_gpus * B * n / (summary["with_barrier"]["mean"] * 1e-3),
+                       "seconds_timed": summary["seconds_timed"],
                        "blocks_with_events": summary.get("blocks_with_events"),
                        "per_rank": ranks_info,
                        "per_rank_ms_per_step_last_block": [x / K * 1e3 for x in blocks[-1]["per_rank_s"]],
-                       "control_plane": ctl.backend, "ranks_share_a_gpu": bool(shared),
+                       "control_plane": ctl.describe(), "ranks_share_a_gpu": bool(shared),
                        "launched_by": os.environ.get("BENCH_SELF_LAUNCHED", "external launcher" if world > 1 else "direct")},
             "kernels": summary.get("kernels"),
             "closure": summary.get("closure"),
@@ -537,6 +642,9 @@ def main():
             return None
 
     traffic = None
+    if rank == 0 and n_gpus > 1 and not args.no_pmc:
+        traffic = {"skipped": "N > 1: the counters are per process and the other ranks' processes hold their GPUs; the "
+                              "per-GPU workload is the N = 1 line's, whose traffic is measured there"}
     if rank == 0 and n_gpus == 1 and not args.no_pmc:
         def _pmc():
             import pmc
@@ -546,7 +654,7 @@ def main():
         # roofline needs the env's geometry only
         class _Geo(object):
             view_size, tile_size, num_agents = vs, ts, n
-        out["roofline"] = roofline_of(_Geo, B, summary, traffic, raster_ms)
+        out["roofline"] = roofline_of(_Geo, B, summary, traffic if n_gpus == 1 else None, raster_ms)
         out["pmc"] = traffic
 
     # strong-scaling N = 1 point: BASELINE.json's whole headline batch on one GPU
@@ -600,10 +708,53 @@ def main():
         out["value_pipelined_shards"] = pts[0]["value"]       # the same batch as two envs on two streams (extra.pipelined_shards)
 
     if rank == 0:
-        if n_gpus == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
+            # rank 0, once, for every N (the other ranks wait in the closing barrier and leave the host cores alone);
+            # with all the CPUs this process is allowed, not only its GPU's NUMA node
+            if cpus_all:
+                try:
+                    os.sched_setaffinity(0, cpus_all)
+                except OSError:
+                    pass
             out["cpu_baseline"] = leg("cpu_baseline", lambda: cpu_baseline(args.cpu_seconds, wl))
         if errors:
             out["errors"] = errors
+        print(json.dumps(out), flush=True)
+    ctl.close()
+
+
+def selftest_cpu(args, rank, local_rank, world, K, Wm):
+    """The distributed measurement skeleton with a sleep() in place of the engine (gloo, no GPU): process-group
+    bring-up incl. the RCCL attempt and its fallback (--control-plane auto / nccl: on a box without GPUs RCCL cannot
+    come up, which is exactly the failure the fallback is for), the barrier / synchronize bracket, the per-rank
+    gather, MAX over ranks of each rank's own time, and ONE JSON line with every field the N > 1 contract line
+    carries for any N — roofline (traffic null), cpu_baseline (rank 0, unless --no-cpu-baseline), per-rank affinity
+    and observation-buffer placement."""
+    prefer = args.control_plane if args.control_plane != "auto" else "gloo"
+    ctl = Control(prefer, None)
+    affinity = {"pinned": False, "why": "selftest: no GPU"}
+    blocks = timed_blocks(lambda i: time.sleep(0.001 * (1 + rank)), lambda: None, ctl, K, args.min_seconds,
+                          args.max_blocks)
+    s = summarise(blocks, K)
+    own = robust([b["per_rank_s"][rank] / K * 1e3 for b in blocks])
+    ranks_info = ctl.gather_objects({"rank": rank, "local_rank": local_rank, "affinity": affinity,
+                                     "ms_per_step_own": own["mean"],
+                                     "obs_placement": {"kept": None, "candidates": 0, "stopped": "selftest", "seconds": 0.0}})
+    if rank == 0:
+        out = {"metric": "selftest (sleep in place of the engine)", "value": None, "n_gpus": world,
+               "steps": K, "warmup": Wm, "ms_per_step": s["plain"]["mean"], "data": "selftest",
+               "blocks": s["plain"], "with_barrier": s["with_barrier"],
+               "launched_by": os.environ.get("BENCH_SELF_LAUNCHED", "external launcher"),
+               "per_rank_ms_per_step": [x / K * 1e3 for x in blocks[-1]["per_rank_s"]],
+               "timing": {"per_rank": ranks_info, "control_plane": ctl.describe()},
+               "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                            "traffic": None},
+               "pmc": {"skipped": "selftest"}}
+        if not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(min(args.cpu_seconds, 1.0))
+            except Exception as e:      # noqa: BLE001
+                out["errors"] = {"cpu_baseline": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(out), flush=True)
     ctl.close()
 
@@ -620,20 +771,28 @@ def cpu_baseline(budget_s, workload=WORKLOAD):
     seeds = 1337 + np.arange(Bc)
     orc = O.OracleBatch(scenarios.registered(workload), seeds)
     orc.reset()
-    threads = orc.max_threads()
+    # one OpenMP thread per CPU this process may run on — passed explicitly: torch.distributed.run exports
+    # OMP_NUM_THREADS=1 to its ranks, which must not turn the N > 1 lines' baseline into a single-thread number
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        allowed = os.cpu_count() or 1
+    threads = max(1, allowed)
     rng = np.random.RandomState(0)
     acts = [rng.randint(0, 7, size=(Bc, orc.n)) for _ in range(16)]
-    orc.step(acts[0], auto_reset=True, reuse_obs=True)
+    orc.step(acts[0], auto_reset=True, reuse_obs=True, threads=threads)
     t0 = time.perf_counter()
     steps = 0
     while time.perf_counter() - t0 < budget_s:
-        orc.step(acts[steps % 16], auto_reset=True, reuse_obs=True)
+        orc.step(acts[steps % 16], auto_reset=True, reuse_obs=True, threads=threads)
         steps += 1
     dt = time.perf_counter() - t0
     return {"value": Bc * orc.n * steps / dt, "unit": "agent-steps/s", "cores": int(threads), "kind": "port",
             "sample": "%d envs x %d steps of %s (C oracle, OpenMP, obs render included), %.1f s" % (
                 Bc, steps, workload, dt),
-            "host_cpus": os.cpu_count()}
+            "host_cpus": os.cpu_count(), "cpus_allowed": allowed,
+            "cores_note": "cores = OpenMP threads = the CPUs this process may run on (sched_getaffinity: hardware "
+                          "threads, SMT siblings included; a container may allow fewer than os.cpu_count())"}
 
 
 if __name__ == "__main__":

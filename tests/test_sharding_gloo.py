@@ -87,6 +87,70 @@ def test_bench_skeleton_two_ranks_gloo():
     per_rank = out["per_rank_ms_per_step"]
     assert len(per_rank) == 2 and per_rank[1] > per_rank[0] >= 1.0
     assert out["ms_per_step"] >= 2.0 and out["blocks"]["count"] >= 4
+    # a block's time is the slowest rank's OWN K steps; the interval that also holds the closing barrier rides along
+    assert out["with_barrier"]["mean"] >= out["ms_per_step"]
+    # what every N > 1 line carries: cpu_baseline (rank 0, once), roofline (traffic may be null),
+    # per-rank affinity and observation-buffer placement, and what the control plane runs on
+    assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["kind"] == "port"
+    assert out["cpu_baseline"]["cores"] == len(os.sched_getaffinity(0))       # not torchrun's OMP_NUM_THREADS=1
+    assert out["roofline"]["bound"] == "hbm" and "traffic" in out["roofline"]
+    ranks = out["timing"]["per_rank"]
+    assert [r["rank"] for r in ranks] == [0, 1]
+    assert all("affinity" in r and "obs_placement" in r and "kept" in r["obs_placement"] for r in ranks)
+    assert out["timing"]["control_plane"] == {"barriers": "gloo", "gathers": "gloo", "fallback": None}
+
+
+@pytest.mark.parametrize("fail", ["natural", "1"])
+def test_bench_rccl_failure_falls_back_to_gloo(fail):
+    """The RCCL group of the control plane does not come up — here for real (`--control-plane nccl` on a box without
+    GPUs: ProcessGroupNCCL refuses), and forced on rank 1 only (BENCH_TEST_FAIL_NCCL: the ranks must AGREE on the
+    fallback over gloo, or the one whose RCCL attempt got further would wait for the other forever): still one JSON
+    line, rc 0, and the line says what happened."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not (k.startswith("MG_") or k.startswith("MARLGRID_"))}
+    if fail != "natural":
+        env["BENCH_TEST_FAIL_NCCL"] = fail
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "5", "--warmup", "1", "--selftest-cpu", "--min-seconds", "0.05",
+           "--control-plane", "nccl", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    cp = json.loads(lines[0])["timing"]["control_plane"]
+    assert cp["barriers"] == "gloo" and cp["fallback"]["asked_for"] == "nccl"
+    errs = cp["fallback"]["errors_by_rank"]
+    assert errs and all(isinstance(v, str) and v for v in errs.values())
+    if fail != "natural":
+        assert "BENCH_TEST_FAIL_NCCL" in errs["1"]
+
+
+def test_timed_blocks_take_the_slowest_ranks_own_time():
+    """timed_blocks with a control plane whose closing barrier is slow: the block time must not contain it"""
+    import time
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    class SlowBarrier(object):
+        world = 1
+
+        def barrier(self):
+            time.sleep(0.02)
+
+        def gather(self, values):
+            return [[float(v) for v in values]]
+
+    blocks = bench.timed_blocks(lambda i: time.sleep(0.001), lambda: None, SlowBarrier(), 5, 0.0, 4)
+    for b in blocks:
+        assert 0.005 <= b["elapsed_s"] < 0.02 <= b["with_barrier_s"] - 0.005
+    s = bench.summarise(blocks, 5)
+    assert s["with_barrier"]["mean"] > s["plain"]["mean"] + 3.0
 
 
 def test_bench_gpus_n_starts_its_own_ranks():
@@ -107,6 +171,7 @@ def test_bench_gpus_n_starts_its_own_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and "bench.py --gpus 2" in out["launched_by"]
     assert len(out["per_rank_ms_per_step"]) == 2
+    assert "cpu_baseline" in out and "roofline" in out and len(out["timing"]["per_rank"]) == 2
     # WORLD_SIZE 1 (as a launcher would set it) but --gpus 2: refused with rc 2
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--selftest-cpu"],
                        capture_output=True, text=True, timeout=120, env=dict(env, WORLD_SIZE="1", RANK="0"), cwd=root)
