@@ -511,7 +511,10 @@ def main():
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="run the distributed measurement skeleton with a sleep() in place of the engine (gloo, no GPU)")
     ap.add_argument("--workload", default=WORKLOAD, help="exploration only; the contract line uses the default")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # (the cpu_baseline leg's child)
     args = ap.parse_args()
+    if args.cpu_baseline_only:
+        return cpu_baseline_child(args.cpu_seconds, args.workload)
 
     bad = sorted(k for k in os.environ if k.startswith("MG_") or k.startswith("MARLGRID_"))
     if bad:
@@ -710,7 +713,7 @@ def main():
     if rank == 0:
         if not args.no_cpu_baseline:
             # rank 0, once, for every N (the other ranks wait in the closing barrier and leave the host cores alone);
-            # with all the CPUs this process is allowed, not only its GPU's NUMA node
+            # a child process with all the CPUs this process was allowed before it pinned itself
             if cpus_all:
                 try:
                     os.sched_setaffinity(0, cpus_all)
@@ -759,25 +762,50 @@ def selftest_cpu(args, rank, local_rank, world, K, Wm):
     ctl.close()
 
 
+def physical_cores(cpus):
+    """how many physical cores the CPU set covers (sysfs thread_siblings_list; the set's size if sysfs is silent)"""
+    groups = set()
+    for c in cpus:
+        try:
+            groups.add(open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c).read().strip())
+        except OSError:
+            return len(cpus)
+    return len(groups) or len(cpus)
+
+
 def cpu_baseline(budget_s, workload=WORKLOAD):
-    """The parity-checked CPU oracle (a C port of the reference algorithm, OpenMP over envs) on a
-    bounded sample of the same workload, on this box's host cores.  The Python reference cannot
-    travel to the GPU box; its own measured speed (2 377 agent-steps/s on one Xeon core) is in
-    BASELINE.md."""
+    """The parity-checked CPU oracle (a C port of the reference algorithm, OpenMP over envs) on a bounded sample of
+    the same workload, on this box's host cores — in a CHILD process started with a clean environment: the bench
+    process itself is pinned to its GPU's NUMA node, carries the HIP runtime's threads and, under
+    torch.distributed.run, OMP_NUM_THREADS=1; none of that may shape the baseline (visit 1 of round 4: 256 OpenMP
+    threads — every SMT sibling — inside the bench process ran the same sample at 47 k agent-steps/s, 40 x below
+    the 128-thread number).  One thread per physical core the process may run on.  The Python reference cannot
+    travel to the GPU box; its own measured speed (2 377 agent-steps/s on one Xeon core) is in BASELINE.md."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if not (k.startswith("OMP_") or k.startswith("GOMP_") or k.startswith("MKL_")
+                   or k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "BENCH_SELF_LAUNCHED"))}
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-seconds", str(budget_s),
+                        "--workload", workload], env=env, capture_output=True, text=True, timeout=budget_s * 4 + 120)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        raise RuntimeError("cpu baseline child failed (rc %d): %s" % (r.returncode, r.stderr[-400:]))
+    return json.loads(lines[-1])
+
+
+def cpu_baseline_child(budget_s, workload):
     import numpy as np
     import scenarios
     from oracle import oracle as O
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cpus = list(range(os.cpu_count() or 1))
+    threads = max(1, physical_cores(cpus))
     Bc = 2048
     seeds = 1337 + np.arange(Bc)
     orc = O.OracleBatch(scenarios.registered(workload), seeds)
     orc.reset()
-    # one OpenMP thread per CPU this process may run on — passed explicitly: torch.distributed.run exports
-    # OMP_NUM_THREADS=1 to its ranks, which must not turn the N > 1 lines' baseline into a single-thread number
-    try:
-        allowed = len(os.sched_getaffinity(0))
-    except (AttributeError, OSError):
-        allowed = os.cpu_count() or 1
-    threads = max(1, allowed)
     rng = np.random.RandomState(0)
     acts = [rng.randint(0, 7, size=(Bc, orc.n)) for _ in range(16)]
     orc.step(acts[0], auto_reset=True, reuse_obs=True, threads=threads)
@@ -787,12 +815,13 @@ def cpu_baseline(budget_s, workload=WORKLOAD):
         orc.step(acts[steps % 16], auto_reset=True, reuse_obs=True, threads=threads)
         steps += 1
     dt = time.perf_counter() - t0
-    return {"value": Bc * orc.n * steps / dt, "unit": "agent-steps/s", "cores": int(threads), "kind": "port",
-            "sample": "%d envs x %d steps of %s (C oracle, OpenMP, obs render included), %.1f s" % (
-                Bc, steps, workload, dt),
-            "host_cpus": os.cpu_count(), "cpus_allowed": allowed,
-            "cores_note": "cores = OpenMP threads = the CPUs this process may run on (sched_getaffinity: hardware "
-                          "threads, SMT siblings included; a container may allow fewer than os.cpu_count())"}
+    print(json.dumps({
+        "value": Bc * orc.n * steps / dt, "unit": "agent-steps/s", "cores": int(threads), "kind": "port",
+        "sample": "%d envs x %d steps of %s (C oracle, OpenMP, obs render included), %.1f s" % (Bc, steps, workload, dt),
+        "host_cpus": os.cpu_count(), "cpus_allowed": len(cpus),
+        "cores_note": "cores = OpenMP threads = one per PHYSICAL core among the CPUs a clean child process may run on "
+                      "(SMT siblings are not counted); measured in a child process with no OMP_* / launcher variables"}),
+          flush=True)
 
 
 if __name__ == "__main__":

@@ -76,16 +76,27 @@ SYMBOLS = ["mg_abi_version", "mg_struct_sizes", "mg_host_flag_alloc", "mg_host_f
            "mg_render_obs_lds_bytes"]
 
 _lib = None
+_path = LIB_PATH
+
+
+def use_library(path):
+    """tools/ only: bind another build of the same ABI (the measurement build libmarlgrid_hip_ab.so) instead of
+    the product library — by an explicit call before the first lib(), never through the environment: the
+    package loads exactly one library, the one next to it, unless a measurement script says otherwise in code."""
+    global _path
+    if _lib is not None:
+        raise RuntimeError("marlgrid_amd: the library is already loaded (%s)" % _path)
+    _path = os.path.abspath(path)
 
 
 def lib():
-    """Load the HIP library (after torch, so that the HIP runtime torch ships is the one bound).
-    MARLGRID_HIP_LIB names another build of the same ABI (tools/ use it for the measurement build)."""
+    """Load the HIP library (after torch, so that the HIP runtime torch ships is the one bound).  Reads no
+    environment variable."""
     global _lib
     if _lib is not None:
         return _lib
     import torch  # noqa: F401  — loads libamdhip64 first; our .so resolves against the same runtime
-    path = os.environ.get("MARLGRID_HIP_LIB") or LIB_PATH
+    path = _path
     if path == LIB_PATH and not os.path.exists(LIB_PATH):
         # not a fallback: build the one and only implementation if the toolchain is at hand
         import shutil

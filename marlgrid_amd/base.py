@@ -404,8 +404,10 @@ class MultiGridEnv(object):
             if a.allow_negative_prestige:
                 raise NotImplementedError("allow_negative_prestige=True raises AttributeError upstream "
                                           "(agents.py:147-148) and is not supported")
-            if a.view_size % 2 == 0 or a.view_size > N.MAX_VIEW:
-                raise NotImplementedError("view_size must be odd and <= %d" % N.MAX_VIEW)
+            if a.view_size < 3:
+                raise ValueError("Grid needs width, height >= 3")      # what upstream's first observation raises (base.py:97-99)
+            if a.view_size > N.MAX_VIEW:
+                raise NotImplementedError("view_size must be <= %d" % N.MAX_VIEW)
             if not (0 <= a.view_offset < a.view_size):
                 raise ValueError("view_offset out of range")
             key = (a.view_size, a.view_tile_size, a.view_offset, bool(a.see_through_walls))
@@ -463,9 +465,11 @@ class MultiGridEnv(object):
             self._ring_i = 0
             self.obs, self.rewards, self.done_t = (self._ring[0][k] for k in ("obs", "rewards", "done"))
             self.done_b = self.done_t.view(torch.bool)      # the same bytes, as the bool tensor step() returns
-        # one word of pinned host memory the kernels raise when they record an error in error_t: polled by
-        # step()/reset() instead of a nonzero() + .item() round trip through the stream
-        self._flag = _HostFlag(self._lib)
+            # one word of pinned host memory the kernels raise when they record an error in error_t: polled by
+            # step()/reset() instead of a nonzero() + .item() round trip through the stream (mapped while the
+            # env's device is current: the device pointer is this device's view of the word)
+            self._flag = _HostFlag(self._lib)
+        self._launch_streams = {}       # streams this env has launched on since the last check_errors()
         self._state = N.State(self.grid_state.data_ptr(), self.agent_state.data_ptr(), self.mt_state.data_ptr(),
                               self.mt_pos.data_ptr(), self.step_count_t.data_ptr(), self.done_t.data_ptr(),
                               self.error_t.data_ptr(),
@@ -496,6 +500,7 @@ class MultiGridEnv(object):
         import torch
         t_begin = time.perf_counter()
         t_end = t_begin + seconds
+        any_replaced = False
         for g in self._groups:
             nbytes = g.ring[0].numel()
             if nbytes < min_bytes:
@@ -549,20 +554,33 @@ class MultiGridEnv(object):
                 if len(seen) >= keep + flat_after and ranked[-1] <= 1.05 * ranked[0]:
                     why = "no spread among %d candidates" % len(seen)
                     break
+            replaced = any(all(t is not kept for _, kept in best) for t in g.ring)
             g.ring = [t for _, t in best]
             for t in g.ring:
                 t.zero_()
             g.obs = g.ring[self._ring_i]
             g.placement_ms = {"kept": [c for c, _ in best], "candidates": len(seen), "stopped": why,
                               "seconds": time.perf_counter() - t_begin, "all": seen}
+            any_replaced = any_replaced or replaced
         for i, r in enumerate(self._ring):
             r["obs"] = self._groups[0].ring[i]
         self.obs = self._ring[self._ring_i]["obs"]
+        if any_replaced:
+            # the torch-allocated ring tensors that lost to a raw candidate are unreferenced now, but torch's caching
+            # allocator would keep their blocks reserved (obs_buffers x the buffer size): hand them back once.  The
+            # kept raw buffers live OUTSIDE torch's allocator (mg_obs_alloc) and are invisible to its accounting.
+            torch.cuda.synchronize(self.device)
+            torch.cuda.empty_cache()
         self._render()                      # the current observation, into the buffer that is current now
 
     def _stream(self):
+        """torch's current stream of the env's device, as the C ABI takes it — and remembered: check_errors()
+        has to wait for the launches on EVERY stream this env was driven on (a ShardPipeline part is stepped
+        under its own stream and checked from wherever the caller happens to be)."""
         import torch
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        s = torch.cuda.current_stream(self.device)
+        self._launch_streams[s.cuda_stream] = s
+        return C.c_void_p(s.cuda_stream)
 
     @_on_device
     def seed(self, seed=1337):
@@ -860,8 +878,18 @@ class MultiGridEnv(object):
         """the attributes _refresh_cfg reads, as one comparable value (what step() checks instead of re-deriving
         every launch config on every step)"""
         kw = self.agent_spawn_kwargs
-        return (self.max_steps, self.reward_decay, self.ghost_mode, self.respawn, self.auto_reset,
-                tuple(sorted((k, tuple(v) if isinstance(v, (list, tuple)) else v) for k, v in kw.items())) if kw else (),
+
+        def plain(v):       # array-likes by value (an ndarray has no truth value to compare with), callables by identity
+            if callable(v):
+                return ("fn", id(v))
+            if isinstance(v, (list, tuple)) or hasattr(v, "tolist"):
+                return tuple(np.asarray(v).reshape(-1).tolist())
+            return v
+        # the DERIVED values where upstream distinguishes more than == does: `ghost_mode is False` (base.py:541)
+        # against `not ghost_mode` (base.py:683) — False and 0 compare equal and configure different engines
+        return (int(self.max_steps), bool(self.reward_decay), self.ghost_mode is not False, bool(self.ghost_mode),
+                bool(self.respawn), bool(self.auto_reset),
+                tuple(sorted((k, plain(v)) for k, v in kw.items())) if kw else (),
                 tuple((a.spawn_delay, a.prestige_beta, a.prestige_scale) for a in self.agents))
 
     def _sync_tables(self):
@@ -1117,6 +1145,9 @@ class MultiGridEnv(object):
         fetched when it is set."""
         import torch
         torch.cuda.current_stream(self.device).synchronize()
+        for s in list(self._launch_streams.values()):      # every stream a launch of this env went to
+            s.synchronize()
+        self._launch_streams.clear()
         if not self._flag.raised():
             return
         self._flag.clear()
@@ -1259,8 +1290,9 @@ class MultiGridEnv(object):
                                                                                     tuple(getattr(self, k).shape)))
         for k in want - {"version"}:
             getattr(self, k).copy_(sd[k])
-        if self.strict is not False and bool((self.error_t != 0).any()):
-            self._flag._host[0] = 1          # the restored batch carries recorded errors
+        if bool((self.error_t != 0).any()):
+            self._flag._host[0] = 1          # the restored batch carries recorded errors (whatever `strict` is:
+                                             # check_errors() looks at the flag first)
 
     # ---- plain-data description (parity tests hand this to the oracle) -----------------------------------
     def scenario_spec(self):

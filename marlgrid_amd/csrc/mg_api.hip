@@ -3,9 +3,6 @@
 // caller's stream.
 #include "mg_device.h"
 #include "mg_launch.h"
-#if defined(MG_AB_VARIANTS)
-#include "mg_mem.h"
-#endif
 
 namespace {
 
@@ -13,7 +10,7 @@ int check_cfg(const MgConfig* c) {
     if (!c) return MG_E_ARG;
     if (c->B < 0 || c->W < 3 || c->H < 3 || c->W > 255 || c->H > 255) return MG_E_ARG;
     if (c->n_agents < 1 || c->n_agents > MG_MAX_AGENTS) return MG_E_UNSUPPORTED;
-    if (c->view_size < 1 || c->view_size > MG_MAX_VIEW || (c->view_size & 1) == 0) return MG_E_UNSUPPORTED;
+    if (c->view_size < 1 || c->view_size > MG_MAX_VIEW) return MG_E_UNSUPPORTED;   // (even sizes included: agents.py:233-266 is written with view_size // 2)
     if (c->tile_size < 1 || c->tile_size > 64) return MG_E_UNSUPPORTED;
     if (c->view_offset < 0 || c->view_offset >= c->view_size) return MG_E_ARG;
     if (c->cells_stride < c->W * c->H || (c->cells_stride & 15)) return MG_E_ARG;
@@ -263,43 +260,5 @@ void* mg_obs_alloc(uint64_t bytes, int32_t device) {
 }
 
 int32_t mg_obs_free(void* ptr) { return ptr ? rc(hipFree(ptr)) : MG_OK; }
-
-#if defined(MG_AB_VARIANTS)
-// measurement build: observation buffers built with HIP virtual memory management (mg_mem.h) — the experiments of
-// profiles/r03/README.md section 2 (tools/placement_vmm*.py, placement_va.py, vmm_reuse_check.py)
-typedef struct MgObsBuffer MgObsBuffer;
-MgObsBuffer* mg_ab_vmm_alloc(uint64_t bytes, int32_t device, int64_t chunk_bytes) {
-    return reinterpret_cast<MgObsBuffer*>(mg::obs_alloc((size_t)bytes, device, (long long)chunk_bytes));
-}
-void* mg_ab_vmm_ptr(const MgObsBuffer* buf) { return buf ? reinterpret_cast<const mg::ObsBuffer*>(buf)->ptr : nullptr; }
-int32_t mg_ab_vmm_info(const MgObsBuffer* buf, uint64_t out[4]) {
-    if (!buf || !out) return MG_E_ARG;
-    const mg::ObsBuffer* b = reinterpret_cast<const mg::ObsBuffer*>(buf);
-    out[0] = b->mapped;
-    out[1] = b->chunk;
-    out[2] = b->handles.size();
-    out[3] = b->ranges.size();
-    return MG_OK;
-}
-int32_t mg_ab_vmm_free(MgObsBuffer* buf) {
-    mg::obs_free(reinterpret_cast<mg::ObsBuffer*>(buf));
-    return MG_OK;
-}
-void* mg_ab_vmm_rebase(MgObsBuffer* buf) { return mg::obs_rebase(reinterpret_cast<mg::ObsBuffer*>(buf)); }
-int32_t mg_ab_vmm_select(MgObsBuffer* buf, int32_t i) {
-    return mg::obs_select(reinterpret_cast<mg::ObsBuffer*>(buf), i) ? MG_OK : MG_E_ARG;
-}
-int32_t mg_ab_vmm_trim(MgObsBuffer* buf) {
-    if (!buf) return MG_E_ARG;
-    mg::obs_trim(reinterpret_cast<mg::ObsBuffer*>(buf));
-    return MG_OK;
-}
-int32_t mg_ab_obs_permute(MgObsBuffer* buf, const int32_t* order) {
-    return mg::obs_permute(reinterpret_cast<mg::ObsBuffer*>(buf), order) ? MG_OK : MG_E_LAUNCH;
-}
-int32_t mg_ab_obs_exchange(MgObsBuffer* a, MgObsBuffer* b, const int32_t* slots, int32_t n) {
-    return mg::obs_exchange(reinterpret_cast<mg::ObsBuffer*>(a), reinterpret_cast<mg::ObsBuffer*>(b), slots, n) ? MG_OK : MG_E_LAUNCH;
-}
-#endif
 
 }  // extern "C"

@@ -15,8 +15,6 @@ struct FusedStep;
 hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, uint8_t* view_cells,
                          uint8_t* view_agent, uint8_t* vis_mask, hipStream_t s, const FusedStep* fused_step = nullptr);
 int render_min_lds_bytes(const MgConfig& cfg);
-bool raster_front_eligible(const MgConfig& cfg);
-hipError_t launch_raster_front(const MgConfig& cfg, const uint16_t* tmap, uint8_t* obs, hipStream_t s);
 hipError_t launch_encode(const MgConfig& cfg, const MgState& st, const uint8_t* vis_mask, uint8_t* out,
                          hipStream_t s);
 hipError_t launch_put_obj(const MgConfig& cfg, const MgState& st, int obj, int x, int y, const uint8_t* mask,

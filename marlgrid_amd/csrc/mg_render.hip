@@ -205,11 +205,7 @@ template <int VS_, int TS_, int WPB, int V_ = 0, int RM_ = 0>
 __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState st, uint8_t* __restrict__ obs,
                                                         uint8_t* __restrict__ dbg_cells,
                                                         uint8_t* __restrict__ dbg_agent,
-                                                        uint8_t* __restrict__ dbg_vis, RenderLaunch lc, FusedStep fs
-#if defined(MG_AB_VARIANTS)
-                                                        , uint16_t* __restrict__ view_out   // measurement build: views only
-#endif
-                                                        ) {
+                                                        uint8_t* __restrict__ dbg_vis, RenderLaunch lc, FusedStep fs) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int VS = VS_ ? VS_ : cfg.view_size;
     const int TS = TS_ ? TS_ : cfg.tile_size;
@@ -805,18 +801,6 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
         }
         }
         wave_lds_sync();
-#if defined(MG_AB_VARIANTS)
-        if constexpr (kChunkRaster && V_ == 0) {
-            // measurement build, two-kernel experiment (mg_raster_front.hip): this launch only derives the
-            // views; the env's tmap — n * VS * VS atlas offsets, 2 bytes each — goes to HBM
-            if (view_out) {
-                uint16_t* vo = view_out + (size_t)e * nv * VV;
-                for (int it = lane; it < nv * VV; it += kWave) vo[it] = w_tmap[it];
-            }
-        }
-        } else if (kChunkRaster && V_ == 0 && view_out) {
-            // (views only: nothing to raster here)
-#endif
         } else {
         // 6. raster: stream the env's n images out
         if constexpr (kChunkRaster) {
@@ -1110,10 +1094,23 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     MG_STAMP(6);
 }
 
+// Compute units of the current device (256 on a whole MI355X; 32 per partition in CPX mode): what the persistent
+// grid is sized for.  Asked once per device (hipDeviceGetAttribute is a host-side table look-up, no stream work).
+static int device_cus() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
+
 template <int VS_, int TS_, int WPB, int V_ = 0, int RM_ = 0>
 static hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_t* obs, uint8_t* c, uint8_t* a,
-                                  uint8_t* v, hipStream_t s, const FusedStep* fs, uint16_t* view_out = nullptr) {
-    const int tile_bytes = cfg.tile_size * cfg.tile_size * 3;
+                                  uint8_t* v, hipStream_t s, const FusedStep* fs) {
     static_assert(RM_ == 1 || TS_ == 0 || (TS_ % 8) != 0 || TS_ == 8 || TS_ == 16 || TS_ == 32, "see render_chunk_raster");
     const RenderScratch L = render_scratch_for(cfg, WPB, RM_);
     const size_t atlas_lds = (V_ == 8 || V_ == 12) ? 0 : (size_t)render_atlas_lds_bytes(cfg);
@@ -1124,7 +1121,7 @@ static hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    // Persistent grid: at most the workgroups that are co-resident on 256 CUs (each stages the atlas
+    // Persistent grid: at most the workgroups that are co-resident on the device's CUs (each stages the atlas
     // once), sized so that every wave walks the same number of envs (an uneven tail costs up to one
     // env-time in ~6).  Registers (~87 VGPRs) admit 5 waves per SIMD = 20 per CU.
     int per_cu = (int)((160 * 1024) / (lds ? lds : 1));
@@ -1133,7 +1130,7 @@ static hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_
     if (const char* f = getenv("MG_RENDER_PER_CU")) { const int v = atoi(f); if (v >= 1 && v < per_cu) per_cu = v; }
 #endif
     if (per_cu < 1) per_cu = 1;
-    const int max_blocks = 256 * per_cu;
+    const int max_blocks = device_cus() * per_cu;
     const int need = (cfg.B + WPB - 1) / WPB;   // workgroups if every wave took one env
     const int rounds = (need + max_blocks - 1) / max_blocks;
     int blocks = (need + rounds - 1) / rounds;
@@ -1156,14 +1153,8 @@ static hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_
 #if defined(MG_AB_VARIANTS)
     if (const char* f = getenv("MG_RENDER_DEPTH")) lc.depth_mode = atoi(f);   // 1: every wave view -> raster env by env
 #endif
-#if defined(MG_AB_VARIANTS)
-    hipLaunchKernelGGL((render_kernel<VS_, TS_, WPB, V_, RM_>), dim3(blocks), dim3(WPB * 64), lds, s, cfg, st, obs, c, a, v,
-                       lc, *fs, view_out);
-#else
-    (void)view_out;
     hipLaunchKernelGGL((render_kernel<VS_, TS_, WPB, V_, RM_>), dim3(blocks), dim3(WPB * 64), lds, s, cfg, st, obs, c, a, v,
                        lc, *fs);
-#endif
     return hipGetLastError();
 }
 
@@ -1187,55 +1178,31 @@ static int choose_wpb(const MgConfig& cfg) {
 #if defined(MG_AB_VARIANTS)
     if (const char* f = getenv("MG_RENDER_WPB")) { int w = atoi(f); if (w == 4 || w == 8 || w == 12 || w == 16) return w; }
 #endif
-    const int tile_bytes = cfg.tile_size * cfg.tile_size * 3;
     const RenderScratch L = render_scratch_for(cfg, 16);
     size_t lds16 = (size_t)render_atlas_lds_bytes(cfg) + kRenderShared + 16 * (size_t)L.total;
     return (cfg.B >= 4096 && lds16 <= 160 * 1024) ? 16 : 4;
 }
 
 #define MG_RENDER_DISPATCH(VS, TS, V)                                                                      \
-    (wpb == 16 ? launch_render_t<VS, TS, 16, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo)           \
-               : launch_render_t<VS, TS, 4, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo))
+    (wpb == 16 ? launch_render_t<VS, TS, 16, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)           \
+               : launch_render_t<VS, TS, 4, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs))
 // run-time view size: its MG_MAX_VIEW-entry shadow-cast arrays need more than the 128 VGPRs a 16-wave
 // workgroup leaves per lane (spills would be VMEM traffic in the middle of the run): 8-wave workgroups
 #define MG_RENDER_DISPATCH_RT(TS, V)                                                                       \
-    (wpb == 16 ? launch_render_t<0, TS, 8, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo)             \
-               : launch_render_t<0, TS, 4, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo))
+    (wpb == 16 ? launch_render_t<0, TS, 8, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)             \
+               : launch_render_t<0, TS, 4, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs))
 // 12-wave workgroups: 3 waves per SIMD, i.e. a 168-VGPR budget instead of the 128 of 16 waves — for the
 // instantiations that spill at 128 (the assemble-and-stream rasters) or need more anyway ('prestige')
 #define MG_RENDER_DISPATCH12(VS, TS, V)                                                                    \
-    (wpb == 12 ? launch_render_t<VS, TS, 12, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo) : MG_RENDER_DISPATCH(VS, TS, V))
+    (wpb == 12 ? launch_render_t<VS, TS, 12, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs) : MG_RENDER_DISPATCH(VS, TS, V))
 #define MG_RENDER_DISPATCH8(VS, TS, V)                                                                     \
-    (wpb == 8 ? launch_render_t<VS, TS, 8, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo) : MG_RENDER_DISPATCH(VS, TS, V))
+    (wpb == 8 ? launch_render_t<VS, TS, 8, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs) : MG_RENDER_DISPATCH(VS, TS, V))
 
-// The kernel launch of mg_render_obs / mg_step_render.  (Measurement build only: with view scratch set through
-// mg_ab_view_scratch and MG_RENDER_FRONT=1, the two-kernel experiment — this file's kernel in views-only mode,
-// then mg_raster_front.hip's dense-front raster; see profiles/r02 for why it is not the product path.)
-static hipError_t launch_render_one(const MgConfig& cfg, const MgState& st, uint8_t* obs, uint8_t* view_cells,
-                                    uint8_t* view_agent, uint8_t* vis_mask, hipStream_t s, const FusedStep* fs,
-                                    uint16_t* vo);
-#if defined(MG_AB_VARIANTS)
-static uint16_t* g_ab_view_scratch = nullptr;
-extern "C" void mg_ab_view_scratch(uint16_t* p) { g_ab_view_scratch = p; }
-#endif
-
+// The kernel launch of mg_render_obs / mg_step_render.
 hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, uint8_t* view_cells,
                          uint8_t* view_agent, uint8_t* vis_mask, hipStream_t s, const FusedStep* fs) {
     if (cfg.B <= 0) return hipSuccess;
-#if defined(MG_AB_VARIANTS)
-    const char* f = getenv("MG_RENDER_FRONT");
-    if (f && atoi(f) != 0 && g_ab_view_scratch && !view_cells && !view_agent && !vis_mask && raster_front_eligible(cfg)) {
-        hipError_t e = launch_render_one(cfg, st, obs, nullptr, nullptr, nullptr, s, fs, g_ab_view_scratch);
-        if (e != hipSuccess) return e;
-        return launch_raster_front(cfg, g_ab_view_scratch, obs, s);
-    }
-#endif
-    return launch_render_one(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, nullptr);
-}
 
-static hipError_t launch_render_one(const MgConfig& cfg, const MgState& st, uint8_t* obs, uint8_t* view_cells,
-                                    uint8_t* view_agent, uint8_t* vis_mask, hipStream_t s, const FusedStep* fs,
-                                    uint16_t* vo) {
     FusedStep none;
     none.enabled = 0;
     none.has_prog = 0;
@@ -1248,7 +1215,7 @@ static hipError_t launch_render_one(const MgConfig& cfg, const MgState& st, uint
     if ((view_cells || view_agent || vis_mask) && !(view_cells && view_agent && vis_mask)) return hipErrorInvalidValue;
 #if defined(MG_DEV_ONLY)   // development: compile ONE instantiation (register / ISA checks without the other sixty),
     // e.g. -DMG_DEV_ONLY="7,5,16,0,0"
-    return launch_render_t<MG_DEV_ONLY>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
+    return launch_render_t<MG_DEV_ONLY>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
 #else
     const int vs = cfg.view_size, ts = cfg.tile_size;
     const int wpb = choose_wpb(cfg);
@@ -1257,10 +1224,10 @@ static hipError_t launch_render_one(const MgConfig& cfg, const MgState& st, uint
         const size_t lds4 = (size_t)render_atlas_lds_bytes(cfg) + kRenderShared +
                             4 * (size_t)L.total;
         if (lds4 > 160 * 1024) {   // the static atlas stays in global memory
-            if (ts == 8) return launch_render_t<0, 8, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
-            if (ts == 16) return launch_render_t<0, 16, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
-            if (ts == 32) return launch_render_t<0, 32, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
-            return launch_render_t<0, 0, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
+            if (ts == 8) return launch_render_t<0, 8, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
+            if (ts == 16) return launch_render_t<0, 16, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
+            if (ts == 32) return launch_render_t<0, 32, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
+            return launch_render_t<0, 0, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
         }
         // the shipped view: compile-time size; 8-wave workgroups when they fit (the recolouring code needs
         // more than the 128 VGPRs a 16-wave workgroup leaves per lane)
@@ -1270,35 +1237,35 @@ static hipError_t launch_render_one(const MgConfig& cfg, const MgState& st, uint
         int pw = wpb;
         if (pw == 16) pw = render_lds_bytes(cfg, 12) <= 160 * 1024 ? 12 : 8;
         if (vs == 7 && ts == 8)
-            return pw == 12 ? launch_render_t<7, 8, 12, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo)
-                 : pw == 8 ? launch_render_t<7, 8, 8, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo)
-                           : launch_render_t<7, 8, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
+            return pw == 12 ? launch_render_t<7, 8, 12, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)
+                 : pw == 8 ? launch_render_t<7, 8, 8, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)
+                           : launch_render_t<7, 8, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
         bool rt_ts = false;
 #if defined(MG_AB_VARIANTS)
         if (const char* f = getenv("MG_RENDER_RT_TS")) rt_ts = atoi(f) != 0;
 #endif
         if (vs == 7 && ts == 11 && !rt_ts)     // examples/human_player.py's view_tile_size
-            return pw == 12 ? launch_render_t<7, 11, 12, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo)
-                 : pw == 8 ? launch_render_t<7, 11, 8, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo)
-                           : launch_render_t<7, 11, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
+            return pw == 12 ? launch_render_t<7, 11, 12, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)
+                 : pw == 8 ? launch_render_t<7, 11, 8, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)
+                           : launch_render_t<7, 11, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
         if (vs == 7 && (ts % 8) != 0)
-            return pw == 12 ? launch_render_t<7, 0, 12, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo)
-                 : pw == 8 ? launch_render_t<7, 0, 8, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo)
-                           : launch_render_t<7, 0, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
-        if (ts == 8) return launch_render_t<0, 8, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
-        if (ts == 16) return launch_render_t<0, 16, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
-        if (ts == 32) return launch_render_t<0, 32, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
-        return launch_render_t<0, 0, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
+            return pw == 12 ? launch_render_t<7, 0, 12, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)
+                 : pw == 8 ? launch_render_t<7, 0, 8, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)
+                           : launch_render_t<7, 0, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
+        if (ts == 8) return launch_render_t<0, 8, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
+        if (ts == 16) return launch_render_t<0, 16, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
+        if (ts == 32) return launch_render_t<0, 32, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
+        return launch_render_t<0, 0, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
     }
     {   // atlas too large for LDS (next to 4 waves of scratch): read it from global memory instead
         const RenderScratch L = render_scratch_for(cfg, 4);
         const size_t lds4 = (size_t)render_atlas_lds_bytes(cfg) + kRenderShared +
                             4 * (size_t)L.total;
         if (lds4 > 160 * 1024) {
-            if (ts == 8) return launch_render_t<0, 8, 4, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
-            if (ts == 16) return launch_render_t<0, 16, 4, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
-            if (ts == 32) return launch_render_t<0, 32, 4, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
-            return launch_render_t<0, 0, 4, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
+            if (ts == 8) return launch_render_t<0, 8, 4, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
+            if (ts == 16) return launch_render_t<0, 16, 4, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
+            if (ts == 32) return launch_render_t<0, 32, 4, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
+            return launch_render_t<0, 0, 4, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
         }
     }
     if (ts == 8 && vs == 7) {
@@ -1312,8 +1279,8 @@ static hipError_t launch_render_one(const MgConfig& cfg, const MgState& st, uint
         default: break;
         }
         if (getenv("MG_RENDER_RASTER") && atoi(getenv("MG_RENDER_RASTER")) == 1)   // assemble-and-stream at tile 8
-            return wpb == 16 ? launch_render_t<7, 8, 16, 0, 1>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo)
-                             : launch_render_t<7, 8, 4, 0, 1>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, vo);
+            return wpb == 16 ? launch_render_t<7, 8, 16, 0, 1>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)
+                             : launch_render_t<7, 8, 4, 0, 1>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
 #endif
         return MG_RENDER_DISPATCH8(7, 8, 0);
     }

@@ -113,5 +113,6 @@ class ShardPipeline(object):
             s.synchronize()
 
     def check_errors(self):
-        for env in self.envs:
-            env.check_errors()
+        """every part's check_errors(), each under its own stream (an env waits for every stream it launched on, so
+        this also holds for parts that were stepped through step_part from elsewhere)"""
+        self._each(lambda k, env: env.check_errors())

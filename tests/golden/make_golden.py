@@ -56,6 +56,8 @@ TRAJ = {  # scenario -> (n_seeds, n_steps, n_full_obs_seeds)
     "Test-4AgentEmpty5x5-ghost0": (6, 120, 1),
     "Test-3AgentEmpty7x11-nonsquare": (6, 120, 2),
     "Test-3AgentCluttered12x6-nonsquare": (6, 120, 2),
+    "Test-3AgentCluttered9x9-view6": (8, 150, 2),
+    "Test-2AgentEmpty8x8-view4-ts5": (6, 100, 2),
 }
 CANON = ("base_enc", "pos", "dir", "active", "done", "carry_enc", "ordinal")
 
@@ -133,7 +135,7 @@ def gen_occlusion(m, out):
     from marlgrid.agents import occlude_mask
     rng = np.random.RandomState(7)
     d = {}
-    for vs in (3, 5, 7, 9, 11):
+    for vs in (3, 5, 7, 9, 11, 2, 4, 6, 8):        # (even sizes appended: the odd ones' draws stay what they were)
         for off in (0, 1, 2):
             if vs - 1 - off < 0:
                 continue

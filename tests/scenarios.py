@@ -139,6 +139,8 @@ def ref_recipe(name):
         "Edge-3AgentCluttered15x15-default-tiles": ("ClutteredMultiGrid", dict(grid_size=15, n_clutter=10)),
         "Test-3AgentEmpty7x11-nonsquare": ("EmptyMultiGrid", dict(width=7, height=11)),
         "Test-3AgentCluttered12x6-nonsquare": ("ClutteredMultiGrid", dict(width=12, height=6, n_clutter=7)),
+        "Test-3AgentCluttered9x9-view6": ("ClutteredMultiGrid", dict(grid_size=9, n_clutter=7, max_steps=60)),
+        "Test-2AgentEmpty8x8-view4-ts5": ("EmptyMultiGrid", dict(grid_size=8, max_steps=50)),
         # the reference's examples/human_player.py configuration (examples/human_player.py:35-55)
         "Edge-3AgentCluttered11x11-offset6": ("ClutteredMultiGrid", dict(grid_size=11, n_clutter=12)),
         "Edge-HumanPlayerConfig": ("ClutteredGoalCycleEnv", dict(grid_size=13, max_steps=250, clutter_density=0.15,
@@ -289,6 +291,11 @@ def registered(name):   # noqa: F811  (extends the table above with test-only sc
         "Edge-3AgentCluttered15x15-default-tiles": lambda: cluttered_spec(3, 15, 7, n_clutter=10, tile_size=5,
                                                                           colors=["red", "red", "red"]),
         "Edge-3AgentCluttered11x11-offset6": lambda: cluttered_spec(3, 11, 7, n_clutter=12, view_offset=6),
+        # EVEN view sizes (agents.py:233-266 is written with view_size // 2: in an even view the agent sits at column
+        # view_size // 2 when it faces up or right and one column to the left of it when it faces down or left, while
+        # the shadow cast always starts from column view_size // 2 — upstream's geometry, reproduced as it is)
+        "Test-3AgentCluttered9x9-view6": lambda: cluttered_spec(3, 9, 6, n_clutter=7, max_steps=60, view_offset=1),
+        "Test-2AgentEmpty8x8-view4-ts5": lambda: empty_spec(2, 8, 4, tile_size=5, max_steps=50),
         "Edge-HumanPlayerConfig": lambda: goalcycle_spec(1, 13, 7, clutter_density=0.15, n_bonus_tiles=3, penalty=-1.5,
                                                          initial_reward=True, max_steps=250, respawn=True,
                                                          reward_decay=False, colors=["prestige"], tile_size=11,
@@ -334,6 +341,10 @@ def fuzz_case(i):
                      initial_reward=r.random() < 0.6, reset_on_mistake=r.random() < 0.4)
         spec = goalcycle_spec(n, W, **extra, **akw, **common)
         recipe = ("ClutteredGoalCycleEnv", dict(grid_size=W, **extra, **common))
+    r2 = random.Random(99100 + i)       # (its own stream: every other knob of case i stays what it was)
+    if r2.random() < 0.25:
+        ev = r2.choice([4, 6, 8])        # (a 2 x 2 view cannot be built upstream: MultiGrid needs >= 3)
+        spec["view_size"], spec["view_offset"] = ev, min(spec["view_offset"], ev - 1)
     if r.random() < 0.3:
         _with_delays(spec, [r.choice([0, 0, 1, 3, 7]) for _ in range(n)])
     if r.random() < 0.3:
@@ -354,6 +365,7 @@ ALL_SCENARIOS = [
     "Test-3AgentCluttered9x9-prestige-mixed", "Test-4AgentEmpty5x5-ghost0", "Test-3AgentEmpty7x11-nonsquare",
     "Test-3AgentCluttered12x6-nonsquare", "Test-3AgentSpawnRect9x9", "Test-3AgentEmpty7x7-rich",
     "Test-3AgentCluttered9x9-hetero-views", "Test-2AgentReject9x9",
+    "Test-3AgentCluttered9x9-view6", "Test-2AgentEmpty8x8-view4-ts5",
 ]
 
 

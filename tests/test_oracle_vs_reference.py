@@ -61,7 +61,7 @@ def test_occlusion_live_random():
     m = refload.load()
     from marlgrid.agents import occlude_mask
     rng = np.random.RandomState(123)
-    for vs in (3, 5, 7, 9, 13):
+    for vs in (3, 5, 7, 9, 13, 2, 4, 6, 8):
         for off in (0, 1):
             for _ in range(150):
                 T = rng.rand(vs, vs) < rng.choice([0.6, 0.8, 0.95])
@@ -106,7 +106,7 @@ def test_agent_geometry_helpers_match_the_reference():
     from marlgrid.agents import GridAgentInterface as RefAgent
     from marlgrid_amd.agents import GridAgentInterface as Agent
     rng = np.random.RandomState(5)
-    for vs, off in ((7, 0), (7, 1), (5, 2), (9, 3), (3, 0), (7, 6)):
+    for vs, off in ((7, 0), (7, 1), (5, 2), (9, 3), (3, 0), (7, 6), (6, 0), (6, 1), (4, 3), (2, 0), (8, 2)):
         ref = RefAgent(view_size=vs, view_offset=off)
         N = 200
         pos = rng.randint(0, 20, size=(N, 2))

@@ -92,7 +92,9 @@ def test_bench_skeleton_two_ranks_gloo():
     # what every N > 1 line carries: cpu_baseline (rank 0, once), roofline (traffic may be null),
     # per-rank affinity and observation-buffer placement, and what the control plane runs on
     assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["kind"] == "port"
-    assert out["cpu_baseline"]["cores"] == len(os.sched_getaffinity(0))       # not torchrun's OMP_NUM_THREADS=1
+    assert out["cpu_baseline"]["cores"] >= 1 and out["cpu_baseline"]["cpus_allowed"] == len(os.sched_getaffinity(0))
+    if len(os.sched_getaffinity(0)) >= 4:
+        assert out["cpu_baseline"]["cores"] > 1                                 # not torchrun's OMP_NUM_THREADS=1
     assert out["roofline"]["bound"] == "hbm" and "traffic" in out["roofline"]
     ranks = out["timing"]["per_rank"]
     assert [r["rank"] for r in ranks] == [0, 1]

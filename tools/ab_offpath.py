@@ -13,9 +13,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("MARLGRID_HIP_LIB", os.path.join(ROOT, "marlgrid_amd", "csrc", "libmarlgrid_hip_ab.so"))
 import torch  # noqa: E402
 from marlgrid_amd import _native as N  # noqa: E402
+N.use_library(os.path.join(ROOT, "marlgrid_amd", "csrc", os.environ.get("AB_LIB", "libmarlgrid_hip_ab.so")))   # the measurement build
 from marlgrid_amd.agents import GridAgentInterface  # noqa: E402
 from marlgrid_amd.envs import ClutteredGoalCycleEnv, ClutteredMultiGrid  # noqa: E402
 

@@ -9,19 +9,15 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 # the measurement build (marlgrid_amd/csrc/build.sh ab): the product library has no switches to flip
-os.environ.setdefault("MARLGRID_HIP_LIB", os.path.join(ROOT, "marlgrid_amd", "csrc", "libmarlgrid_hip_ab.so"))
 import torch  # noqa: E402
 from marlgrid_amd import _native as N  # noqa: E402
+N.use_library(os.path.join(ROOT, "marlgrid_amd", "csrc", os.environ.get("AB_LIB", "libmarlgrid_hip_ab.so")))   # the measurement build
 from marlgrid_amd.envs import make  # noqa: E402
 
 variants = sys.argv[1:] or ["0", "2", "3", "4", "6", "11"]      # "V" or "V:waves_per_workgroup"
 B = int(os.environ.get("B", "32768"))
 env = make(os.environ.get("WL", "MarlGrid-3AgentCluttered15x15-v0"), batch_size=B, auto_reset=True, strict=False)
 env.reset()
-if os.environ.get("MARLGRID_HIP_LIB", "").endswith("_ab.so"):      # two-kernel experiment: its view scratch
-    _vs = torch.zeros((B, env.num_agents * env.view_size ** 2), dtype=torch.int16, device=env.device)
-    env._lib.mg_ab_view_scratch.restype = None
-    env._lib.mg_ab_view_scratch(C.c_void_p(_vs.data_ptr()))
 g = torch.Generator().manual_seed(0)
 for i in range(30):
     env.step(torch.randint(0, 7, (B, env.num_agents), generator=g).cuda())

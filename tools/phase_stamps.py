@@ -6,11 +6,11 @@ import ctypes as C
 import os
 import sys
 
-os.environ["MARLGRID_HIP_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                              "marlgrid_amd", "csrc", os.environ.get("AB_LIB", "libmarlgrid_hip_ab.so"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 from marlgrid_amd import _native as N  # noqa: E402
+N.use_library(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "marlgrid_amd", "csrc",
+                           os.environ.get("AB_LIB", "libmarlgrid_hip_ab.so")))      # the measurement build
 from marlgrid_amd.envs import make  # noqa: E402
 
 B = int(os.environ.get("B", "32768"))
