@@ -55,10 +55,10 @@
 extern "C" {
 #endif
 
-#define MG_ABI_VERSION 3
+#define MG_ABI_VERSION 4
 #define MG_MAX_AGENTS 16
 #define MG_MAX_OBJ 64
-#define MG_MAX_GEN 16
+#define MG_MAX_GEN 32
 #define MG_MAX_VIEW 15
 #define MG_KEY_WORDS 2
 #define MG_MT_N 624
@@ -184,7 +184,11 @@ typedef struct MgState {
 
 /* `_gen_grid` as data: a static template (walls / put_obj results) + ordered random placements */
 typedef struct MgGenOp {
-    int32_t obj, count, max_tries;
+    int32_t obj, count, max_tries; /* max_tries >= 1: place_obj(obj, max_tries) x count (rejection sampling, below).
+                                   * max_tries == 0 (ABI 4): a STATIC edit that `_gen_grid` makes after a random placement
+                                   * (put_obj / grid.set / a wall helper, base.py:655-662, 160-176): `obj` (0 = None) is
+                                   * written into every cell of [x0,x1) x [y0,y1), replacing what is there; no RNG draw.
+                                   * Static edits BEFORE the first placement are part of template_grid. */
     int32_t x0, y0, x1, y1;       /* sampling rectangle [x0,x1) x [y0,y1): place_obj(top=, size=) clamped
                                    * to the grid (base.py:692-695); the whole grid by default */
     int32_t reject;               /* place_obj(reject_fn=) (base.py:690, 700-701): the callback tabulated once over the
@@ -194,7 +198,7 @@ typedef struct MgGenOp {
 typedef struct MgGenProgram {
     const uint8_t* template_grid; /* device, [cells_stride] */
     int32_t n_ops;
-    MgGenOp ops[MG_MAX_GEN];      /* place_obj(obj, max_tries) x count, in order */
+    MgGenOp ops[MG_MAX_GEN];      /* placements and late static edits, in `_gen_grid` order */
     const uint8_t* reject;        /* device, [n_reject][cells_stride], index x*H + y, != 0 = rejected; NULL if no op
                                    * has a reject table */
     int32_t n_reject;

@@ -7,8 +7,8 @@ this module raises.  Build it with `python -c "import __graft_entry__ as g; g.bu
 import ctypes as C
 import os
 
-MAX_AGENTS, MAX_OBJ, MAX_GEN, MAX_VIEW, KEY_WORDS, MT_N, MT_HEAD = 16, 64, 16, 15, 2, 624, 16
-ABI_VERSION = 3
+MAX_AGENTS, MAX_OBJ, MAX_GEN, MAX_VIEW, KEY_WORDS, MT_N, MT_HEAD = 16, 64, 32, 15, 2, 624, 16
+ABI_VERSION = 4
 
 OK = 0
 ERR_VALUE, ERR_RECURSION, ERR_TYPE, ERR_ASSERT, ERR_ATTRIBUTE = 1, 2, 3, 4, 5

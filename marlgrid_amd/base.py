@@ -37,7 +37,7 @@ from .objects import COLOR_TO_IDX, OBJECT_TYPES, BonusTile, Box, Door, Goal, Key
 
 TILE_PIXELS = 32
 DEFAULT_PLACE_OBS = "search"
-STATE_DICT_VERSION = 3              # = the C ABI whose MgState layout / RNG form the tensors follow
+STATE_DICT_VERSION = 3              # the C ABI version that last changed the MgState layout / RNG form the tensors follow
 
 _trace = threading.local()
 
@@ -148,34 +148,39 @@ class MultiGrid(object):
         assert j >= 0 and j < self.height
         env = self._env
         if env._tracing:
-            env._tr_static(("put", self.obj_reg.get_key(obj), int(i), int(j)))
-            self._template[i, j] = self.obj_reg.get_key(obj)
+            key = self.obj_reg.get_key(obj)
+            if env._tr_static(("put", key, int(i), int(j)), key, [(int(i), int(j), int(i) + 1, int(j) + 1)]):
+                self._template[i, j] = key
         else:
             env.put_obj(obj, i, j)
 
     def horz_wall(self, x, y, length=None, obj_type=Wall):
         if length is None:
             length = self.width - x
-        self._wall(("horz_wall", int(x), int(y), int(length)), [(x + i, y) for i in range(length)], obj_type)
+        self._wall(("horz_wall", int(x), int(y), int(length)), [(x + i, y) for i in range(length)], obj_type,
+                   [(x, y, x + length, y + 1)])
 
     def vert_wall(self, x, y, length=None, obj_type=Wall):
         if length is None:
             length = self.height - y
-        self._wall(("vert_wall", int(x), int(y), int(length)), [(x, y + j) for j in range(length)], obj_type)
+        self._wall(("vert_wall", int(x), int(y), int(length)), [(x, y + j) for j in range(length)], obj_type,
+                   [(x, y, x + 1, y + length)])
 
     def wall_rect(self, x, y, w, h, obj_type=Wall):
         cells = ([(x + i, y) for i in range(w)] + [(x + i, y + h - 1) for i in range(w)]
                  + [(x, y + j) for j in range(h)] + [(x + w - 1, y + j) for j in range(h)])
-        self._wall(("wall_rect", int(x), int(y), int(w), int(h)), cells, obj_type)
+        self._wall(("wall_rect", int(x), int(y), int(w), int(h)), cells, obj_type,
+                   [(x, y, x + w, y + 1), (x, y + h - 1, x + w, y + h), (x, y, x + 1, y + h), (x + w - 1, y, x + w, y + h)])
 
-    def _wall(self, sym, cells, obj_type):
+    def _wall(self, sym, cells, obj_type, rects):
         env = self._env
         if obj_type is Wall and env._tracing:
             key = self.obj_reg.get_key(Wall())
-            env._tr_static(sym)
             for (i, j) in cells:
                 assert 0 <= i < self.width and 0 <= j < self.height
-                self._template[i, j] = key
+            if env._tr_static(sym, key, [tuple(int(v) for v in r) for r in rects if r[2] > r[0] and r[3] > r[1]]):
+                for (i, j) in cells:
+                    self._template[i, j] = key
         else:
             for (i, j) in cells:
                 self.set(i, j, obj_type())
@@ -616,12 +621,21 @@ class MultiGridEnv(object):
         self._tr_grid = grid
         self._tr_sym = []
         self._tr_ops = []
+        self._tr_late = {}          # index into _tr_ops -> the symbolic form of a static edit recorded as op(s)
 
-    def _tr_static(self, sym):
-        if self._tr_ops:
-            raise NotImplementedError("static layout edits after a random place_obj are not supported: "
-                                      "put walls / fixed objects first")
-        self._tr_sym.append(sym)
+    def _tr_static(self, sym, key, rects):
+        """A static layout edit of `_gen_grid` (grid.set / put_obj / the wall helpers).  Before the first random
+        place_obj it goes into the template (returns True: the caller writes the template); AFTER one — upstream's
+        `_gen_grid` is free Python, envs/cluttered.py:25-36 could as well put its goal last — it is recorded in the
+        ordered program as fill ops (max_tries 0: write `key` into every cell of a rectangle, replacing what a
+        placement put there, base.py:655-662) and replayed per env between the placements (returns False)."""
+        if not self._tr_ops:
+            self._tr_sym.append(sym)
+            return True
+        self._tr_late[len(self._tr_ops)] = sym
+        for (x0, y0, x1, y1) in rects:
+            self._tr_ops.append((int(key), 1, 0, x0, y0, x1, y1, None))
+        return False
 
     def _trace_gen_grid(self):
         self._tracing = True
@@ -637,7 +651,7 @@ class MultiGridEnv(object):
             raise RuntimeError("_gen_grid must assign self.grid = MultiGrid((width, height))")
         if len(self._tr_ops) > N.MAX_GEN:
             raise NotImplementedError("more than %d placement groups in _gen_grid" % N.MAX_GEN)
-        self._spec_last = dict(sym=list(self._tr_sym), ops=list(self._tr_ops))
+        self._spec_last = dict(sym=list(self._tr_sym), ops=list(self._tr_ops), late=dict(self._tr_late))
         return g._template, list(self._tr_ops)
 
     @_on_device
@@ -725,7 +739,7 @@ class MultiGridEnv(object):
         region = self._place_region(top, size)
         rej = self._reject_table(reject_fn, region)
         op = (key, 1, max_tries) + region + (None if rej is None else rej.tobytes(),)
-        if self._tr_ops and self._tr_ops[-1][0] == key and self._tr_ops[-1][2:] == op[2:]:
+        if self._tr_ops and self._tr_ops[-1][0] == key and self._tr_ops[-1][2:] == op[2:] and self._tr_ops[-1][2] > 0:
             self._tr_ops[-1] = (key, self._tr_ops[-1][1] + 1) + op[2:]
         else:
             self._tr_ops.append(op)
@@ -1309,7 +1323,12 @@ class MultiGridEnv(object):
 
         def prog(p):
             out = list(p["sym"])
-            for (k, c, t, x0, y0, x1, y1, rej) in p["ops"]:
+            late = p.get("late", {})
+            for i, (k, c, t, x0, y0, x1, y1, rej) in enumerate(p["ops"]):
+                if t == 0:               # a static edit after a placement: its symbolic form, once
+                    if i in late:
+                        out.append(late[i])
+                    continue
                 full = (x0, y0, x1, y1) == (0, 0, self.width, self.height)
                 if rej is not None:      # reject_fn, tabulated: the rejected cells of the sampling rectangle
                     cells = np.argwhere(np.frombuffer(rej, np.uint8).reshape(self.width, self.height))

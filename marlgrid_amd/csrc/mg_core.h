@@ -355,6 +355,11 @@ MG_HD int reset_env(const MgConfig& cfg, const MgState& st, const MgGenProgram& 
     // base.py:669-679; no agent is on the fresh grid yet)
     for (int o = 0; o < prog.n_ops && !err; o++) {
         const MgGenOp op = prog.ops[o];
+        if (op.max_tries == 0) {      // a static edit after a placement (put_obj / wall helper): replaces what is there
+            for (int x = op.x0; x < op.x1; x++)
+                for (int y = op.y0; y < op.y1; y++) g[x * H + y] = (uint8_t)op.obj;
+            continue;
+        }
         for (int c = 0; c < op.count && !err; c++) {
             bool ok = false;
             for (int t = 0; t < op.max_tries; t++) {

@@ -58,6 +58,7 @@ TRAJ = {  # scenario -> (n_seeds, n_steps, n_full_obs_seeds)
     "Test-3AgentCluttered12x6-nonsquare": (6, 120, 2),
     "Test-3AgentCluttered9x9-view6": (8, 150, 2),
     "Test-2AgentEmpty8x8-view4-ts5": (6, 100, 2),
+    "Test-2AgentLateStatic10x10": (8, 120, 1),
 }
 CANON = ("base_enc", "pos", "dir", "active", "done", "carry_enc", "ordinal")
 

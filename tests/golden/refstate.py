@@ -31,6 +31,8 @@ def make_ref_env(spec, recipe, seed=1337):
         return _spawn_rect_env_class()(agents=agents, **kw)
     if cls_name == "RejectTestEnv":
         return _reject_env_class()(agents=agents, **kw)
+    if cls_name == "LateStaticTestEnv":
+        return _late_static_env_class()(agents=agents, **kw)
     return getattr(E, cls_name)(agents=agents, **kw)
 
 
@@ -75,6 +77,30 @@ def _reject_env_class():
             self.place_obj(Door(color="yellow", state=3), top=(1, 1), size=(4, 4), reject_fn=eval(scenarios.REJECT_DOOR),
                            max_tries=100)
     return RejectTestEnv
+
+
+def _late_static_env_class():
+    """A test-only scenario ON TOP OF the reference's classes whose `_gen_grid` makes static edits AFTER random
+    placements (upstream's `_gen_grid` is free Python: put_obj / wall helpers replace whatever a placement put there,
+    base.py:655-662, 160-176) — and places again after them."""
+    from marlgrid.base import MultiGridEnv, MultiGrid
+    from marlgrid.objects import Goal, Wall
+
+    class LateStaticTestEnv(MultiGridEnv):
+        mission = ""
+        metadata = {}
+
+        def _gen_grid(self, width, height):
+            self.grid = MultiGrid((width, height))
+            self.grid.wall_rect(0, 0, width, height)
+            for _ in range(6):
+                self.place_obj(Wall(), max_tries=100)                       # random clutter FIRST ...
+            self.put_obj(Goal(color="green", reward=1), width - 2, height - 2)   # ... then the fixed goal (replaces clutter there)
+            self.grid.horz_wall(2, height // 2, width - 4)                  # a wall segment over whatever was placed
+            self.put_obj(None, 3, height // 2)                              # with a gap (put None)
+            self.place_obj(Goal(color="green", reward=1), top=(1, 1), size=(3, 3), max_tries=100)   # and a placement after
+            self.grid.wall_rect(width - 4, 1, 3, 3)                         # a 3 x 3 ring in the corner, last
+    return LateStaticTestEnv
 
 
 def _region_env_class():

@@ -27,6 +27,8 @@ def build(name, **kw):
         return _spawn_rect_env_class()(agents=agents, **{**kwargs, **kw})
     if cls_name == "RejectTestEnv":
         return _reject_env_class()(agents=agents, **{**kwargs, **kw})
+    if cls_name == "LateStaticTestEnv":
+        return _late_static_env_class()(agents=agents, **{**kwargs, **kw})
     return getattr(E, cls_name)(agents=agents, **{**kwargs, **kw})
 
 
@@ -45,6 +47,25 @@ def _region_env_class():
             for _ in range(3):
                 self.place_obj(Wall(), top=(width // 2 + 1, 2), size=(width, height - 3), max_tries=50)
     return RegionTestEnv
+
+
+def _late_static_env_class():
+    """the product-side twin of tests/golden/refstate.py:_late_static_env_class (same _gen_grid text)"""
+    from marlgrid_amd.base import MultiGridEnv, MultiGrid
+    from marlgrid_amd.objects import Goal, Wall
+
+    class LateStaticTestEnv(MultiGridEnv):
+        def _gen_grid(self, width, height):
+            self.grid = MultiGrid((width, height))
+            self.grid.wall_rect(0, 0, width, height)
+            for _ in range(6):
+                self.place_obj(Wall(), max_tries=100)                       # random clutter FIRST ...
+            self.put_obj(Goal(color="green", reward=1), width - 2, height - 2)   # ... then the fixed goal (replaces clutter there)
+            self.grid.horz_wall(2, height // 2, width - 4)                  # a wall segment over whatever was placed
+            self.put_obj(None, 3, height // 2)                              # with a gap (put None)
+            self.place_obj(Goal(color="green", reward=1), top=(1, 1), size=(3, 3), max_tries=100)   # and a placement after
+            self.grid.wall_rect(width - 4, 1, 3, 3)                         # a 3 x 3 ring in the corner, last
+    return LateStaticTestEnv
 
 
 def _reject_env_class():

@@ -139,6 +139,7 @@ def ref_recipe(name):
         "Edge-3AgentCluttered15x15-default-tiles": ("ClutteredMultiGrid", dict(grid_size=15, n_clutter=10)),
         "Test-3AgentEmpty7x11-nonsquare": ("EmptyMultiGrid", dict(width=7, height=11)),
         "Test-3AgentCluttered12x6-nonsquare": ("ClutteredMultiGrid", dict(width=12, height=6, n_clutter=7)),
+        "Test-2AgentLateStatic10x10": ("LateStaticTestEnv", dict(grid_size=10, respawn=True, max_steps=50)),
         "Test-3AgentCluttered9x9-view6": ("ClutteredMultiGrid", dict(grid_size=9, n_clutter=7, max_steps=60)),
         "Test-2AgentEmpty8x8-view4-ts5": ("EmptyMultiGrid", dict(grid_size=8, max_steps=50)),
         # the reference's examples/human_player.py configuration (examples/human_player.py:35-55)
@@ -210,6 +211,19 @@ def reject_spec():
     return s
 
 
+def late_static_spec():
+    """test-only scenario whose `_gen_grid` edits the layout AFTER random placements and places again after the edits:
+    see tests/golden/refstate.py:_late_static_env_class"""
+    s = _base(2, 10, 7, respawn=True, max_steps=50)
+    W = H = 10
+    s["objects"] = [None, WALL, GOAL]
+    s["wall_obj"] = 1
+    prog = [("wall_rect", 0, 0, W, H), ("place", 1, 6, 100), ("put", 2, W - 2, H - 2), ("horz_wall", 2, H // 2, W - 4),
+            ("put", 0, 3, H // 2), ("place", 2, 1, 100, 1, 1, 4, 4), ("wall_rect", W - 4, 1, 3, 3)]
+    s["gen_ctor"], s["gen_reset"] = prog, prog
+    return s
+
+
 def _with_views(spec, views):
     """per-agent view geometry (agents.py:19-35); spec-level view_size / tile_size / ... stay the first agent's"""
     for a, v in zip(spec["agents"], views):
@@ -258,6 +272,7 @@ def registered(name):   # noqa: F811  (extends the table above with test-only sc
         "Test-2AgentRegion9x9": lambda: region_spec(),
         "Test-3AgentSpawnRect9x9": lambda: spawn_rect_spec(),
         "Test-2AgentReject9x9": lambda: reject_spec(),
+        "Test-2AgentLateStatic10x10": lambda: late_static_spec(),
         # every agent its own view (agents.py:19-35): a 5x5 view at 8 px, a 7x7 view at 5 px looking through walls,
         # a 5x5 view at 8 px again (same group as the first) with the agent one row up
         "Test-3AgentCluttered9x9-hetero-views": lambda: _with_views(
@@ -365,7 +380,7 @@ ALL_SCENARIOS = [
     "Test-3AgentCluttered9x9-prestige-mixed", "Test-4AgentEmpty5x5-ghost0", "Test-3AgentEmpty7x11-nonsquare",
     "Test-3AgentCluttered12x6-nonsquare", "Test-3AgentSpawnRect9x9", "Test-3AgentEmpty7x7-rich",
     "Test-3AgentCluttered9x9-hetero-views", "Test-2AgentReject9x9",
-    "Test-3AgentCluttered9x9-view6", "Test-2AgentEmpty8x8-view4-ts5",
+    "Test-3AgentCluttered9x9-view6", "Test-2AgentEmpty8x8-view4-ts5", "Test-2AgentLateStatic10x10",
 ]
 
 

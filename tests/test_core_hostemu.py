@@ -66,6 +66,9 @@ def test_numpy_form_round_trip():
     ("Test-3AgentSpawnRect9x9", 48, 200, True),      # agent_spawn_kwargs: reset, late spawn and respawn
     ("Test-2AgentReject9x9", 48, 200, True),         # place_obj(reject_fn=) tables in _gen_grid and agent_spawn_kwargs
     ("Test-3AgentSpawnRect9x9", 16, 130, False),
+    ("Test-2AgentLateStatic10x10", 48, 160, True),   # static edits after random placements (fill ops in the reset program)
+    ("Test-2AgentLateStatic10x10", 16, 110, False),
+    ("Test-3AgentCluttered9x9-view6", 16, 70, True),
 ])
 def test_core_bodies_vs_oracle(name, B, T, auto):
     import hostemu

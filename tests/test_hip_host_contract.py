@@ -1,4 +1,4 @@
-"""GPU tests of the host contract around the kernels (C ABI version 3): how per-env errors reach the caller
+"""GPU tests of the host contract around the kernels (C ABI version 4): how per-env errors reach the caller
 without a host sync per step, where the observation buffers come from, checkpoints."""
 import ctypes as C
 

@@ -76,7 +76,7 @@ def test_production_library_has_no_measurement_switches():
     L = ctypes.CDLL(so)
     L.mg_build_info.restype = ctypes.c_char_p
     info = L.mg_build_info().decode()
-    assert info.startswith("libmarlgrid_hip gfx950 abi3 src-") and "variants" not in info
+    assert info.startswith("libmarlgrid_hip gfx950 abi4 src-") and "variants" not in info
 
 
 def test_product_never_imports_the_oracle():
@@ -139,6 +139,29 @@ def test_fuzz_specs_product_equals_restatement():
         a, b = env.scenario_spec(), scenarios.registered(name)
         for k in b:
             assert a[k] == b[k], (name, k, a[k], b[k])
+
+
+def test_static_edits_after_placements_are_recorded_in_order():
+    """`_gen_grid` may edit the layout after a random place_obj (upstream's is free Python): the recorder keeps the
+    template for what comes before the first placement and turns every later put_obj / wall helper into fill ops
+    (max_tries 0) between the placements; the plain-data spec lists everything in `_gen_grid` order."""
+    import product_envs
+    name = "Test-2AgentLateStatic10x10"
+    env = product_envs.build(name, _dry=True)
+    env.reset()
+    a, b = env.scenario_spec(), scenarios.registered(name)
+    for k in b:
+        assert a[k] == b[k], (k, a[k], b[k])
+    template, ops = env._dry_trace
+    assert template[0].all() and template[:, 0].all() and template[8, 8] == 0       # outer walls only: the goal comes later
+    kinds = [(op[0], op[1], op[2]) + tuple(op[3:7]) for op in ops]
+    wall, goal = env.obj_reg.find(__import__("marlgrid_amd").objects.Wall()), 2
+    assert kinds[0] == (wall, 6, 100, 0, 0, 10, 10)                                 # six random walls first
+    assert kinds[1] == (goal, 1, 0, 8, 8, 9, 9)                                     # put_obj(Goal) as a 1 x 1 fill
+    assert kinds[2] == (wall, 1, 0, 2, 5, 8, 6)                                     # horz_wall(2, 5, 6)
+    assert kinds[3] == (0, 1, 0, 3, 5, 4, 6)                                        # put_obj(None): a gap
+    assert kinds[4] == (goal, 1, 100, 1, 1, 4, 4)                                   # a placement after the edits
+    assert [k[2] for k in kinds[5:]] == [0, 0, 0, 0] and len(ops) == 9              # wall_rect: four fills
 
 
 @pytest.mark.parametrize("ts", [5, 8, 11, 32])
