@@ -425,22 +425,26 @@ def measure_pipeline(wl, B, parts, dev, ctl, K, Wm, min_seconds, max_blocks, act
     """The same batch as `parts` envs on as many streams (marlgrid_amd.sharding.ShardPipeline: overlapping launches
     of independent shards), timed like the contract line: K-step blocks, barrier + synchronize on both sides."""
     import torch
-    from marlgrid_amd.sharding import ShardPipeline
+    from marlgrid_amd.envs import make
     if parts not in _PIPE_STREAMS:      # the same streams for every pipeline of this process (hardware queues are few)
         _PIPE_STREAMS[parts] = [torch.cuda.Stream(device=dev) for _ in range(parts)]
-    pipe = ShardPipeline(lambda batch_size, seeds, device: build_env(wl, batch_size, device, seeds, fused), B, parts=parts,
-                         seed=1337, device=dev, streams=_PIPE_STREAMS[parts])
+    # the public path: make(id, pipeline=P) and the sampler's own call, step_part(k, actions), part after part
+    pipe = make(wl, pipeline=parts, batch_size=B, device=dev, seed=1337, auto_reset=True, fused_step=fused,
+                streams=_PIPE_STREAMS[parts])
     pipe.reset()
     n = pipe.envs[0].num_agents
     g = torch.Generator(device="cpu").manual_seed(action_seed)
     pool = [torch.randint(0, 7, (B, n), generator=g).to(dev) for _ in range(64)]
     pool = [[pipe.part(k, a).contiguous() for k in range(parts)] for a in pool]
     torch.cuda.synchronize(dev)
+    def step(i):
+        acts = pool[i % 64]
+        for k in range(parts):
+            pipe.step_part(k, acts[k])
     for i in range(Wm):
-        pipe.step(pool[i % 64])
+        step(i)
     settle_interpreter()
-    blocks = timed_blocks(lambda i: pipe.step(pool[(Wm + i) % 64]), lambda: torch.cuda.synchronize(dev), ctl, K,
-                          min_seconds, max_blocks, None)
+    blocks = timed_blocks(lambda i: step(Wm + i), lambda: torch.cuda.synchronize(dev), ctl, K, min_seconds, max_blocks, None)
     pipe.check_errors()
     placement = [{k: v for k, v in (getattr(e._groups[0], "placement_ms", None) or {}).items() if k != "all"} for e in pipe.envs]
     return n, summarise(blocks, K), placement
@@ -704,8 +708,8 @@ def main():
     pts = leg("pipelined_shards", _pipeline) if (n_gpus == 1 and not args.no_pipeline and wl == WORKLOAD) else None
     if pts:
         out.setdefault("extra", {})["pipelined_shards"] = {
-            "what": "the per-GPU batch as TWO envs on two streams (marlgrid_amd.sharding.ShardPipeline), stepped without "
-                    "a join in between: launches of independent shards overlap (the store-free head of one under the "
+            "what": "the per-GPU batch as TWO envs on two streams — make(id, pipeline=2), stepped part after part with "
+                    "step_part(k, actions) as a double-buffered sampler does, no join in between: launches of independent shards overlap (the store-free head of one under the "
                     "stores of the other); same trajectories env by env; the contract line above is ONE env, one stream",
             "points": pts}
         out["value_pipelined_shards"] = pts[0]["value"]       # the same batch as two envs on two streams (extra.pipelined_shards)

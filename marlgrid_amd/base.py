@@ -384,6 +384,23 @@ class MultiGridEnv(object):
         self._spec_ctor = self._spec_last     # the constructor-time `_gen_grid` (base.py:369)
         self._retrace = True
 
+    @classmethod
+    def pipelined(cls, agents, parts=2, batch_size=1, seed=1337, device=None, streams=None, **kwargs):
+        """The batch as `parts` envs of this class on `parts` streams (marlgrid_amd.sharding.ShardPipeline): what a
+        double-buffered sampler steps in turn so that the launches of independent shards overlap.  Part 0 is built
+        with `agents` themselves, the other parts with shallow copies (a learner's networks and buffers are shared,
+        the binding to an env — agent.pos, .dir, ... — is per part)."""
+        import copy
+        from .sharding import ShardPipeline
+        agents = list(agents)
+        made = []
+
+        def make_part(batch_size, seeds, device):
+            team = agents if not made else [copy.copy(a) for a in agents]
+            made.append(True)
+            return cls(agents=team, batch_size=batch_size, seeds=seeds, device=device, **kwargs)
+        return ShardPipeline(make_part, batch_size, parts=parts, seed=seed, device=device, streams=streams)
+
     # ---- configuration ----------------------------------------------------------------------------
     def add_agent(self, agent_interface):
         if isinstance(agent_interface, dict):

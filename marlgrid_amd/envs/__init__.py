@@ -34,13 +34,26 @@ def register_marl_env(env_name, env_class, n_agents, grid_size, view_size, view_
     registered_envs.append(env_name)
 
 
-def make(env_name, **kwargs):
-    """`gym.make` stand-in; kwargs (batch_size, device, seed, seeds, auto_reset, strict, ...) reach the env."""
+def make(env_name, pipeline=None, **kwargs):
+    """`gym.make` stand-in; kwargs (batch_size, device, seed, seeds, auto_reset, strict, ...) reach the env.
+
+    pipeline=P (P >= 2): the batch as P independent envs of batch_size / P on P streams — a
+    `marlgrid_amd.sharding.ShardPipeline` whose parts a sampler steps in turn (`pipe.step_part(k, actions)` under
+    `pipe.on(k)`): the launches of independent shards overlap (+10 % at 32 768 envs, +17 % at 65 536 on one
+    MI355X), and env g of the batch keeps its seed `seed + g`, so trajectories are those of the one big env."""
     try:
         factory = _registry[env_name]
     except KeyError:
         raise KeyError("unknown env id %r; registered: %s" % (env_name, ", ".join(registered_envs))) from None
-    return factory(**kwargs)
+    if pipeline is None or int(pipeline) <= 1:
+        return factory(**kwargs)
+    from ..sharding import ShardPipeline
+    if "seeds" in kwargs:
+        raise ValueError("make(pipeline=): per-env seeds come from `seed` + the env's index in the whole batch")
+    batch_size, seed, device = kwargs.pop("batch_size"), kwargs.pop("seed", 1337), kwargs.pop("device", None)
+    streams = kwargs.pop("streams", None)
+    return ShardPipeline(lambda batch_size, seeds, device: factory(batch_size=batch_size, seeds=seeds, device=device, **kwargs),
+                         batch_size, parts=int(pipeline), seed=seed, device=device, streams=streams)
 
 
 def _scenario_classes():

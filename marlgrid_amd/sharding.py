@@ -79,6 +79,45 @@ class ShardPipeline(object):
         if len(self.streams) != self.parts:
             raise ValueError("one stream per part")
 
+    # what a training loop asks an env for
+    @property
+    def num_agents(self):
+        return self.envs[0].num_agents
+
+    @property
+    def agents(self):
+        """part 0's agent interfaces (every part has its own, bound to its own env: agent.pos etc. are per part)"""
+        return self.envs[0].agents
+
+    @property
+    def action_space(self):
+        return self.envs[0].action_space
+
+    @property
+    def observation_space(self):
+        return self.envs[0].observation_space
+
+    def on(self, k):
+        """`with pipe.on(k): ...` — part k's stream as torch's current stream: the policy's kernels for part k and
+        everything else that consumes its observations belong here, so that they queue behind part k's step and
+        overlap the OTHER part's (the double-buffered sampler:
+
+            obs = pipe.reset()
+            while ...:
+                for k in range(pipe.parts):
+                    with pipe.on(k):
+                        act = agents.action_step(obs[k])
+                        nxt, rew, done, _ = pipe.step_part(k, act)
+                        agents.save_step(obs[k], act, nxt, rew, done)
+                        obs[k] = nxt
+        )"""
+        import torch
+        return torch.cuda.stream(self.streams[k])
+
+    def reset_part(self, k, **kw):
+        with self.on(k):
+            return self.envs[k].reset(**kw)
+
     def _each(self, fn):
         import torch
         out = []
@@ -107,6 +146,10 @@ class ShardPipeline(object):
         import torch
         with torch.cuda.stream(self.streams[k]):
             return self.envs[k].step(actions)
+
+    def close(self):
+        self.synchronize()
+        self.envs = []
 
     def synchronize(self):
         for s in self.streams:

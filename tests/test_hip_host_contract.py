@@ -189,3 +189,63 @@ def test_shard_pipeline_equals_one_env():
     pipe.check_errors()
     with pytest.raises(ValueError):
         ShardPipeline(lambda **kw: None, 7, parts=2)
+
+
+@pytest.mark.gpu
+def test_pipeline_public_path_alternating_loop_equals_one_env():
+    """make(id, pipeline=2) and MultiGridEnv.pipelined(learners, parts=2): the double-buffered loop — part after part,
+    each under its own stream, policy included — yields, env by env, the trajectories of ONE env of the whole batch;
+    an error recorded by a part surfaces through pipe.check_errors() from any stream."""
+    import torch
+    from marlgrid_amd.agents import IndependentLearners, LearningAgent
+    from marlgrid_amd.envs import ClutteredMultiGrid, make
+    name, B = "MarlGrid-3AgentCluttered11x11-v0", 512
+    one = make(name, batch_size=B, seeds=[1337 + g for g in range(B)], auto_reset=True)
+    pipe = make(name, pipeline=2, batch_size=B, seed=1337, auto_reset=True)
+    assert pipe.parts == 2 and pipe.num_agents == 3 and len(pipe.agents) == 3
+    o = one.reset()
+    obs = pipe.reset()
+    rng = np.random.RandomState(9)
+    for t in range(110):
+        a = torch.from_numpy(rng.randint(0, 7, size=(B, 3))).cuda()
+        o, r, d, _ = one.step(a)
+        for k in range(2):
+            with pipe.on(k):
+                assert torch.cuda.current_stream().cuda_stream == pipe.streams[k].cuda_stream
+                o2, r2, d2, _ = pipe.step_part(k, pipe.part(k, a).contiguous())
+        pipe.synchronize()
+        for k in range(2):
+            env = pipe.envs[k]
+            assert torch.equal(pipe.part(k, o), env.obs) and torch.equal(pipe.part(k, r), env.rewards) \
+                and torch.equal(pipe.part(k, d), env.done_b), (t, k)
+    # an invalid action in part 1, stepped under its own stream; checked from the default stream
+    bad = torch.full((B // 2, 3), 9, dtype=torch.int64, device="cuda")
+    with pipe.on(1):
+        pipe.envs[1].strict = False
+        pipe.step_part(1, bad)
+    with pytest.raises(ValueError):
+        pipe.check_errors()
+
+    class Rand(LearningAgent):
+        seen = 0
+
+        def action_step(self, obs):
+            return torch.randint(0, 3, (obs.shape[0],), device=obs.device)
+
+        def save_step(self, obs, act, nxt, rew, done):
+            Rand.seen += obs.shape[0]
+
+    learners = IndependentLearners(Rand(color="red", view_tile_size=8), Rand(color="blue", view_tile_size=8))
+    pipe2 = ClutteredMultiGrid.pipelined(learners, parts=2, grid_size=9, n_clutter=4, batch_size=64, auto_reset=True)
+    assert pipe2.envs[0].agents[0] is learners[0] and pipe2.envs[1].agents[0] is not learners[0]
+    obs = pipe2.reset()
+    with learners.episode():
+        for t in range(12):
+            for k in range(2):
+                with pipe2.on(k):
+                    act = learners.action_step(obs[k])
+                    nxt, rew, done, _ = pipe2.step_part(k, act)
+                    learners.save_step(obs[k], act, nxt, rew, done)
+                    obs[k] = nxt
+    pipe2.check_errors()
+    assert Rand.seen == 12 * 2 * 32 * 2

@@ -87,6 +87,36 @@ int main(int argc, char** argv) {
     uint8_t* A = arena + 1 * GiB;                  // physically contiguous from here on (inside the first 32 GiB block)
     char name[256];
 
+    if (argc > 2 && !strcmp(argv[2], "scan")) {
+        // `stream_conflicts <GiB> scan [step MiB]`: the raster's stream set at every step of a big arena — where are the
+        // valleys (visit 3: one at the 32 GiB | 8 GiB block boundary of a 40 GiB arena, at fill speed), how far apart, and
+        // does a GAP of 16 / 32 / 64 GiB between the two halves of the set — inside ONE physical block — do what the
+        // block boundary does?
+        const size_t step = (argc > 3 ? atoi(argv[3]) : 512) * MiB;
+        const size_t span = (size_t)total + MiB;
+        printf("--- scan: baseline pattern every %zu MiB (offset_GiB:GB/s; < 6000 GB/s printed only every 4th)\n", step / MiB);
+        int i = 0;
+        for (size_t off = 0; off + span < arena_bytes; off += step, i++) {
+            Pattern p = linear(S);
+            const int nw = (int)p.start.size();
+            CK(hipMemcpy(d_start, p.start.data(), nw * 8, hipMemcpyHostToDevice));
+            CK(hipMemcpy(d_rot, p.rot.data(), nw * 4, hipMemcpyHostToDevice));
+            uint8_t* base = arena + off;
+            const float ms = timeit([&] { hipLaunchKernelGGL(k_streams, dim3(256), dim3(1024), 0, 0, base, d_start, d_rot, p.run, nw, 16); }, 4);
+            const double gbs = total / ms / 1e6;
+            if (gbs >= 5700 || i % 4 == 0) printf("%.2f:%.0f%s ", off / (double)GiB, gbs, gbs >= 5700 ? "*" : "");
+        }
+        printf("\n--- gaps between the two halves of the set (streams w >= 2048 moved up by D), base at +1 GiB and at +33 GiB\n");
+        for (size_t b0 : {1 * GiB, 33 * GiB}) for (double dg : {0.0, 4.0, 8.0, 12.0, 16.0, 24.0, 31.0, 32.0, 33.0, 48.0, 64.0}) {
+            if (b0 + (size_t)(dg * GiB) + span >= arena_bytes) continue;
+            Pattern p = linear(S);
+            for (uint32_t w = 2048; w < W; w++) p.start[w] += (uint64_t)(dg * GiB);
+            snprintf(name, sizeof name, "base +%zu GiB, upper half + %.0f GiB", b0 / GiB, dg);
+            run(name, arena + b0, p);
+        }
+        return 0;
+    }
+
     {   // for scale
         const size_t nch = (size_t)total / 16;
         const float f = timeit([&] { hipLaunchKernelGGL(k_fill, dim3((nch + 255) / 256), dim3(256), 0, 0, (uint4*)A, nch); });

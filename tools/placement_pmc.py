@@ -176,6 +176,65 @@ def scan():
     print("%.4f ms per fill" % (e0.elapsed_time(e1) / 5))
 
 
+def walk():
+    """Does a sequence of buffer-sized hipMallocs that are all KEPT walk the physical memory in order — so that the
+    one that straddles a 32 GiB physical boundary (the fast spot of the arena scan) comes up within ~36 draws?  And can
+    the straddle then be CENTRED: the straddler and its predecessor freed, one allocation of 4 buffer sizes made in
+    their place, and the raster timed into a window sliding over it?"""
+    import ctypes as C
+    import time
+    import torch
+    from marlgrid_amd import _native as N
+    from marlgrid_amd.base import _LibBuffer
+    from marlgrid_amd.envs import make
+    env = make("MarlGrid-3AgentCluttered15x15-v0", batch_size=32768, auto_reset=True, strict=False, place_obs=False)
+    env.reset()
+    L, ms, nbytes, dev = N.lib(), C.c_float(0), env.obs.numel(), env.device
+    MiB = 1 << 20
+
+    def raster(ptr, iters=3):
+        N.check(L.mg_time_render_obs(C.byref(env._cfg), C.byref(env._state), C.c_void_p(ptr), iters, C.byref(ms), env._stream()))
+        return ms.value
+
+    t0 = time.perf_counter()
+    keep, times = [], []
+    found = []
+    for i in range(int(os.environ.get("WALK", "90"))):
+        m = _LibBuffer(L, nbytes, dev)
+        if not m.ok:
+            print("allocation %d failed" % i)
+            break
+        keep.append(m)
+        times.append(raster(m.ptr))
+    print("walk: %d candidates kept alive, %.2f s; index:ms (ptr delta to the previous in MiB)" % (len(keep), time.perf_counter() - t0))
+    print("  " + " ".join("%d:%.3f(%+d)" % (i, t, 0 if i == 0 else (keep[i].ptr - keep[i - 1].ptr) // MiB) for i, t in enumerate(times)))
+    med = sorted(times)[len(times) // 2]
+    dips = [i for i, t in enumerate(times) if t < 0.97 * med]
+    print("median %.4f; dips (< 0.97 x median): %s" % (med, ["%d:%.4f" % (i, times[i]) for i in dips]))
+    # centre the first dip that has a predecessor
+    for c in dips:
+        if c == 0:
+            continue
+        t0 = time.perf_counter()
+        a, b = keep[c - 1], keep[c]
+        lo_ptr = min(a.ptr, b.ptr)
+        keep[c - 1] = keep[c] = None
+        del a, b
+        torch.cuda.synchronize()
+        D = _LibBuffer(L, 4 * nbytes, dev)
+        print("dip at %d: freed %d and %d, allocated 4 x buffer at %#x (the pair was at %#x): %s" % (
+            c, c - 1, c, D.ptr if D.ok else 0, lo_ptr, "same start" if D.ok and D.ptr == lo_ptr else "elsewhere"))
+        if not D.ok:
+            break
+        step = 32 * MiB
+        sc = [(off, raster(D.ptr + off, 2)) for off in range(0, 3 * nbytes, step)]
+        print("  window every 32 MiB: " + " ".join("%d:%.3f" % (o // MiB, t) for o, t in sc))
+        best = min(sc, key=lambda ot: ot[1])
+        print("  best window at +%d MiB: %.4f ms (%.2f s for the centring)" % (best[0] // MiB, best[1], time.perf_counter() - t0))
+        keep.append(D)
+        break
+
+
 def pearson(xs, ys):
     n = len(xs)
     if n < 3:
@@ -275,6 +334,8 @@ if __name__ == "__main__":
         subranges()
     elif "--scan" in sys.argv:
         scan()
+    elif "--walk" in sys.argv:
+        walk()
     else:
         args = [a for a in sys.argv[1:] if not a.startswith("--")]
         driver(args[0] if args else os.path.join(ROOT, "gpurun_out", "placement_pmc"), int(os.environ.get("N", "20")))
