@@ -499,25 +499,30 @@ class MultiGridEnv(object):
                               self.mt_head.data_ptr(), self._flag.dev)
 
     @_on_device
-    def _place_obs_buffers(self, batch=8, max_candidates=256, min_bytes=256 << 20, iters=3, budget=32 << 30, gain=0.12,
-                           seconds=1.5, flat_after=128):
-        """place_obs="search" (default): choose WHERE in HBM the observation buffers live.  Measured on MI355X
-        (profiles/r02/README.md section 3, profiles/r03/README.md section 2): the rate at which the raster's
-        write pattern — thousands of waves, each streaming its own env — is absorbed depends on the ALLOCATION
-        it writes into, reproducibly per buffer and by up to 25 % (0.160 vs 0.205 ms for the bench workload's
-        925 MB), while a dense fill of the same buffers is flat; on one box 4 in 24 fresh allocations are in the
-        fast class, on another most are.  Round 3 took such buffers apart with the virtual-memory API — the class
-        does not travel with the physical pages, remapping the same memory never draws a fast one, and freed
-        virtual ranges come back with stale translations on ROCm 7.2 — so what remains is drawing new allocations
-        and measuring: candidates are raw hipMalloc allocations made and freed through the library (never torch's
-        caching allocator: nothing is cached, nothing else is flushed), the raster itself is timed into each (HIP
-        events, `iters` launches; about a millisecond per candidate), at most `batch` of them alive at a time
-        next to the best `keep` so far; the search stops when the buffers it would keep are `gain` faster than
-        the median candidate (they are in the fast class), when `flat_after` candidates show no spread (only then:
-        on a box where one allocation in thirty is fast the first eighteen all came out slow, within 5 % of each
-        other — profiles/r03: 469 M instead of 576 M agent-steps/s), or at `max_candidates` / `budget` bytes alive
-        / a quarter of the memory that is free when a batch starts / `seconds`.  Running out of memory ends the search with what it has.  Buffers under `min_bytes` (where no
-        classes are seen) are left alone."""
+    def _place_obs_buffers(self, max_candidates=64, min_bytes=256 << 20, iters=3, budget=64 << 30, gain=0.12, seconds=2.5):
+        """place_obs="search" (default): choose WHERE in HBM the observation buffers live.
+
+        What is known (MI355X, profiles/r04/README.md section 1): the HBM of the chip is two REGIONS, and each takes
+        the raster's write pattern — 4 096 concurrent sequential streams — at 5.3 TB/s at most, while a dense fill of
+        the same bytes runs at 6.9 TB/s anywhere.  A buffer whose streams are split between the two regions runs at
+        fill speed (0.153 instead of 0.193 ms for the bench workload's 925 MB), in proportion to the smaller share.
+        Nothing else matters: not the distance between the halves inside one region (0.25 MiB .. 48 GiB), not the
+        stride or the phase of the streams, not their number, not which wave writes which.  The driver builds an
+        allocation from power-of-two blocks, largest first (884 MiB = 512 + 256 + 64 + 32 + 16 + 4), each from the free
+        list of its order, wherever that happens to be: a plain allocation is in the fast class when its 512 MiB block
+        and the rest come from different regions (58 : 42), in a middle class when the split is at 256 MiB (0.176 ms)
+        or at 116 MiB (0.182) — the "allocation lottery" of rounds 2 and 3, 1 draw in 6 .. 30.
+
+        So the buffer is CONSTRUCTED on a block boundary: a candidate is one allocation of 3 P bytes (P = the power of
+        two >= half the buffer) — a 2 P block followed by a P block — and the buffer is the window centred on the
+        boundary between the two, [2 P - n / 2, 2 P + n / 2).  Whether the two blocks lie in different regions is the
+        one thing that is still measured (the raster itself, `iters` launches, HIP events): candidates are drawn — and
+        kept, so that the allocator moves on through its free lists — until `keep` of them run `gain` under the median
+        candidate, or `max_candidates` / `budget` bytes / a quarter of the free memory / `seconds` are spent; then every
+        other candidate goes back to the driver.  Raw hipMalloc through the library (mg_obs_alloc: never torch's
+        caching allocator); a kept buffer holds 3 P bytes for its n (1.5 .. 3 x).  Without a candidate in the fast
+        class the best seen is kept (the plain torch allocations included).  Buffers under `min_bytes` are left alone
+        (the effect needs thousands of concurrent streams)."""
         import time
         import torch
         t_begin = time.perf_counter()
@@ -534,55 +539,53 @@ class MultiGridEnv(object):
                                                      C.byref(ms), self._stream()))
                 return ms.value
 
+            half = (nbytes + 1) // 2
+            P0 = 1 << max(21, (half - 1).bit_length())         # power of two >= half the buffer (>= 2 MiB)
             keep = len(g.ring)
-            best = [(cost_of(t), t) for t in g.ring]          # (ms, tensor), the `keep` fastest so far
-            seen = [c for c, _ in best]
+            cands = [(cost_of(t), t) for t in g.ring]           # (ms, tensor): the plain torch allocations first
             why = "cap"
-            polish = 0
-            while len(seen) < keep + max_candidates:
+            alive = misses = level = 0
+            while len(cands) < keep + max_candidates:
                 if time.perf_counter() > t_end:
                     why = "time"
                     break
+                # a run of candidates that all miss: the free lists these two block sizes come from are in ONE region
+                # for now (profiles/r04: 46 plain allocations in a row) — take the next larger pair of blocks
+                if misses >= 12 and level < 2:
+                    level, misses = level + 1, 0
+                P = P0 << level
+                arena = 3 * P
+                offset = (2 * P - nbytes // 2) & ~4095          # the window centred on the 2 P | P block boundary
                 free, _total = torch.cuda.mem_get_info(self.device)
-                room = int(min(free // 4, budget) // nbytes)
-                nb = min(batch, room, keep + max_candidates - len(seen))
-                if nb < 1:
+                if alive + arena > min((free + alive) // 4, budget):
                     why = "memory"
                     break
-                cands = []
-                for _ in range(nb):
-                    mem = _LibBuffer(self._lib, nbytes, self.device)
-                    if not mem.ok:
-                        why = "out of memory"
-                        break
-                    cands.append(mem.tensor(g.shape))
-                for t in cands:
-                    c = cost_of(t)
-                    seen.append(c)
-                    best.append((c, t))
-                best.sort(key=lambda ct: ct[0])
-                del best[keep:], cands                  # the rejected ones go back to the driver here
-                if why == "out of memory":
+                mem = _LibBuffer(self._lib, arena, self.device)
+                if not mem.ok:
+                    why = "out of memory"
                     break
-                ranked = sorted(seen)
-                median = ranked[len(ranked) // 2]
-                if len(seen) >= keep + 2 * batch and best[keep - 1][0] <= (1.0 - gain) * median:
-                    # in the fast class; a few more batches while the kept buffers are not equally good (the fast
-                    # class has a spread of its own: 0.153 .. 0.160 ms for the bench workload's 925 MB)
-                    polish += 1
-                    if best[keep - 1][0] <= 1.02 * best[0][0] or polish > 6:
-                        why = "kept set %d%% under the median candidate" % round(100 * (1 - best[keep - 1][0] / median))
-                        break
-                if len(seen) >= keep + flat_after and ranked[-1] <= 1.05 * ranked[0]:
-                    why = "no spread among %d candidates" % len(seen)
+                alive += arena                                  # (what the candidates drawn so far hold)
+                t = mem.tensor((arena,))[offset:offset + nbytes].view(g.shape)
+                del mem                                         # (the tensor keeps the allocation alive)
+                cands.append((cost_of(t), t))
+                costs = sorted(c for c, _ in cands)
+                median = costs[len(costs) // 2]
+                misses = 0 if cands[-1][0] <= (1.0 - gain) * median else misses + 1
+                if len(cands) >= keep + 4 and costs[keep - 1] <= (1.0 - gain) * median:
+                    why = "kept set %d%% under the median candidate" % round(100 * (1 - costs[keep - 1] / median))
                     break
+            seen = [c for c, _ in cands]
+            best = sorted(cands, key=lambda ct: ct[0])[:keep]
             replaced = any(all(t is not kept for _, kept in best) for t in g.ring)
+            del cands                                           # the rejected candidates go back to the driver here
             g.ring = [t for _, t in best]
             for t in g.ring:
                 t.zero_()
             g.obs = g.ring[self._ring_i]
             g.placement_ms = {"kept": [c for c, _ in best], "candidates": len(seen), "stopped": why,
-                              "seconds": time.perf_counter() - t_begin, "all": seen}
+                              "seconds": time.perf_counter() - t_begin, "all": seen,
+                              "candidate_bytes": 3 * P0, "window_offset": (2 * P0 - nbytes // 2) & ~4095,
+                              "buffer_bytes": nbytes, "block_pair_level": level}
             any_replaced = any_replaced or replaced
         for i, r in enumerate(self._ring):
             r["obs"] = self._groups[0].ring[i]

@@ -97,6 +97,11 @@ def test_obs_buffer_placement_search():
             pm = env._groups[0].placement_ms
             assert 2 <= pm["candidates"] <= 258 and pm["seconds"] < 4.0 and len(pm["kept"]) == 2
             assert sorted(pm["all"])[:2] == sorted(pm["kept"])          # the fastest two were kept
+            # a candidate is a 2 P block followed by a P block, the buffer the window centred on their boundary
+            P = pm["candidate_bytes"] // 3
+            assert pm["candidate_bytes"] == 3 * P and P & (P - 1) == 0 and P >= pm["buffer_bytes"] / 2
+            assert abs(pm["window_offset"] + pm["buffer_bytes"] / 2 - 2 * P) <= 4096
+            assert env.obs.data_ptr() % 4096 == 0
             assert torch.cuda.mem_get_info()[0] > free0 - (4 << 30)     # the rejected candidates are back
         outs.setdefault(mode, []).append((o.cpu(), r.cpu(), d.cpu()))
         del env, o, r, d
