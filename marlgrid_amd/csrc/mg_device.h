@@ -129,6 +129,9 @@ struct RenderLaunch {
     uint32_t m_n, m_nv, m_nvVV, m_VV, m_VS;     // Div20 multipliers of n, nv, nv * VS^2, VS^2, VS
     int depth_mode;                             // measurement builds: look-ahead depth forced for all waves (0: by wave)
     int atlas_lds;                              // bytes the atlas takes in LDS (render_atlas_lds_bytes; 0: read in place)
+#if defined(MG_AB_VARIANTS)
+    unsigned long long* stamps;                 // measurement build: phase stamps of every wave (tools/phase_stamps.py), or null
+#endif
 };
 // n: the env's agents (records, who stands where); nv: the viewers this launch renders (view-sized arrays)
 __host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride, int n, int nv, int vs, int stage_envs = 1,
