@@ -545,21 +545,41 @@ class MultiGridEnv(object):
             cands = [(cost_of(t), t) for t in g.ring]           # (ms, tensor): the plain torch allocations first
             why = "cap"
             alive = misses = level = 0
+            plain = False                                       # last stage: plain buffer-sized allocations (below)
+            found = False
+
+            def drop_losers():
+                """the candidates that are not among the best `keep` go back to the driver (their ms stays on record)"""
+                ranked = sorted((ct for ct in cands if ct[1] is not None), key=lambda ct: ct[0])
+                keepers = set(id(t) for _, t in ranked[:keep])
+                cands[:] = [(c, t if (t is not None and id(t) in keepers) else None) for c, t in cands]
+                return sum(t._base.numel() for _, t in ranked[:keep] if t._base is not None)    # (what the kept library buffers hold)
+
             while len(cands) < keep + max_candidates:
                 if time.perf_counter() > t_end:
                     why = "time"
                     break
-                # a run of candidates that all miss: the free lists these two block sizes come from are in ONE region
-                # for now (profiles/r04: 46 plain allocations in a row) — take the next larger pair of blocks
-                if misses >= 12 and level < 2:
-                    level, misses = level + 1, 0
+                # A run of candidates that all miss: the free lists these two block sizes come from are in ONE region
+                # for now (profiles/r04: 46 plain allocations in a row) — take the next larger pair of blocks, and after
+                # those plain allocations of the buffer's own size (512 + 256 + ... MiB blocks: another set of free lists;
+                # in the fast class when the largest block and the rest come from different regions, 58 : 42).  Every
+                # stage starts with the losers of the stage before handed back.
                 P = P0 << level
-                arena = 3 * P
-                offset = (2 * P - nbytes // 2) & ~4095          # the window centred on the 2 P | P block boundary
+                arena = nbytes if plain else 3 * P
                 free, _total = torch.cuda.mem_get_info(self.device)
-                if alive + arena > min((free + alive) // 4, budget):
+                short = alive + arena > min((free + alive) // 4, budget)
+                if (misses >= 12 or short) and not plain:
+                    misses = 0
+                    if level < 2 and not short:
+                        level += 1
+                    else:
+                        plain = True
+                    alive = drop_losers()
+                    continue
+                if short:
                     why = "memory"
                     break
+                offset = 0 if plain else (2 * P - nbytes // 2) & ~4095      # the window centred on the 2 P | P block boundary
                 mem = _LibBuffer(self._lib, arena, self.device)
                 if not mem.ok:
                     why = "out of memory"
@@ -573,9 +593,10 @@ class MultiGridEnv(object):
                 misses = 0 if cands[-1][0] <= (1.0 - gain) * median else misses + 1
                 if len(cands) >= keep + 4 and costs[keep - 1] <= (1.0 - gain) * median:
                     why = "kept set %d%% under the median candidate" % round(100 * (1 - costs[keep - 1] / median))
+                    found = True
                     break
             seen = [c for c, _ in cands]
-            best = sorted(cands, key=lambda ct: ct[0])[:keep]
+            best = sorted((ct for ct in cands if ct[1] is not None), key=lambda ct: ct[0])[:keep]
             replaced = any(all(t is not kept for _, kept in best) for t in g.ring)
             del cands                                           # the rejected candidates go back to the driver here
             g.ring = [t for _, t in best]
@@ -585,7 +606,7 @@ class MultiGridEnv(object):
             g.placement_ms = {"kept": [c for c, _ in best], "candidates": len(seen), "stopped": why,
                               "seconds": time.perf_counter() - t_begin, "all": seen,
                               "candidate_bytes": 3 * P0, "window_offset": (2 * P0 - nbytes // 2) & ~4095,
-                              "buffer_bytes": nbytes, "block_pair_level": level}
+                              "buffer_bytes": nbytes, "block_pair_level": level, "plain_stage": plain, "found": found}
             any_replaced = any_replaced or replaced
         for i, r in enumerate(self._ring):
             r["obs"] = self._groups[0].ring[i]

@@ -33,6 +33,9 @@ def build():
 
 env = build()
 n = env.num_agents
+_pm = getattr(env._groups[0], "placement_ms", None)
+if _pm:
+    print("obs buffers: kept %s of %d candidates (%s)" % (["%.4f" % c for c in _pm["kept"]], _pm["candidates"], _pm["stopped"]))
 acts = [torch.randint(0, 7, (B, n), generator=g).cuda() for _ in range(16)]
 vp, i32 = C.c_void_p, C.c_int32
 libs = {}

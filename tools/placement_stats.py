@@ -1,0 +1,20 @@
+#!/usr/bin/env python
+"""What the constructed obs-buffer placement (MultiGridEnv._place_obs_buffers) finds in THIS process: kept buffers,
+candidates drawn, every candidate's ms, why it stopped.  usage: placement_stats.py [B] [tile]"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402,F401
+from marlgrid_amd.agents import GridAgentInterface  # noqa: E402
+from marlgrid_amd.envs import ClutteredMultiGrid  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
+ts = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+env = ClutteredMultiGrid(agents=[GridAgentInterface(color=c, view_size=7, view_tile_size=ts) for c in ("red", "blue", "purple")],
+                         grid_size=15, clutter_density=0.15, batch_size=B, strict=False, auto_reset=True)
+pm = dict(env._groups[0].placement_ms)
+pm["all"] = [round(x, 4) for x in pm["all"]]
+pm["kept"] = [round(x, 4) for x in pm["kept"]]
+print(json.dumps({"B": B, "tile": ts, **pm}))
