@@ -496,7 +496,7 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=32768)
     ap.add_argument("--min-seconds", type=float, default=10.0, help="keep timing K-step blocks until this much is timed "
                     "(10 s of back-to-back blocks: long enough for clocks and any utilisation sampler to see the card busy)")
-    ap.add_argument("--max-blocks", type=int, default=2000)
+    ap.add_argument("--max-blocks", type=int, default=6000)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic = null)")
