@@ -110,12 +110,55 @@ MG_HD void mt_generate(uint32_t* w, int& pos, int cnt, uint32_t* out) {
     pos = p;
 }
 
+// A whole head of 16 words in ONE memory round trip, through LDS-DMA (gfx950: global_load_lds_dwordx4 — the data goes from
+// HBM into LDS without passing through registers): mt_generate's batch of 8 keeps its 24 operands in registers, which is
+// why a head refill is two DEPENDENT round trips; a batch of 16 in registers (33 operands) spilled seventy registers of the
+// obs kernel's 16-wave instantiation.  Here the operands — words p .. p+16 and p+397 .. p+412, two contiguous runs — land in
+// the wave's scratch `dma` (9 rows of 128 bytes: row r holds 16 bytes for each of the 8 stepping lanes, lane l at byte 16 l:
+// the LDS address of an LDS-DMA load is wave-uniform, the lane's place in the row is its lane id) and are read back one at
+// a time.  Why it matters: a reset draws ~70 words on ONE lane, i.e. four or five refills, and every other lane of the
+// wave — and the launch, which lasts as long as its slowest wave — waits for each of them (profiles/r04/README.md
+// section 3: a step in which a few envs finish 0.207 -> 0.195 ms, the step in which all do 0.36 -> 0.31 ms).  Returns
+// false, having done nothing, when a run would wrap around the end of the state (5 % of the refills: the caller takes the
+// register path).  (Requesting the NEXT batch's operands right after a refill, so that a chain of refills waits for
+// memory once, was measured too: correct, ten spilled registers instead of two, and slower — profiles/r04.)
+constexpr int kMtDmaBufDwords = 9 * 32;        // the landing zone: 9 rows of 128 bytes
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ bool mt_generate16_dma(uint32_t* w, int& pos, uint32_t* head, int hstride, uint32_t* dma, int dcol) {
+    const int p = pos;
+    const int pm = p + 397 >= MG_MT_N ? p + 397 - MG_MT_N : p + 397;
+    if (p + 20 > MG_MT_N || pm + 16 > MG_MT_N) return false;
+    typedef const __attribute__((address_space(1))) void* gptr;
+    typedef __attribute__((address_space(3))) void* lptr;
+#pragma unroll
+    for (int i = 0; i < 5; i++) __builtin_amdgcn_global_load_lds((gptr)(w + p + 4 * i), (lptr)(dma + 32 * i), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; i++) __builtin_amdgcn_global_load_lds((gptr)(w + pm + 4 * i), (lptr)(dma + 32 * (5 + i)), 16, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint32_t* mine = dma + 4 * dcol;
+    uint32_t a = mine[0];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const uint32_t b = mine[32 * ((i + 1) >> 2) + ((i + 1) & 3)];
+        const uint32_t c = mine[32 * (5 + (i >> 2)) + (i & 3)];
+        const uint32_t x = mt_twist(a, b, c);
+        w[p + i] = x;
+        head[i * hstride] = mt_temper(x);
+        a = b;
+    }
+    pos = p + 16 >= MG_MT_N ? p + 16 - MG_MT_N : p + 16;
+    return true;
+}
+#endif
+
 struct Mt {
     uint32_t* w;            // this env's 624 words (HBM)
     int pos;                // next word to regenerate
     uint32_t* head;         // head word i at head[i * hstride] (HBM: stride 1; LDS column: stride S)
     int hstride;
     int used;               // draws taken since the kernel started
+    uint32_t* dma = nullptr;   // the obs kernel's fused step: the wave's LDS landing zone for mt_generate16_dma (null: none) ...
+    int dcol = 0;              // ... and this lane's column in it
 
     // The head is consumed as a ring: draw number `used` is head[used % 16]; when a whole head has
     // been consumed and more is needed (placements, resets) the next 16 outputs are generated into it
@@ -123,12 +166,18 @@ struct Mt {
     MG_HD uint32_t next() {
         const int r = used & (MG_MT_HEAD - 1);
         if (r == 0 && used != 0) {
+            bool refilled = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (dma) refilled = mt_generate16_dma(w, pos, head, hstride, dma, dcol);
+#endif
+            if (!refilled) {
 #pragma unroll
-            for (int h = 0; h < MG_MT_HEAD; h += 8) {
-                uint32_t t[8];
-                mt_generate(w, pos, 8, t);
+                for (int h = 0; h < MG_MT_HEAD; h += 8) {
+                    uint32_t t[8];
+                    mt_generate(w, pos, 8, t);
 #pragma unroll
-                for (int i = 0; i < 8; i++) head[(h + i) * hstride] = t[i];
+                    for (int i = 0; i < 8; i++) head[(h + i) * hstride] = t[i];
+                }
             }
         }
         used++;
@@ -407,6 +456,7 @@ struct StepScratch {        // per-workgroup arrays, this env is column `col`, e
     const uint8_t* oflags;  // [MG_MAX_OBJ] object flags (shared)
     int S, col;
     bool defer_writeback = false;   // the caller writes records and RNG head back itself (StepOut::head_k; the obs kernel)
+    uint32_t* dma = nullptr;        // the obs kernel: the wave's LDS landing zone for one-round-trip head refills (mt_generate16_dma)
 #if defined(MG_AB_VARIANTS)
     unsigned long long* stamp = nullptr;   // measurement build: 5 words, wall_clock64 at the section ends of step_run (or null)
 #endif
@@ -451,6 +501,8 @@ MG_HD StepOut step_run(const MgConfig& cfg, const MgState& st, const MgGenProgra
     const int n = cfg.n_agents, W = cfg.W, H = cfg.H, S = sc.S, col = sc.col;
     uint64_t* s_rec = sc.rec;
     Mt mt{st.mt + (size_t)b * MG_MT_N, env.pos0, sc.head + col, S, 0};
+    mt.dma = sc.dma;
+    mt.dcol = col;
     int err = 0;
     MG_STEP_STAMP(0);
 

@@ -499,6 +499,9 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 bool wrote = false;
                 int head_k = 0;
                 sc.defer_writeback = true;      // records and RNG heads go back to HBM from the whole wave, below
+                // one-round-trip head refills through LDS-DMA (mt_generate16_dma): their landing zone, 9 rows of 128 bytes,
+                // is the tmap area — the views have not begun
+                sc.dma = (size_t)L.tmap_slots * L.tmap_stride >= kMtDmaBufDwords * 4 ? reinterpret_cast<uint32_t*>(w_tmap0) : nullptr;
                 if (lane < kb) {
                     const StepOut so = step_run(cfg, st, fs.prog, fs.has_prog != 0, fs.rewards, eb + lane, se, sc,
                                                 w_stage_g + (size_t)lane * cfg.cells_stride);
