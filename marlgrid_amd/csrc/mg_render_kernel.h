@@ -97,6 +97,57 @@ __device__ __forceinline__ void or_segment_padded(const uint8_t* __restrict__ ro
     for (int i = 0; i < NC; i++) atomicOr(&D[i], __builtin_amdgcn_alignbyte(w[i + 1], w[i], sh));
 }
 
+// A second look at a by-value kernel parameter, through a pointer the compiler cannot see through: the loads
+// stay where the values are used (scalar loads from the kernarg segment) instead of being hoisted to the kernel's
+// entry and carried — spilled — across the whole env loop.  (The parameter list of render_kernel as a struct: the
+// kernarg segment is laid out by the same rules.)
+struct RenderKernargs { MgConfig cfg; MgState st; uint8_t* obs; uint8_t* dbg[3]; RenderLaunch lc; FusedStep fs; };
+template <class T>
+__device__ __forceinline__ const T& kernarg_again(size_t offset) {
+    typedef const __attribute__((address_space(4))) char* kptr;
+    kptr p = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *(const T*)(p + offset);
+}
+
+// The launch constants of a REGION of the env loop (staging, step, an env's views and raster), re-read through
+// kernarg_again and re-derived there: declared once in front of the loop they were ~290 SGPRs of loop invariants,
+// spilled to VGPR lanes (five VGPRs of an instantiation that runs at its 128-VGPR limit) and read back with a
+// v_readlane wherever one was used.  The names shadow the kernel's own.
+#define MG_REGION_LOCALS                                                                                       \
+    const MgConfig& cfg = kernarg_again<MgConfig>(offsetof(RenderKernargs, cfg));                              \
+    const RenderLaunch& lc = kernarg_again<RenderLaunch>(offsetof(RenderKernargs, lc));                        \
+    const RenderScratch& L = lc.L;                                                                             \
+    uint8_t* const ws = smem + (kGlobalAtlas ? 0 : lc.atlas_lds) + kRenderShared + (size_t)wave * L.total;     \
+    uint8_t* const w_stage_g = ws + L.grid;                                                                    \
+    uint64_t* const w_stage_r = reinterpret_cast<uint64_t*>(ws + L.rec);                                       \
+    double* const w_stage_p = reinterpret_cast<double*>(ws + L.pres);                                          \
+    uint32_t* const w_stage_c = reinterpret_cast<uint32_t*>(ws + L.pcol);                                      \
+    uint2* const w_vaff = reinterpret_cast<uint2*>(ws + L.vaff);                                               \
+    uint8_t* const w_first = ws + L.first;                                                                     \
+    uint8_t* const w_second = ws + L.second;                                                                   \
+    uint8_t* const w_vbase = ws + L.vbase;                                                                     \
+    uint8_t* const w_vshow = ws + L.vshow;                                                                     \
+    uint32_t* const w_trow = reinterpret_cast<uint32_t*>(ws + L.trow);                                         \
+    uint32_t* const w_vis = reinterpret_cast<uint32_t*>(ws + L.vis);                                           \
+    uint16_t* const w_tmap0 = reinterpret_cast<uint16_t*>(ws + L.tmap);                                        \
+    uint8_t* const w_dyn = ws + L.dyn;                                                                         \
+    uint8_t* const w_out = ws + L.out;                                                                         \
+    const uint32_t dyn_off = (uint32_t)(w_dyn - smem);                                                         \
+    const int VS = VS_ ? VS_ : cfg.view_size, TS = TS_ ? TS_ : cfg.tile_size, VV = VS * VS, h = VS / 2;        \
+    const int tile_bytes = TS * TS * 3;                                                                        \
+    const size_t img_bytes = (size_t)VS * TS * VS * TS * 3;                                                    \
+    const Div20 by_VV = VS_ ? Div20((uint32_t)VV) : Div20((uint32_t)VV, lc.m_VV);                              \
+    const Div20 by_VS = VS_ ? Div20((uint32_t)VS) : Div20((uint32_t)VS, lc.m_VS);                              \
+    (void)h; (void)tile_bytes; (void)img_bytes; (void)by_VV; (void)by_VS;                                      \
+    const int n = cfg.n_agents, W = cfg.W, H = cfg.H, nv = cfg.n_view ? cfg.n_view : n;                        \
+    const int gdw = cfg.cells_stride / 4, off = cfg.view_offset, rec_stride = L.rec_stride;                    \
+    const uint32_t NT4 = 4u * (uint32_t)cfg.n_tiles;                                                           \
+    const Div20 by_n((uint32_t)n, lc.m_n), by_nv((uint32_t)nv, lc.m_nv), by_nvVV((uint32_t)(nv * VV), lc.m_nvVV); \
+    (void)W; (void)H; (void)gdw; (void)off; (void)rec_stride; (void)NT4; (void)by_n; (void)by_nv; (void)by_nvVV;   \
+    (void)w_stage_p; (void)w_stage_c; (void)w_vaff; (void)w_first; (void)w_second; (void)w_vbase; (void)w_vshow; \
+    (void)w_trow; (void)w_vis; (void)w_tmap0; (void)w_out; (void)dyn_off; (void)w_stage_g; (void)w_stage_r; (void)cfg
+
 // ---- mg_step_render: the step of a batch of staged envs, lane j < kb steps env eb + j (mg_core.h) ----
 // The wave steps the envs it is about to render ON THEIR STAGED COPIES: the loads whose addresses are known up
 // front (records, actions, RNG look-ahead, counters: step_load) are issued together with the batch's grid loads
@@ -294,8 +345,6 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     // (the pure-store microbenchmark loses 25 % of its throughput to one such load per env).  At the bench batch
     // a wave's run is one batch: it reads before its first store and never again.
     const int K = L.stage_envs, rec_stride = L.rec_stride;
-    StepScratch sc0;
-    if (fs.enabled) sc0 = fused_step_scratch(cfg, lane, ws + L.step, s_obj, s_oflags);
     MG_STAMP(13);
 
     // assemble-and-stream raster: the wave's run of envs is ONE contiguous output stream.  w_out[0] is
@@ -331,6 +380,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
         const bool first = (eb == e0);
         if (eb >= e_end && !first) break;
         const int kb = max(0, min(K, e_end - eb));
+        MG_REGION_LOCALS;
         // 0. stage the batch (contiguous in HBM): loads first, all in flight, then one wait.  mg_step_render:
         //    the step's own up-front loads ride the same round trip, the envs are stepped on the staged grids
         //    (lane j: env eb + j) and their records are staged from the step's scratch.
@@ -424,12 +474,15 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                     vmap0 = cfg.view_agent[tidl];
                 }
             }
-            StepScratch sc = sc0;
+            StepScratch sc;
+            if (fs.enabled) sc = fused_step_scratch(cfg, lane, ws + L.step, s_obj, s_oflags);
             StepEnv se = {0, 0};
 #if defined(MG_AB_VARIANTS)
             sc.stamp = (d_ab_stamps && lane == 0) ? d_ab_stamps + (size_t)(blockIdx.x * WPB + wave) * 24 + (first ? 8 : 16) : nullptr;
 #endif
             if (fs.enabled) {
+                const MgState& st = kernarg_again<MgState>(offsetof(RenderKernargs, st));
+                const FusedStep& fs = kernarg_again<FusedStep>(offsetof(RenderKernargs, fs));
                 const StepLoadRegs r = step_load_issue(cfg, st, fs.actions, fs.action_bytes, eb, kb, lanel);
                 __builtin_amdgcn_sched_barrier(0);
                 se = step_load_commit(cfg, r, kb, lanel, sc, by_n);
@@ -491,6 +544,9 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             if (eb >= e_end) break;
             if (eb == e0) MG_STAMP(2);
             if (fs.enabled) {
+                MG_REGION_LOCALS;
+                const MgState& st = kernarg_again<MgState>(offsetof(RenderKernargs, st));
+                const FusedStep& fs = kernarg_again<FusedStep>(offsetof(RenderKernargs, fs));
                 // (The whole batch is stepped here, before its first store.  Stepping group by group — each view
                 // group right before its views, so that the wave's first store waits for the step of ONE env — was
                 // measured 11 % SLOWER (profiles/r03/ab_fused_step_per_group*.txt): the step's RNG refill is a
@@ -566,6 +622,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     for (int ej0 = 0; ej0 < kb; ej0 += gd, gd = ramp ? min(2 * gd, L.view_slots) : depth)
     for (int pass = 0; pass < 2; pass++)
     for (int ej = ej0; ej < min(kb, ej0 + gd); ej++) {
+        MG_REGION_LOCALS;
         const int e = eb + ej;
         uint16_t* w_tmap = w_tmap0 + (size_t)(ej - ej0) * (L.tmap_stride / 2);
         if (pass == 0) {
