@@ -499,7 +499,8 @@ class MultiGridEnv(object):
                               self.mt_head.data_ptr(), self._flag.dev)
 
     @_on_device
-    def _place_obs_buffers(self, max_candidates=64, min_bytes=256 << 20, iters=3, budget=64 << 30, gain=0.12, seconds=2.5):
+    def _place_obs_buffers(self, max_candidates=96, min_bytes=256 << 20, iters=3, budget=128 << 30, gain=0.12, seconds=6.0,
+                           slow_alloc=0.02, stir_cap=192 << 30):
         """place_obs="search" (default): choose WHERE in HBM the observation buffers live.
 
         What is known (MI355X, profiles/r04/README.md section 1): the HBM of the chip is two REGIONS, and each takes
@@ -518,8 +519,11 @@ class MultiGridEnv(object):
         boundary between the two, [2 P - n / 2, 2 P + n / 2).  Whether the two blocks lie in different regions is the
         one thing that is still measured (the raster itself, `iters` launches, HIP events): candidates are drawn — and
         kept, so that the allocator moves on through its free lists — until `keep` of them run `gain` under the median
-        candidate, or `max_candidates` / `budget` bytes / a quarter of the free memory / `seconds` are spent; then every
-        other candidate goes back to the driver.  Raw hipMalloc through the library (mg_obs_alloc: never torch's
+        candidate, or `max_candidates` / `budget` bytes / half of the free memory / `seconds` are spent; then every
+        other candidate goes back to the driver.  (Kept through ALL stages: a freed block is the first the driver hands
+        out again, so a search that released its losers would draw the same memory over and over — seen on a box whose
+        memory had never been allocated before: every allocation next to the one before, all in one region, 100 ms per
+        candidate, 27 candidates in the 2.5 s this search then had, none fast — profiles/r04/README.md section 1.)  Raw hipMalloc through the library (mg_obs_alloc: never torch's
         caching allocator); a kept buffer holds 3 P bytes for its n (1.5 .. 3 x).  Without a candidate in the fast
         class the best seen is kept (the plain torch allocations included).  Buffers under `min_bytes` are left alone
         (the effect needs thousands of concurrent streams)."""
@@ -546,6 +550,10 @@ class MultiGridEnv(object):
             why = "cap"
             alive = misses = level = 0
             plain = False                                       # last stage: plain buffer-sized allocations (below)
+            dropped = False                                     # the losers went back to the driver once (memory short)
+            probes = [0]                                        # windows measured (a candidate: one, or several — below)
+            alloc_s, alloc_bytes, stir = 0.0, 0, None           # time in hipMalloc; the one big allocate-and-free (below)
+            offsets = {}                                        # id(candidate tensor) -> its window's offset in its allocation
             found = False
 
             def drop_losers():
@@ -562,32 +570,83 @@ class MultiGridEnv(object):
                 # A run of candidates that all miss: the free lists these two block sizes come from are in ONE region
                 # for now (profiles/r04: 46 plain allocations in a row) — take the next larger pair of blocks, and after
                 # those plain allocations of the buffer's own size (512 + 256 + ... MiB blocks: another set of free lists;
-                # in the fast class when the largest block and the rest come from different regions, 58 : 42).  Every
-                # stage starts with the losers of the stage before handed back.
+                # in the fast class when the largest block and the rest come from different regions, 58 : 42).  The
+                # losers stay allocated (see above); only when memory runs short do they go back, once.
                 P = P0 << level
                 arena = nbytes if plain else 3 * P
                 free, _total = torch.cuda.mem_get_info(self.device)
-                short = alive + arena > min((free + alive) // 4, budget)
+                short = alive + arena > min((free + alive) // 2, budget)
                 if (misses >= 12 or short) and not plain:
                     misses = 0
+                    if stir is None and not short and alloc_bytes and alloc_s / alloc_bytes >= slow_alloc / (1 << 30):
+                        # Allocations at 30 GB/s (`slow_alloc`: 20 ms per GiB and slower): memory nobody has had before, cleared as it is
+                        # handed out — front to back, one region.  One allocation of half of what is free, given
+                        # straight back, leaves the driver's free lists holding blocks from all over the memory
+                        # (measured: a search right after one finds its pair of blocks within six candidates); the
+                        # seconds it takes are added to the search's.
+                        t0 = time.perf_counter()
+                        big = min(free // 2, stir_cap)
+                        mem = _LibBuffer(self._lib, big, self.device)
+                        ok = mem.ok
+                        del mem
+                        stir = {"bytes": big if ok else 0, "seconds": time.perf_counter() - t0}
+                        t_end += stir["seconds"]
+                        continue
                     if level < 2 and not short:
                         level += 1
                     else:
                         plain = True
-                    alive = drop_losers()
                     continue
                 if short:
-                    why = "memory"
-                    break
+                    if dropped:
+                        why = "memory"
+                        break
+                    alive = drop_losers()
+                    dropped = True
+                    continue
                 offset = 0 if plain else (2 * P - nbytes // 2) & ~4095      # the window centred on the 2 P | P block boundary
+                t0 = time.perf_counter()
                 mem = _LibBuffer(self._lib, arena, self.device)
                 if not mem.ok:
                     why = "out of memory"
                     break
+                alloc_s += time.perf_counter() - t0
+                alloc_bytes += arena
                 alive += arena                                  # (what the candidates drawn so far hold)
-                t = mem.tensor((arena,))[offset:offset + nbytes].view(g.shape)
+                full = mem.tensor((arena,))
                 del mem                                         # (the tensor keeps the allocation alive)
-                cands.append((cost_of(t), t))
+
+                def window(o):
+                    w = full[o:o + nbytes].view(g.shape)
+                    probes[0] += 1
+                    return cost_of(w), w, o
+
+                pick = window(offset)
+                so_far = sorted(c for c, _ in cands)
+                median = so_far[len(so_far) // 2]
+                # Memory that was never allocated before is handed out front to back: the two blocks of a candidate
+                # are then NEIGHBOURS, the junction is no boundary at all, and the one region boundary the search
+                # will eventually walk across lies anywhere inside some candidate.  After four misses in a row the
+                # other window positions of a candidate are measured too (a fifth of a buffer apart: 0.6 ms each) ...
+                scanned = not plain and misses >= 4 and pick[0] > (1.0 - gain) * median
+                if scanned:
+                    step = max(4096, nbytes // 5) & ~4095
+                    for o in range(0, arena - nbytes + 1, step):
+                        if abs(o - offset) >= step // 2:
+                            pick = min(pick, window(o), key=lambda cwo: cwo[0])
+                # ... and a window that is partly across a boundary (the gain is in proportion to the smaller share of
+                # the streams) is moved until it is centred
+                partial = pick[0] > (1.0 - gain) * median
+                if not plain and pick[0] <= 0.96 * median and (partial or scanned):
+                    step = max(4096, nbytes // 10) & ~4095
+                    for _ in range(4):
+                        for o in (pick[2] - step, pick[2] + step):
+                            if 0 <= o <= arena - nbytes:
+                                pick = min(pick, window(o), key=lambda cwo: cwo[0])
+                        step = max(4096, step // 2) & ~4095
+                del full
+                cands.append((pick[0], pick[1]))
+                offsets[id(pick[1])] = pick[2]
                 costs = sorted(c for c, _ in cands)
                 median = costs[len(costs) // 2]
                 misses = 0 if cands[-1][0] <= (1.0 - gain) * median else misses + 1
@@ -606,7 +665,9 @@ class MultiGridEnv(object):
             g.placement_ms = {"kept": [c for c, _ in best], "candidates": len(seen), "stopped": why,
                               "seconds": time.perf_counter() - t_begin, "all": seen,
                               "candidate_bytes": 3 * P0, "window_offset": (2 * P0 - nbytes // 2) & ~4095,
-                              "buffer_bytes": nbytes, "block_pair_level": level, "plain_stage": plain, "found": found}
+                              "buffer_bytes": nbytes, "block_pair_level": level, "plain_stage": plain, "found": found,
+                              "windows_measured": probes[0], "kept_window_offsets": [offsets.get(id(t)) for _, t in best],
+                              "alloc_ms_per_GiB": 1e3 * alloc_s / max(alloc_bytes, 1) * (1 << 30), "stirred": stir}
             any_replaced = any_replaced or replaced
         for i, r in enumerate(self._ring):
             r["obs"] = self._groups[0].ring[i]

@@ -95,14 +95,14 @@ def test_obs_buffer_placement_search():
             o, r, d, _ = env.step(torch.randint(0, 7, (B, 3), generator=g))
         if mode == "search":
             pm = env._groups[0].placement_ms
-            assert 2 <= pm["candidates"] <= 258 and pm["seconds"] < 4.0 and len(pm["kept"]) == 2
+            assert 2 <= pm["candidates"] <= 258 and pm["seconds"] < 20.0 and len(pm["kept"]) == 2
             assert sorted(pm["all"])[:2] == sorted(pm["kept"])          # the fastest two were kept
             # a candidate is a 2 P block followed by a P block, the buffer the window centred on their boundary
             P = pm["candidate_bytes"] // 3
             assert pm["candidate_bytes"] == 3 * P and P & (P - 1) == 0 and P >= pm["buffer_bytes"] / 2
             assert abs(pm["window_offset"] + pm["buffer_bytes"] / 2 - 2 * P) <= 4096
             assert env.obs.data_ptr() % 4096 == 0
-            assert torch.cuda.mem_get_info()[0] > free0 - (4 << 30)     # the rejected candidates are back
+            assert torch.cuda.mem_get_info()[0] > free0 - (8 << 30)     # the rejected candidates are back
         outs.setdefault(mode, []).append((o.cpu(), r.cpu(), d.cpu()))
         del env, o, r, d
         gc.collect()
@@ -120,6 +120,36 @@ def test_obs_buffer_placement_search():
     gc.collect()
     torch.cuda.empty_cache()
     assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)
+
+
+def test_obs_buffer_placement_search_when_nothing_is_found():
+    """The search's later stages, forced (no candidate can be 60 % under the median; every allocation counts as slow):
+    twelve misses, the one big allocate-and-free that stirs the driver's free lists, larger block pairs with several
+    window positions measured per candidate, plain allocations — then the best seen is kept, everything else goes back,
+    and the env computes what an env on torch's buffers computes."""
+    import gc
+    import torch
+    B = 16384
+    env = product_envs.build("MarlGrid-3AgentCluttered15x15-v0", batch_size=B, place_obs=False)
+    twin = product_envs.build("MarlGrid-3AgentCluttered15x15-v0", batch_size=B, place_obs=False)
+    env.reset()
+    twin.reset()
+    free0 = torch.cuda.mem_get_info()[0]
+    env._place_obs_buffers(gain=0.6, slow_alloc=0.0, stir_cap=4 << 30, seconds=60.0, max_candidates=56)
+    pm = env._groups[0].placement_ms
+    assert pm["found"] is False and pm["stopped"] == "cap" and pm["candidates"] == 58
+    assert pm["stirred"] and pm["stirred"]["bytes"] == 4 << 30
+    assert pm["block_pair_level"] == 2 and pm["plain_stage"] is True
+    assert pm["windows_measured"] > pm["candidates"]                 # window positions besides the junction
+    assert sorted(pm["all"])[:2] == sorted(pm["kept"])
+    assert all(o is None or o % 4096 == 0 for o in pm["kept_window_offsets"])
+    gc.collect()
+    assert torch.cuda.mem_get_info()[0] > free0 - (8 << 30)          # the losers went back
+    g = torch.Generator().manual_seed(11)
+    for _ in range(4):
+        a = torch.randint(0, 7, (B, 3), generator=g)
+        for x, y in zip(env.step(a)[:3], twin.step(a)[:3]):
+            assert torch.equal(x, y)
 
 
 def test_state_dict_round_trip_and_versioning():
