@@ -523,152 +523,168 @@ class MultiGridEnv(object):
         other candidate goes back to the driver.  (Kept through ALL stages: a freed block is the first the driver hands
         out again, so a search that released its losers would draw the same memory over and over — seen on a box whose
         memory had never been allocated before: every allocation next to the one before, all in one region, 100 ms per
-        candidate, 27 candidates in the 2.5 s this search then had, none fast — profiles/r04/README.md section 1.)  Raw hipMalloc through the library (mg_obs_alloc: never torch's
-        caching allocator); a kept buffer holds 3 P bytes for its n (1.5 .. 3 x).  Without a candidate in the fast
-        class the best seen is kept (the plain torch allocations included).  Buffers under `min_bytes` are left alone
-        (the effect needs thousands of concurrent streams)."""
+        candidate, 27 candidates in the 2.5 s this search then had, none fast — profiles/r04/README.md section 1.)
+        For that state the search has three more means (all in the loop below): after four misses in a row it measures
+        the other window positions of a candidate too and centres a partial hit; when the first stage missed and the
+        allocations were slow it makes one big allocation and frees it, which leaves the driver's free lists mixed;
+        and a pass that found nothing is followed by a second one, from the best two of the first.  Raw hipMalloc
+        through the library (mg_obs_alloc: never torch's caching allocator); a kept buffer holds its whole candidate
+        (3 P bytes for its n at the first stage: 1.5 .. 3 x).  Without a candidate in the fast class the best seen is
+        kept (the plain torch allocations included).  Buffers under `min_bytes` are left alone (the effect needs
+        thousands of concurrent streams)."""
         import time
         import torch
-        t_begin = time.perf_counter()
-        t_end = t_begin + seconds
         any_replaced = False
         for g in self._groups:
             nbytes = g.ring[0].numel()
             if nbytes < min_bytes:
                 continue
-            ms = C.c_float(0)
 
-            def cost_of(buf):
-                N.check(self._lib.mg_time_render_obs(C.byref(g.cfg), C.byref(self._state), buf.data_ptr(), iters,
-                                                     C.byref(ms), self._stream()))
-                return ms.value
+            def search(t_begin):
+                """one pass over the stages below; returns whether a ring buffer was replaced"""
+                t_end = t_begin + seconds
+                ms = C.c_float(0)
 
-            half = (nbytes + 1) // 2
-            P0 = 1 << max(21, (half - 1).bit_length())         # power of two >= half the buffer (>= 2 MiB)
-            keep = len(g.ring)
-            cands = [(cost_of(t), t) for t in g.ring]           # (ms, tensor): the plain torch allocations first
-            why = "cap"
-            alive = misses = level = 0
-            plain = False                                       # last stage: plain buffer-sized allocations (below)
-            dropped = False                                     # the losers went back to the driver once (memory short)
-            probes = [0]                                        # windows measured (a candidate: one, or several — below)
-            alloc_s, alloc_bytes, stir = 0.0, 0, None           # time in hipMalloc; the one big allocate-and-free (below)
-            offsets = {}                                        # id(candidate tensor) -> its window's offset in its allocation
-            found = False
+                def cost_of(buf):
+                    N.check(self._lib.mg_time_render_obs(C.byref(g.cfg), C.byref(self._state), buf.data_ptr(), iters,
+                                                         C.byref(ms), self._stream()))
+                    return ms.value
 
-            def drop_losers():
-                """the candidates that are not among the best `keep` go back to the driver (their ms stays on record)"""
-                ranked = sorted((ct for ct in cands if ct[1] is not None), key=lambda ct: ct[0])
-                keepers = set(id(t) for _, t in ranked[:keep])
-                cands[:] = [(c, t if (t is not None and id(t) in keepers) else None) for c, t in cands]
-                return sum(t._base.numel() for _, t in ranked[:keep] if t._base is not None)    # (what the kept library buffers hold)
+                half = (nbytes + 1) // 2
+                P0 = 1 << max(21, (half - 1).bit_length())         # power of two >= half the buffer (>= 2 MiB)
+                keep = len(g.ring)
+                cands = [(cost_of(t), t) for t in g.ring]           # (ms, tensor): the plain torch allocations first
+                why = "cap"
+                alive = misses = level = 0
+                plain = False                                       # last stage: plain buffer-sized allocations (below)
+                dropped = False                                     # the losers went back to the driver once (memory short)
+                probes = [0]                                        # windows measured (a candidate: one, or several — below)
+                alloc_s, alloc_bytes, stir = 0.0, 0, None           # time in hipMalloc; the one big allocate-and-free (below)
+                offsets = {}                                        # id(candidate tensor) -> its window's offset in its allocation
+                found = False
 
-            while len(cands) < keep + max_candidates:
-                if time.perf_counter() > t_end:
-                    why = "time"
-                    break
-                # A run of candidates that all miss: the free lists these two block sizes come from are in ONE region
-                # for now (profiles/r04: 46 plain allocations in a row) — take the next larger pair of blocks, and after
-                # those plain allocations of the buffer's own size (512 + 256 + ... MiB blocks: another set of free lists;
-                # in the fast class when the largest block and the rest come from different regions, 58 : 42).  The
-                # losers stay allocated (see above); only when memory runs short do they go back, once.
-                P = P0 << level
-                arena = nbytes if plain else 3 * P
-                free, _total = torch.cuda.mem_get_info(self.device)
-                short = alive + arena > min((free + alive) // 2, budget)
-                if (misses >= 12 or short) and not plain:
-                    misses = 0
-                    if stir is None and not short and alloc_bytes and alloc_s / alloc_bytes >= slow_alloc / (1 << 30):
-                        # Allocations at 30 GB/s (`slow_alloc`: 20 ms per GiB and slower): memory nobody has had before, cleared as it is
-                        # handed out — front to back, one region.  One allocation of half of what is free, given
-                        # straight back, leaves the driver's free lists holding blocks from all over the memory
-                        # (measured: a search right after one finds its pair of blocks within six candidates); the
-                        # seconds it takes are added to the search's.
-                        t0 = time.perf_counter()
-                        big = min(free // 2, stir_cap)
-                        mem = _LibBuffer(self._lib, big, self.device)
-                        ok = mem.ok
-                        del mem
-                        stir = {"bytes": big if ok else 0, "seconds": time.perf_counter() - t0}
-                        t_end += stir["seconds"]
-                        continue
-                    if level < 2 and not short:
-                        level += 1
-                    else:
-                        plain = True
-                    continue
-                if short:
-                    if dropped:
-                        why = "memory"
+                def drop_losers():
+                    """the candidates that are not among the best `keep` go back to the driver (their ms stays on record)"""
+                    ranked = sorted((ct for ct in cands if ct[1] is not None), key=lambda ct: ct[0])
+                    keepers = set(id(t) for _, t in ranked[:keep])
+                    cands[:] = [(c, t if (t is not None and id(t) in keepers) else None) for c, t in cands]
+                    return sum(t._base.numel() for _, t in ranked[:keep] if t._base is not None)    # (what the kept library buffers hold)
+
+                while len(cands) < keep + max_candidates:
+                    if time.perf_counter() > t_end:
+                        why = "time"
                         break
-                    alive = drop_losers()
-                    dropped = True
-                    continue
-                offset = 0 if plain else (2 * P - nbytes // 2) & ~4095      # the window centred on the 2 P | P block boundary
-                t0 = time.perf_counter()
-                mem = _LibBuffer(self._lib, arena, self.device)
-                if not mem.ok:
-                    why = "out of memory"
-                    break
-                alloc_s += time.perf_counter() - t0
-                alloc_bytes += arena
-                alive += arena                                  # (what the candidates drawn so far hold)
-                full = mem.tensor((arena,))
-                del mem                                         # (the tensor keeps the allocation alive)
+                    # A run of candidates that all miss: the free lists these two block sizes come from are in ONE region
+                    # for now (profiles/r04: 46 plain allocations in a row) — take the next larger pair of blocks, and after
+                    # those plain allocations of the buffer's own size (512 + 256 + ... MiB blocks: another set of free lists;
+                    # in the fast class when the largest block and the rest come from different regions, 58 : 42).  The
+                    # losers stay allocated (see above); only when memory runs short do they go back, once.
+                    P = P0 << level
+                    arena = nbytes if plain else 3 * P
+                    free, _total = torch.cuda.mem_get_info(self.device)
+                    short = alive + arena > min((free + alive) // 2, budget)
+                    if (misses >= 12 or short) and not plain:
+                        misses = 0
+                        if stir is None and not short and alloc_bytes and alloc_s / alloc_bytes >= slow_alloc / (1 << 30):
+                            # Allocations at 30 GB/s (`slow_alloc`: 20 ms per GiB and slower): memory nobody has had before, cleared as it is
+                            # handed out — front to back, one region.  One allocation of half of what is free, given
+                            # straight back, leaves the driver's free lists holding blocks from all over the memory
+                            # (measured: a search right after one finds its pair of blocks within six candidates); the
+                            # seconds it takes are added to the search's.
+                            t0 = time.perf_counter()
+                            big = min(free // 2, stir_cap)
+                            mem = _LibBuffer(self._lib, big, self.device)
+                            ok = mem.ok
+                            del mem
+                            stir = {"bytes": big if ok else 0, "seconds": time.perf_counter() - t0}
+                            t_end += stir["seconds"]
+                            continue
+                        if level < 2 and not short:
+                            level += 1
+                        else:
+                            plain = True
+                        continue
+                    if short:
+                        if dropped:
+                            why = "memory"
+                            break
+                        alive = drop_losers()
+                        dropped = True
+                        continue
+                    offset = 0 if plain else (2 * P - nbytes // 2) & ~4095      # the window centred on the 2 P | P block boundary
+                    t0 = time.perf_counter()
+                    mem = _LibBuffer(self._lib, arena, self.device)
+                    if not mem.ok:
+                        why = "out of memory"
+                        break
+                    alloc_s += time.perf_counter() - t0
+                    alloc_bytes += arena
+                    alive += arena                                  # (what the candidates drawn so far hold)
+                    full = mem.tensor((arena,))
+                    del mem                                         # (the tensor keeps the allocation alive)
 
-                def window(o):
-                    w = full[o:o + nbytes].view(g.shape)
-                    probes[0] += 1
-                    return cost_of(w), w, o
+                    def window(o):
+                        w = full[o:o + nbytes].view(g.shape)
+                        probes[0] += 1
+                        return cost_of(w), w, o
 
-                pick = window(offset)
-                so_far = sorted(c for c, _ in cands)
-                median = so_far[len(so_far) // 2]
-                # Memory that was never allocated before is handed out front to back: the two blocks of a candidate
-                # are then NEIGHBOURS, the junction is no boundary at all, and the one region boundary the search
-                # will eventually walk across lies anywhere inside some candidate.  After four misses in a row the
-                # other window positions of a candidate are measured too (a fifth of a buffer apart: 0.6 ms each) ...
-                scanned = not plain and misses >= 4 and pick[0] > (1.0 - gain) * median
-                if scanned:
-                    step = max(4096, nbytes // 5) & ~4095
-                    for o in range(0, arena - nbytes + 1, step):
-                        if abs(o - offset) >= step // 2:
-                            pick = min(pick, window(o), key=lambda cwo: cwo[0])
-                # ... and a window that is partly across a boundary (the gain is in proportion to the smaller share of
-                # the streams) is moved until it is centred
-                partial = pick[0] > (1.0 - gain) * median
-                if not plain and pick[0] <= 0.96 * median and (partial or scanned):
-                    step = max(4096, nbytes // 10) & ~4095
-                    for _ in range(4):
-                        for o in (pick[2] - step, pick[2] + step):
-                            if 0 <= o <= arena - nbytes:
+                    pick = window(offset)
+                    so_far = sorted(c for c, _ in cands)
+                    median = so_far[len(so_far) // 2]
+                    # Memory that was never allocated before is handed out front to back: the two blocks of a candidate
+                    # are then NEIGHBOURS, the junction is no boundary at all, and the one region boundary the search
+                    # will eventually walk across lies anywhere inside some candidate.  After four misses in a row the
+                    # other window positions of a candidate are measured too (a fifth of a buffer apart: 0.6 ms each) ...
+                    scanned = not plain and misses >= 4 and pick[0] > (1.0 - gain) * median
+                    if scanned:
+                        step = max(4096, nbytes // 5) & ~4095
+                        for o in range(0, arena - nbytes + 1, step):
+                            if abs(o - offset) >= step // 2:
                                 pick = min(pick, window(o), key=lambda cwo: cwo[0])
-                        step = max(4096, step // 2) & ~4095
-                del full
-                cands.append((pick[0], pick[1]))
-                offsets[id(pick[1])] = pick[2]
-                costs = sorted(c for c, _ in cands)
-                median = costs[len(costs) // 2]
-                misses = 0 if cands[-1][0] <= (1.0 - gain) * median else misses + 1
-                if len(cands) >= keep + 4 and costs[keep - 1] <= (1.0 - gain) * median:
-                    why = "kept set %d%% under the median candidate" % round(100 * (1 - costs[keep - 1] / median))
-                    found = True
+                    # ... and a window that is partly across a boundary (the gain is in proportion to the smaller share of
+                    # the streams) is moved until it is centred
+                    partial = pick[0] > (1.0 - gain) * median
+                    if not plain and pick[0] <= 0.96 * median and (partial or scanned):
+                        step = max(4096, nbytes // 10) & ~4095
+                        for _ in range(4):
+                            for o in (pick[2] - step, pick[2] + step):
+                                if 0 <= o <= arena - nbytes:
+                                    pick = min(pick, window(o), key=lambda cwo: cwo[0])
+                            step = max(4096, step // 2) & ~4095
+                    del full
+                    cands.append((pick[0], pick[1]))
+                    offsets[id(pick[1])] = pick[2]
+                    costs = sorted(c for c, _ in cands)
+                    median = costs[len(costs) // 2]
+                    misses = 0 if cands[-1][0] <= (1.0 - gain) * median else misses + 1
+                    if len(cands) >= keep + 4 and costs[keep - 1] <= (1.0 - gain) * median:
+                        why = "kept set %d%% under the median candidate" % round(100 * (1 - costs[keep - 1] / median))
+                        found = True
+                        break
+                seen = [c for c, _ in cands]
+                best = sorted((ct for ct in cands if ct[1] is not None), key=lambda ct: ct[0])[:keep]
+                replaced = any(all(t is not kept for _, kept in best) for t in g.ring)
+                del cands                                           # the rejected candidates go back to the driver here
+                g.ring = [t for _, t in best]
+                for t in g.ring:
+                    t.zero_()
+                g.obs = g.ring[self._ring_i]
+                g.placement_ms = {"kept": [c for c, _ in best], "candidates": len(seen), "stopped": why,
+                                  "seconds": time.perf_counter() - t_begin, "all": seen,
+                                  "candidate_bytes": 3 * P0, "window_offset": (2 * P0 - nbytes // 2) & ~4095,
+                                  "buffer_bytes": nbytes, "block_pair_level": level, "plain_stage": plain, "found": found,
+                                  "windows_measured": probes[0], "kept_window_offsets": [offsets.get(id(t)) for _, t in best],
+                                  "alloc_ms_per_GiB": 1e3 * alloc_s / max(alloc_bytes, 1) * (1 << 30), "stirred": stir}
+                return replaced
+
+            # A pass that ends without a pair of buffers in the fast class has, by handing its candidates back, left
+            # the driver's free lists in another order (seen: the same process finds its buffers for the NEXT env it
+            # builds): one more pass, which starts from the best two of the first.
+            for attempt in (1, 2):
+                any_replaced = search(time.perf_counter()) or any_replaced
+                g.placement_ms["passes"] = attempt
+                if g.placement_ms["found"]:
                     break
-            seen = [c for c, _ in cands]
-            best = sorted((ct for ct in cands if ct[1] is not None), key=lambda ct: ct[0])[:keep]
-            replaced = any(all(t is not kept for _, kept in best) for t in g.ring)
-            del cands                                           # the rejected candidates go back to the driver here
-            g.ring = [t for _, t in best]
-            for t in g.ring:
-                t.zero_()
-            g.obs = g.ring[self._ring_i]
-            g.placement_ms = {"kept": [c for c, _ in best], "candidates": len(seen), "stopped": why,
-                              "seconds": time.perf_counter() - t_begin, "all": seen,
-                              "candidate_bytes": 3 * P0, "window_offset": (2 * P0 - nbytes // 2) & ~4095,
-                              "buffer_bytes": nbytes, "block_pair_level": level, "plain_stage": plain, "found": found,
-                              "windows_measured": probes[0], "kept_window_offsets": [offsets.get(id(t)) for _, t in best],
-                              "alloc_ms_per_GiB": 1e3 * alloc_s / max(alloc_bytes, 1) * (1 << 30), "stirred": stir}
-            any_replaced = any_replaced or replaced
         for i, r in enumerate(self._ring):
             r["obs"] = self._groups[0].ring[i]
         self.obs = self._ring[self._ring_i]["obs"]

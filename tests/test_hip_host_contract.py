@@ -138,6 +138,7 @@ def test_obs_buffer_placement_search_when_nothing_is_found():
     env._place_obs_buffers(gain=0.6, slow_alloc=0.0, stir_cap=4 << 30, seconds=60.0, max_candidates=56)
     pm = env._groups[0].placement_ms
     assert pm["found"] is False and pm["stopped"] == "cap" and pm["candidates"] == 58
+    assert pm["passes"] == 2                                         # nothing found: a second pass, from the best two of the first
     assert pm["stirred"] and pm["stirred"]["bytes"] == 4 << 30
     assert pm["block_pair_level"] == 2 and pm["plain_stage"] is True
     assert pm["windows_measured"] > pm["candidates"]                 # window positions besides the junction
