@@ -136,7 +136,8 @@ struct RenderLaunch {
 // n: the env's agents (records, who stands where); nv: the viewers this launch renders (view-sized arrays)
 __host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride, int n, int nv, int vs, int stage_envs = 1,
                                                                int dyn_bytes = 0, int out_bytes = 0, int piece_rows = 0,
-                                                               bool batch_views = false, bool any_hide = true) {
+                                                               bool batch_views = false, bool any_hide = true,
+                                                               int max_view_slots = 0) {
     RenderScratch s;
     int o = 0;
     s.stage_envs = stage_envs;
@@ -152,6 +153,7 @@ __host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride,
     // (chunk raster — out_bytes == 0 —: up to 4 envs of views at a time; it is HBM-bound and a wave's first store
     // should not wait for eight envs of views; the assemble-and-stream rasters take the whole staged batch)
     s.view_slots = batch_views ? (out_bytes == 0 && stage_envs > 4 ? 4 : stage_envs) : 1;
+    if (max_view_slots > 0 && s.view_slots > max_view_slots) s.view_slots = max_view_slots;
     s.cell_stride = round_up(cells_stride, 16);
     // (trow doubles as the per-agent colour words of the 'prestige' recolouring: at least n dwords)
     s.trow_stride = round_up((nv * vs > n ? nv * vs : n) * 4, 16) / 4;
@@ -198,15 +200,21 @@ __host__ __device__ inline RenderScratch render_scratch_for(const MgConfig& cfg,
         if (rows > nv * vs * ts) rows = nv * vs * ts;
         out = 32 + rows * rb;
     }
-    // without recoloured tiles the views of several envs are derived together — one lane per viewer in the shadow
-    // cast (its ~420 instructions run once per group instead of once per env), full trips in the per-cell phases —
-    // with one slot of view scratch per env of the group (see the kernel's pass 0)
-    const bool batch_views = dyn == 0;
+    // the views of several envs are derived together — one lane per viewer in the shadow cast (its ~420 instructions
+    // run once per group instead of once per env), full trips in the per-cell phases — with one slot of view scratch per
+    // env of the group (see the kernel's pass 0); the recoloured tiles of a 'prestige' env keep their one slot (they are
+    // made right before the env's raster)
+    const bool batch_views = true;
     const RenderScratch b = render_scratch_layout(cfg.cells_stride, n, nv, vs, 1, dyn, out, rows);
     const int resident = (atlas_b + 4 * b.total + misc <= 160 * 1024) ? atlas_b : 0;   // else the atlas is read in place
+    // ('prestige' — 12-wave workgroups next to a large atlas —: fewer view slots before fewer staged envs or fewer waves)
+    for (int slots = dyn ? 8 : 0; dyn && slots >= 1; slots >>= 1) {
+        const RenderScratch t = render_scratch_layout(cfg.cells_stride, n, nv, vs, 8, dyn, out, rows, batch_views, cfg.any_hide != 0, slots);
+        if (resident + wpb * t.total + (misc > kRenderShared ? misc : kRenderShared) <= 160 * 1024) return t;   // (the launcher's sum)
+    }
     int k = 8;
-    while (k > 1 && resident + wpb * render_scratch_layout(cfg.cells_stride, n, nv, vs, k, dyn, out, rows, batch_views, cfg.any_hide != 0).total + misc > 160 * 1024) k >>= 1;
-    return render_scratch_layout(cfg.cells_stride, n, nv, vs, k, dyn, out, rows, batch_views, cfg.any_hide != 0);
+    while (k > 1 && resident + wpb * render_scratch_layout(cfg.cells_stride, n, nv, vs, k, dyn, out, rows, batch_views, cfg.any_hide != 0, dyn ? 1 : 0).total + misc > 160 * 1024) k >>= 1;
+    return render_scratch_layout(cfg.cells_stride, n, nv, vs, k, dyn, out, rows, batch_views, cfg.any_hide != 0, dyn ? 1 : 0);
 }
 
 }  // namespace mg

@@ -308,7 +308,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     // env's agents differ in view size / tile size / offset and are rendered group by group (agents.py:19-35).
     const int nv = cfg.n_view ? cfg.n_view : n;
     constexpr bool kChunkRaster = TS_ > 0 && (TS_ % 8) == 0 && RM_ == 0;
-    constexpr bool kBatchViews = !kPrestige;   // as render_scratch_for: views of a group of envs at once, a scratch slot each
+    constexpr bool kBatchViews = true;         // as render_scratch_for: views of a group of envs at once, a scratch slot each
     const RenderScratch& L = lc.L;      // (= render_scratch_for(cfg, WPB, RM_), worked out by the launcher)
     uint8_t* ws = smem + atlas_bytes + kRenderShared + (size_t)wave * L.total;
     uint8_t* w_stage_g = ws + L.grid;                                      // [stage_envs][cells_stride] grids of a batch of envs
@@ -369,7 +369,10 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     if (kBatchViews && !kChunkRaster && TS < 8 && depth_mode <= 0) depth = L.tmap_slots;   // issue-bound: views of the whole batch at once
     if (depth > L.tmap_slots) depth = L.tmap_slots;
     if (kBatchViews && depth > L.view_slots) depth = L.view_slots;   // (a group's views need a scratch slot per env)
-    if constexpr (kPrestige) depth = 1;
+    // ('prestige': bound by the latency of the view phases — one or three viewers leave most lanes of a trip idle when
+    // the envs are taken one at a time —: the views of as many envs together as there are slots; the per-env recoloured
+    // tiles, which have ONE slot, are made right before the env's raster, phase 4b)
+    if (kPrestige && !kChunkRaster && depth_mode <= 0) depth = L.view_slots;
     // item -> (slot, rest), view cell -> (viewer, row, column): 24-bit multiplies only (Div20)
     const Div20 by_n((uint32_t)n, lc.m_n), by_nv((uint32_t)nv, lc.m_nv), by_nvVV((uint32_t)(nv * VV), lc.m_nvVV);
     const Div20 by_VV = VS_ ? Div20((uint32_t)VV) : Div20((uint32_t)VV, lc.m_VV), by_VS = VS_ ? Div20((uint32_t)VS) : Div20((uint32_t)VS, lc.m_VS);
@@ -755,64 +758,6 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             for (int it = lane; it < G * nv; it += kWave) { const int g = (int)by_nv.div((uint32_t)it); visibility(g, it - __mul24(g, nv)); }
         } else if (lane < nv) visibility(0, lane);
         wave_lds_sync();
-        if constexpr (kPrestige) {
-            // 4b. tiles of active 'prestige' agents are recoloured per env (render_post) — and blended
-            //     with the object they stand on — before rotation, for all 4 orientations.  With
-            //     hide_item_types a viewer may hide that object and see the agent as a plain cell
-            //     object instead: a second set (hv = 1) on the empty tile.
-            //     Colours first, one lane per agent (the float64 tanh runs once per env, not once per
-            //     agent); w_trow is free after the shadow cast.  Then per agent the tile in orientation
-            //     0 (the only pass with per-pixel arithmetic) and three rotated byte copies of it.
-            const int npx = TS * TS;
-            const uint8_t* abase = kGlobalAtlas ? cfg.atlas : s_atlas;
-            const uint8_t* w_grid = g_grid;      // (G == 1: per-env recoloured tiles have one slot)
-            const uint64_t* w_rec = g_rec;
-            uint32_t* w_col = w_trow;
-            if (lane < n && ((cfg.prestige_mask >> lane) & 1u)) {
-                if (fs.enabled) w_col[lane] = w_stage_c[(size_t)ej * rec_stride + lane];   // (computed by the env's stepping lane)
-                else {
-                    const PrestigeColor c = prestige_color(w_stage_p[(size_t)ej * rec_stride + lane], s_pscale[lane]);
-                    w_col[lane] = c.r | (c.g << 8) | (c.b << 16);
-                }
-            }
-            wave_lds_sync();
-            for (int Xh = 0; Xh < (cfg.any_hide ? 2 * n : n); Xh++) {
-                const int hv = Xh >= n, X = Xh - hv * n;
-                if (!((cfg.prestige_mask >> X) & 1u)) continue;
-                const uint64_t rx = w_rec[X];
-                if ((rec_byte(rx, MG_AG_FLAGS) & (MG_AF_ACTIVE | MG_AF_PLACED)) != (MG_AF_ACTIVE | MG_AF_PLACED)) continue;
-                uint32_t base = w_grid[rec_byte(rx, MG_AG_X) * H + rec_byte(rx, MG_AG_Y)];
-                if (hv) { if (!base) continue; base = 0; }
-                const uint32_t sdir = rec_byte(rx, MG_AG_DIR);
-                const uint32_t pc = w_col[X];
-                const PrestigeColor col = {pc & 0xFFu, (pc >> 8) & 0xFFu, (pc >> 16) & 0xFFu};
-                const uint32_t amax4 = (uint32_t)cfg.prestige_amax[0] | ((uint32_t)cfg.prestige_amax[1] << 8) |
-                                       ((uint32_t)cfg.prestige_amax[2] << 16) | ((uint32_t)cfg.prestige_amax[3] << 24);
-                const uint32_t amax = (amax4 >> (8u * sdir)) & 0xFFu;   // (no indexed kernarg load: that is a VMEM load)
-                const uint32_t M = ((amax * col.r) >> 8) + ((amax * col.g) >> 8) + ((amax * col.b) >> 8);
-                const uint8_t* white = abase + (size_t)(cfg.prestige_sprite_tile + sdir) * tile_bytes;   // orientation 0, no border
-                const uint8_t* btile = base ? abase + (size_t)(1 + base) * tile_bytes : nullptr;
-                const bool border = (s_oflags2[base] & 1) != 0;
-                const uint8_t* etile = abase + (size_t)tile_bytes;                                   // empty tile
-                uint8_t* t0 = w_dyn + (size_t)(Xh * 4) * npx * 3;
-                for (int p = lane; p < npx; p += kWave) {
-                    const int sp = p * 3;
-                    prestige_pixel(white[sp], col, M, btile ? btile + sp : nullptr, border ? etile + sp : nullptr, t0 + sp);
-                }
-                wave_lds_sync();
-                for (int idx = lane; idx < 3 * npx; idx += kWave) {
-                    const int o = 1 + idx / npx, p = idx - (o - 1) * npx, r = p / TS, c = p - r * TS;
-                    int sr, sc;   // source pixel of output pixel (r, c) at orientation o (rotate_grid, base.py:67-80)
-                    if (o == 3) { sr = c; sc = TS - 1 - r; }
-                    else if (o == 1) { sr = TS - 1 - c; sc = r; }
-                    else { sr = TS - 1 - r; sc = TS - 1 - c; }
-                    const uint8_t* src = t0 + (sr * TS + sc) * 3;
-                    uint8_t* dst = t0 + ((size_t)o * npx + p) * 3;
-                    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
-                }
-            }
-            wave_lds_sync();
-        }
         // 5. tile selection (base.py:275-299) -> atlas byte offset / 4 per view cell
         for (uint32_t it = (uint32_t)lane; it < (uint32_t)(G * nvVV); it += kWave) {
             uint32_t g = 0, iv = it;
@@ -864,6 +809,71 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
         }
         wave_lds_sync();
         } else {
+        if constexpr (kPrestige) {
+            // 4b. tiles of active 'prestige' agents are recoloured per env (render_post) — and blended
+            //     with the object they stand on — before rotation, for all 4 orientations.  With
+            //     hide_item_types a viewer may hide that object and see the agent as a plain cell
+            //     object instead: a second set (hv = 1) on the empty tile.
+            //     Colours first, one lane per agent (the float64 tanh runs once per env, not once per
+            //     agent); w_trow is free after the shadow cast.  Then per agent the tile in orientation
+            //     0 (the only pass with per-pixel arithmetic) and three rotated byte copies of it.
+            const int npx = TS * TS;
+            const uint8_t* abase = kGlobalAtlas ? cfg.atlas : s_atlas;
+            const uint8_t* w_grid = w_stage_g + (size_t)ej * cfg.cells_stride;      // (here, per env: the recoloured tiles have ONE slot;
+            const uint64_t* w_rec = w_stage_r + (size_t)ej * rec_stride;            //  the views of the group are done, w_trow is free)
+            uint32_t* w_col = w_trow;
+            if (lane < n && ((cfg.prestige_mask >> lane) & 1u)) {
+                if (fs.enabled) w_col[lane] = w_stage_c[(size_t)ej * rec_stride + lane];   // (computed by the env's stepping lane)
+                else {
+                    const PrestigeColor c = prestige_color(w_stage_p[(size_t)ej * rec_stride + lane], s_pscale[lane]);
+                    w_col[lane] = c.r | (c.g << 8) | (c.b << 16);
+                }
+            }
+            wave_lds_sync();
+            // (an agent's tile is looked at in the orientation of the VIEWER — phase 5 —: only those of this env's
+            // viewers are made, one of the four for a single agent)
+            uint32_t omask = 0;
+            for (int v = 0; v < nv; v++) omask |= 1u << ((w_vaff[(ej - ej0) * nv + v].y >> 24) & 3u);
+            for (int Xh = 0; Xh < (cfg.any_hide ? 2 * n : n); Xh++) {
+                const int hv = Xh >= n, X = Xh - hv * n;
+                if (!((cfg.prestige_mask >> X) & 1u)) continue;
+                const uint64_t rx = w_rec[X];
+                if ((rec_byte(rx, MG_AG_FLAGS) & (MG_AF_ACTIVE | MG_AF_PLACED)) != (MG_AF_ACTIVE | MG_AF_PLACED)) continue;
+                uint32_t base = w_grid[rec_byte(rx, MG_AG_X) * H + rec_byte(rx, MG_AG_Y)];
+                if (hv) { if (!base) continue; base = 0; }
+                const uint32_t sdir = rec_byte(rx, MG_AG_DIR);
+                const uint32_t pc = w_col[X];
+                const PrestigeColor col = {pc & 0xFFu, (pc >> 8) & 0xFFu, (pc >> 16) & 0xFFu};
+                const uint32_t amax4 = (uint32_t)cfg.prestige_amax[0] | ((uint32_t)cfg.prestige_amax[1] << 8) |
+                                       ((uint32_t)cfg.prestige_amax[2] << 16) | ((uint32_t)cfg.prestige_amax[3] << 24);
+                const uint32_t amax = (amax4 >> (8u * sdir)) & 0xFFu;   // (no indexed kernarg load: that is a VMEM load)
+                const uint32_t M = ((amax * col.r) >> 8) + ((amax * col.g) >> 8) + ((amax * col.b) >> 8);
+                const uint8_t* white = abase + (size_t)(cfg.prestige_sprite_tile + sdir) * tile_bytes;   // orientation 0, no border
+                const uint8_t* btile = base ? abase + (size_t)(1 + base) * tile_bytes : nullptr;
+                const bool border = (s_oflags2[base] & 1) != 0;
+                const uint8_t* etile = abase + (size_t)tile_bytes;                                   // empty tile
+                uint8_t* t0 = w_dyn + (size_t)(Xh * 4) * npx * 3;
+                for (int p = lane; p < npx; p += kWave) {
+                    const int sp = p * 3;
+                    prestige_pixel(white[sp], col, M, btile ? btile + sp : nullptr, border ? etile + sp : nullptr, t0 + sp);
+                }
+                wave_lds_sync();
+                for (int o = 1; o < 4; o++) {
+                    if (!((omask >> o) & 1u)) continue;
+                    for (int p = lane; p < npx; p += kWave) {
+                        const int r = p / TS, c = p - r * TS;
+                        int sr, sc;   // source pixel of output pixel (r, c) at orientation o (rotate_grid, base.py:67-80)
+                        if (o == 3) { sr = c; sc = TS - 1 - r; }
+                        else if (o == 1) { sr = TS - 1 - c; sc = r; }
+                        else { sr = TS - 1 - r; sc = TS - 1 - c; }
+                        const uint8_t* src = t0 + (sr * TS + sc) * 3;
+                        uint8_t* dst = t0 + ((size_t)o * npx + p) * 3;
+                        dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+                    }
+                }
+            }
+            wave_lds_sync();
+        }
         // 6. raster: stream the env's n images out
         if constexpr (kChunkRaster) {
             // The env's n images are one contiguous run of 8-byte *pairs*: PR pairs per pixel row,

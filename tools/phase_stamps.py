@@ -19,6 +19,14 @@ if os.environ.get("TILE"):          # the bench scenario's shape with another vi
     from marlgrid_amd.envs import ClutteredMultiGrid
     env = ClutteredMultiGrid(agents=[GridAgentInterface(color=c, view_size=7, view_tile_size=int(os.environ["TILE"])) for c in ("red", "blue", "purple")],
                              grid_size=15, clutter_density=0.15, batch_size=B, strict=False, auto_reset=True)
+elif os.environ.get("PRESTIGE"):    # PRESTIGE=<agents>,<tile>: the goal-cycle scenario of tools/bench_cases.py ('prestige'-coloured agents)
+    from marlgrid_amd.agents import GridAgentInterface
+    from marlgrid_amd.envs import ClutteredGoalCycleEnv
+    _n, _ts = (int(x) for x in os.environ["PRESTIGE"].split(","))
+    env = ClutteredGoalCycleEnv(
+        agents=[GridAgentInterface(color="prestige", view_size=7, view_tile_size=_ts, view_offset=1) for _ in range(_n)],
+        grid_size=13, clutter_density=0.15, n_bonus_tiles=3, max_steps=250, respawn=True, reward_decay=False,
+        initial_reward=True, penalty=-1.5, batch_size=B, strict=False, auto_reset=True)
 else:
     env = make(os.environ.get("WL", "MarlGrid-3AgentCluttered15x15-v0"), batch_size=B, auto_reset=True, strict=False)
 env.reset()
