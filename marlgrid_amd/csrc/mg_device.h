@@ -91,7 +91,7 @@ struct Div20 {
 
 // per-wave LDS scratch of the obs-render kernel (bytes), shared by host launch code and kernel
 struct RenderScratch {
-    int grid, rec, pres, pcol, vaff, first, second, vbase, vshow, trow, vis, tmap, dyn, out, step, total;
+    int grid, rec, pres, pcol, vaff, first, second, trow, tmap, dyn, out, step, total;
     int stage_envs;    // envs whose inputs (grid + agent records) are staged per batch: 1..8
     int tmap_slots;    // tmaps a wave can hold at once (= stage_envs): the look-ahead depth of its env loop
     int tmap_stride;   // bytes per tmap slot
@@ -136,8 +136,7 @@ struct RenderLaunch {
 // n: the env's agents (records, who stands where); nv: the viewers this launch renders (view-sized arrays)
 __host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride, int n, int nv, int vs, int stage_envs = 1,
                                                                int dyn_bytes = 0, int out_bytes = 0, int piece_rows = 0,
-                                                               bool batch_views = false, bool any_hide = true,
-                                                               int max_view_slots = 0) {
+                                                               bool any_hide = true, int max_view_slots = 0) {
     RenderScratch s;
     int o = 0;
     s.stage_envs = stage_envs;
@@ -146,24 +145,20 @@ __host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride,
     s.rec = o;   o += stage_envs * s.rec_stride * 8;
     s.pres = o;  o += dyn_bytes ? stage_envs * s.rec_stride * 8 : 0;   // agent.prestige of the staged envs
     s.pcol = o;  o += dyn_bytes ? round_up(stage_envs * s.rec_stride * 4, 16) : 0;   // ... and the sprite colours it gives them (fused step)
-    // Views one env at a time: first / second (agents of a cell), vbase / vshow (a view cell's object and
-    // agent, phase 3 -> 5), trow / vis (transparency and visibility rows).  Views of the whole batch at once
-    // (batch_views): a slot of first (second: only with hide_item_types) and trow per staged env; the
-    // (object, agent) pair waits in the env's tmap slot and visibility replaces transparency in place.
+    // Views of a GROUP of envs at once: a slot of first (second: only with hide_item_types — the agents of a cell) and
+    // of trow (transparency rows; visibility replaces them in place) per env of the group; a view cell's (object,
+    // agent) pair waits in the env's tmap slot.
     // (chunk raster — out_bytes == 0 —: up to 4 envs of views at a time; it is HBM-bound and a wave's first store
     // should not wait for eight envs of views; the assemble-and-stream rasters take the whole staged batch)
-    s.view_slots = batch_views ? (out_bytes == 0 && stage_envs > 4 ? 4 : stage_envs) : 1;
+    s.view_slots = out_bytes == 0 && stage_envs > 4 ? 4 : stage_envs;
     if (max_view_slots > 0 && s.view_slots > max_view_slots) s.view_slots = max_view_slots;
     s.cell_stride = round_up(cells_stride, 16);
     // (trow doubles as the per-agent colour words of the 'prestige' recolouring: at least n dwords)
     s.trow_stride = round_up((nv * vs > n ? nv * vs : n) * 4, 16) / 4;
     s.vaff = o;  o += round_up(s.view_slots * nv * 8, 16);   // per viewer: its view's affine map and identity (phase 2b)
     s.first = o; o += s.view_slots * s.cell_stride;
-    s.second = o; o += (batch_views && !any_hide) ? 0 : s.view_slots * s.cell_stride;
-    s.vbase = o; o += batch_views ? 0 : round_up(nv * vs * vs, 16);
-    s.vshow = o; o += batch_views ? 0 : round_up(nv * vs * vs, 16);
+    s.second = o; o += any_hide ? s.view_slots * s.cell_stride : 0;
     s.trow = o;  o += s.view_slots * s.trow_stride * 4;
-    s.vis = batch_views ? s.trow : o; o += batch_views ? 0 : s.trow_stride * 4;
     s.tmap_slots = stage_envs;
     s.tmap_stride = round_up(nv * vs * vs * 2, 16);
     s.tmap = o;  o += s.tmap_slots * s.tmap_stride;
@@ -204,17 +199,16 @@ __host__ __device__ inline RenderScratch render_scratch_for(const MgConfig& cfg,
     // run once per group instead of once per env), full trips in the per-cell phases — with one slot of view scratch per
     // env of the group (see the kernel's pass 0); the recoloured tiles of a 'prestige' env keep their one slot (they are
     // made right before the env's raster)
-    const bool batch_views = true;
     const RenderScratch b = render_scratch_layout(cfg.cells_stride, n, nv, vs, 1, dyn, out, rows);
     const int resident = (atlas_b + 4 * b.total + misc <= 160 * 1024) ? atlas_b : 0;   // else the atlas is read in place
     // ('prestige' — 12-wave workgroups next to a large atlas —: fewer view slots before fewer staged envs or fewer waves)
     for (int slots = dyn ? 8 : 0; dyn && slots >= 1; slots >>= 1) {
-        const RenderScratch t = render_scratch_layout(cfg.cells_stride, n, nv, vs, 8, dyn, out, rows, batch_views, cfg.any_hide != 0, slots);
+        const RenderScratch t = render_scratch_layout(cfg.cells_stride, n, nv, vs, 8, dyn, out, rows, cfg.any_hide != 0, slots);
         if (resident + wpb * t.total + (misc > kRenderShared ? misc : kRenderShared) <= 160 * 1024) return t;   // (the launcher's sum)
     }
     int k = 8;
-    while (k > 1 && resident + wpb * render_scratch_layout(cfg.cells_stride, n, nv, vs, k, dyn, out, rows, batch_views, cfg.any_hide != 0, dyn ? 1 : 0).total + misc > 160 * 1024) k >>= 1;
-    return render_scratch_layout(cfg.cells_stride, n, nv, vs, k, dyn, out, rows, batch_views, cfg.any_hide != 0, dyn ? 1 : 0);
+    while (k > 1 && resident + wpb * render_scratch_layout(cfg.cells_stride, n, nv, vs, k, dyn, out, rows, cfg.any_hide != 0, dyn ? 1 : 0).total + misc > 160 * 1024) k >>= 1;
+    return render_scratch_layout(cfg.cells_stride, n, nv, vs, k, dyn, out, rows, cfg.any_hide != 0, dyn ? 1 : 0);
 }
 
 }  // namespace mg

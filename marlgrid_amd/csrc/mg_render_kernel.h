@@ -126,10 +126,8 @@ __device__ __forceinline__ const T& kernarg_again(size_t offset) {
     uint2* const w_vaff = reinterpret_cast<uint2*>(ws + L.vaff);                                               \
     uint8_t* const w_first = ws + L.first;                                                                     \
     uint8_t* const w_second = ws + L.second;                                                                   \
-    uint8_t* const w_vbase = ws + L.vbase;                                                                     \
-    uint8_t* const w_vshow = ws + L.vshow;                                                                     \
     uint32_t* const w_trow = reinterpret_cast<uint32_t*>(ws + L.trow);                                         \
-    uint32_t* const w_vis = reinterpret_cast<uint32_t*>(ws + L.vis);                                           \
+    uint32_t* const w_vis = w_trow;              /* (visibility replaces transparency in place) */              \
     uint16_t* const w_tmap0 = reinterpret_cast<uint16_t*>(ws + L.tmap);                                        \
     uint8_t* const w_dyn = ws + L.dyn;                                                                         \
     uint8_t* const w_out = ws + L.out;                                                                         \
@@ -145,7 +143,7 @@ __device__ __forceinline__ const T& kernarg_again(size_t offset) {
     const uint32_t NT4 = 4u * (uint32_t)cfg.n_tiles;                                                           \
     const Div20 by_n((uint32_t)n, lc.m_n), by_nv((uint32_t)nv, lc.m_nv), by_nvVV((uint32_t)(nv * VV), lc.m_nvVV); \
     (void)W; (void)H; (void)gdw; (void)off; (void)rec_stride; (void)NT4; (void)by_n; (void)by_nv; (void)by_nvVV;   \
-    (void)w_stage_p; (void)w_stage_c; (void)w_vaff; (void)w_first; (void)w_second; (void)w_vbase; (void)w_vshow; \
+    (void)w_stage_p; (void)w_stage_c; (void)w_vaff; (void)w_first; (void)w_second;                                 \
     (void)w_trow; (void)w_vis; (void)w_tmap0; (void)w_out; (void)dyn_off; (void)w_stage_g; (void)w_stage_r; (void)cfg
 
 // ---- mg_step_render: the step of a batch of staged envs, lane j < kb steps env eb + j (mg_core.h) ----
@@ -308,7 +306,6 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     // env's agents differ in view size / tile size / offset and are rendered group by group (agents.py:19-35).
     const int nv = cfg.n_view ? cfg.n_view : n;
     constexpr bool kChunkRaster = TS_ > 0 && (TS_ % 8) == 0 && RM_ == 0;
-    constexpr bool kBatchViews = true;         // as render_scratch_for: views of a group of envs at once, a scratch slot each
     const RenderScratch& L = lc.L;      // (= render_scratch_for(cfg, WPB, RM_), worked out by the launcher)
     uint8_t* ws = smem + atlas_bytes + kRenderShared + (size_t)wave * L.total;
     uint8_t* w_stage_g = ws + L.grid;                                      // [stage_envs][cells_stride] grids of a batch of envs
@@ -318,10 +315,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     uint2* w_vaff = reinterpret_cast<uint2*>(ws + L.vaff);     // [view_slots][nv] (phase 2b)
     uint8_t* w_first = ws + L.first;
     uint8_t* w_second = ws + L.second;
-    uint8_t* w_vbase = ws + L.vbase;
-    uint8_t* w_vshow = ws + L.vshow;
     uint32_t* w_trow = reinterpret_cast<uint32_t*>(ws + L.trow);
-    uint32_t* w_vis = reinterpret_cast<uint32_t*>(ws + L.vis);       // (views of a batch at once: the same rows as trow)
     uint16_t* w_tmap0 = reinterpret_cast<uint16_t*>(ws + L.tmap);   // [tmap_slots][n*VV]
     uint8_t* w_dyn = ws + L.dyn;                               // [n][4 orientations][tile_bytes]
     uint8_t* w_out = ws + L.out;                               // assemble-and-stream raster: [32 + piece_rows * 3 * P]
@@ -366,9 +360,9 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     // look-ahead depth of this wave (see the env loop): 1, 2, 4, 8 by wave; depth_mode > 0 (measurement
     // builds) forces one depth for all.  Per-env recoloured tiles ('prestige') have one slot only.
     int depth = depth_mode > 0 ? depth_mode : (1 << (wave & 3));
-    if (kBatchViews && !kChunkRaster && TS < 8 && depth_mode <= 0) depth = L.tmap_slots;   // issue-bound: views of the whole batch at once
+    if (!kChunkRaster && TS < 8 && depth_mode <= 0) depth = L.tmap_slots;   // issue-bound: views of the whole batch at once
     if (depth > L.tmap_slots) depth = L.tmap_slots;
-    if (kBatchViews && depth > L.view_slots) depth = L.view_slots;   // (a group's views need a scratch slot per env)
+    if (depth > L.view_slots) depth = L.view_slots;   // (a group's views need a scratch slot per env)
     // ('prestige': bound by the latency of the view phases — one or three viewers leave most lanes of a trip idle when
     // the envs are taken one at a time —: the views of as many envs together as there are slots; the per-env recoloured
     // tiles, which have ONE slot, are made right before the env's raster, phase 4b)
@@ -620,7 +614,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     // Chunk raster (HBM-bound: a launch's store-free head is pure loss): every wave RAMPS — its first env alone, so
     // that its first store leaves as early as possible, then groups of 2, 4, ... up to its depth, where the shadow
     // cast runs once per group and the per-cell phases fill their trips.
-    const bool ramp = kChunkRaster && kBatchViews && depth_mode <= 0 && eb == e0;
+    const bool ramp = kChunkRaster && depth_mode <= 0 && eb == e0;
     int gd = ramp ? 1 : depth;                  // size of the current group
     for (int ej0 = 0; ej0 < kb; ej0 += gd, gd = ramp ? min(2 * gd, L.view_slots) : depth)
     for (int pass = 0; pass < 2; pass++)
@@ -634,13 +628,13 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
         // assemble-and-stream raster the whole look-ahead group: its small-tile configurations are bound
         // by instruction issue, phases 2 and 4 have one lane per AGENT — a lone env leaves 61 of 64 lanes
         // idle — and 3 x 49 view cells fill 2.3 trips of 64 lanes where 8 envs fill 18.4 of 19.
-        if (kBatchViews && ej != ej0) continue;
-        const int G = kBatchViews ? min(kb, ej0 + gd) - ej0 : 1;
+        if (ej != ej0) continue;
+        const int G = min(kb, ej0 + gd) - ej0;
         const int nvVV = nv * VV;
         const uint8_t* g_grid = w_stage_g + (size_t)ej * cfg.cells_stride;      // env ej + g: + g * cells_stride
         const uint64_t* g_rec = w_stage_r + (size_t)ej * rec_stride;            //            + g * rec_stride
         // 1. scratch of the G slots
-        const bool has_second = !kBatchViews || cfg.any_hide;    // (batched: no `second` slots without hide_item_types)
+        const bool has_second = cfg.any_hide;                    // (no `second` slots without hide_item_types)
         for (int i = lane; i < G * (L.cell_stride / 4); i += kWave) {
             reinterpret_cast<uint32_t*>(w_first)[i] = 0xFFFFFFFFu;
             if (has_second) reinterpret_cast<uint32_t*>(w_second)[i] = 0xFFFFFFFFu;
@@ -670,9 +664,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 else if (below == 1 && has_second) w_second[cell] = (uint8_t)a;   // only hide_item_types looks at it
             }
         };
-        if constexpr (kBatchViews) {
-            for (int it = lane; it < G * n; it += kWave) { const int g = (int)by_n.div((uint32_t)it); first_of_cell(g, it - __mul24(g, n)); }
-        } else if (lane < n) first_of_cell(0, lane);
+        for (int it = lane; it < G * n; it += kWave) { const int g = (int)by_n.div((uint32_t)it); first_of_cell(g, it - __mul24(g, n)); }
         // 2b. one lane per VIEWER: its view as an affine map of (column va, row vb) — SURVEY.md A.4's four cases
         //     folded into an origin, a swap bit and two signs — and who it is, so that phase 3 does no per-cell
         //     case analysis (as nested branches it ran every lane through all four headings):
@@ -693,15 +685,12 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             w_vaff[__mul24(g, nv) + v] = make_uint2((uint32_t)(x0 + 256) | ((uint32_t)(y0 + 256) << 10) | (bits << 20),
                                                     (uint32_t)x | ((uint32_t)y << 8) | (k << 16) | (((3u - (uint32_t)dir) & 3u) << 24) | (placed << 26));
         };
-        if constexpr (kBatchViews) {
-            for (int it = lane; it < G * nv; it += kWave) { const int g = (int)by_nv.div((uint32_t)it); view_affine(g, it - __mul24(g, nv)); }
-        } else if (lane < nv) view_affine(0, lane);
+        for (int it = lane; it < G * nv; it += kWave) { const int g = (int)by_nv.div((uint32_t)it); view_affine(g, it - __mul24(g, nv)); }
         wave_lds_sync();
         // 3. egocentric crop + rotate: view cell (a = column, b = row) -> world cell.  All index
         //    arithmetic in 24-bit multiplies (Div20; offsets of slot g are products of small numbers).
         for (uint32_t it = (uint32_t)lane; it < (uint32_t)(G * nvVV); it += kWave) {
-            uint32_t g = 0, iv = it;
-            if constexpr (kBatchViews) { g = by_nvVV.div(it); iv = it - __umul24(g, (uint32_t)nvVV); }
+            const uint32_t g = by_nvVV.div(it), iv = it - __umul24(g, (uint32_t)nvVV);
             const uint32_t v = by_VV.template div<kExactVV>(iv), c = iv - __umul24(v, (uint32_t)VV);
             const uint32_t vb = by_VS.template div<(VS_ > 0)>(c), va = c - __umul24(vb, (uint32_t)VS);
             const uint8_t* w_grid = g_grid + __umul24(g, (uint32_t)cfg.cells_stride);
@@ -732,12 +721,8 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 else if (base == 0 && first != 0xFF && first != k && ((cfg.hide_agent_mask >> k) & 1u))
                     show = w_second[gcell + cell];
             }
-            if constexpr (kBatchViews) {   // the pair waits where phase 5 puts the tile it selects
-                w_tmap[__umul24(g, (uint32_t)(L.tmap_stride / 2)) + iv] = (uint16_t)(base | (show << 8));
-            } else {
-                w_vbase[iv] = (uint8_t)base;
-                w_vshow[iv] = (uint8_t)show;
-            }
+            // the pair waits where phase 5 puts the tile it selects
+            w_tmap[__umul24(g, (uint32_t)(L.tmap_stride / 2)) + iv] = (uint16_t)(base | (show << 8));
         }
         wave_lds_sync();
         // 4. visibility, one lane per viewer
@@ -754,14 +739,11 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             }
             for (int j = 0; j < VS; j++) w_vis[row0 + j] = m[j];
         };
-        if constexpr (kBatchViews) {
-            for (int it = lane; it < G * nv; it += kWave) { const int g = (int)by_nv.div((uint32_t)it); visibility(g, it - __mul24(g, nv)); }
-        } else if (lane < nv) visibility(0, lane);
+        for (int it = lane; it < G * nv; it += kWave) { const int g = (int)by_nv.div((uint32_t)it); visibility(g, it - __mul24(g, nv)); }
         wave_lds_sync();
         // 5. tile selection (base.py:275-299) -> atlas byte offset / 4 per view cell
         for (uint32_t it = (uint32_t)lane; it < (uint32_t)(G * nvVV); it += kWave) {
-            uint32_t g = 0, iv = it;
-            if constexpr (kBatchViews) { g = by_nvVV.div(it); iv = it - __umul24(g, (uint32_t)nvVV); }
+            const uint32_t g = by_nvVV.div(it), iv = it - __umul24(g, (uint32_t)nvVV);
             const uint32_t v = by_VV.template div<kExactVV>(iv), c = iv - __umul24(v, (uint32_t)VV);
             const uint32_t vb = by_VS.template div<(VS_ > 0)>(c), va = c - __umul24(vb, (uint32_t)VS);
             const uint8_t* w_grid = g_grid + __umul24(g, (uint32_t)cfg.cells_stride);
@@ -769,9 +751,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             uint16_t* tmap = w_tmap + __umul24(g, (uint32_t)(L.tmap_stride / 2));
             const uint32_t visible = (w_vis[__umul24(g, (uint32_t)L.trow_stride) + __umul24(v, (uint32_t)VS) + vb] >> va) & 1u;
             const uint32_t orient = (w_vaff[__umul24(g, (uint32_t)nv) + v].y >> 24) & 3u;   // -(dir+1) mod 4 of the viewer
-            uint32_t base, show;
-            if constexpr (kBatchViews) { const uint32_t pair = tmap[iv]; base = pair & 0xFFu; show = pair >> 8; }
-            else { base = w_vbase[iv]; show = w_vshow[iv]; }
+            const uint32_t pair = tmap[iv], base = pair & 0xFFu, show = pair >> 8;
             uint32_t tile = 0;   // shadow
             if (visible) {
                 const uint32_t slot = s_oslot[base];
