@@ -357,16 +357,15 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
         wave_lds_sync();
     }
 
-    // look-ahead depth of this wave (see the env loop): 1, 2, 4, 8 by wave; depth_mode > 0 (measurement
-    // builds) forces one depth for all.  Per-env recoloured tiles ('prestige') have one slot only.
-    int depth = depth_mode > 0 ? depth_mode : (1 << (wave & 3));
-    if (!kChunkRaster && TS < 8 && depth_mode <= 0) depth = L.tmap_slots;   // issue-bound: views of the whole batch at once
+    // look-ahead depth of this wave (see the env loop).  Chunk raster (HBM-bound): 1, 2, 4, 8 by wave.  The
+    // assemble-and-stream rasters are not HBM-bound: the views of the whole staged batch at once (tile 11: +1.5 %
+    // against the by-wave depths, `profiles/r04/ab_render_depth_tile11_7_16_v31.txt`; the 'prestige' variants are bound by
+    // the latency of the view phases — one or three viewers leave most lanes of a trip idle when the envs are taken one at
+    // a time; their per-env recoloured tiles, which have ONE slot, are made right before the env's raster, phase 4b).
+    // depth_mode > 0 (measurement builds) forces one depth for all.
+    int depth = depth_mode > 0 ? depth_mode : kChunkRaster ? (1 << (wave & 3)) : L.tmap_slots;
     if (depth > L.tmap_slots) depth = L.tmap_slots;
     if (depth > L.view_slots) depth = L.view_slots;   // (a group's views need a scratch slot per env)
-    // ('prestige': bound by the latency of the view phases — one or three viewers leave most lanes of a trip idle when
-    // the envs are taken one at a time —: the views of as many envs together as there are slots; the per-env recoloured
-    // tiles, which have ONE slot, are made right before the env's raster, phase 4b)
-    if (kPrestige && !kChunkRaster && depth_mode <= 0) depth = L.view_slots;
     // item -> (slot, rest), view cell -> (viewer, row, column): 24-bit multiplies only (Div20)
     const Div20 by_n((uint32_t)n, lc.m_n), by_nv((uint32_t)nv, lc.m_nv), by_nvVV((uint32_t)(nv * VV), lc.m_nvVV);
     const Div20 by_VV = VS_ ? Div20((uint32_t)VV) : Div20((uint32_t)VV, lc.m_VV), by_VS = VS_ ? Div20((uint32_t)VS) : Div20((uint32_t)VS, lc.m_VS);

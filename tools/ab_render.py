@@ -16,7 +16,13 @@ from marlgrid_amd.envs import make  # noqa: E402
 
 variants = sys.argv[1:] or ["0", "2", "3", "4", "6", "11"]      # "V" or "V:waves_per_workgroup"
 B = int(os.environ.get("B", "32768"))
-env = make(os.environ.get("WL", "MarlGrid-3AgentCluttered15x15-v0"), batch_size=B, auto_reset=True, strict=False)
+if os.environ.get("TILE"):          # the bench scenario's shape with another view_tile_size
+    from marlgrid_amd.agents import GridAgentInterface
+    from marlgrid_amd.envs import ClutteredMultiGrid
+    env = ClutteredMultiGrid(agents=[GridAgentInterface(color=c, view_size=7, view_tile_size=int(os.environ["TILE"])) for c in ("red", "blue", "purple")],
+                             grid_size=15, clutter_density=0.15, batch_size=B, strict=False, auto_reset=True)
+else:
+    env = make(os.environ.get("WL", "MarlGrid-3AgentCluttered15x15-v0"), batch_size=B, auto_reset=True, strict=False)
 env.reset()
 g = torch.Generator().manual_seed(0)
 for i in range(30):
