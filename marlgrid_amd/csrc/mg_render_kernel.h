@@ -357,13 +357,16 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
         wave_lds_sync();
     }
 
-    // look-ahead depth of this wave (see the env loop).  Chunk raster (HBM-bound): 1, 2, 4, 8 by wave.  The
-    // assemble-and-stream rasters are not HBM-bound: the views of the whole staged batch at once (tile 11: +1.5 %
-    // against the by-wave depths, `profiles/r04/ab_render_depth_tile11_7_16_v31.txt`; the 'prestige' variants are bound by
-    // the latency of the view phases — one or three viewers leave most lanes of a trip idle when the envs are taken one at
-    // a time; their per-env recoloured tiles, which have ONE slot, are made right before the env's raster, phase 4b).
-    // depth_mode > 0 (measurement builds) forces one depth for all.
-    int depth = depth_mode > 0 ? depth_mode : kChunkRaster ? (1 << (wave & 3)) : L.tmap_slots;
+    // How many envs' views a wave derives together before it rasters them (see the env loop).  Chunk raster (HBM-bound;
+    // a wave's stores stop while it is in the view phases, so the waves of a workgroup should not all be there at once, and
+    // a group's one shadow cast serves all its envs): groups of TWO at tile 8, env by env at tile 16 / 32 — measured against
+    // one, three, four and against round 3's scheme (1 / 2 / 4 / 8 by wave behind a ramp 1, 2, 4): the whole step -0.96 %
+    // (`profiles/r04/ab_fused_depth_policies_v33.txt`, `ab_render_depth_*`); the 'prestige' variants keep that scheme.  The
+    // assemble-and-stream rasters are not HBM-bound: the views of the whole staged batch at once (tile 11: +1.5 % against
+    // the by-wave depths; the 'prestige' variants are bound by the latency of the view phases — one or three viewers leave
+    // most lanes of a trip idle when the envs are taken one at a time; their per-env recoloured tiles, which have ONE slot,
+    // are made right before the env's raster, phase 4b).  depth_mode > 0 (measurement builds) forces one depth for all.
+    int depth = depth_mode > 0 ? depth_mode : !kChunkRaster ? L.tmap_slots : kPrestige ? (1 << (wave & 3)) : (TS_ == 8 ? 2 : 1);
     if (depth > L.tmap_slots) depth = L.tmap_slots;
     if (depth > L.view_slots) depth = L.view_slots;   // (a group's views need a scratch slot per env)
     // item -> (slot, rest), view cell -> (viewer, row, column): 24-bit multiplies only (Div20)
@@ -606,14 +609,10 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
         }
         wave_lds_sync();
         if (eb == e0) MG_STAMP(3);
-    // `depth` envs at a time: first all their views (phases 1-5 -> one tmap slot each), then all their
-    // rasters.  Waves of a workgroup use different depths (1, 2, 4, 8): otherwise every wave of the chip —
-    // they all start together and do identical work — would sit in the store-free phases 1-5 at the same
-    // moments, env after env, and the HBM write stream would stall chip-wide each time.
-    // Chunk raster (HBM-bound: a launch's store-free head is pure loss): every wave RAMPS — its first env alone, so
-    // that its first store leaves as early as possible, then groups of 2, 4, ... up to its depth, where the shadow
-    // cast runs once per group and the per-cell phases fill their trips.
-    const bool ramp = kChunkRaster && depth_mode <= 0 && eb == e0;
+    // `depth` envs at a time: first all their views (phases 1-5 -> one tmap slot each), then all their rasters (how many:
+    // where `depth` is chosen, above).  The 'prestige' chunk-raster variants RAMP in their first batch — the first env
+    // alone, so that the wave's first store leaves early, then groups of 2, 4, ... up to the wave's depth.
+    const bool ramp = kChunkRaster && kPrestige && depth_mode <= 0 && eb == e0;
     int gd = ramp ? 1 : depth;                  // size of the current group
     for (int ej0 = 0; ej0 < kb; ej0 += gd, gd = ramp ? min(2 * gd, L.view_slots) : depth)
     for (int pass = 0; pass < 2; pass++)
