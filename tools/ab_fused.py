@@ -3,7 +3,7 @@
 build of an earlier commit next to the current one).  First a parity check of every build against the first one
 (two envs, same seeds and actions, 130 steps: observations, rewards, done, records, grids and the whole RNG state
 must be equal), then 9 interleaved rounds of 100 launches each, all into the SAME observation buffer.
-usage: [TILE=5] [B=...] ab_fused.py path/to/ref.so path/to/new.so [...]"""
+usage: [TILE=5 | PRESTIGE=3,8] [B=...] ab_fused.py path/to/ref.so path/to/new.so [...]"""
 import ctypes as C
 import os
 import statistics
@@ -28,6 +28,14 @@ def build():
         from marlgrid_amd.envs import ClutteredMultiGrid
         return ClutteredMultiGrid(agents=[GridAgentInterface(color=c, view_size=7, view_tile_size=int(os.environ["TILE"])) for c in ("red", "blue", "purple")],
                                   grid_size=15, clutter_density=0.15, batch_size=B, strict=False, auto_reset=True, place_obs=PLACE)
+    if os.environ.get("PRESTIGE"):  # PRESTIGE=<agents>,<tile>: the goal-cycle scenario of tools/bench_cases.py ('prestige'-coloured agents)
+        from marlgrid_amd.agents import GridAgentInterface
+        from marlgrid_amd.envs import ClutteredGoalCycleEnv
+        k, ts = (int(x) for x in os.environ["PRESTIGE"].split(","))
+        return ClutteredGoalCycleEnv(
+            agents=[GridAgentInterface(color="prestige", view_size=7, view_tile_size=ts, view_offset=1) for _ in range(k)],
+            grid_size=13, clutter_density=0.15, n_bonus_tiles=3, max_steps=250, respawn=True, reward_decay=False,
+            initial_reward=True, penalty=-1.5, batch_size=B, strict=False, auto_reset=True, place_obs=PLACE)
     return make(WL, batch_size=B, auto_reset=True, strict=False, place_obs=PLACE)
 
 
