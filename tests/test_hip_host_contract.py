@@ -95,7 +95,7 @@ def test_obs_buffer_placement_search():
             o, r, d, _ = env.step(torch.randint(0, 7, (B, 3), generator=g))
         if mode == "search":
             pm = env._groups[0].placement_ms
-            assert 2 <= pm["candidates"] <= 258 and pm["seconds"] < 20.0 and len(pm["kept"]) == 2
+            assert 2 <= pm["candidates"] <= 258 and pm["seconds"] < 90.0 and len(pm["kept"]) == 2    # (seconds: two passes and a stir on never-allocated memory)
             assert sorted(pm["all"])[:2] == sorted(pm["kept"])          # the fastest two were kept
             # a candidate is a 2 P block followed by a P block, the buffer the window centred on their boundary
             P = pm["candidate_bytes"] // 3
