@@ -621,11 +621,9 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
         const int e = eb + ej;
         uint16_t* w_tmap = w_tmap0 + (size_t)(ej - ej0) * (L.tmap_stride / 2);
         if (pass == 0) {
-        // Views of G envs at once (phases 1-5 -> one tmap slot each).  G = 1, env by env, under the
-        // 16-byte-chunk raster (HBM-bound: these phases hide under the other waves' stores).  Under the
-        // assemble-and-stream raster the whole look-ahead group: its small-tile configurations are bound
-        // by instruction issue, phases 2 and 4 have one lane per AGENT — a lone env leaves 61 of 64 lanes
-        // idle — and 3 x 49 view cells fill 2.3 trips of 64 lanes where 8 envs fill 18.4 of 19.
+        // Views of the group's G envs at once (phases 1-5 -> one tmap slot each; G: where `depth` is chosen).  Phases 2
+        // and 4 have one lane per AGENT / VIEWER — a lone env leaves 61 of 64 lanes idle — and 3 x 49 view cells fill
+        // 2.3 trips of 64 lanes where 8 envs fill 18.4 of 19.
         if (ej != ej0) continue;
         const int G = min(kb, ej0 + gd) - ej0;
         const int nvVV = nv * VV;
