@@ -258,14 +258,9 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                                                         uint8_t* __restrict__ dbg_agent,
                                                         uint8_t* __restrict__ dbg_vis, RenderLaunch lc, FusedStep fs) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int VS = VS_ ? VS_ : cfg.view_size;
-    const int TS = TS_ ? TS_ : cfg.tile_size;
-    const int n = cfg.n_agents, W = cfg.W, H = cfg.H;
-    const int tile_bytes = TS * TS * 3;
     // the wave index is uniform: told to the compiler, everything derived from it (the wave's scratch
     // pointers, its run of envs, loop bounds) lives in SGPRs instead of one VGPR each
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int VV = VS * VS;
     MG_STAMP(0);
 #if defined(MG_AB_VARIANTS)
     if (d_ab_stamps && lane == 0)      // where this wave runs: XCC_ID (hwreg 20) << 16 | HW_ID (hwreg 4) [15:0]
@@ -282,7 +277,6 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     // exactly those configs)
     constexpr bool kPadRows = VS_ == 7 && (TS_ == 5 || TS_ == 6) && V_ == 0 && RM_ == 0;
     constexpr int kRowB = kPadRows ? (3 * TS_ + 8 + 7) / 8 * 8 : 0, kRowW = kRowB / 4;
-    const int gdw = cfg.cells_stride / 4;
     const int per_wave = lc.per_wave, depth_mode = lc.depth_mode;
     const int e0 = (blockIdx.x * WPB + wave) * per_wave;
     const int e_end = min(cfg.B, e0 + per_wave);
@@ -302,32 +296,15 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     uint8_t* s_oflags2 = reinterpret_cast<uint8_t*>(s_pscale + MG_MAX_AGENTS); // [MG_MAX_OBJ]
     MgObjDesc* s_obj = reinterpret_cast<MgObjDesc*>(s_oflags2 + MG_MAX_OBJ);      // [MG_MAX_OBJ] (fused step only)
     uint8_t* s_vmap = reinterpret_cast<uint8_t*>(s_obj + MG_MAX_OBJ);             // [MG_MAX_AGENTS] viewer slot -> agent
-    // Viewers: the agents whose observations this launch renders.  All n by default; a subset when the
-    // env's agents differ in view size / tile size / offset and are rendered group by group (agents.py:19-35).
-    const int nv = cfg.n_view ? cfg.n_view : n;
     constexpr bool kChunkRaster = TS_ > 0 && (TS_ % 8) == 0 && RM_ == 0;
-    const RenderScratch& L = lc.L;      // (= render_scratch_for(cfg, WPB, RM_), worked out by the launcher)
-    uint8_t* ws = smem + atlas_bytes + kRenderShared + (size_t)wave * L.total;
-    uint8_t* w_stage_g = ws + L.grid;                                      // [stage_envs][cells_stride] grids of a batch of envs
-    uint64_t* w_stage_r = reinterpret_cast<uint64_t*>(ws + L.rec);        // [stage_envs][rec_stride] their agent records
-    double* w_stage_p = reinterpret_cast<double*>(ws + L.pres);          // [stage_envs][rec_stride] agent.prestige ('prestige' agents only)
-    uint32_t* w_stage_c = reinterpret_cast<uint32_t*>(ws + L.pcol);      // [stage_envs][rec_stride] ... and their sprite colours (fused step)
-    uint2* w_vaff = reinterpret_cast<uint2*>(ws + L.vaff);     // [view_slots][nv] (phase 2b)
-    uint8_t* w_first = ws + L.first;
-    uint8_t* w_second = ws + L.second;
-    uint32_t* w_trow = reinterpret_cast<uint32_t*>(ws + L.trow);
-    uint16_t* w_tmap0 = reinterpret_cast<uint16_t*>(ws + L.tmap);   // [tmap_slots][n*VV]
-    uint8_t* w_dyn = ws + L.dyn;                               // [n][4 orientations][tile_bytes]
-    uint8_t* w_out = ws + L.out;                               // assemble-and-stream raster: [32 + piece_rows * 3 * P]
-    const uint32_t dyn_off = (uint32_t)(w_dyn - smem);         // byte offset from the atlas base
-    const uint32_t NT4 = 4u * (uint32_t)cfg.n_tiles;           // first virtual tile index of the dynamic tiles
-
-    const int h = VS / 2, off = cfg.view_offset;
-    const size_t img_bytes = (size_t)VS * TS * VS * TS * 3;
+    // The wave's scratch pointers (w_stage_g ... w_out), the launch's dimensions (VS, TS, n, nv: the viewers —
+    // all n agents by default; a subset when the env's agents differ in view size / tile size / offset and are
+    // rendered group by group, agents.py:19-35) and the dividers have ONE definition: MG_REGION_LOCALS, expanded
+    // in every region that uses them (lc.L = render_scratch_for(cfg, WPB, RM_), worked out by the launcher).
 
     // raster geometry of the 16-byte-chunk path (see phase 6): pairs per pixel row, a lane's start
     // position and its per-trip advance — constants of the launch, folded at compile time when VS_ > 0
-    const uint32_t PR = (uint32_t)VS * (uint32_t)(TS * 3 / 8);
+    const uint32_t PR = (uint32_t)(VS_ ? VS_ : cfg.view_size) * (uint32_t)((TS_ ? TS_ : cfg.tile_size) * 3 / 8);
     constexpr uint32_t CH_STRIDE = kWave;                             // chunks a wave advances per trip
     const uint32_t c_first = (uint32_t)lane;
     const uint32_t STEP_R = PR ? (2u * CH_STRIDE) / PR : 0u, STEP_P = PR ? (2u * CH_STRIDE) - STEP_R * PR : 0u;
@@ -338,7 +315,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     // wave's stores, so every load consumed in the middle of the run drains the wave's whole store queue first
     // (the pure-store microbenchmark loses 25 % of its throughput to one such load per env).  At the bench batch
     // a wave's run is one batch: it reads before its first store and never again.
-    const int K = L.stage_envs, rec_stride = L.rec_stride;
+    const int K = lc.L.stage_envs;
     MG_STAMP(13);
 
     // assemble-and-stream raster: the wave's run of envs is ONE contiguous output stream.  w_out[0] is
@@ -348,15 +325,6 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     // global_store — through uintptr_t it emitted flat_store, which also counts in lgkmcnt, the LDS counter)
     uint8_t* out_base = obs;
     uint32_t carry = 0, head = 0;
-    if constexpr (!kChunkRaster) {
-        const size_t a0 = (size_t)e0 * nv * img_bytes;
-        head = (uint32_t)((reinterpret_cast<uintptr_t>(obs) + a0) & 15);
-        carry = head;
-        out_base = obs + a0 - head;
-        for (int i = lane; i < L.out_chunks; i += kWave) reinterpret_cast<uint4*>(w_out)[i] = make_uint4(0, 0, 0, 0);
-        wave_lds_sync();
-    }
-
     // How many envs' views a wave derives together before it rasters them (see the env loop).  Chunk raster (HBM-bound;
     // a wave's stores stop while it is in the view phases, so the waves of a workgroup should not all be there at once, and
     // a group's one shadow cast serves all its envs): groups of TWO at tile 8, env by env at tile 16 / 32 — measured against
@@ -366,12 +334,22 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     // the by-wave depths; the 'prestige' variants are bound by the latency of the view phases — one or three viewers leave
     // most lanes of a trip idle when the envs are taken one at a time; their per-env recoloured tiles, which have ONE slot,
     // are made right before the env's raster, phase 4b).  depth_mode > 0 (measurement builds) forces one depth for all.
-    int depth = depth_mode > 0 ? depth_mode : !kChunkRaster ? L.tmap_slots : kPrestige ? (1 << (wave & 3)) : (TS_ == 8 ? 2 : 1);
-    if (depth > L.tmap_slots) depth = L.tmap_slots;
-    if (depth > L.view_slots) depth = L.view_slots;   // (a group's views need a scratch slot per env)
-    // item -> (slot, rest), view cell -> (viewer, row, column): 24-bit multiplies only (Div20)
-    const Div20 by_n((uint32_t)n, lc.m_n), by_nv((uint32_t)nv, lc.m_nv), by_nvVV((uint32_t)(nv * VV), lc.m_nvVV);
-    const Div20 by_VV = VS_ ? Div20((uint32_t)VV) : Div20((uint32_t)VV, lc.m_VV), by_VS = VS_ ? Div20((uint32_t)VS) : Div20((uint32_t)VS, lc.m_VS);
+    int depth;
+    {
+        MG_REGION_LOCALS;
+        if constexpr (!kChunkRaster) {
+            const size_t a0 = (size_t)e0 * nv * img_bytes;
+            head = (uint32_t)((reinterpret_cast<uintptr_t>(obs) + a0) & 15);
+            carry = head;
+            out_base = obs + a0 - head;
+            for (int i = lane; i < L.out_chunks; i += kWave) reinterpret_cast<uint4*>(w_out)[i] = make_uint4(0, 0, 0, 0);
+            wave_lds_sync();
+        }
+        depth = depth_mode > 0 ? depth_mode : !kChunkRaster ? L.tmap_slots : kPrestige ? (1 << (wave & 3)) : (TS_ == 8 ? 2 : 1);
+        if (depth > L.tmap_slots) depth = L.tmap_slots;
+        if (depth > L.view_slots) depth = L.view_slots;   // (a group's views need a scratch slot per env)
+    }
+    // item -> (slot, rest), view cell -> (viewer, row, column): 24-bit multiplies only (Div20; MG_REGION_LOCALS)
     constexpr bool kExactVV = VS_ > 0 && VS_ <= 9;     // 16 viewers * VS^2 cells: x * (m*d - 2^20) < 2^20 holds (checked below)
     static_assert(VS_ == 0 || VS_ > 9 || (16u * VS_ * VS_ * ((((1u << 20) + VS_ * VS_ - 1u) / (VS_ * VS_)) * (VS_ * VS_) - (1u << 20)) < (1u << 20)), "Div20 exactness");
 
