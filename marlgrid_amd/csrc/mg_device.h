@@ -111,12 +111,25 @@ struct RenderScratch {
 __host__ __device__ inline bool render_pad_rows(const MgConfig& cfg) {
     return cfg.view_size == 7 && (cfg.tile_size == 5 || cfg.tile_size == 6) && cfg.prestige_mask == 0;
 }
+// ... and the configurations the GATHER raster (mg_gather.h; the kernel's RM_ == 2, `mode` 2 below) is instantiated for:
+// the reference's default view with its default 5-pixel tiles (agents.py:21-22), and 6-pixel tiles.  Its tile rows sit
+// in LDS with 16 zero bytes in front (GatherGeom::RS bytes per row, 32 zero bytes behind the last).
+__host__ __device__ inline bool render_gather(const MgConfig& cfg) {
+#if defined(MG_EXP) && (MG_EXP & 1)
+    return false;      // (A/B builds: the assemble-and-stream raster on padded rows, as before)
+#else
+    return cfg.view_size == 7 && (cfg.tile_size == 5 || cfg.tile_size == 6) && cfg.prestige_mask == 0;
+#endif
+}
 __host__ __device__ inline int render_row_bytes(int ts) { return (3 * ts + 8 + 7) / 8 * 8; }
+__host__ __device__ inline int render_gather_row_bytes(int ts) { return (16 + 3 * ts + 3) / 4 * 4; }
 __host__ __device__ inline int render_atlas_raw_bytes(const MgConfig& cfg) {
     return (4 * cfg.n_tiles * cfg.tile_size * cfg.tile_size * 3 + 15) / 16 * 16;
 }
-__host__ __device__ inline int render_atlas_lds_bytes(const MgConfig& cfg) {
-    if (!render_pad_rows(cfg)) return render_atlas_raw_bytes(cfg);
+// `mode`: the kernel's RM_ (0: by tile size, 1: assemble-and-stream forced — measurement builds —, 2: gather)
+__host__ __device__ inline int render_atlas_lds_bytes(const MgConfig& cfg, int mode) {
+    if (mode == 2) return (4 * cfg.n_tiles * cfg.tile_size * render_gather_row_bytes(cfg.tile_size) + 32 + 15) / 16 * 16;
+    if (mode != 0 || !render_pad_rows(cfg)) return render_atlas_raw_bytes(cfg);
     return (4 * cfg.n_tiles * cfg.tile_size * render_row_bytes(cfg.tile_size) + 8 + 15) / 16 * 16;   // (+ 8 zero bytes behind the last row)
 }
 
@@ -136,7 +149,7 @@ struct RenderLaunch {
 // n: the env's agents (records, who stands where); nv: the viewers this launch renders (view-sized arrays)
 __host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride, int n, int nv, int vs, int stage_envs = 1,
                                                                int dyn_bytes = 0, int out_bytes = 0, int piece_rows = 0,
-                                                               bool any_hide = true, int max_view_slots = 0) {
+                                                               bool any_hide = true, int max_view_slots = 0, bool gather = false) {
     RenderScratch s;
     int o = 0;
     s.stage_envs = stage_envs;
@@ -150,7 +163,8 @@ __host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride,
     // agent) pair waits in the env's tmap slot.
     // (chunk raster — out_bytes == 0 —: up to 4 envs of views at a time; it is HBM-bound and a wave's first store
     // should not wait for eight envs of views; the assemble-and-stream rasters take the whole staged batch)
-    s.view_slots = out_bytes == 0 && stage_envs > 4 ? 4 : stage_envs;
+    // (the gather raster: no piece buffer either, but a group's raster is ONE stream over all its envs: the whole batch)
+    s.view_slots = out_bytes == 0 && !gather && stage_envs > 4 ? 4 : stage_envs;
     if (max_view_slots > 0 && s.view_slots > max_view_slots) s.view_slots = max_view_slots;
     s.cell_stride = round_up(cells_stride, 16);
     // (trow doubles as the per-agent colour words of the 'prestige' recolouring: at least n dwords)
@@ -160,8 +174,8 @@ __host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride,
     s.second = o; o += any_hide ? s.view_slots * s.cell_stride : 0;
     s.trow = o;  o += s.view_slots * s.trow_stride * 4;
     s.tmap_slots = stage_envs;
-    s.tmap_stride = round_up(nv * vs * vs * 2, 16);
-    s.tmap = o;  o += s.tmap_slots * s.tmap_stride;
+    s.tmap_stride = gather ? nv * vs * vs * 2 : round_up(nv * vs * vs * 2, 16);   // (gather: DENSE — band g of a group is entry g * vs)
+    s.tmap = o;  o += round_up(s.tmap_slots * s.tmap_stride, 16);
     s.dyn = o;   o += round_up(dyn_bytes, 16);   // per-env recoloured ('prestige') agent tiles
     s.out = o;   o += round_up(out_bytes, 16);   // assemble-and-stream raster: the piece being assembled
     s.piece_rows = piece_rows;
@@ -185,12 +199,14 @@ __host__ __device__ inline RenderScratch render_scratch_for(const MgConfig& cfg,
     const int n = cfg.n_agents, vs = cfg.view_size, ts = cfg.tile_size;
     const int nv = cfg.n_view ? cfg.n_view : n;
     const int dyn = cfg.prestige_mask ? (cfg.any_hide ? 2 : 1) * n * 4 * ts * ts * 3 : 0;
-    const int atlas_b = render_atlas_lds_bytes(cfg), misc = 1024;
+    // (`fixed`: what a workgroup holds besides its waves' scratch — exactly the launcher's sum, launch_render_t)
+    const int atlas_b = render_atlas_lds_bytes(cfg, mode), fixed = kRenderShared;
+    const bool gather = mode == 2;
     int rows = 0, out = 0;
-    if (!render_chunk_raster(cfg, mode)) {
+    if (!gather && !render_chunk_raster(cfg, mode)) {
         const int rb = 3 * vs * ts;
         rows = 4096 / rb;
-        if (render_pad_rows(cfg)) rows = rows / (64 / vs) * (64 / vs);      // whole trips of 64 / vs pixel rows (mg_render.hip)
+        if (mode == 0 && render_pad_rows(cfg)) rows = rows / (64 / vs) * (64 / vs);      // whole trips of 64 / vs pixel rows (mg_render.hip)
         if (rows < 1) rows = 1;
         if (rows > nv * vs * ts) rows = nv * vs * ts;
         out = 32 + rows * rb;
@@ -199,16 +215,16 @@ __host__ __device__ inline RenderScratch render_scratch_for(const MgConfig& cfg,
     // run once per group instead of once per env), full trips in the per-cell phases — with one slot of view scratch per
     // env of the group (see the kernel's pass 0); the recoloured tiles of a 'prestige' env keep their one slot (they are
     // made right before the env's raster)
-    const RenderScratch b = render_scratch_layout(cfg.cells_stride, n, nv, vs, 1, dyn, out, rows);
-    const int resident = (atlas_b + 4 * b.total + misc <= 160 * 1024) ? atlas_b : 0;   // else the atlas is read in place
+    const RenderScratch b = render_scratch_layout(cfg.cells_stride, n, nv, vs, 1, dyn, out, rows, true, 0, gather);
+    const int resident = (atlas_b + 4 * b.total + fixed <= 160 * 1024) ? atlas_b : 0;   // else the atlas is read in place
     // ('prestige' — 12-wave workgroups next to a large atlas —: fewer view slots before fewer staged envs or fewer waves)
     for (int slots = dyn ? 8 : 0; dyn && slots >= 1; slots >>= 1) {
         const RenderScratch t = render_scratch_layout(cfg.cells_stride, n, nv, vs, 8, dyn, out, rows, cfg.any_hide != 0, slots);
-        if (resident + wpb * t.total + (misc > kRenderShared ? misc : kRenderShared) <= 160 * 1024) return t;   // (the launcher's sum)
+        if (resident + wpb * t.total + fixed <= 160 * 1024) return t;
     }
     int k = 8;
-    while (k > 1 && resident + wpb * render_scratch_layout(cfg.cells_stride, n, nv, vs, k, dyn, out, rows, cfg.any_hide != 0, dyn ? 1 : 0).total + misc > 160 * 1024) k >>= 1;
-    return render_scratch_layout(cfg.cells_stride, n, nv, vs, k, dyn, out, rows, cfg.any_hide != 0, dyn ? 1 : 0);
+    while (k > 1 && resident + wpb * render_scratch_layout(cfg.cells_stride, n, nv, vs, k, dyn, out, rows, cfg.any_hide != 0, dyn ? 1 : 0, gather).total + fixed > 160 * 1024) k >>= 1;
+    return render_scratch_layout(cfg.cells_stride, n, nv, vs, k, dyn, out, rows, cfg.any_hide != 0, dyn ? 1 : 0, gather);
 }
 
 }  // namespace mg

@@ -19,32 +19,43 @@ MG_RENDER_GROUP_B(MG_RENDER_EXTERN)
 MG_RENDER_GROUP_C(MG_RENDER_EXTERN)
 MG_RENDER_GROUP_D(MG_RENDER_EXTERN)
 MG_RENDER_GROUP_E(MG_RENDER_EXTERN)
+MG_RENDER_GROUP_G(MG_RENDER_EXTERN)
 MG_RENDER_GROUP_V(MG_RENDER_EXTERN)
 #endif
 
+// The raster a configuration gets (the kernel's RM_): 2 = gather (mg_gather.h) where it is instantiated and its padded
+// atlas fits LDS next to 4 waves of scratch, else 0 = by tile size (16-byte chunks / assemble-and-stream).
+static int render_mode_for(const MgConfig& cfg) {
+    if (!render_gather(cfg)) return 0;
+    const RenderScratch L = render_scratch_for(cfg, 4, 2);
+    return (size_t)render_atlas_lds_bytes(cfg, 2) + kRenderShared + 4 * (size_t)L.total <= 160 * 1024 ? 2 : 0;
+}
+
 int render_min_lds_bytes(const MgConfig& cfg) {
-    const RenderScratch L = render_scratch_for(cfg, 4);
-    const int atlas_b = render_atlas_lds_bytes(cfg);
+    const int mode = render_mode_for(cfg);
+    const RenderScratch L = render_scratch_for(cfg, 4, mode);
+    const int atlas_b = render_atlas_lds_bytes(cfg, mode);
     const int rest = kRenderShared + 4 * L.total;
     return atlas_b + rest <= 160 * 1024 ? atlas_b + rest : rest;   // else the atlas is read in place
 }
 
-static size_t render_lds_bytes(const MgConfig& cfg, int wpb) {
-    const RenderScratch L = render_scratch_for(cfg, wpb);
-    return (size_t)render_atlas_lds_bytes(cfg) + kRenderShared + (size_t)wpb * L.total;
+static size_t render_lds_bytes(const MgConfig& cfg, int wpb, int mode = 0) {
+    const RenderScratch L = render_scratch_for(cfg, wpb, mode);
+    return (size_t)render_atlas_lds_bytes(cfg, mode) + kRenderShared + (size_t)wpb * L.total;
 }
 
 // Workgroup shape.  16 waves per workgroup walk 16 *adjacent* envs at a time (a 450 KB contiguous
 // output window per workgroup, one atlas copy per 16 waves): measured +7..13 % HBM write throughput
 // over 4-wave workgroups at the bench batch.  Small batches keep 4-wave workgroups so that they
 // still spread over all CUs.
-static int choose_wpb(const MgConfig& cfg) {
+static int choose_wpb(const MgConfig& cfg, int mode) {
 #if defined(MG_AB_VARIANTS)
     if (const char* f = getenv("MG_RENDER_WPB")) { int w = atoi(f); if (w == 4 || w == 8 || w == 12 || w == 16) return w; }
 #endif
-    const RenderScratch L = render_scratch_for(cfg, 16);
-    size_t lds16 = (size_t)render_atlas_lds_bytes(cfg) + kRenderShared + 16 * (size_t)L.total;
-    return (cfg.B >= 4096 && lds16 <= 160 * 1024) ? 16 : 4;
+#if defined(MG_EXP) && (MG_EXP & 6)      // experiment builds (tools/wpb_sweep.py): one workgroup shape for every batch
+    return (MG_EXP & 6) == 2 ? 4 : (MG_EXP & 6) == 4 ? 8 : 16;
+#endif
+    return (cfg.B >= 4096 && render_lds_bytes(cfg, 16, mode) <= 160 * 1024) ? 16 : 4;
 }
 
 #define MG_RENDER_DISPATCH(VS, TS, V)                                                                      \
@@ -82,10 +93,11 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
     return launch_render_t<MG_DEV_ONLY>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
 #else
     const int vs = cfg.view_size, ts = cfg.tile_size;
-    const int wpb = choose_wpb(cfg);
+    const int mode = render_mode_for(cfg);
+    const int wpb = choose_wpb(cfg, mode);
     if (cfg.prestige_mask) {   // per-env recoloured agent tiles (LDS), 4-wave workgroups
         const RenderScratch L = render_scratch_for(cfg, 4);
-        const size_t lds4 = (size_t)render_atlas_lds_bytes(cfg) + kRenderShared +
+        const size_t lds4 = (size_t)render_atlas_lds_bytes(cfg, 0) + kRenderShared +
                             4 * (size_t)L.total;
         if (lds4 > 160 * 1024) {   // the static atlas stays in global memory
             if (ts == 8) return launch_render_t<0, 8, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
@@ -121,9 +133,15 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
         if (ts == 32) return launch_render_t<0, 32, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
         return launch_render_t<0, 0, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
     }
+    if (mode == 2) {   // the gather raster: view 7 with 5- or 6-pixel tiles (GridAgentInterface's defaults, agents.py:21-22)
+        if (ts == 5) return wpb == 16 ? launch_render_t<7, 5, 16, 0, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)
+                                      : launch_render_t<7, 5, 4, 0, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
+        return wpb == 16 ? launch_render_t<7, 6, 16, 0, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)
+                         : launch_render_t<7, 6, 4, 0, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
+    }
     {   // atlas too large for LDS (next to 4 waves of scratch): read it from global memory instead
         const RenderScratch L = render_scratch_for(cfg, 4);
-        const size_t lds4 = (size_t)render_atlas_lds_bytes(cfg) + kRenderShared +
+        const size_t lds4 = (size_t)render_atlas_lds_bytes(cfg, 0) + kRenderShared +
                             4 * (size_t)L.total;
         if (lds4 > 160 * 1024) {
             if (ts == 8) return launch_render_t<0, 8, 4, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);

@@ -34,6 +34,7 @@
 #include <stdlib.h>   // getenv: the measurement build only (libmarlgrid_hip_ab.so, loaded by tools/)
 #endif
 #include "mg_occlude.h"
+#include "mg_gather.h"
 
 namespace mg {
 
@@ -275,8 +276,14 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     const int atlas_bytes = kGlobalAtlas ? 0 : lc.atlas_lds;       // in LDS (render_atlas_lds_bytes)
     // tile rows padded with zeros in LDS (mg_device.h: render_pad_rows — the launcher takes this instantiation for
     // exactly those configs)
-    constexpr bool kPadRows = VS_ == 7 && (TS_ == 5 || TS_ == 6) && V_ == 0 && RM_ == 0;
-    constexpr int kRowB = kPadRows ? (3 * TS_ + 8 + 7) / 8 * 8 : 0, kRowW = kRowB / 4;
+    // ... and, RM_ == 2, for the gather raster (mg_gather.h): 16 zero bytes in front of every row)
+    constexpr bool kGather = RM_ == 2;
+    static_assert(!kGather || (VS_ > 0 && TS_ >= 5 && (TS_ % 8) != 0 && V_ == 0), "gather raster: compile-time view and tile size, static atlas in LDS");
+    typedef GatherGeom<kGather ? VS_ : 7, kGather ? TS_ : 5> Gm;
+    constexpr bool kPadRows = (VS_ == 7 && (TS_ == 5 || TS_ == 6) && V_ == 0 && RM_ == 0) || kGather;
+    constexpr int kRowB = kGather ? Gm::RS : kPadRows ? (3 * TS_ + 8 + 7) / 8 * 8 : 0, kRowW = kRowB / 4;
+    constexpr int kPadFrontW = kGather ? Gm::FRONT / 4 : 1, kPadTailW = kGather ? Gm::TAIL / 4 : 2;   // zero dwords in front of a row / behind the last
+    constexpr int kPadQ = kGather ? 6 : 4;                          // padded dwords per thread in the prologue's first round trip
     const int per_wave = lc.per_wave, depth_mode = lc.depth_mode;
     const int e0 = (blockIdx.x * WPB + wave) * per_wave;
     const int e_end = min(cfg.B, e0 + per_wave);
@@ -297,6 +304,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     MgObjDesc* s_obj = reinterpret_cast<MgObjDesc*>(s_oflags2 + MG_MAX_OBJ);      // [MG_MAX_OBJ] (fused step only)
     uint8_t* s_vmap = reinterpret_cast<uint8_t*>(s_obj + MG_MAX_OBJ);             // [MG_MAX_AGENTS] viewer slot -> agent
     constexpr bool kChunkRaster = TS_ > 0 && (TS_ % 8) == 0 && RM_ == 0;
+    constexpr bool kStreamRaster = !kChunkRaster && !kGather;     // assemble-and-stream
     // The wave's scratch pointers (w_stage_g ... w_out), the launch's dimensions (VS, TS, n, nv: the viewers —
     // all n agents by default; a subset when the env's agents differ in view size / tile size / offset and are
     // rendered group by group, agents.py:19-35) and the dividers have ONE definition: MG_REGION_LOCALS, expanded
@@ -337,7 +345,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     int depth;
     {
         MG_REGION_LOCALS;
-        if constexpr (!kChunkRaster) {
+        if constexpr (kStreamRaster) {
             const size_t a0 = (size_t)e0 * nv * img_bytes;
             head = (uint32_t)((reinterpret_cast<uintptr_t>(obs) + a0) & 15);
             carry = head;
@@ -419,24 +427,18 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             uint64_t hide0 = 0;
             double pscale0 = 0.;
             // padded tile rows (kPadRows): LDS dword d is 4 bytes of row d / kRowW, read as the 8 aligned bytes of the
-            // atlas around them (pad_window) and cut out when they are stored
-            const int raw16 = render_atlas_raw_bytes(cfg), npd = kPadRows ? 4 * cfg.n_tiles * TS * kRowW + 2 : 0;
-            auto pad_window = [&](int d, uint32_t& cut, uint32_t& keep) -> int {     // byte offset of the window, -1: zeros
-                const int row = d / (kRowW ? kRowW : 1), k = d - row * kRowW, j0 = 4 * k - 4;    // row bytes [j0, j0 + 4)
-                const int nvb = min(4, 3 * TS - j0);
-                if (k == 0 || nvb <= 0 || row >= 4 * cfg.n_tiles * TS) return -1;
-                const int sb = row * 3 * TS + j0, a = min(sb & ~3, raw16 - 8);
-                cut = (uint32_t)(sb - a) * 8u;                                        // (0 .. 56 bits)
-                keep = nvb >= 4 ? 0xFFFFFFFFu : (1u << (8 * nvb)) - 1u;
-                return a;
-            };
-            uint2 pw[4] = {make_uint2(0, 0), make_uint2(0, 0), make_uint2(0, 0), make_uint2(0, 0)};
+            // atlas around them (pad_source, mg_gather.h) and cut out when they are stored
+            const int raw16 = render_atlas_raw_bytes(cfg), pad_rows = 4 * cfg.n_tiles * TS, npd = kPadRows ? pad_rows * kRowW + kPadTailW : 0;
+            (void)raw16; (void)pad_rows;
+            uint2 pw[kPadQ];
+#pragma unroll
+            for (int q = 0; q < kPadQ; q++) pw[q] = make_uint2(0, 0);
             if (first) {
                 if constexpr (kPadRows) {
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
+                    for (int q = 0; q < kPadQ; q++) {
                         uint32_t cut, keep;
-                        const int a = tidl + q * T < npd ? pad_window(tidl + q * T, cut, keep) : -1;
+                        const int a = tidl + q * T < npd ? pad_source<3 * TS_, kPadFrontW, kRowW>(tidl + q * T, pad_rows, raw16, cut, keep) : -1;
                         if (a >= 0) pw[q] = *reinterpret_cast<const uint2*>(cfg.atlas + a);
                     }
                 } else {
@@ -479,19 +481,18 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             if (first) {
                 if constexpr (kPadRows) {
                     uint32_t* adst = reinterpret_cast<uint32_t*>(s_atlas);
-                    auto cut_out = [&](uint2 w, uint32_t cut, uint32_t keep) -> uint32_t {
-                        return (uint32_t)((((uint64_t)w.y << 32) | w.x) >> cut) & keep;
-                    };
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
+                    for (int q = 0; q < kPadQ; q++) {
                         const int d = tidl + q * T;
                         uint32_t cut = 0, keep = 0;
-                        if (d < npd) adst[d] = pad_window(d, cut, keep) >= 0 ? cut_out(pw[q], cut, keep) : 0u;
+                        if (d < npd) adst[d] = pad_source<3 * TS_, kPadFrontW, kRowW>(d, pad_rows, raw16, cut, keep) >= 0 ? pad_cut(pw[q].x, pw[q].y, cut, keep) : 0u;
                     }
-                    for (int d = tidl + 4 * T; d < npd; d += T) {                 // (larger atlases: the rest, a second trip)
+                    for (int d = tidl + kPadQ * T; d < npd; d += T) {             // (larger atlases: the rest, a second trip)
                         uint32_t cut = 0, keep = 0;
-                        const int a = pad_window(d, cut, keep);
-                        adst[d] = a >= 0 ? cut_out(*reinterpret_cast<const uint2*>(cfg.atlas + a), cut, keep) : 0u;
+                        const int a = pad_source<3 * TS_, kPadFrontW, kRowW>(d, pad_rows, raw16, cut, keep);
+                        uint2 w = make_uint2(0, 0);
+                        if (a >= 0) w = *reinterpret_cast<const uint2*>(cfg.atlas + a);
+                        adst[d] = a >= 0 ? pad_cut(w.x, w.y, cut, keep) : 0u;
                     }
                 } else {
                 uint4* adst = reinterpret_cast<uint4*>(s_atlas);
@@ -829,7 +830,13 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             wave_lds_sync();
         }
         // 6. raster: stream the env's n images out
-        if constexpr (kChunkRaster) {
+        if constexpr (kGather) {
+            // the whole GROUP's images as one stream (mg_gather.h): when the group's first env comes up
+            if (ej == ej0) {
+                const int G = min(kb, ej0 + gd) - ej0;
+                gather_group<VS_, TS_>(lane, reinterpret_cast<const uint8_t*>(w_tmap0), s_atlas, obs + (size_t)e * nv * img_bytes, (uint32_t)((size_t)G * nv * img_bytes));
+            }
+        } else if constexpr (kChunkRaster) {
             // The env's n images are one contiguous run of 8-byte *pairs*: PR pairs per pixel row,
             // PT per tile row (TD even => a pair never straddles a tile row, and every pair is
             // 8-byte aligned in the atlas: ds_read_b64).  A 16-byte chunk is pairs (2c, 2c+1).
@@ -1139,7 +1146,7 @@ hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_t* obs,
                                   uint8_t* v, hipStream_t s, const FusedStep* fs) {
     static_assert(RM_ == 1 || TS_ == 0 || (TS_ % 8) != 0 || TS_ == 8 || TS_ == 16 || TS_ == 32, "see render_chunk_raster");
     const RenderScratch L = render_scratch_for(cfg, WPB, RM_);
-    const size_t atlas_lds = (V_ == 8 || V_ == 12) ? 0 : (size_t)render_atlas_lds_bytes(cfg);
+    const size_t atlas_lds = (V_ == 8 || V_ == 12) ? 0 : (size_t)render_atlas_lds_bytes(cfg, RM_);
     size_t lds = atlas_lds + kRenderShared + WPB * (size_t)L.total;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {
@@ -1204,6 +1211,8 @@ hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_t* obs,
 #define MG_RENDER_GROUP_E(X)                                                                                               \
     X(7, 0, 12, 9, 0) X(7, 0, 8, 9, 0) X(7, 0, 4, 9, 0) X(0, 32, 4, 9, 0) X(0, 0, 4, 9, 0)                                      \
     X(0, 8, 4, 12, 0) X(0, 16, 4, 12, 0) X(0, 32, 4, 12, 0) X(0, 0, 4, 12, 0)
+#define MG_RENDER_GROUP_G(X) /* the gather raster (mg_gather.h): view 7, 5- and 6-pixel tiles */                          \
+    X(7, 5, 16, 0, 2) X(7, 5, 4, 0, 2) X(7, 6, 16, 0, 2) X(7, 6, 4, 0, 2)
 #if defined(MG_AB_VARIANTS)
 #define MG_RENDER_GROUP_V(X) /* measurement variants (tools/ab_render.py) */                                               \
     X(7, 8, 16, 2, 0) X(7, 8, 4, 2, 0) X(7, 8, 16, 3, 0) X(7, 8, 4, 3, 0) X(7, 8, 16, 4, 0) X(7, 8, 4, 4, 0)                     \

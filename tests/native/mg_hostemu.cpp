@@ -11,6 +11,14 @@
 
 #include "mg_core.h"
 
+// the gather raster's index arithmetic (mg_gather.h), every LDS offset it forms checked against the buffers
+static uint32_t g_gather_tmap_bytes = 0, g_gather_atlas_bytes = 0, g_gather_oob = 0;
+#define MG_GATHER_BOUNDS(tmap_off, atlas_off)                                                               \
+    do {                                                                                                    \
+        if ((uint32_t)(tmap_off) + 2u > g_gather_tmap_bytes || (uint32_t)(atlas_off) + 20u > g_gather_atlas_bytes) g_gather_oob++; \
+    } while (0)
+#include "mg_gather.h"
+
 namespace {
 struct Scratch {
     std::vector<uint64_t> rec;
@@ -83,6 +91,55 @@ int emu_place(const MgConfig* cfg, const MgState* st, int what, int x0, int y0, 
                       s.rec.data(), 1, 0);
     }
     return 0;
+}
+
+}  // extern "C"
+
+namespace {
+// The obs kernel's gather raster for one GROUP of envs as one wave runs it: the padded atlas built dword by dword as
+// the kernel's prologue does (pad_source / pad_cut), then gather_group lane by lane (the lanes of the raster do not
+// talk to each other).  Returns the number of out-of-range LDS offsets formed (0 = none), -1 for bad arguments.
+template <int VS, int TS>
+int gather_emu(int n_vt, const uint8_t* atlas_raw, const uint16_t* tmap, int tmap_entries, uint8_t* dst, uint32_t stream_bytes) {
+    typedef mg::GatherGeom<VS, TS> Gm;
+    const int rows = n_vt * TS, raw16 = (rows * Gm::SEG + 15) / 16 * 16;
+    std::vector<uint8_t> raw(raw16, 0);
+    memcpy(raw.data(), atlas_raw, (size_t)rows * Gm::SEG);
+    constexpr int ROW_W = Gm::RS / 4;
+    const int npd = rows * ROW_W + Gm::TAIL / 4;
+    std::vector<uint32_t> padded(npd, 0xA5A5A5A5u);
+    for (int d = 0; d < npd; d++) {
+        uint32_t cut, keep;
+        const int a = mg::pad_source<Gm::SEG, Gm::FRONT / 4, ROW_W>(d, rows, raw16, cut, keep);
+        uint32_t lo = 0, hi = 0;
+        if (a >= 0) { memcpy(&lo, raw.data() + a, 4); memcpy(&hi, raw.data() + a + 4, 4); }
+        padded[d] = a >= 0 ? mg::pad_cut(lo, hi, cut, keep) : 0u;
+    }
+    g_gather_tmap_bytes = (uint32_t)tmap_entries * 2u;
+    g_gather_atlas_bytes = (uint32_t)npd * 4u;
+    g_gather_oob = 0;
+    for (int lane = 0; lane < 64; lane++)
+        mg::gather_group<VS, TS>(lane, reinterpret_cast<const uint8_t*>(tmap), reinterpret_cast<const uint8_t*>(padded.data()), dst, stream_bytes);
+    return (int)g_gather_oob;
+}
+}  // namespace
+
+extern "C" {
+
+// geometry of (vs, ts) as the kernel sees it: out[0..7] = SEG, RS, PC, PR, C, NT, LPT, kConstBand
+int emu_gather(int vs, int ts, int n_vt, const uint8_t* atlas_raw, const uint16_t* tmap, int tmap_entries, uint8_t* dst,
+               uint32_t stream_bytes, int32_t* geom) {
+#define MG_EMU_GATHER(VS, TS)                                                                                           \
+    if (vs == VS && ts == TS) {                                                                                         \
+        typedef mg::GatherGeom<VS, TS> Gm;                                                                              \
+        if (geom) { const int32_t g[8] = {Gm::SEG, Gm::RS, Gm::PC, Gm::PR, Gm::C, Gm::NT, Gm::LPT, Gm::kConstBand};    \
+                    memcpy(geom, g, sizeof(g)); }                                                                       \
+        return gather_emu<VS, TS>(n_vt, atlas_raw, tmap, tmap_entries, dst, stream_bytes);                              \
+    }
+    MG_EMU_GATHER(7, 5) MG_EMU_GATHER(7, 6) MG_EMU_GATHER(7, 7) MG_EMU_GATHER(7, 9) MG_EMU_GATHER(7, 10) MG_EMU_GATHER(7, 11)
+    MG_EMU_GATHER(7, 12) MG_EMU_GATHER(5, 5) MG_EMU_GATHER(9, 6) MG_EMU_GATHER(3, 5) MG_EMU_GATHER(6, 5) MG_EMU_GATHER(4, 6)
+#undef MG_EMU_GATHER
+    return -1;
 }
 
 int emu_sizeof(int which) {
