@@ -24,13 +24,16 @@
  *   mg_place        MultiGridEnv.place_obj / try_place_obj outside _gen_grid (base.py:664-708)
  *   mg_render_frame MultiGridEnv.render's whole-grid image: MultiGrid.render(top_agent=None) +
  *                   visibility highlight         (base.py:714-759, 301-331)
+ *   mg_obs_place    the observation arrays MultiGridEnv's constructor / gen_obs allocate (base.py:334-347, 453-474),
+ *                   for a batch: where in HBM they lie (construction time; mg_obs_release, mg_obs_trim)
  *
  * Conventions: plain pointers and sizes only (no torch types).  Every buffer is owned by the
  * caller and lives in device memory (HBM) unless marked HOST; kernels never allocate.  All calls
  * are asynchronous on `stream` (a hipStream_t passed as void*; NULL = the default stream) and
  * return 0 or a negative MG_E_* code for argument errors detected on the host.  Per-env runtime
  * errors (the reference's exceptions) are recorded in MgState.error[b] (first error sticks) and
- * surfaced by the host wrapper as the matching Python exception.  Re-entrant: no mutable globals.
+ * surfaced by the host wrapper as the matching Python exception.  Re-entrant: no mutable globals (the one
+ * exception, behind a mutex: the record of placed observation buffers, mg_obs_place below).
  *
  * HBM layout (struct-of-arrays over the env batch, sized for 288 GB):
  *   grid        uint8  [B][cells_stride]      object id per cell, index x*H + y (= MultiGrid.grid[i,j]);
@@ -55,7 +58,7 @@
 extern "C" {
 #endif
 
-#define MG_ABI_VERSION 4
+#define MG_ABI_VERSION 5
 #define MG_MAX_AGENTS 16
 #define MG_MAX_OBJ 64
 #define MG_MAX_GEN 32
@@ -69,6 +72,7 @@ extern "C" {
 #define MG_E_ARG (-100)
 #define MG_E_UNSUPPORTED (-101)
 #define MG_E_LAUNCH (-102)
+#define MG_E_NOMEM (-103)   /* mg_obs_place: the device could not hold the buffers */
 
 /* per-env runtime errors (MgState.error), mirroring the reference's exceptions */
 #define MG_ERR_VALUE 1     /* ValueError: unknown action               base.py:619-620 */
@@ -205,10 +209,10 @@ typedef struct MgGenProgram {
 } MgGenProgram;
 
 int32_t mg_abi_version(void);
-/* sizeof of the five structs above as THIS build sees them: out[0..4] = MgConfig, MgState, MgObjDesc, MgGenOp,
- * MgGenProgram.  A binding compares them with its own mirror of the structs at load time (the layouts have no
- * other self-description; MG_ABI_VERSION changes whenever one of them does).  Returns 5. */
-int32_t mg_struct_sizes(int32_t out[5]);
+/* sizeof of the structs of this header as THIS build sees them: out[0..6] = MgConfig, MgState, MgObjDesc, MgGenOp,
+ * MgGenProgram, MgPlaceTuning, MgPlaceStats.  A binding compares them with its own mirror of the structs at load time
+ * (the layouts have no other self-description; MG_ABI_VERSION changes whenever one of them does).  Returns 7. */
+int32_t mg_struct_sizes(int32_t out[7]);
 /* "<library> gfx950 abi<N> <source id>": which build answered (bench.py echoes it) */
 const char* mg_build_info(void);
 const char* mg_error_string(int32_t code);
@@ -291,15 +295,81 @@ int32_t mg_time_render_obs(const MgConfig* cfg, const MgState* st, uint8_t* obs,
 int32_t mg_host_flag_alloc(int32_t** host, int32_t** dev);
 int32_t mg_host_flag_free(int32_t* host);
 
-/* mg_obs_alloc / mg_obs_free: an observation buffer (the obs argument of mg_render_obs / mg_step_render) straight
- * from the driver (hipMalloc on `device`), outside any caching allocator: the rate at which HBM absorbs the obs
- * raster's write pattern depends on the allocation it writes into by up to 25 % (profiles/r03/README.md section
- * 2), so hosts choose among candidate allocations by timing the raster into each (mg_time_render_obs) — and a
- * rejected candidate must go back to the driver at once, which a caching allocator does not do.  NULL on failure.
- * Nothing on the step path allocates: these are construction-time helpers, and any other device memory is as
- * valid an `obs` argument. */
+/* mg_obs_alloc / mg_obs_free: device memory straight from the driver (hipMalloc on `device`), outside any caching
+ * allocator.  NULL on failure.  Nothing on the step path allocates: these are construction-time helpers, and any other
+ * device memory is as valid an `obs` argument. */
 void* mg_obs_alloc(uint64_t bytes, int32_t device);
 int32_t mg_obs_free(void* ptr);
+
+/* ---- where the observation buffers live ---------------------------------------------------------------------------
+ *
+ * MultiGridEnv's constructor allocates the observation arrays it returns (base.py:334-347, 453-474); for a batch they are
+ * the one large output of a step, and WHERE in HBM they lie decides a fifth of the raster's speed (measured, MI355X,
+ * profiles/r04/README.md section 1 + profiles/r05/README.md): the raster writes thousands of concurrent sequential
+ * streams, and that pattern runs at 5.3 TB/s into a buffer that lies inside one of the driver's physical blocks, at the
+ * speed of a dense fill (6.9 TB/s) into one that straddles the boundary between two blocks half and half — one valley per
+ * allocation, at the block boundary, half a buffer wide on either side.  Nothing else moves it (stride, phase and number
+ * of the streams, gaps, who writes what, address translation, L2 counters: all the same).
+ *
+ * mg_obs_place CONSTRUCTS `n_buffers` buffers on such boundaries for the launch configuration `cfg` (obs of
+ * B * n_view-or-n_agents * P * P * 3 bytes each): a candidate is one hipMalloc of 3 P' bytes (P' = the power of two >= half
+ * the buffer — the driver builds it from a 2 P' block and a P' block), the buffer the window centred on the junction;
+ * candidates are timed with the raster itself (the state `st` as it is: HIP events around `iters` mg_render_obs launches on
+ * `stream`, blocking) and kept alive until `n_buffers` of them run 12 % under the median candidate, then all the others
+ * go back to the driver.  Buffers under 256 MiB are plain allocations (the effect needs thousands of streams).
+ *   budget_bytes  bytes of candidates alive at any time; 0 = min(a quarter of the free memory, 32 GiB)
+ *   seconds       time limit of a pass; <= 0 = 2 s
+ *   flags         MG_PLACE_THOROUGH: larger block pairs (candidates of 6 P' and 12 P' bytes — a kept buffer then pins up
+ *                 to 12x its size) and a second pass when the first found nothing; MG_PLACE_STIR: when nothing was found
+ *                 and allocations were slow (memory nobody had before is cleared as it is handed out, front to back, all in
+ *                 one block), one allocate-and-free of half the free memory (64 GiB at most) to mix the driver's free lists;
+ *                 MG_PLACE_NO_REUSE: do not take released arenas (below)
+ *   tuning        NULL, or overrides of the search's constants (tests force its later stages with them)
+ *   out           [n_buffers] device pointers, 4 KiB-aligned, owned by the library: give each back with mg_obs_release
+ *   stats         NULL, or what happened: found (0: no candidate was in the fast class — the best seen were kept, the caller
+ *                 may try again later or with MG_PLACE_THOROUGH), kept_ms, pinned_bytes (what the kept buffers' allocations
+ *                 hold: 1.5 .. 3 x the buffers at the default level) ...
+ * Returns MG_OK, MG_E_ARG, MG_E_NOMEM (nothing handed out) or MG_E_LAUNCH.
+ *
+ * mg_obs_release gives a placed buffer back.  An arena of the fast class is REMEMBERED (per process and device; at most
+ * min(8 GiB, a sixteenth of the device) of them): the next mg_obs_place of the same buffer size on that device takes it,
+ * checks it with one measurement and does not search (stats->reused).  mg_obs_trim(device) (-1: every device) returns
+ * the remembered arenas to the driver and reports how many there were.  This record is the library's only process state
+ * (a mutex guards it); everything else in this header is re-entrant. */
+#define MG_PLACE_MAX 8      /* buffers per call */
+#define MG_PLACE_ALL 136    /* candidates recorded in MgPlaceStats.all_ms */
+#define MG_PLACE_STIR 1
+#define MG_PLACE_THOROUGH 2
+#define MG_PLACE_NO_REUSE 4
+#define MG_PLACE_STOP_FOUND 1   /* MgPlaceStats.stopped: the kept set is `gain` under the median candidate */
+#define MG_PLACE_STOP_CAP 2     /* max_candidates measured */
+#define MG_PLACE_STOP_TIME 3
+#define MG_PLACE_STOP_MEMORY 4  /* the budget was reached twice */
+#define MG_PLACE_STOP_OOM 5     /* hipMalloc failed */
+#define MG_PLACE_STOP_SMALL 6   /* buffers under min_bytes: plain allocations */
+typedef struct MgPlaceTuning {  /* 0 = the default of each */
+    double gain;                /* 0.12 */
+    double slow_alloc_s_per_gib;/* MG_PLACE_STIR only when allocations took at least this long: 0.02; < 0: always */
+    uint64_t min_bytes;         /* 256 MiB */
+    uint64_t stir_bytes;        /* cap of the allocate-and-free: 64 GiB */
+    int32_t max_candidates;     /* per pass: 64 (at most MG_PLACE_ALL - MG_PLACE_MAX) */
+    int32_t iters;              /* raster launches per measurement: 3 */
+} MgPlaceTuning;
+typedef struct MgPlaceStats {
+    int32_t found, reused, candidates, windows;   /* windows: positions measured (>= candidates) */
+    int32_t passes, level, plain_stage, stopped;  /* level: the largest block pair tried (candidates of 3 P' << level) */
+    float kept_ms[MG_PLACE_MAX];                  /* the raster into each kept buffer */
+    float median_ms, reserved0;                   /* ... and into the median candidate */
+    double seconds, alloc_seconds;                /* the whole call; inside hipMalloc */
+    uint64_t buffer_bytes, candidate_bytes, alloc_bytes, pinned_bytes, stirred_bytes, budget_bytes;
+    uint64_t window_offset[MG_PLACE_MAX];         /* of each kept buffer inside its allocation */
+    uint64_t arena_bytes[MG_PLACE_MAX];           /* ... and that allocation's size */
+    float all_ms[MG_PLACE_ALL];                   /* every candidate measured, in order (the first n_buffers: plain allocations) */
+} MgPlaceStats;
+int32_t mg_obs_place(const MgConfig* cfg, const MgState* st, int32_t n_buffers, uint64_t budget_bytes, double seconds,
+                     int32_t flags, const MgPlaceTuning* tuning, void** out, MgPlaceStats* stats, void* stream);
+int32_t mg_obs_release(void* ptr);
+int32_t mg_obs_trim(int32_t device);
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 MAX_AGENTS, MAX_OBJ, MAX_GEN, MAX_VIEW, KEY_WORDS, MT_N, MT_HEAD = 16, 64, 32, 15, 2, 624, 16
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 OK = 0
 ERR_VALUE, ERR_RECURSION, ERR_TYPE, ERR_ASSERT, ERR_ATTRIBUTE = 1, 2, 3, 4, 5
@@ -67,10 +67,32 @@ class GenProgram(C.Structure):
                 ("reject", C.c_void_p), ("n_reject", C.c_int32)]
 
 
+PLACE_MAX, PLACE_ALL = 8, 136
+PLACE_STIR, PLACE_THOROUGH, PLACE_NO_REUSE = 1, 2, 4
+PLACE_STOP = {0: "", 1: "found", 2: "cap", 3: "time", 4: "memory", 5: "out of memory", 6: "small"}
+E_NOMEM = -103
+
+
+class PlaceTuning(C.Structure):
+    _fields_ = [("gain", C.c_double), ("slow_alloc_s_per_gib", C.c_double), ("min_bytes", C.c_uint64),
+                ("stir_bytes", C.c_uint64), ("max_candidates", C.c_int32), ("iters", C.c_int32)]
+
+
+class PlaceStats(C.Structure):
+    _fields_ = [("found", C.c_int32), ("reused", C.c_int32), ("candidates", C.c_int32), ("windows", C.c_int32),
+                ("passes", C.c_int32), ("level", C.c_int32), ("plain_stage", C.c_int32), ("stopped", C.c_int32),
+                ("kept_ms", C.c_float * PLACE_MAX), ("median_ms", C.c_float), ("reserved0", C.c_float),
+                ("seconds", C.c_double), ("alloc_seconds", C.c_double),
+                ("buffer_bytes", C.c_uint64), ("candidate_bytes", C.c_uint64), ("alloc_bytes", C.c_uint64),
+                ("pinned_bytes", C.c_uint64), ("stirred_bytes", C.c_uint64), ("budget_bytes", C.c_uint64),
+                ("window_offset", C.c_uint64 * PLACE_MAX), ("arena_bytes", C.c_uint64 * PLACE_MAX),
+                ("all_ms", C.c_float * PLACE_ALL)]
+
+
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmarlgrid_hip.so")
 
 # every symbol include/marlgrid_hip.h declares
-SYMBOLS = ["mg_abi_version", "mg_struct_sizes", "mg_host_flag_alloc", "mg_host_flag_free", "mg_obs_alloc", "mg_obs_free", "mg_build_info", "mg_error_string", "mg_mt_seed", "mg_reset", "mg_step", "mg_step_render",
+SYMBOLS = ["mg_abi_version", "mg_struct_sizes", "mg_host_flag_alloc", "mg_host_flag_free", "mg_obs_alloc", "mg_obs_free", "mg_obs_place", "mg_obs_release", "mg_obs_trim", "mg_build_info", "mg_error_string", "mg_mt_seed", "mg_reset", "mg_step", "mg_step_render",
            "mg_render_obs",
            "mg_encode", "mg_put_obj", "mg_place", "mg_render_frame", "mg_time_render_obs",
            "mg_render_obs_lds_bytes"]
@@ -116,20 +138,24 @@ def lib():
                           % (path, L.mg_abi_version(), ABI_VERSION))
     # the struct mirrors above against the library's own sizeof: a layout change that forgot this file (or
     # the ABI version) fails here, at load time, instead of shifting every later field of a launch config
-    sizes = (i32 * 5)()
+    sizes = (i32 * 7)()
     L.mg_struct_sizes.argtypes = [C.POINTER(i32)]
     L.mg_struct_sizes.restype = i32
-    if L.mg_struct_sizes(sizes) != 5:
+    if L.mg_struct_sizes(sizes) != 7:
         raise ImportError("marlgrid_amd: %s: mg_struct_sizes failed" % path)
-    mine = [C.sizeof(t) for t in (Config, State, ObjDesc, GenOp, GenProgram)]
+    mine = [C.sizeof(t) for t in (Config, State, ObjDesc, GenOp, GenProgram, PlaceTuning, PlaceStats)]
     if list(sizes) != mine:
         raise ImportError("marlgrid_amd: struct layouts differ between %s %r and marlgrid_amd/_native.py %r "
-                          "(MgConfig, MgState, MgObjDesc, MgGenOp, MgGenProgram)" % (path, list(sizes), mine))
+                          "(MgConfig, MgState, MgObjDesc, MgGenOp, MgGenProgram, MgPlaceTuning, MgPlaceStats)" % (path, list(sizes), mine))
     L.mg_host_flag_alloc.argtypes = [C.POINTER(C.POINTER(i32)), C.POINTER(C.POINTER(i32))]
     L.mg_host_flag_free.argtypes = [C.POINTER(i32)]
     L.mg_obs_alloc.argtypes = [C.c_uint64, i32]
     L.mg_obs_alloc.restype = vp
     L.mg_obs_free.argtypes = [vp]
+    L.mg_obs_place.argtypes = [C.POINTER(Config), C.POINTER(State), i32, C.c_uint64, C.c_double, i32, C.POINTER(PlaceTuning),
+                               C.POINTER(vp), C.POINTER(PlaceStats), vp]
+    L.mg_obs_release.argtypes = [vp]
+    L.mg_obs_trim.argtypes = [i32]
     L.mg_error_string.restype = C.c_char_p
     L.mg_error_string.argtypes = [i32]
     L.mg_build_info.restype = C.c_char_p

@@ -290,6 +290,47 @@ class _LibBuffer(object):
             self.ptr = None
 
 
+class _PlacedBuffer(object):
+    """An observation buffer mg_obs_place handed out (a window of a raw driver allocation chosen for where it lies in
+    HBM), as torch sees it through the CUDA array interface.  The tensor keeps this object alive; with its last view the
+    buffer goes back to the library (mg_obs_release), which remembers an arena of the fast class for the next env of the
+    same size in this process."""
+
+    def __init__(self, lib, ptr, nbytes, device):
+        self._lib, self.device, self.nbytes, self.ptr = lib, device, int(nbytes), int(ptr)
+        self.__cuda_array_interface__ = {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False),
+                                         "version": 2, "strides": None}
+
+    def tensor(self, shape):
+        import torch
+        t = torch.as_tensor(self, device=self.device).view(shape)
+        assert t.data_ptr() == self.ptr            # shares the memory (no copy)
+        return t
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            try:
+                import torch
+                with torch.cuda.device(self.device):
+                    torch.cuda.synchronize(self.device)      # no launch may still be writing it
+                    self._lib.mg_obs_release(self.ptr)
+            except Exception:   # interpreter shutdown
+                pass
+            self.ptr = None
+
+
+def release_obs_cache(device=None):
+    """Return the observation arenas this process remembers (released buffers of the fast class, kept for the next env
+    of the same size: mg_obs_release) to the driver.  `device`: a torch device / index, or None for every device.
+    Returns how many there were."""
+    idx = -1
+    if device is not None:
+        import torch
+        idx = torch.device(device).index if not isinstance(device, int) else device
+        idx = torch.cuda.current_device() if idx is None else idx
+    return N.lib().mg_obs_trim(idx)
+
+
 class _ViewGroup(object):
     """agents that share one view geometry: their launch config, atlas and observation buffers"""
 
@@ -335,11 +376,13 @@ class MultiGridEnv(object):
         self.obs_buffers = max(1, int(obs_buffers))
         self.fused_step = bool(fused_step)     # step() = one launch (mg_step_render) instead of mg_step + mg_render_obs
         # where the observation buffers live: "search" (= True) picks the fastest of a bounded set of candidate
-        # allocations by timing the raster itself into each (_place_obs_buffers); False = plain torch allocations
+        # allocations by timing the raster itself into each (_place_obs_buffers -> mg_obs_place: <= 2 s, candidates <=
+        # min(a quarter of the free memory, 32 GiB)); "thorough": the long search (a second pass, larger candidates, one
+        # big allocate-and-free: for a process that owns the GPU); False = plain torch allocations
         if place_obs is True:
             place_obs = DEFAULT_PLACE_OBS
-        if place_obs not in ("search", False):
-            raise ValueError("place_obs must be 'search' (= True) or False")
+        if place_obs not in ("search", "thorough", False):
+            raise ValueError("place_obs must be 'search' (= True), 'thorough' or False")
         self.place_obs = place_obs
         self._dry = bool(_dry)
         if self.batch_size < 1:
@@ -379,7 +422,8 @@ class MultiGridEnv(object):
         self._seeds_arg = seeds
         self.seed(seed=seed)
         self.reset()
-        if not self._dry and self.place_obs == "search":
+        self.obs_placement = []
+        if not self._dry and self.place_obs in ("search", "thorough"):
             self._place_obs_buffers()
         self._spec_ctor = self._spec_last     # the constructor-time `_gen_grid` (base.py:369)
         self._retrace = True
@@ -499,202 +543,77 @@ class MultiGridEnv(object):
                               self.mt_head.data_ptr(), self._flag.dev)
 
     @_on_device
-    def _place_obs_buffers(self, max_candidates=96, min_bytes=256 << 20, iters=3, budget=128 << 30, gain=0.12, seconds=6.0,
-                           slow_alloc=0.02, stir_cap=192 << 30):
-        """place_obs="search" (default): choose WHERE in HBM the observation buffers live.
+    def _place_obs_buffers(self, budget=0, seconds=0.0, thorough=None, stir=None, reuse=True, min_bytes=0, gain=0.0, max_candidates=0,
+                           slow_alloc=0.0, stir_cap=0, iters=0):
+        """place_obs="search" (default) / "thorough": choose WHERE in HBM the observation buffers live — mg_obs_place
+        (include/marlgrid_hip.h; marlgrid_amd/csrc/mg_place_obs.hip) does the work, this is its caller.
 
-        What is known (MI355X, profiles/r04/README.md section 1): the HBM of the chip is two REGIONS, and each takes
-        the raster's write pattern — 4 096 concurrent sequential streams — at 5.3 TB/s at most, while a dense fill of
-        the same bytes runs at 6.9 TB/s anywhere.  A buffer whose streams are split between the two regions runs at
-        fill speed (0.153 instead of 0.193 ms for the bench workload's 925 MB), in proportion to the smaller share.
-        Nothing else matters: not the distance between the halves inside one region (0.25 MiB .. 48 GiB), not the
-        stride or the phase of the streams, not their number, not which wave writes which.  The driver builds an
-        allocation from power-of-two blocks, largest first (884 MiB = 512 + 256 + 64 + 32 + 16 + 4), each from the free
-        list of its order, wherever that happens to be: a plain allocation is in the fast class when its 512 MiB block
-        and the rest come from different regions (58 : 42), in a middle class when the split is at 256 MiB (0.176 ms)
-        or at 116 MiB (0.182) — the "allocation lottery" of rounds 2 and 3, 1 draw in 6 .. 30.
+        What is measured (MI355X, profiles/r04/README.md section 1, profiles/r05/README.md): the raster's write pattern —
+        thousands of concurrent sequential streams — runs at 5.3 TB/s into a buffer that lies inside one of the driver's
+        physical blocks and at the speed of a dense fill (6.9 TB/s) into one that straddles the boundary between two blocks:
+        0.153 instead of 0.193 ms for the bench workload's 925 MB.  The library constructs candidates on such boundaries
+        (one hipMalloc of 3 P bytes, P = the power of two >= half the buffer; the buffer = the window centred on the
+        2 P | P junction), times the raster into each and keeps the fastest `obs_buffers` once they run 12 % under the median.
 
-        So the buffer is CONSTRUCTED on a block boundary: a candidate is one allocation of 3 P bytes (P = the power of
-        two >= half the buffer) — a 2 P block followed by a P block — and the buffer is the window centred on the
-        boundary between the two, [2 P - n / 2, 2 P + n / 2).  Whether the two blocks lie in different regions is the
-        one thing that is still measured (the raster itself, `iters` launches, HIP events): candidates are drawn — and
-        kept, so that the allocator moves on through its free lists — until `keep` of them run `gain` under the median
-        candidate, or `max_candidates` / `budget` bytes / half of the free memory / `seconds` are spent; then every
-        other candidate goes back to the driver.  (Kept through ALL stages: a freed block is the first the driver hands
-        out again, so a search that released its losers would draw the same memory over and over — seen on a box whose
-        memory had never been allocated before: every allocation next to the one before, all in one region, 100 ms per
-        candidate, 27 candidates in the 2.5 s this search then had, none fast — profiles/r04/README.md section 1.)
-        For that state the search has three more means (all in the loop below): after four misses in a row it measures
-        the other window positions of a candidate too and centres a partial hit; when the first stage missed and the
-        allocations were slow it makes one big allocation and frees it, which leaves the driver's free lists mixed;
-        and a pass that found nothing is followed by a second one, from the best two of the first.  Raw hipMalloc
-        through the library (mg_obs_alloc: never torch's caching allocator); a kept buffer holds its whole candidate
-        (3 P bytes for its n at the first stage: 1.5 .. 3 x).  Without a candidate in the fast class the best seen is
-        kept (the plain torch allocations included).  Buffers under `min_bytes` are left alone (the effect needs
-        thousands of concurrent streams)."""
-        import time
+        What it costs (the defaults are meant to be survivable for whoever shares the GPU): candidates alive at any time
+        <= min(a quarter of the free memory, 32 GiB); 2 s at most; a kept buffer pins its whole candidate — 1.5 .. 3 x its
+        size, outside torch's allocator (`env.obs_placement[g]["pinned_bytes"]`); buffers under 256 MiB are plain torch
+        allocations.  "thorough" adds what round 4 found necessary on memory nobody had allocated before: larger block
+        pairs (a kept buffer may then pin up to 12 x its size), a second pass, and one big allocate-and-free (half of the
+        free memory, 64 GiB at most) that mixes the driver's free lists.  A released buffer of the fast class is
+        remembered by the library: the next env of the same size in this process takes it without a search
+        (`release_obs_cache()` gives them back).  Without a candidate in the fast class the best seen is kept and
+        `found` is False: try again later, or with place_obs="thorough"."""
         import torch
+        if thorough is None:
+            thorough = self.place_obs == "thorough"
+        if stir is None:
+            stir = thorough
+        flags = (N.PLACE_THOROUGH if thorough else 0) | (N.PLACE_STIR if stir else 0) | (0 if reuse else N.PLACE_NO_REUSE)
+        tn = N.PlaceTuning(gain=gain, slow_alloc_s_per_gib=slow_alloc, min_bytes=min_bytes, stir_bytes=stir_cap,
+                           max_candidates=max_candidates, iters=iters)
+        threshold = min_bytes or (256 << 20)
         any_replaced = False
+        self.obs_placement = []
         for g in self._groups:
             nbytes = g.ring[0].numel()
-            if nbytes < min_bytes:
+            if nbytes < threshold:
+                self.obs_placement.append(None)
                 continue
-
-            def search(t_begin):
-                """one pass over the stages below; returns whether a ring buffer was replaced"""
-                t_end = t_begin + seconds
-                ms = C.c_float(0)
-
-                def cost_of(buf):
-                    N.check(self._lib.mg_time_render_obs(C.byref(g.cfg), C.byref(self._state), buf.data_ptr(), iters,
-                                                         C.byref(ms), self._stream()))
-                    return ms.value
-
-                half = (nbytes + 1) // 2
-                P0 = 1 << max(21, (half - 1).bit_length())         # power of two >= half the buffer (>= 2 MiB)
-                keep = len(g.ring)
-                cands = [(cost_of(t), t) for t in g.ring]           # (ms, tensor): the plain torch allocations first
-                why = "cap"
-                alive = misses = level = 0
-                plain = False                                       # last stage: plain buffer-sized allocations (below)
-                dropped = False                                     # the losers went back to the driver once (memory short)
-                probes = [0]                                        # windows measured (a candidate: one, or several — below)
-                alloc_s, alloc_bytes, stir = 0.0, 0, None           # time in hipMalloc; the one big allocate-and-free (below)
-                offsets = {}                                        # id(candidate tensor) -> its window's offset in its allocation
-                found = False
-
-                def drop_losers():
-                    """the candidates that are not among the best `keep` go back to the driver (their ms stays on record)"""
-                    ranked = sorted((ct for ct in cands if ct[1] is not None), key=lambda ct: ct[0])
-                    keepers = set(id(t) for _, t in ranked[:keep])
-                    cands[:] = [(c, t if (t is not None and id(t) in keepers) else None) for c, t in cands]
-                    return sum(t._base.numel() for _, t in ranked[:keep] if t._base is not None)    # (what the kept library buffers hold)
-
-                while len(cands) < keep + max_candidates:
-                    if time.perf_counter() > t_end:
-                        why = "time"
-                        break
-                    # A run of candidates that all miss: the free lists these two block sizes come from are in ONE region
-                    # for now (profiles/r04: 46 plain allocations in a row) — take the next larger pair of blocks, and after
-                    # those plain allocations of the buffer's own size (512 + 256 + ... MiB blocks: another set of free lists;
-                    # in the fast class when the largest block and the rest come from different regions, 58 : 42).  The
-                    # losers stay allocated (see above); only when memory runs short do they go back, once.
-                    P = P0 << level
-                    arena = nbytes if plain else 3 * P
-                    free, _total = torch.cuda.mem_get_info(self.device)
-                    short = alive + arena > min((free + alive) // 2, budget)
-                    if (misses >= 12 or short) and not plain:
-                        misses = 0
-                        if stir is None and not short and alloc_bytes and alloc_s / alloc_bytes >= slow_alloc / (1 << 30):
-                            # Allocations at 30 GB/s (`slow_alloc`: 20 ms per GiB and slower): memory nobody has had before, cleared as it is
-                            # handed out — front to back, one region.  One allocation of half of what is free, given
-                            # straight back, leaves the driver's free lists holding blocks from all over the memory
-                            # (measured: a search right after one finds its pair of blocks within six candidates); the
-                            # seconds it takes are added to the search's.
-                            t0 = time.perf_counter()
-                            big = min(free // 2, stir_cap)
-                            mem = _LibBuffer(self._lib, big, self.device)
-                            ok = mem.ok
-                            del mem
-                            stir = {"bytes": big if ok else 0, "seconds": time.perf_counter() - t0}
-                            t_end += stir["seconds"]
-                            continue
-                        if level < 2 and not short:
-                            level += 1
-                        else:
-                            plain = True
-                        continue
-                    if short:
-                        if dropped:
-                            why = "memory"
-                            break
-                        alive = drop_losers()
-                        dropped = True
-                        continue
-                    offset = 0 if plain else (2 * P - nbytes // 2) & ~4095      # the window centred on the 2 P | P block boundary
-                    t0 = time.perf_counter()
-                    mem = _LibBuffer(self._lib, arena, self.device)
-                    if not mem.ok:
-                        why = "out of memory"
-                        break
-                    alloc_s += time.perf_counter() - t0
-                    alloc_bytes += arena
-                    alive += arena                                  # (what the candidates drawn so far hold)
-                    full = mem.tensor((arena,))
-                    del mem                                         # (the tensor keeps the allocation alive)
-
-                    def window(o):
-                        w = full[o:o + nbytes].view(g.shape)
-                        probes[0] += 1
-                        return cost_of(w), w, o
-
-                    pick = window(offset)
-                    so_far = sorted(c for c, _ in cands)
-                    median = so_far[len(so_far) // 2]
-                    # Memory that was never allocated before is handed out front to back: the two blocks of a candidate
-                    # are then NEIGHBOURS, the junction is no boundary at all, and the one region boundary the search
-                    # will eventually walk across lies anywhere inside some candidate.  After four misses in a row the
-                    # other window positions of a candidate are measured too (a fifth of a buffer apart: 0.6 ms each) ...
-                    scanned = not plain and misses >= 4 and pick[0] > (1.0 - gain) * median
-                    if scanned:
-                        step = max(4096, nbytes // 5) & ~4095
-                        for o in range(0, arena - nbytes + 1, step):
-                            if abs(o - offset) >= step // 2:
-                                pick = min(pick, window(o), key=lambda cwo: cwo[0])
-                    # ... and a window that is partly across a boundary (the gain is in proportion to the smaller share of
-                    # the streams) is moved until it is centred
-                    partial = pick[0] > (1.0 - gain) * median
-                    if not plain and pick[0] <= 0.96 * median and (partial or scanned):
-                        step = max(4096, nbytes // 10) & ~4095
-                        for _ in range(4):
-                            for o in (pick[2] - step, pick[2] + step):
-                                if 0 <= o <= arena - nbytes:
-                                    pick = min(pick, window(o), key=lambda cwo: cwo[0])
-                            step = max(4096, step // 2) & ~4095
-                    del full
-                    cands.append((pick[0], pick[1]))
-                    offsets[id(pick[1])] = pick[2]
-                    costs = sorted(c for c, _ in cands)
-                    median = costs[len(costs) // 2]
-                    misses = 0 if cands[-1][0] <= (1.0 - gain) * median else misses + 1
-                    if len(cands) >= keep + 4 and costs[keep - 1] <= (1.0 - gain) * median:
-                        why = "kept set %d%% under the median candidate" % round(100 * (1 - costs[keep - 1] / median))
-                        found = True
-                        break
-                seen = [c for c, _ in cands]
-                best = sorted((ct for ct in cands if ct[1] is not None), key=lambda ct: ct[0])[:keep]
-                replaced = any(all(t is not kept for _, kept in best) for t in g.ring)
-                del cands                                           # the rejected candidates go back to the driver here
-                g.ring = [t for _, t in best]
-                for t in g.ring:
-                    t.zero_()
-                g.obs = g.ring[self._ring_i]
-                g.placement_ms = {"kept": [c for c, _ in best], "candidates": len(seen), "stopped": why,
-                                  "seconds": time.perf_counter() - t_begin, "all": seen,
-                                  "candidate_bytes": 3 * P0, "window_offset": (2 * P0 - nbytes // 2) & ~4095,
-                                  "buffer_bytes": nbytes, "block_pair_level": level, "plain_stage": plain, "found": found,
-                                  "windows_measured": probes[0], "kept_window_offsets": [offsets.get(id(t)) for _, t in best],
-                                  "alloc_ms_per_GiB": 1e3 * alloc_s / max(alloc_bytes, 1) * (1 << 30), "stirred": stir}
-                return replaced
-
-            # A pass that ends without a pair of buffers in the fast class has, by handing its candidates back, left
-            # the driver's free lists in another order (seen: the same process finds its buffers for the NEXT env it
-            # builds): one more pass, which starts from the best two of the first.
-            for attempt in (1, 2):
-                any_replaced = search(time.perf_counter()) or any_replaced
-                g.placement_ms["passes"] = attempt
-                if g.placement_ms["found"]:
-                    break
+            keep = len(g.ring)
+            out = (C.c_void_p * keep)()
+            st = N.PlaceStats()
+            rc = self._lib.mg_obs_place(C.byref(g.cfg), C.byref(self._state), keep, int(budget), float(seconds), flags, C.byref(tn),
+                                        out, C.byref(st), self._stream())
+            if rc == N.E_NOMEM:
+                g.placement_ms = {"found": False, "stopped": "out of memory", "kept": [], "candidates": st.candidates,
+                                  "seconds": st.seconds, "buffer_bytes": nbytes, "pinned_bytes": 0}
+                self.obs_placement.append(g.placement_ms)
+                continue                                            # the torch allocations stay
+            N.check(rc)
+            g.ring = [_PlacedBuffer(self._lib, out[i], nbytes, self.device).tensor(g.shape) for i in range(keep)]
+            for t in g.ring:
+                t.zero_()
+            g.obs = g.ring[self._ring_i]
+            any_replaced = True
+            g.placement_ms = {"found": bool(st.found), "reused": st.reused, "kept": [st.kept_ms[i] for i in range(keep)],
+                              "candidates": st.candidates, "windows_measured": st.windows, "passes": st.passes,
+                              "stopped": N.PLACE_STOP.get(st.stopped, str(st.stopped)), "seconds": st.seconds,
+                              "median_ms": st.median_ms, "all": [st.all_ms[i] for i in range(min(st.candidates, N.PLACE_ALL))],
+                              "buffer_bytes": st.buffer_bytes, "candidate_bytes": st.candidate_bytes,
+                              "window_offset": ((2 * (st.candidate_bytes // 3) - nbytes // 2) & ~4095) if st.candidate_bytes else None,
+                              "kept_window_offsets": [st.window_offset[i] for i in range(keep)],
+                              "pinned_bytes": st.pinned_bytes, "budget_bytes": st.budget_bytes, "block_pair_level": st.level,
+                              "plain_stage": bool(st.plain_stage), "stirred": ({"bytes": st.stirred_bytes} if st.stirred_bytes else None),
+                              "alloc_ms_per_GiB": 1e3 * st.alloc_seconds / max(st.alloc_bytes, 1) * (1 << 30)}
+            self.obs_placement.append(g.placement_ms)
         for i, r in enumerate(self._ring):
             r["obs"] = self._groups[0].ring[i]
         self.obs = self._ring[self._ring_i]["obs"]
+        # (the torch-allocated ring tensors that were replaced are unreferenced now; their blocks stay in torch's caching
+        # allocator for the caller's next allocations — this package does not empty a cache it does not own)
         if any_replaced:
-            # the torch-allocated ring tensors that lost to a raw candidate are unreferenced now, but torch's caching
-            # allocator would keep their blocks reserved (obs_buffers x the buffer size): hand them back once.  The
-            # kept raw buffers live OUTSIDE torch's allocator (mg_obs_alloc) and are invisible to its accounting.
-            torch.cuda.synchronize(self.device)
-            torch.cuda.empty_cache()
-        self._render()                      # the current observation, into the buffer that is current now
+            self._render()                  # the current observation, into the buffer that is current now
 
     def _stream(self):
         """torch's current stream of the env's device, as the C ABI takes it — and remembered: check_errors()

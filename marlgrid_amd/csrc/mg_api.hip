@@ -63,14 +63,16 @@ extern "C" {
 
 int32_t mg_abi_version(void) { return MG_ABI_VERSION; }
 
-int32_t mg_struct_sizes(int32_t out[5]) {
+int32_t mg_struct_sizes(int32_t out[7]) {
     if (!out) return MG_E_ARG;
     out[0] = (int32_t)sizeof(MgConfig);
     out[1] = (int32_t)sizeof(MgState);
     out[2] = (int32_t)sizeof(MgObjDesc);
     out[3] = (int32_t)sizeof(MgGenOp);
     out[4] = (int32_t)sizeof(MgGenProgram);
-    return 5;
+    out[5] = (int32_t)sizeof(MgPlaceTuning);
+    out[6] = (int32_t)sizeof(MgPlaceStats);
+    return 7;
 }
 
 #define MG_STR2(x) #x
@@ -92,6 +94,7 @@ const char* mg_error_string(int32_t code) {
     case MG_E_ARG: return "invalid argument";
     case MG_E_UNSUPPORTED: return "unsupported configuration";
     case MG_E_LAUNCH: return "HIP launch failed";
+    case MG_E_NOMEM: return "out of device memory";
     case MG_ERR_VALUE: return "ValueError: environment can't handle action";
     case MG_ERR_RECURSION: return "RecursionError: rejection sampling failed in place_obj";
     case MG_ERR_TYPE: return "TypeError: toggle() arity (Box)";

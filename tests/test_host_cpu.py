@@ -35,10 +35,14 @@ def test_struct_sizes_match_the_binding():
     silently misread launch configs)."""
     from marlgrid_amd import _native as N
     L = N.lib()
-    out = (ctypes.c_int32 * 5)()
-    assert L.mg_struct_sizes(out) == 5
-    assert list(out) == [ctypes.sizeof(t) for t in (N.Config, N.State, N.ObjDesc, N.GenOp, N.GenProgram)]
+    out = (ctypes.c_int32 * 7)()
+    assert L.mg_struct_sizes(out) == 7
+    assert list(out) == [ctypes.sizeof(t) for t in (N.Config, N.State, N.ObjDesc, N.GenOp, N.GenProgram, N.PlaceTuning, N.PlaceStats)]
     assert L.mg_struct_sizes(None) == -100
+    # argument errors of the placement calls are answered on the host, without a device
+    assert L.mg_obs_place(None, None, 2, 0, 0.0, 0, None, None, None, None) == -100
+    assert L.mg_obs_release(None) == 0 and L.mg_obs_release(ctypes.c_void_p(4096)) == -100      # (not a placed buffer)
+    assert L.mg_obs_trim(-1) == 0
 
 
 def test_integration_stub_executes(monkeypatch):
@@ -54,7 +58,8 @@ def test_integration_stub_executes(monkeypatch):
     ns = {}
     exec(compile(m.group(1), "INTEGRATION.md:binding-stub", "exec"), ns)
     for mine, theirs in ((N.Config, ns["MgConfig"]), (N.State, ns["MgState"]), (N.ObjDesc, ns["MgObjDesc"]),
-                         (N.GenOp, ns["MgGenOp"]), (N.GenProgram, ns["MgGenProgram"])):
+                         (N.GenOp, ns["MgGenOp"]), (N.GenProgram, ns["MgGenProgram"]), (N.PlaceTuning, ns["MgPlaceTuning"]),
+                         (N.PlaceStats, ns["MgPlaceStats"])):
         assert ctypes.sizeof(mine) == ctypes.sizeof(theirs)
         a = [(n, getattr(mine, n).offset, getattr(mine, n).size) for n, *_ in mine._fields_]
         b = [(n, getattr(theirs, n).offset, getattr(theirs, n).size) for n, *_ in theirs._fields_]
@@ -62,7 +67,7 @@ def test_integration_stub_executes(monkeypatch):
     # every entry point on the reference's path is bound by the stub
     bound = set(re.findall(r"_L\.(mg_[a-z_0-9]+)\.argtypes", m.group(1))) | {"mg_abi_version", "mg_struct_sizes"}
     for need in ("mg_mt_seed", "mg_reset", "mg_step", "mg_step_render", "mg_render_obs", "mg_encode", "mg_put_obj",
-                 "mg_place", "mg_render_frame"):
+                 "mg_place", "mg_render_frame", "mg_obs_place", "mg_obs_release", "mg_obs_trim"):
         assert need in bound, need
 
 
@@ -76,7 +81,7 @@ def test_production_library_has_no_measurement_switches():
     L = ctypes.CDLL(so)
     L.mg_build_info.restype = ctypes.c_char_p
     info = L.mg_build_info().decode()
-    assert info.startswith("libmarlgrid_hip gfx950 abi4 src-") and "variants" not in info
+    assert info.startswith("libmarlgrid_hip gfx950 abi5 src-") and "variants" not in info
 
 
 def test_product_never_imports_the_oracle():
