@@ -102,26 +102,14 @@ struct RenderScratch {
     int cell_stride;   // bytes per slot of first / second
     int trow_stride;   // dwords per slot of trow
 };
-// The atlas in LDS.  As it is in HBM ([4 orientations][n_tiles][ts][ts][3], rounded up to 16 bytes) — except for
-// the assemble-and-stream raster at the reference's default view with 5- or 6-pixel tiles (render_pad_rows), where
-// every tile ROW gets 4 zero bytes in front and at least 4 behind (render_row_bytes: 24 bytes for a 15-byte row):
-// a row segment copied to an arbitrary byte phase is then whole aligned dwords read around the row — no edge
-// masks, no conditional reads (or_segment_padded in mg_render.hip): 62 -> 42 instructions per segment, the whole step
-// -5.7 % at tile 5, -2.0 % at tile 6 against the same build without (profiles/r03/ab_fused_padded_rows_tile*_v21.txt).
-__host__ __device__ inline bool render_pad_rows(const MgConfig& cfg) {
-    return cfg.view_size == 7 && (cfg.tile_size == 5 || cfg.tile_size == 6) && cfg.prestige_mask == 0;
-}
-// ... and the configurations the GATHER raster (mg_gather.h; the kernel's RM_ == 2, `mode` 2 below) is instantiated for:
-// the reference's default view with its default 5-pixel tiles (agents.py:21-22), and 6-pixel tiles.  Its tile rows sit
-// in LDS with 16 zero bytes in front (GatherGeom::RS bytes per row, 32 zero bytes behind the last).
+// The atlas in LDS.  As it is in HBM ([4 orientations][n_tiles][ts][ts][3], rounded up to 16 bytes) — except for the
+// GATHER raster (mg_gather.h; the kernel's RM_ == 2, `mode` 2 below), which is instantiated for the reference's default
+// view with its default 5-pixel tiles (agents.py:21-22) and for 6-pixel tiles: there every tile ROW gets 16 zero bytes in
+// front (GatherGeom::RS bytes per row, 32 zero bytes behind the last), so that a 16-byte window anywhere around a row is
+// whole aligned dwords with zeros outside the row — no edge masks, no conditional reads.
 __host__ __device__ inline bool render_gather(const MgConfig& cfg) {
-#if defined(MG_EXP) && (MG_EXP & 1)
-    return false;      // (A/B builds: the assemble-and-stream raster on padded rows, as before)
-#else
     return cfg.view_size == 7 && (cfg.tile_size == 5 || cfg.tile_size == 6) && cfg.prestige_mask == 0;
-#endif
 }
-__host__ __device__ inline int render_row_bytes(int ts) { return (3 * ts + 8 + 7) / 8 * 8; }
 __host__ __device__ inline int render_gather_row_bytes(int ts) { return (16 + 3 * ts + 3) / 4 * 4; }
 __host__ __device__ inline int render_atlas_raw_bytes(const MgConfig& cfg) {
     return (4 * cfg.n_tiles * cfg.tile_size * cfg.tile_size * 3 + 15) / 16 * 16;
@@ -129,8 +117,7 @@ __host__ __device__ inline int render_atlas_raw_bytes(const MgConfig& cfg) {
 // `mode`: the kernel's RM_ (0: by tile size, 1: assemble-and-stream forced — measurement builds —, 2: gather)
 __host__ __device__ inline int render_atlas_lds_bytes(const MgConfig& cfg, int mode) {
     if (mode == 2) return (4 * cfg.n_tiles * cfg.tile_size * render_gather_row_bytes(cfg.tile_size) + 32 + 15) / 16 * 16;
-    if (mode != 0 || !render_pad_rows(cfg)) return render_atlas_raw_bytes(cfg);
-    return (4 * cfg.n_tiles * cfg.tile_size * render_row_bytes(cfg.tile_size) + 8 + 15) / 16 * 16;   // (+ 8 zero bytes behind the last row)
+    return render_atlas_raw_bytes(cfg);
 }
 
 // What a launch of the obs kernel would otherwise work out in every wave before it requests its first byte — the
@@ -206,7 +193,6 @@ __host__ __device__ inline RenderScratch render_scratch_for(const MgConfig& cfg,
     if (!gather && !render_chunk_raster(cfg, mode)) {
         const int rb = 3 * vs * ts;
         rows = 4096 / rb;
-        if (mode == 0 && render_pad_rows(cfg)) rows = rows / (64 / vs) * (64 / vs);      // whole trips of 64 / vs pixel rows (mg_render.hip)
         if (rows < 1) rows = 1;
         if (rows > nv * vs * ts) rows = nv * vs * ts;
         out = 32 + rows * rb;

@@ -66,13 +66,6 @@ static int choose_wpb(const MgConfig& cfg, int mode) {
 #define MG_RENDER_DISPATCH_RT(TS, V)                                                                       \
     (wpb == 16 ? launch_render_t<0, TS, 8, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)             \
                : launch_render_t<0, TS, 4, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs))
-// 12-wave workgroups: 3 waves per SIMD, i.e. a 168-VGPR budget instead of the 128 of 16 waves — for the
-// instantiations that spill at 128 (the assemble-and-stream rasters) or need more anyway ('prestige')
-#define MG_RENDER_DISPATCH12(VS, TS, V)                                                                    \
-    (wpb == 12 ? launch_render_t<VS, TS, 12, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs) : MG_RENDER_DISPATCH(VS, TS, V))
-#define MG_RENDER_DISPATCH8(VS, TS, V)                                                                     \
-    (wpb == 8 ? launch_render_t<VS, TS, 8, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs) : MG_RENDER_DISPATCH(VS, TS, V))
-
 // The kernel launch of mg_render_obs / mg_step_render.
 hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, uint8_t* view_cells,
                          uint8_t* view_agent, uint8_t* vis_mask, hipStream_t s, const FusedStep* fs) {
@@ -164,7 +157,7 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
             return wpb == 16 ? launch_render_t<7, 8, 16, 0, 1>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)
                              : launch_render_t<7, 8, 4, 0, 1>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
 #endif
-        return MG_RENDER_DISPATCH8(7, 8, 0);
+        return MG_RENDER_DISPATCH(7, 8, 0);
     }
     if (ts == 8 && vs == 9) return MG_RENDER_DISPATCH(9, 8, 0);
     if (ts == 8 && vs == 5) return MG_RENDER_DISPATCH(5, 8, 0);
@@ -178,10 +171,8 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
 #if defined(MG_AB_VARIANTS)
     if (const char* f = getenv("MG_RENDER_RT_TS")) rt_ts = atoi(f) != 0;
 #endif
-    if (vs == 7 && ts == 5 && !rt_ts) return MG_RENDER_DISPATCH12(7, 5, 0);   // GridAgentInterface's defaults (agents.py:21-22)
-    if (vs == 7 && ts == 6 && !rt_ts) return MG_RENDER_DISPATCH(7, 6, 0);
     if (vs == 7 && ts == 11 && !rt_ts) return MG_RENDER_DISPATCH(7, 11, 0);
-    if (vs == 7) return MG_RENDER_DISPATCH12(7, 0, 0);      // the default view with any other tile size
+    if (vs == 7) return MG_RENDER_DISPATCH(7, 0, 0);        // the default view with any other tile size
     return MG_RENDER_DISPATCH_RT(0, 0);                   // anything else
 #endif
 }

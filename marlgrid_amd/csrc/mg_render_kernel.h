@@ -18,11 +18,12 @@
 //   * the raster then emits the env's n*P*P*3 contiguous output bytes as 16-byte
 //     (global_store_dwordx4) chunks, consecutive lanes -> consecutive chunks.  Tile sizes that are a
 //     multiple of 8: each chunk is assembled in registers from two 8-byte LDS look-ups
-//     atlas[tmap[cell] + row*TD + k].  Any other tile size: a few KiB of whole pixel rows at a time are
-//     first ASSEMBLED in an LDS piece buffer — one lane per (row, view column) segment ORs its 3*TS bytes
-//     from the atlas tile row into the zeroed buffer (aligned dwords cut with v_alignbyte and ds_or_b32:
-//     unaligned DS accesses are serialised on gfx950; at tile 5 / 6 the atlas rows sit in LDS padded with zeros, so
-//     that a segment is whole dwords read around the row: no edge masks) — and then STREAMED out as linear
+//     atlas[tmap[cell] + row*TD + k].  The reference's default view with 5- or 6-pixel tiles: the GATHER raster
+//     (mg_gather.h) — a lane composes an aligned 16-byte chunk from the (at most two) tile rows it spans, which sit
+//     in LDS padded with zeros, with aligned dword reads and v_alignbyte, and stores it.  Any other tile size: a few
+//     KiB of whole pixel rows at a time are first ASSEMBLED in an LDS piece buffer — one lane per (row, view column)
+//     segment ORs its 3*TS bytes from the atlas tile row into the zeroed buffer (aligned dwords cut with v_alignbyte
+//     and ds_or_b32: unaligned DS accesses are serialised on gfx950) — and then STREAMED out as linear
 //     ds_read_b128 -> aligned dwordx4 stores; the bytes of a chunk that straddles two pieces (or two
 //     envs of the wave's run) are carried over in the buffer, so everything but the first and last
 //     <16 bytes of a wave's whole run leaves as aligned 16-byte stores.
@@ -76,26 +77,6 @@ __device__ __forceinline__ void or_segment(const uint8_t* __restrict__ sb, uint3
         }
         lo = w[CH];
     }
-}
-
-// The same for tile rows that sit in LDS PADDED with zeros (render_pad_rows: 4 zero bytes, the SEG bytes of the row,
-// >= 4 zero bytes; ROWB bytes per row, 8-byte aligned): the NC destination dwords are whole aligned dwords read
-// around the row and cut to the destination's phase — what lies outside the segment reads as zero, so there is
-// nothing to mask and nothing conditional.  `row`: the padded row.  Destination dword i holds padded bytes
-// [4 i + 4 - phi, 4 i + 8 - phi): for phi = 1..3 that is v_alignbyte(w[i + 1], w[i], 4 - phi); for phi = 0 it is
-// w[i + 1] — the same expression with the reads one dword further and a shift of 0.
-template <int SEG, int ROWB>
-__device__ __forceinline__ void or_segment_padded(const uint8_t* __restrict__ row, uint8_t* __restrict__ lds0, uint32_t dl) {
-    constexpr int NC = (SEG + 6) / 4;                    // destination dwords a segment can touch
-    static_assert(NC + 2 <= ROWB / 4 + 1, "padded row: NC + 1 source dwords from dword 0 or 1 (the last one may be the next row's zeros)");
-    const uint32_t phi = dl & 3u, sh = (4u - phi) & 3u;
-    const uint32_t* A = reinterpret_cast<const uint32_t*>(row) + (phi == 0u ? 1 : 0);
-    uint32_t* D = reinterpret_cast<uint32_t*>(lds0 + (dl & ~3u));
-    uint32_t w[NC + 1];
-#pragma unroll
-    for (int i = 0; i <= NC; i++) w[i] = A[i];
-#pragma unroll
-    for (int i = 0; i < NC; i++) atomicOr(&D[i], __builtin_amdgcn_alignbyte(w[i + 1], w[i], sh));
 }
 
 // A second look at a by-value kernel parameter, through a pointer the compiler cannot see through: the loads
@@ -274,16 +255,14 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     // (measured +5 % HBM write throughput over a grid-strided walk).
     constexpr bool kGlobalAtlas = (V_ == 8 || V_ == 12);
     const int atlas_bytes = kGlobalAtlas ? 0 : lc.atlas_lds;       // in LDS (render_atlas_lds_bytes)
-    // tile rows padded with zeros in LDS (mg_device.h: render_pad_rows — the launcher takes this instantiation for
-    // exactly those configs)
-    // ... and, RM_ == 2, for the gather raster (mg_gather.h): 16 zero bytes in front of every row)
+    // RM_ == 2: the gather raster (mg_gather.h) — tile rows padded with zeros in LDS: 16 zero bytes in front of every row
     constexpr bool kGather = RM_ == 2;
     static_assert(!kGather || (VS_ > 0 && TS_ >= 5 && (TS_ % 8) != 0 && V_ == 0), "gather raster: compile-time view and tile size, static atlas in LDS");
     typedef GatherGeom<kGather ? VS_ : 7, kGather ? TS_ : 5> Gm;
-    constexpr bool kPadRows = (VS_ == 7 && (TS_ == 5 || TS_ == 6) && V_ == 0 && RM_ == 0) || kGather;
-    constexpr int kRowB = kGather ? Gm::RS : kPadRows ? (3 * TS_ + 8 + 7) / 8 * 8 : 0, kRowW = kRowB / 4;
-    constexpr int kPadFrontW = kGather ? Gm::FRONT / 4 : 1, kPadTailW = kGather ? Gm::TAIL / 4 : 2;   // zero dwords in front of a row / behind the last
-    constexpr int kPadQ = kGather ? 6 : 4;                          // padded dwords per thread in the prologue's first round trip
+    constexpr bool kPadRows = kGather;                                // (the prologue pads the atlas as it copies it)
+    constexpr int kRowB = kGather ? Gm::RS : 0, kRowW = kRowB / 4;
+    constexpr int kPadFrontW = Gm::FRONT / 4, kPadTailW = Gm::TAIL / 4;   // zero dwords in front of a row / behind the last
+    constexpr int kPadQ = 6;                                         // padded dwords per thread in the prologue's first round trip
     const int per_wave = lc.per_wave, depth_mode = lc.depth_mode;
     const int e0 = (blockIdx.x * WPB + wave) * per_wave;
     const int e_end = min(cfg.B, e0 + per_wave);
@@ -1046,23 +1025,6 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             };
             for (uint32_t R0 = 0; R0 < NR; R0 += (uint32_t)L.piece_rows) {
                 const uint32_t rows = min((uint32_t)L.piece_rows, NR - R0), nseg = rows * (uint32_t)VS;
-                if constexpr (kPadRows) {
-                    // A lane keeps its view column: a trip is RT = 64 / VS whole pixel rows (63 lanes = 9 rows of 7 at the
-                    // default view), so the (row, column) of a lane's segment is a constant plus RT rows per trip — no
-                    // division by VS per segment —, and the layout makes a piece a whole number of trips
-                    // (render_scratch_for: piece_rows a multiple of RT).
-                    constexpr uint32_t RT = kWave / VS_;
-                    const uint32_t rl = (uint32_t)lane / (uint32_t)VS_, col = (uint32_t)lane - rl * VS_;
-                    if (rl < RT) {
-                        for (uint32_t Rl = rl; Rl < rows; Rl += RT) {
-                            const uint32_t prod = __umul24(R0 + Rl, by_TS.m);       // (kExactTS holds for these tile sizes)
-                            const uint32_t band = prod >> 20, rr = __umul24(prod & 0xFFFFFu, (uint32_t)TS) >> 20;
-                            const uint32_t vt = (uint32_t)w_tmap[__umul24(band, (uint32_t)VS) + col];
-                            or_segment_padded<3 * TS_, kRowB>(s_atlas + __umul24(__umul24(vt, (uint32_t)TS) + rr, (uint32_t)kRowB), w_out,
-                                                              carry + __umul24(__umul24(Rl, (uint32_t)VS) + col, SEG));
-                        }
-                    }
-                } else
                 for (uint32_t g = lane; g < nseg; g += kWave) {
                     const uint32_t Rl = by_VS.div(g), col = g - __umul24(Rl, (uint32_t)VS), R = R0 + Rl;
                     // band = R / TS and rr = R % TS from ONE 24-bit product when the quotient is exact (R - band * TS
@@ -1197,14 +1159,13 @@ hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_t* obs,
 // The instantiations, in groups: one translation unit per group (mg_render_inst_<g>.hip) makes them — in parallel —,
 // the dispatcher (mg_render.hip) only refers to them.  MG_RENDER_GROUP_x(X): X(VS, TS, WPB, V, RM).
 #define MG_RENDER_GROUP_A(X) /* the chunk raster at tile 8 */                                                              \
-    X(7, 8, 16, 0, 0) X(7, 8, 8, 0, 0) X(7, 8, 4, 0, 0) X(9, 8, 16, 0, 0) X(9, 8, 4, 0, 0) X(5, 8, 16, 0, 0) X(5, 8, 4, 0, 0)   \
+    X(7, 8, 16, 0, 0) X(7, 8, 4, 0, 0) X(9, 8, 16, 0, 0) X(9, 8, 4, 0, 0) X(5, 8, 16, 0, 0) X(5, 8, 4, 0, 0)   \
     X(3, 8, 16, 0, 0) X(3, 8, 4, 0, 0) X(0, 8, 8, 0, 0) X(0, 8, 4, 0, 0)
 #define MG_RENDER_GROUP_B(X) /* tile 16 / 32, the atlas in global memory */                                                \
     X(7, 16, 16, 0, 0) X(7, 16, 4, 0, 0) X(7, 32, 16, 0, 0) X(7, 32, 4, 0, 0) X(0, 16, 8, 0, 0) X(0, 16, 4, 0, 0)               \
     X(0, 32, 8, 0, 0) X(0, 32, 4, 0, 0) X(0, 8, 4, 8, 0) X(0, 16, 4, 8, 0) X(0, 32, 4, 8, 0) X(0, 0, 4, 8, 0)
 #define MG_RENDER_GROUP_C(X) /* assemble-and-stream: any other tile size */                                                \
-    X(7, 5, 16, 0, 0) X(7, 5, 12, 0, 0) X(7, 5, 4, 0, 0) X(7, 6, 16, 0, 0) X(7, 6, 4, 0, 0) X(7, 11, 16, 0, 0) X(7, 11, 4, 0, 0) \
-    X(7, 0, 16, 0, 0) X(7, 0, 12, 0, 0) X(7, 0, 4, 0, 0) X(0, 0, 8, 0, 0) X(0, 0, 4, 0, 0)
+    X(7, 11, 16, 0, 0) X(7, 11, 4, 0, 0) X(7, 0, 16, 0, 0) X(7, 0, 4, 0, 0) X(0, 0, 8, 0, 0) X(0, 0, 4, 0, 0)
 #define MG_RENDER_GROUP_D(X) /* 'prestige': per-env recoloured tiles */                                                     \
     X(7, 8, 12, 9, 0) X(7, 8, 8, 9, 0) X(7, 8, 4, 9, 0) X(7, 11, 12, 9, 0) X(7, 11, 8, 9, 0) X(7, 11, 4, 9, 0)                  \
     X(0, 8, 4, 9, 0) X(0, 16, 4, 9, 0)

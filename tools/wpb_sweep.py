@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """Workgroup shape of the obs kernel by batch size: builds of the library that force 4 / 8 / 16 waves per workgroup
-(`make -C marlgrid_amd/csrc exp EXP=2|4|6`) against the product's own choice, interleaved in one process on the
+(`make -C marlgrid_amd/csrc exp EXP=2|6`; EXP=4, 8 waves, needs the <7, 8, 8> instantiation that round 5 measured and dropped) against the product's own choice, interleaved in one process on the
 one-launch step (mg_step_render) and on the raster alone (mg_render_obs), for B in a list.
-usage: [WL=MarlGrid-3AgentCluttered11x11-v0] [BS=1024,2048,...] wpb_sweep.py product.so exp2.so exp4.so exp6.so"""
+usage: [WL=MarlGrid-3AgentCluttered11x11-v0] [BS=1024,2048,...] wpb_sweep.py product.so exp2.so exp6.so"""
 import ctypes as C
 import json
 import os
