@@ -140,6 +140,9 @@ class MultiGrid(object):
         self._env = env
         self.obj_reg = env.obj_reg
         self._template = np.zeros((self.width, self.height), np.uint8)
+        # what `_gen_grid` itself has drawn so far — the template plus the static edits made after a place_obj (which go
+        # into the reset program, not the template): what get() answers while `_gen_grid` runs
+        self._shadow = np.zeros((self.width, self.height), np.uint8)
         env._tr_begin(self)
 
     # ---- layout recording / live edits --------------------------------------------------------
@@ -151,6 +154,7 @@ class MultiGrid(object):
             key = self.obj_reg.get_key(obj)
             if env._tr_static(("put", key, int(i), int(j)), key, [(int(i), int(j), int(i) + 1, int(j) + 1)]):
                 self._template[i, j] = key
+            self._shadow[i, j] = key
         else:
             env.put_obj(obj, i, j)
 
@@ -174,13 +178,20 @@ class MultiGrid(object):
 
     def _wall(self, sym, cells, obj_type, rects):
         env = self._env
-        if obj_type is Wall and env._tracing:
-            key = self.obj_reg.get_key(Wall())
+        # (objects are value types here: every obj_type() of a helper is the same table row.  Walls of Walls are recorded
+        # as what they are; a helper drawn with another type is, before the first place_obj, its cells one by one — the
+        # template does not care — and after one a handful of rectangle fills in the reset program, not an op per cell)
+        if env._tracing and (obj_type is Wall or env._tr_ops):
+            key = self.obj_reg.get_key(obj_type())
             for (i, j) in cells:
                 assert 0 <= i < self.width and 0 <= j < self.height
+            if obj_type is not Wall:
+                sym = [("put", key, int(i), int(j)) for (i, j) in dict.fromkeys(cells)]
             if env._tr_static(sym, key, [tuple(int(v) for v in r) for r in rects if r[2] > r[0] and r[3] > r[1]]):
                 for (i, j) in cells:
                     self._template[i, j] = key
+            for (i, j) in cells:
+                self._shadow[i, j] = key
         else:
             for (i, j) in cells:
                 self.set(i, j, obj_type())
@@ -196,6 +207,8 @@ class MultiGrid(object):
         """the non-agent object kind in cell (i, j) of env `env` (host sync; debugging aid)"""
         assert i >= 0 and i < self.width
         assert j >= 0 and j < self.height
+        if self._env._tracing:      # inside `_gen_grid`: what it has drawn so far (random placements are per env: not in here)
+            return self.obj_reg.obj_of_key(int(self._shadow[i, j]))
         return self.obj_reg.obj_of_key(int(self.grid[env, i, j].item()))
 
     def encode(self, vis_mask=None):
@@ -667,11 +680,27 @@ class MultiGridEnv(object):
         ordered program as fill ops (max_tries 0: write `key` into every cell of a rectangle, replacing what a
         placement put there, base.py:655-662) and replayed per env between the placements (returns False)."""
         if not self._tr_ops:
-            self._tr_sym.append(sym)
+            self._tr_sym.extend(sym if isinstance(sym, list) else [sym])
             return True
-        self._tr_late[len(self._tr_ops)] = sym
+        first = None                # the op this edit's first rectangle went into: where its symbolic form is listed
         for (x0, y0, x1, y1) in rects:
-            self._tr_ops.append((int(key), 1, 0, x0, y0, x1, y1, None))
+            # a fill that continues the one before it (same object, same rows or columns, adjacent) is the same op, larger
+            last = self._tr_ops[-1]
+            merged = None
+            if last[2] == 0 and last[0] == int(key) and last[7] is None:
+                lx0, ly0, lx1, ly1 = last[3:7]
+                if (ly0, ly1) == (y0, y1) and (lx1 == x0 or x1 == lx0):
+                    merged = (int(key), 1, 0, min(lx0, x0), y0, max(lx1, x1), y1, None)
+                elif (lx0, lx1) == (x0, x1) and (ly1 == y0 or y1 == ly0):
+                    merged = (int(key), 1, 0, x0, min(ly0, y0), x1, max(ly1, y1), None)
+            if merged is not None:
+                self._tr_ops[-1] = merged
+            else:
+                self._tr_ops.append((int(key), 1, 0, x0, y0, x1, y1, None))
+            if first is None:
+                first = len(self._tr_ops) - 1
+        if first is not None:
+            self._tr_late.setdefault(first, []).extend(sym if isinstance(sym, list) else [sym])
         return False
 
     def _trace_gen_grid(self):
@@ -687,7 +716,11 @@ class MultiGridEnv(object):
         if g is None or self.grid is not g:
             raise RuntimeError("_gen_grid must assign self.grid = MultiGrid((width, height))")
         if len(self._tr_ops) > N.MAX_GEN:
-            raise NotImplementedError("more than %d placement groups in _gen_grid" % N.MAX_GEN)
+            fills = sum(1 for op in self._tr_ops if op[2] == 0)
+            raise NotImplementedError("_gen_grid records %d reset-program ops — %d groups of random placements and %d rectangle "
+                                      "fills for static edits made after the first place_obj — and the device program holds %d "
+                                      "(MG_MAX_GEN): draw the static layout before the first place_obj (it then costs nothing)"
+                                      % (len(self._tr_ops), len(self._tr_ops) - fills, fills, N.MAX_GEN))
         self._spec_last = dict(sym=list(self._tr_sym), ops=list(self._tr_ops), late=dict(self._tr_late))
         return g._template, list(self._tr_ops)
 
@@ -1363,8 +1396,7 @@ class MultiGridEnv(object):
             late = p.get("late", {})
             for i, (k, c, t, x0, y0, x1, y1, rej) in enumerate(p["ops"]):
                 if t == 0:               # a static edit after a placement: its symbolic form, once
-                    if i in late:
-                        out.append(late[i])
+                    out.extend(late.get(i, []))
                     continue
                 full = (x0, y0, x1, y1) == (0, 0, self.width, self.height)
                 if rej is not None:      # reject_fn, tabulated: the rejected cells of the sampling rectangle

@@ -73,11 +73,18 @@ class ShardPipeline(object):
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.batch_size, self.parts = int(batch_size), int(parts)
         self.part_size = self.batch_size // self.parts
-        self.envs = [make_env(batch_size=self.part_size, seeds=shard_seeds(seed, self.batch_size, k, self.parts),
-                              device=self.device) for k in range(self.parts)]
         self.streams = list(streams) if streams is not None else [torch.cuda.Stream(device=self.device) for _ in range(self.parts)]
         if len(self.streams) != self.parts:
             raise ValueError("one stream per part")
+        # Part k is BUILT on the stream it will be stepped on: a constructor ends with launches nobody waits for (the
+        # first observation; the seeding and reset of a non-strict env), and torch's side streams do not wait for the
+        # stream that happened to be current — on its own stream the part's first reset() / step_part() simply queues
+        # behind them.
+        self.envs = []
+        for k in range(self.parts):
+            with torch.cuda.stream(self.streams[k]):
+                self.envs.append(make_env(batch_size=self.part_size, seeds=shard_seeds(seed, self.batch_size, k, self.parts),
+                                          device=self.device))
 
     # what a training loop asks an env for
     @property

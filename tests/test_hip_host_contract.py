@@ -68,13 +68,14 @@ def test_default_strict_step_does_not_synchronize():
 
 
 def test_obs_buffer_placement_search():
-    """place_obs='search' (default): the observation ring is chosen among raw candidate allocations (mg_obs_alloc:
-    hipMalloc outside torch's caching allocator) by timing the raster into each; False = torch allocations.  Same
-    observations either way; candidates are bounded and go back to the driver; so does the ring when the env dies."""
+    """place_obs='search' (default): the observation ring is placed by the library (mg_obs_place: raw candidate
+    allocations timed with the raster itself, bounded in memory and time); False = torch allocations.  Same observations
+    either way; the candidates go back to the driver; a released ring of the fast class is remembered, so the second env
+    of the same size in this process does not search; release_obs_cache() returns what is remembered."""
     import gc
     import torch
     from marlgrid_amd import _native as N
-    from marlgrid_amd.base import _LibBuffer
+    from marlgrid_amd.base import _LibBuffer, release_obs_cache
     B = 16384                                          # 462 MB of observations per buffer: above the 256 MiB threshold
     # (what the process allocates once — code objects, the runtime's pools, a first env's launch — is not this test's
     # business: it has happened before `free0` is read, also when the test runs alone)
@@ -84,9 +85,10 @@ def test_obs_buffer_placement_search():
     torch.cuda.synchronize()
     del warm
     gc.collect()
+    release_obs_cache()
     torch.cuda.empty_cache()
     free0 = torch.cuda.mem_get_info()[0]
-    outs = {}
+    outs, found = {}, []
     for mode in ("search", False, "search"):
         env = product_envs.build("MarlGrid-3AgentCluttered15x15-v0", batch_size=B, place_obs=mode)
         env.reset()
@@ -95,20 +97,34 @@ def test_obs_buffer_placement_search():
             o, r, d, _ = env.step(torch.randint(0, 7, (B, 3), generator=g))
         if mode == "search":
             pm = env._groups[0].placement_ms
-            assert 2 <= pm["candidates"] <= 258 and pm["seconds"] < 90.0 and len(pm["kept"]) == 2    # (seconds: two passes and a stir on never-allocated memory)
-            assert sorted(pm["all"])[:2] == sorted(pm["kept"])          # the fastest two were kept
-            # a candidate is a 2 P block followed by a P block, the buffer the window centred on their boundary
-            P = pm["candidate_bytes"] // 3
-            assert pm["candidate_bytes"] == 3 * P and P & (P - 1) == 0 and P >= pm["buffer_bytes"] / 2
-            assert abs(pm["window_offset"] + pm["buffer_bytes"] / 2 - 2 * P) <= 4096
+            assert env.obs_placement == [pm]
+            found.append(pm["found"])
+            assert len(pm["kept"]) == 2 and pm["seconds"] < 8.0              # one pass of 2 s, allocations, the reused check
+            assert pm["budget_bytes"] <= 32 << 30 or pm["reused"] == 2
+            assert 2 * pm["buffer_bytes"] <= pm["pinned_bytes"] <= 2 * 3 * pm["buffer_bytes"]   # 1 .. 3 x per kept buffer
+            if len(found) == 2 and found[0]:
+                # the first env's ring was released when it died: taken back without a search
+                assert pm["reused"] == 2 and pm["candidates"] == 0 and pm["found"] and pm["seconds"] < 0.25
+            elif pm["reused"] == 0:
+                assert 2 <= pm["candidates"] <= 66 and pm["passes"] == 1 and not pm["stirred"] and pm["block_pair_level"] == 0
+                assert sorted(pm["all"])[:2] == sorted(pm["kept"])          # the fastest two were kept
+                if not pm["plain_stage"]:
+                    # a candidate is a 2 P block followed by a P block, the buffer the window centred on their boundary
+                    P = pm["candidate_bytes"] // 3
+                    assert pm["candidate_bytes"] == 3 * P and P & (P - 1) == 0 and P >= pm["buffer_bytes"] / 2
+                    assert abs(pm["window_offset"] + pm["buffer_bytes"] / 2 - 2 * P) <= 4096
             assert env.obs.data_ptr() % 4096 == 0
             assert torch.cuda.mem_get_info()[0] > free0 - (8 << 30)     # the rejected candidates are back
+        else:
+            assert env.obs_placement == []
         outs.setdefault(mode, []).append((o.cpu(), r.cpu(), d.cpu()))
         del env, o, r, d
         gc.collect()
     for got in outs["search"]:
         for x, y in zip(got, outs[False][0]):
             assert torch.equal(x, y)
+    n_kept = release_obs_cache()
+    assert n_kept == (2 if found[-1] else 0)
     # a library buffer by itself: usable by torch without a copy, freed with its last view
     mem = _LibBuffer(N.lib(), 100 << 20, torch.device("cuda", torch.cuda.current_device()))
     assert mem.ok
@@ -123,10 +139,10 @@ def test_obs_buffer_placement_search():
 
 
 def test_obs_buffer_placement_search_when_nothing_is_found():
-    """The search's later stages, forced (no candidate can be 60 % under the median; every allocation counts as slow):
-    twelve misses, the one big allocate-and-free that stirs the driver's free lists, larger block pairs with several
-    window positions measured per candidate, plain allocations — then the best seen is kept, everything else goes back,
-    and the env computes what an env on torch's buffers computes."""
+    """The search's later stages, forced (no candidate can be 60 % under the median; every allocation counts as slow),
+    with place_obs='thorough' semantics: twelve misses, the one big allocate-and-free that stirs the driver's free lists,
+    larger block pairs with several window positions measured per candidate, plain allocations, a second pass — then
+    the best seen is kept, everything else goes back, and the env computes what an env on torch's buffers computes."""
     import gc
     import torch
     B = 16384
@@ -135,15 +151,16 @@ def test_obs_buffer_placement_search_when_nothing_is_found():
     env.reset()
     twin.reset()
     free0 = torch.cuda.mem_get_info()[0]
-    env._place_obs_buffers(gain=0.6, slow_alloc=0.0, stir_cap=4 << 30, seconds=60.0, max_candidates=56)
+    env._place_obs_buffers(thorough=True, stir=True, reuse=False, gain=0.6, slow_alloc=-1.0, stir_cap=4 << 30, seconds=60.0,
+                           max_candidates=40, budget=128 << 30)
     pm = env._groups[0].placement_ms
-    assert pm["found"] is False and pm["stopped"] == "cap" and pm["candidates"] == 58
+    assert pm["found"] is False and pm["stopped"] == "cap" and pm["candidates"] == 82        # 2 + 2 passes of 40 (12 + 12 + 12 by level, 4 plain)
     assert pm["passes"] == 2                                         # nothing found: a second pass, from the best two of the first
     assert pm["stirred"] and pm["stirred"]["bytes"] == 4 << 30
     assert pm["block_pair_level"] == 2 and pm["plain_stage"] is True
     assert pm["windows_measured"] > pm["candidates"]                 # window positions besides the junction
     assert sorted(pm["all"])[:2] == sorted(pm["kept"])
-    assert all(o is None or o % 4096 == 0 for o in pm["kept_window_offsets"])
+    assert all(o % 4096 == 0 for o in pm["kept_window_offsets"])
     gc.collect()
     assert torch.cuda.mem_get_info()[0] > free0 - (8 << 30)          # the losers went back
     g = torch.Generator().manual_seed(11)
@@ -151,6 +168,72 @@ def test_obs_buffer_placement_search_when_nothing_is_found():
         a = torch.randint(0, 7, (B, 3), generator=g)
         for x, y in zip(env.step(a)[:3], twin.step(a)[:3]):
             assert torch.equal(x, y)
+
+
+def test_obs_place_through_the_c_abi():
+    """mg_obs_place / mg_obs_release / mg_obs_trim as a foreign binding calls them (ctypes, no package helper in
+    between): buffers for the bench shard's launch config, 4 KiB-aligned, inside what the stats say they pin; the raster
+    into them is what kept_ms says; released fast buffers come back without a search in <= 20 ms; a pointer that was not
+    handed out is refused; MG_PLACE_NO_REUSE searches again; trim empties the record."""
+    import ctypes as C
+    import time
+    import torch
+    from marlgrid_amd import _native as N
+    L = N.lib()
+    B = 32768
+    env = product_envs.build("MarlGrid-3AgentCluttered15x15-v0", batch_size=B, place_obs=False)
+    env.reset()
+    torch.cuda.synchronize()
+    L.mg_obs_trim(-1)
+    cfg, st = env._groups[0].cfg, env._state
+    nbytes = B * 3 * 56 * 56 * 3
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def place(flags=0, budget=0, seconds=0.0):
+        out, stats = (C.c_void_p * 2)(), N.PlaceStats()
+        t0 = time.perf_counter()
+        rc = L.mg_obs_place(C.byref(cfg), C.byref(st), 2, budget, seconds, flags, None, out, C.byref(stats), stream)
+        return rc, [out[0], out[1]], stats, time.perf_counter() - t0
+
+    free0 = torch.cuda.mem_get_info()[0]
+    rc, bufs, s1, dt = place()
+    assert rc == 0 and all(b and b % 4096 == 0 for b in bufs) and bufs[0] != bufs[1]
+    assert s1.buffer_bytes == nbytes and s1.reused == 0 and s1.passes == 1 and s1.level == 0 and s1.stirred_bytes == 0
+    assert s1.budget_bytes <= 32 << 30 and s1.seconds < 6.0 and 2 <= s1.candidates <= 66 and s1.windows >= s1.candidates
+    assert 2 * nbytes <= s1.pinned_bytes <= 6 * nbytes == 6 * s1.buffer_bytes
+    assert free0 - torch.cuda.mem_get_info()[0] <= s1.pinned_bytes + (64 << 20)          # every other candidate is back
+    for i in range(2):
+        assert s1.window_offset[i] + nbytes <= s1.arena_bytes[i]
+    # the buffers are ordinary device memory: the raster into one of them is what the search measured
+    ms = C.c_float(0)
+    N.check(L.mg_time_render_obs(C.byref(cfg), C.byref(st), bufs[0], 5, C.byref(ms), stream))
+    assert abs(ms.value - s1.kept_ms[0]) <= 0.12 * s1.kept_ms[0], (ms.value, s1.kept_ms[0])
+    if s1.found:
+        assert s1.kept_ms[1] <= 0.88 * s1.median_ms * 1.001
+    assert L.mg_obs_release(C.c_void_p(bufs[0] + 4096)) == -100                           # not a placed buffer
+    for b in bufs:
+        assert L.mg_obs_release(C.c_void_p(b)) == 0
+    assert L.mg_obs_release(C.c_void_p(bufs[0])) == -100                                  # released twice
+    if s1.found:
+        rc, bufs2, s2, dt2 = place()
+        assert rc == 0 and sorted(bufs2) == sorted(bufs) and s2.reused == 2 and s2.candidates == 0 and s2.found == 1
+        assert dt2 <= 0.020, dt2                                                          # remembered: no search
+        for b in bufs2:
+            assert L.mg_obs_release(C.c_void_p(b)) == 0
+        rc, bufs3, s3, _ = place(flags=N.PLACE_NO_REUSE, seconds=1.0)
+        assert rc == 0 and s3.reused == 0 and s3.candidates >= 2
+        for b in bufs3:
+            assert L.mg_obs_release(C.c_void_p(b)) == 0
+    assert L.mg_obs_trim(-1) >= (2 if s1.found else 0)
+    assert L.mg_obs_trim(-1) == 0
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)
+    # too little memory allowed for even one candidate: the plain buffers are still handed out (found = 0), nothing leaks
+    rc, bufs4, s4, _ = place(budget=1 << 20, seconds=0.5)
+    assert rc == 0 and s4.found == 0 and s4.stopped in (2, 3, 4) and s4.pinned_bytes == 2 * nbytes
+    for b in bufs4:
+        assert L.mg_obs_release(C.c_void_p(b)) == 0
+    assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)
 
 
 def test_state_dict_round_trip_and_versioning():

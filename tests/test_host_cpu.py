@@ -396,3 +396,49 @@ def test_shard_pipeline_arguments():
         ShardPipeline(lambda **kw: None, 8, parts=0)
     # the seeds a part gets are those of its slice of the one big env
     assert shard_seeds(1337, 8, 1, 2) == [1341, 1342, 1343, 1344]
+
+
+def test_late_static_edits_are_rectangle_fills_and_visible_to_get():
+    """`_gen_grid` edits after the first place_obj (upstream's `_gen_grid` is free Python): a wall helper drawn with
+    another type than Wall is a handful of rectangle fills in the reset program, not an op per cell; single cells put one
+    after the other along a row are ONE fill; grid.get() inside `_gen_grid` sees what `_gen_grid` drew, late edits
+    included; the spec lists the cells as the oracle's program wants them; and the limit's message says what it counts."""
+    from marlgrid_amd.base import MultiGridEnv, MultiGrid
+    from marlgrid_amd.objects import Wall, Goal, Floor
+    seen = {}
+
+    class Late(MultiGridEnv):
+        def _gen_grid(self, width, height):
+            self.grid = MultiGrid((width, height))
+            self.grid.wall_rect(0, 0, width, height)
+            self.place_obj(Goal(color="green", reward=1), max_tries=100)
+            self.grid.horz_wall(2, 3, 5, obj_type=Floor)               # after a placement, not a Wall: one fill
+            for x in range(2, 7):
+                self.grid.set(x, 5, Wall())                            # five single cells in a row: one fill
+            self.grid.wall_rect(2, 7, 4, 2, obj_type=Floor)            # 4 x 2: top and bottom row adjacent -> merged
+            seen["floor"] = self.grid.get(3, 3)
+            seen["wall"] = self.grid.get(6, 5)
+            seen["border"] = self.grid.get(0, 0)
+            seen["none"] = self.grid.get(4, 4)
+            self.place_agents = None
+
+    env = Late(agents=[dict(color="red")], grid_size=11, _dry=True)
+    template, ops = env._dry_trace
+    fills = [o for o in ops if o[2] == 0]
+    assert [(o[3], o[4], o[5], o[6]) for o in fills][:2] == [(2, 3, 7, 4), (2, 5, 7, 6)]
+    assert len(fills) <= 5 and len(ops) <= 7
+    assert isinstance(seen["floor"], Floor) and isinstance(seen["wall"], Wall) and isinstance(seen["border"], Wall)
+    assert seen["none"] is None
+    prog = env.scenario_spec()["gen_ctor"]
+    puts = [g for g in prog if g[0] == "put"]
+    assert len(puts) == 5 + 5 + 8                                       # horz_wall cells, the row of Walls, the 4 x 2 ring
+
+    class TooMany(MultiGridEnv):
+        def _gen_grid(self, width, height):
+            self.grid = MultiGrid((width, height))
+            self.place_obj(Goal(color="green", reward=1), max_tries=100)
+            for k in range(40):
+                self.grid.set(1 + (k * 2) % 9, 1 + (k * 4) // 9 * 2 % 9, Wall() if k % 2 else Floor())
+
+    with pytest.raises(NotImplementedError, match=r"1 groups of random placements and \d+ rectangle fills"):
+        TooMany(agents=[dict(color="red")], grid_size=11, _dry=True)

@@ -99,7 +99,8 @@ def test_bench_skeleton_two_ranks_gloo():
     ranks = out["timing"]["per_rank"]
     assert [r["rank"] for r in ranks] == [0, 1]
     assert all("affinity" in r and "obs_placement" in r and "kept" in r["obs_placement"] for r in ranks)
-    assert out["timing"]["control_plane"] == {"barriers": "gloo", "gathers": "gloo", "fallback": None}
+    assert out["timing"]["control_plane"] == {"barriers": "gloo", "gathers": "gloo", "fallback": None, "test_hooks": None}
+    assert out["cpu_baseline"]["one_thread"] > 0 and out["cpu_baseline"]["per_thread"] > 0 and len(out["cpu_baseline"]["points"]) >= 1
 
 
 @pytest.mark.parametrize("fail", ["natural", "1"])
@@ -127,7 +128,18 @@ def test_bench_rccl_failure_falls_back_to_gloo(fail):
     errs = cp["fallback"]["errors_by_rank"]
     assert errs and all(isinstance(v, str) and v for v in errs.values())
     if fail != "natural":
-        assert "BENCH_TEST_FAIL_NCCL" in errs["1"]
+        assert "BENCH_TEST_FAIL_NCCL" in errs["1"] and cp["test_hooks"] == {"BENCH_TEST_FAIL_NCCL": fail}
+
+
+def test_bench_refuses_test_hooks_outside_the_cpu_skeleton():
+    """BENCH_TEST_* switches exist for the CPU skeleton's tests; a measuring run must not be shaped by one"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict({k: v for k, v in os.environ.items() if not (k.startswith("MG_") or k.startswith("MARLGRID_"))},
+               BENCH_TEST_FAIL_NCCL="all")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=120, env=env, cwd=root)
+    assert r.returncode == 2 and "BENCH_TEST_FAIL_NCCL" in r.stderr and not r.stdout.strip()
 
 
 def test_timed_blocks_take_the_slowest_ranks_own_time():
