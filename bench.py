@@ -810,6 +810,22 @@ def physical_cores(cpus):
     return len(groups) or len(cpus)
 
 
+def cpu_quota_cores():
+    """the container's CPU bandwidth limit in cores (cgroup v2 cpu.max / v1 cfs quota), or None: a box may show 256 CPUs in
+    its affinity mask and still be given the time of a few"""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / p
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(budget_s, workload=WORKLOAD):
     """The parity-checked CPU oracle (a C port of the reference algorithm, OpenMP over envs) on a bounded sample of
     the same workload, on this box's host cores — in a CHILD process started with a clean environment: the bench
@@ -865,9 +881,13 @@ def cpu_baseline_child(budget_s, workload):
 
     share = max(1.0, budget_s / 6.0)
     pts = [run(64, 1, share)]
+    quota = cpu_quota_cores()
     if threads > 1:
         pts.append(run(64 * threads, threads, 2 * share))
-        if pts[-1]["setup_seconds"] < budget_s:                                  # (building 256 envs per thread takes 4 x as long)
+        if quota is not None and 1 < int(quota + 0.999) < threads:
+            # the container is given the time of fewer cores than it may run on: as many threads as it has cores' time
+            pts.append(run(64 * int(quota + 0.999), int(quota + 0.999), 2 * share))
+        elif pts[-1]["setup_seconds"] < budget_s:                                # (building 256 envs per thread takes 4 x as long)
             pts.append(run(256 * threads, threads, 2 * share))
     best = max(pts[1:] or pts, key=lambda q: q["value"])        # (the box's cores: the one-thread point is reported beside it)
     print(json.dumps({
@@ -876,7 +896,9 @@ def cpu_baseline_child(budget_s, workload):
         "sample": "%d envs x %d steps of %s (C oracle, OpenMP over envs, obs render included), %.1f s on %d threads; "
                   "one thread alone: %d envs x %d steps, %.1f s" % (best["envs"], best["steps"], workload, best["seconds"],
                                                                     best["threads"], pts[0]["envs"], pts[0]["steps"], pts[0]["seconds"]),
-        "points": pts, "host_cpus": os.cpu_count(), "cpus_allowed": len(cpus),
+        "points": pts, "host_cpus": os.cpu_count(), "cpus_allowed": len(cpus), "cpu_quota_cores": quota,
+        "scaling_vs_one_thread": best["value"] / pts[0]["value"],
+        "loadavg": (os.getloadavg() if hasattr(os, "getloadavg") else None),
         "omp": {k: os.environ.get(k) for k in ("OMP_PROC_BIND", "OMP_PLACES")},
         "cores_note": "cores = OpenMP threads = one per PHYSICAL core among the CPUs a clean child process may run on "
                       "(SMT siblings are not counted), bound to cores (OMP_PROC_BIND=spread, OMP_PLACES=cores); measured in a "

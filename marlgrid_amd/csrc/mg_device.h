@@ -126,7 +126,7 @@ __host__ __device__ inline int render_atlas_lds_bytes(const MgConfig& cfg, int m
 struct RenderLaunch {
     RenderScratch L;
     int per_wave;                               // envs per wave of the persistent grid
-    uint32_t m_n, m_nv, m_nvVV, m_VV, m_VS;     // Div20 multipliers of n, nv, nv * VS^2, VS^2, VS
+    uint32_t m_n, m_nv, m_nvVV, m_VV, m_VS, m_nvVS;   // Div20 multipliers of n, nv, nv * VS^2, VS^2, VS, nv * VS
     int depth_mode;                             // measurement builds: look-ahead depth forced for all waves (0: by wave)
     int atlas_lds;                              // bytes the atlas takes in LDS (render_atlas_lds_bytes; 0: read in place)
 #if defined(MG_AB_VARIANTS)

@@ -675,8 +675,37 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 else if (base == 0 && first != 0xFF && first != k && ((cfg.hide_agent_mask >> k) & 1u))
                     show = w_second[gcell + cell];
             }
-            // the pair waits where phase 5 puts the tile it selects
-            w_tmap[__umul24(g, (uint32_t)(L.tmap_stride / 2)) + iv] = (uint16_t)(base | (show << 8));
+            // tile selection (base.py:275-299) as if the cell were visible -> atlas offset of the view cell; phase 5
+            // puts the shadow tile where it is not.  (Selected HERE, where the cell's object, agent and viewer are in
+            // registers: as a per-cell phase of its own behind the shadow cast it re-derived the cell's coordinates
+            // and re-read all of it — 82 instructions per trip, now 7 conditional stores per view ROW.)
+            const uint32_t orient = (aff.y >> 24) & 3u;                                 // -(dir+1) mod 4 of the viewer
+            const uint8_t* w_recb = reinterpret_cast<const uint8_t*>(g_rec + __umul24(g, (uint32_t)rec_stride));   // records, bytewise
+            const uint32_t slot = s_oslot[base];
+            const bool stacked = show != 0xFF && slot != 0xFF;                          // an agent on an overlappable object / an empty cell
+            uint32_t tile = 1 + base;
+            if (stacked) tile = 1 + cfg.n_obj + (__umul24(slot, (uint32_t)n) + show) * 4 + w_recb[show * 8 + MG_AG_DIR];
+            uint32_t vt = __umul24(orient, (uint32_t)cfg.n_tiles) + tile;             // (virtual) tile index
+            bool dyn = false;
+            if constexpr (kPrestige) {
+                if (stacked && ((cfg.prestige_mask >> show) & 1u) && (w_recb[show * 8 + MG_AG_FLAGS] & MG_AF_ACTIVE)) {
+                    // hidden object under it: the plain-cell-object set
+                    const uint32_t hv = (cfg.any_hide && base == 0 &&
+                                         w_grid[__umul24(w_recb[show * 8 + MG_AG_X], (uint32_t)H) + w_recb[show * 8 + MG_AG_Y]] != 0) ? (uint32_t)n : 0u;
+                    vt = NT4 + (hv + show) * 4 + orient;
+                    dyn = true;
+                }
+            }
+            uint16_t* tmap = w_tmap + __umul24(g, (uint32_t)(L.tmap_stride / 2));
+            if constexpr (kChunkRaster && !kGlobalAtlas)                                // dword offset from the atlas base
+                tmap[iv] = (uint16_t)(dyn ? dyn_off / 4 + __umul24(vt - NT4, (uint32_t)(TS_ * TS_ * 3 / 4)) : __umul24(vt, (uint32_t)(TS_ * TS_ * 3 / 4)));
+            else
+                tmap[iv] = (uint16_t)vt;
+            if (dbg_cells) {
+                const size_t o = ((size_t)(e + (int)g) * nv + v) * VV + va * VS + vb;  // [i][j] like the reference
+                dbg_cells[o] = (uint8_t)base;
+                dbg_agent[o] = (uint8_t)show;
+            }
         }
         wave_lds_sync();
         // 4. visibility, one lane per viewer
@@ -695,47 +724,22 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
         };
         for (int it = lane; it < G * nv; it += kWave) { const int g = (int)by_nv.div((uint32_t)it); visibility(g, it - __mul24(g, nv)); }
         wave_lds_sync();
-        // 5. tile selection (base.py:275-299) -> atlas byte offset / 4 per view cell
-        for (uint32_t it = (uint32_t)lane; it < (uint32_t)(G * nvVV); it += kWave) {
-            const uint32_t g = by_nvVV.div(it), iv = it - __umul24(g, (uint32_t)nvVV);
-            const uint32_t v = by_VV.template div<kExactVV>(iv), c = iv - __umul24(v, (uint32_t)VV);
-            const uint32_t vb = by_VS.template div<(VS_ > 0)>(c), va = c - __umul24(vb, (uint32_t)VS);
-            const uint8_t* w_grid = g_grid + __umul24(g, (uint32_t)cfg.cells_stride);
-            const uint8_t* w_recb = reinterpret_cast<const uint8_t*>(g_rec + __umul24(g, (uint32_t)rec_stride));   // records, bytewise
-            uint16_t* tmap = w_tmap + __umul24(g, (uint32_t)(L.tmap_stride / 2));
-            const uint32_t visible = (w_vis[__umul24(g, (uint32_t)L.trow_stride) + __umul24(v, (uint32_t)VS) + vb] >> va) & 1u;
-            const uint32_t orient = (w_vaff[__umul24(g, (uint32_t)nv) + v].y >> 24) & 3u;   // -(dir+1) mod 4 of the viewer
-            const uint32_t pair = tmap[iv], base = pair & 0xFFu, show = pair >> 8;
-            uint32_t tile = 0;   // shadow
-            if (visible) {
-                const uint32_t slot = s_oslot[base];
-                if (show == 0xFF || slot == 0xFF) tile = 1 + base;
-                else {
-                    const uint32_t sdir = w_recb[show * 8 + MG_AG_DIR];
-                    tile = 1 + cfg.n_obj + (__umul24(slot, (uint32_t)n) + show) * 4 + sdir;
+        // 5. shadow (base.py:313-316): the cells a viewer does not see take tile 0 — the same pixels in every
+        //    orientation, offset 0 of the atlas.  One lane per view ROW: its visibility mask, then its VS cells.
+        {
+            const uint32_t nvVS = (uint32_t)(nv * VS);
+            const Div20 by_nvVS(nvVS, lc.m_nvVS);
+            for (uint32_t it = (uint32_t)lane; it < (uint32_t)G * nvVS; it += kWave) {
+                const uint32_t g = by_nvVS.div(it), r = it - __umul24(g, nvVS);          // r = viewer * VS + view row
+                const uint32_t mask = w_vis[__umul24(g, (uint32_t)L.trow_stride) + r];
+                uint16_t* row = w_tmap + __umul24(g, (uint32_t)(L.tmap_stride / 2)) + __umul24(r, (uint32_t)VS);
+                for (int va = 0; va < VS; va++)
+                    if (!((mask >> va) & 1u)) row[va] = 0;
+                if (dbg_cells) {
+                    const uint32_t v = by_VS.template div<(VS_ > 0)>(r), vb = r - __umul24(v, (uint32_t)VS);
+                    for (int va = 0; va < VS; va++)
+                        dbg_vis[((size_t)(e + (int)g) * nv + v) * VV + va * VS + vb] = (uint8_t)((mask >> va) & 1u);
                 }
-            }
-            uint32_t vt = __umul24(orient, (uint32_t)cfg.n_tiles) + tile;         // (virtual) tile index
-            bool dyn = false;
-            if constexpr (kPrestige) {
-                if (visible && show != 0xFF && s_oslot[base] != 0xFF && ((cfg.prestige_mask >> show) & 1u) &&
-                    (w_recb[show * 8 + MG_AG_FLAGS] & MG_AF_ACTIVE)) {
-                    // hidden object under it: the plain-cell-object set
-                    const uint32_t hv = (cfg.any_hide && base == 0 &&
-                                         w_grid[__umul24(w_recb[show * 8 + MG_AG_X], (uint32_t)H) + w_recb[show * 8 + MG_AG_Y]] != 0) ? (uint32_t)n : 0u;
-                    vt = NT4 + (hv + show) * 4 + orient;
-                    dyn = true;
-                }
-            }
-            if constexpr (kChunkRaster && !kGlobalAtlas)                          // dword offset from the atlas base
-                tmap[iv] = (uint16_t)(dyn ? dyn_off / 4 + __umul24(vt - NT4, (uint32_t)(TS_ * TS_ * 3 / 4)) : __umul24(vt, (uint32_t)(TS_ * TS_ * 3 / 4)));
-            else
-                tmap[iv] = (uint16_t)vt;
-            if (dbg_cells) {
-                const size_t o = ((size_t)(e + (int)g) * nv + v) * VV + va * VS + vb;  // [i][j] like the reference
-                dbg_cells[o] = (uint8_t)base;
-                dbg_agent[o] = (uint8_t)show;
-                dbg_vis[o] = (uint8_t)visible;
             }
         }
         wave_lds_sync();
@@ -1143,6 +1147,7 @@ hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_t* obs,
     lc.m_nvVV = Div20(nv * vs * vs).m;
     lc.m_VV = Div20(vs * vs).m;
     lc.m_VS = Div20(vs).m;
+    lc.m_nvVS = Div20(nv * vs).m;
     lc.depth_mode = 0;
     lc.atlas_lds = (int)atlas_lds;
 #if defined(MG_AB_VARIANTS)

@@ -137,6 +137,8 @@ def ref_recipe(name):
         "Edge-3AgentCluttered13x13-view13-ts8": ("ClutteredMultiGrid", dict(grid_size=13, n_clutter=20)),
         "Edge-2AgentEmpty6x6-view3-ts33": ("EmptyMultiGrid", dict(grid_size=6)),
         "Edge-3AgentCluttered15x15-default-tiles": ("ClutteredMultiGrid", dict(grid_size=15, n_clutter=10)),
+        "Edge-3AgentCluttered15x15-tile6": ("ClutteredMultiGrid", dict(grid_size=15, n_clutter=10)),
+        "Edge-5AgentEmpty9x9-tile5-offset3": ("EmptyMultiGrid", dict(grid_size=9)),
         "Test-3AgentEmpty7x11-nonsquare": ("EmptyMultiGrid", dict(width=7, height=11)),
         "Test-3AgentCluttered12x6-nonsquare": ("ClutteredMultiGrid", dict(width=12, height=6, n_clutter=7)),
         "Test-2AgentLateStatic10x10": ("LateStaticTestEnv", dict(grid_size=10, respawn=True, max_steps=50)),
@@ -306,6 +308,10 @@ def registered(name):   # noqa: F811  (extends the table above with test-only sc
         "Edge-3AgentCluttered15x15-default-tiles": lambda: cluttered_spec(3, 15, 7, n_clutter=10, tile_size=5,
                                                                           colors=["red", "red", "red"]),
         "Edge-3AgentCluttered11x11-offset6": lambda: cluttered_spec(3, 11, 7, n_clutter=12, view_offset=6),
+        # the gather raster's other instantiation (view 7, 6-pixel tiles), and 5-pixel tiles with five viewers: an env's
+        # stream is then 18 375 bytes — every env of a wave's run starts at another byte phase
+        "Edge-3AgentCluttered15x15-tile6": lambda: cluttered_spec(3, 15, 7, n_clutter=10, tile_size=6),
+        "Edge-5AgentEmpty9x9-tile5-offset3": lambda: empty_spec(5, 9, 7, tile_size=5, view_offset=3, colors=_MANY[:5]),
         # EVEN view sizes (agents.py:233-266 is written with view_size // 2: in an even view the agent sits at column
         # view_size // 2 when it faces up or right and one column to the left of it when it faces down or left, while
         # the shadow cast always starts from column view_size // 2 — upstream's geometry, reproduced as it is)

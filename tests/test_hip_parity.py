@@ -159,6 +159,10 @@ def test_rng_seeding_golden():
                                        ("MarlGrid-3AgentCluttered11x11-v0", 65, 30),
                                        ("MarlGrid-4AgentEmpty9x9-v0", 4097, 20),
                                        ("Edge-3AgentCluttered15x15-default-tiles", 4100, 40),
+                                       ("Edge-3AgentCluttered15x15-tile6", 4099, 30),
+                                       ("Edge-3AgentCluttered15x15-tile6", 37, 30),
+                                       ("Edge-5AgentEmpty9x9-tile5-offset3", 4133, 25),
+                                       ("Edge-5AgentEmpty9x9-tile5-offset3", 9, 25),
                                        ("Test-3AgentCluttered9x9-prestige-mixed", 256, 160)])
 def test_batch_vs_oracle(name, B, T):
     """same seeds, same actions: HIP batch == B oracle envs, every step, full observations."""

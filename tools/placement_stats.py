@@ -27,7 +27,22 @@ if front > 0:
     print(json.dumps({"front_GiB": front, "alloc_s": t1 - t0, "free_s": time.perf_counter() - t1}), flush=True)
 env = ClutteredMultiGrid(agents=[GridAgentInterface(color=c, view_size=7, view_tile_size=ts) for c in ("red", "blue", "purple")],
                          grid_size=15, clutter_density=0.15, batch_size=B, strict=False, auto_reset=True)
-pm = dict(env._groups[0].placement_ms)
-pm["all"] = [round(x, 4) for x in pm["all"]]
-pm["kept"] = [round(x, 4) for x in pm["kept"]]
-print(json.dumps({"B": B, "tile": ts, **pm}))
+def show(env, what):
+    pm = dict(env._groups[0].placement_ms)
+    pm["all"] = [round(x, 4) for x in pm["all"]]
+    pm["kept"] = [round(x, 4) for x in pm["kept"]]
+    print(json.dumps({"what": what, "B": B, "tile": ts, **pm}), flush=True)
+
+
+show(env, "first env of the process (mg_obs_place, defaults)")
+# a second env of the same size while the first is alive (a new search), then one after the first is gone (its released
+# buffers are remembered by the library: no search)
+env2 = ClutteredMultiGrid(agents=[GridAgentInterface(color=c, view_size=7, view_tile_size=ts) for c in ("red", "blue", "purple")],
+                          grid_size=15, clutter_density=0.15, batch_size=B, strict=False, auto_reset=True)
+show(env2, "second env, the first still alive")
+del env, env2
+import gc  # noqa: E402
+gc.collect()
+env3 = ClutteredMultiGrid(agents=[GridAgentInterface(color=c, view_size=7, view_tile_size=ts) for c in ("red", "blue", "purple")],
+                          grid_size=15, clutter_density=0.15, batch_size=B, strict=False, auto_reset=True)
+show(env3, "third env, after the first two were released")
