@@ -332,7 +332,9 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             for (int i = lane; i < L.out_chunks; i += kWave) reinterpret_cast<uint4*>(w_out)[i] = make_uint4(0, 0, 0, 0);
             wave_lds_sync();
         }
-        depth = depth_mode > 0 ? depth_mode : !kChunkRaster ? L.tmap_slots : kPrestige ? (1 << (wave & 3)) : (TS_ == 8 ? 2 : 1);
+        // (the gather raster: groups of FOUR — measured against 1, 2, 3 and the whole batch of 8, raster alone: -4.0 % at tile 5,
+        // -3.8 % at tile 6 against 8; with 8 the first store of a launch waits for 23 us of views, profiles/r05)
+        depth = depth_mode > 0 ? depth_mode : kGather ? 4 : !kChunkRaster ? L.tmap_slots : kPrestige ? (1 << (wave & 3)) : (TS_ == 8 ? 2 : 1);
         if (depth > L.tmap_slots) depth = L.tmap_slots;
         if (depth > L.view_slots) depth = L.view_slots;   // (a group's views need a scratch slot per env)
     }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Every configuration that is NOT the contract line, on the product library with the product's defaults (placed
-observation buffers): the other BASELINE.json configs at their per-GPU batch, the tile / view sizes off the fast path,
+"""Every configuration that is NOT the contract line, on the product library with placed observation buffers
+(place_obs="thorough": this tool owns the GPU and measures kernels, not the placement search's bounded default): the other BASELINE.json configs at their per-GPU batch, the tile / view sizes off the fast path,
 the 'prestige' cases and the reference's one runnable example.  Per case one JSON line: the raster alone
 (mg_render_obs, HIP events inside the library) and the whole env.step() (HIP events around 30 steps), both as a
 fraction of 8 TB/s on the observation bytes.  usage: bench_cases.py [substring of a case label ...]"""
@@ -18,7 +18,7 @@ from marlgrid_amd.agents import GridAgentInterface  # noqa: E402
 from marlgrid_amd.envs import ClutteredGoalCycleEnv, ClutteredMultiGrid, make  # noqa: E402
 
 COLS = ["red", "blue", "purple", "orange", "olive", "pink", "cyan", "yellow"]
-KW = dict(strict=False, auto_reset=True)
+KW = dict(strict=False, auto_reset=True, place_obs="thorough")
 
 
 def agents(n, vs, ts, **kw):
@@ -83,7 +83,7 @@ for label, mk in cases:
         print(json.dumps({"case": label, "B": B, "n": env.num_agents, "view": env.view_size, "tile": env.tile_size, "obs_bytes": nb,
                           "raster_ms": r, "raster_frac_of_8TBps": nb / r / 1e6 / 8000, "step_ms": s,
                           "step_frac_of_8TBps": nb / s / 1e6 / 8000, "agent_steps_per_s": B * env.num_agents / s * 1e3,
-                          "obs_placement": {k: pm.get(k) for k in ("kept", "candidates", "stopped")}}), flush=True)
+                          "obs_placement": {k: pm.get(k) for k in ("found", "kept", "candidates", "stopped", "seconds", "pinned_bytes")}}), flush=True)
         del env
     except Exception as e:      # noqa: BLE001 — one case must not cost the others
         print(json.dumps({"case": label, "error": "%s: %s" % (type(e).__name__, e)}), flush=True)
