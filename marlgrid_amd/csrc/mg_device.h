@@ -104,11 +104,13 @@ struct RenderScratch {
 };
 // The atlas in LDS.  As it is in HBM ([4 orientations][n_tiles][ts][ts][3], rounded up to 16 bytes) — except for the
 // GATHER raster (mg_gather.h; the kernel's RM_ == 2, `mode` 2 below), which is instantiated for the reference's default
-// view with its default 5-pixel tiles (agents.py:21-22) and for 6-pixel tiles: there every tile ROW gets 16 zero bytes in
+// view with its default 5-pixel tiles (agents.py:21-22) and for 6-, 7-, 9-, 10-, 11- and 12-pixel tiles (the tile sizes
+// under 16 that the 16-byte-chunk raster does not take): there every tile ROW gets 16 zero bytes in
 // front (GatherGeom::RS bytes per row, 32 zero bytes behind the last), so that a 16-byte window anywhere around a row is
 // whole aligned dwords with zeros outside the row — no edge masks, no conditional reads.
 __host__ __device__ inline bool render_gather(const MgConfig& cfg) {
-    return cfg.view_size == 7 && (cfg.tile_size == 5 || cfg.tile_size == 6) && cfg.prestige_mask == 0;
+    const int ts = cfg.tile_size;
+    return cfg.view_size == 7 && (ts == 5 || ts == 6 || ts == 7 || ts == 9 || ts == 10 || ts == 11 || ts == 12) && cfg.prestige_mask == 0;
 }
 __host__ __device__ inline int render_gather_row_bytes(int ts) { return (16 + 3 * ts + 3) / 4 * 4; }
 __host__ __device__ inline int render_atlas_raw_bytes(const MgConfig& cfg) {

@@ -184,55 +184,62 @@ MG_HD uint8_t gather_byte(const uint8_t* tmap, const uint8_t* atlas, uint32_t q)
 struct alignas(16) GatherChunk { uint32_t x, y, z, w; };     // one aligned 16-byte store
 
 // One cycle (NT trips) of a lane: chunk y * CC + t * LPT + lane for every set t, in three phases with nothing scheduled
-// across them — all tmap look-ups, all window reads, then compose and store.  kTail: the group's last, incomplete
-// cycle — chunks >= nfull are not touched (their tmap entries lie behind the group's).
+// across them — all tmap look-ups, all window reads, then compose and store — for up to three sets at a time (four
+// sets: two and two; their forty window registers do not fit a 16-wave workgroup's 128).  kTail: the group's last,
+// incomplete cycle — chunks >= nfull are not touched (their tmap entries lie behind the group's).
 template <int VS, int TS, bool kTail>
 MG_HD void gather_cycle(const GatherLane<GatherGeom<VS, TS>::NT>& c, int lane, uint32_t y, const uint8_t* tmap,
                         const uint8_t* atlas, GatherChunk* out, uint32_t nfull) {
     typedef GatherGeom<VS, TS> Gm;
-    constexpr int NT = Gm::NT;
+    constexpr int NT = Gm::NT, SB = NT <= 3 ? NT : 2;           // sets per batch
     const uint32_t tcyc = y * (uint32_t)(Gm::CYC_BANDS * VS * 2), rowbase = y * (uint32_t)Gm::CYC_ROWS;
     const uint32_t i0 = y * (uint32_t)Gm::CC + (uint32_t)lane;
-    bool on[NT];
 #pragma unroll
-    for (int t = 0; t < NT; t++) on[t] = lane < Gm::lanes_of(t) && (!kTail || i0 + (uint32_t)(t * Gm::LPT) < nfull);
-    uint32_t pa[NT], pb[NT];
+    for (int t0 = 0; t0 < NT; t0 += SB) {
+        bool on[SB];
 #pragma unroll
-    for (int t = 0; t < NT; t++) {
-        pa[t] = pb[t] = 0;
-        if (!kTail || on[t]) {
-            uint32_t rra, rrb;
-            const uint32_t oa = gather_tmap_off<VS, TS>(c.ta[t], c.ra[t], tcyc, rowbase, rra);
-            const uint32_t ob = gather_tmap_off<VS, TS>(c.tb[t], c.rb[t], tcyc, rowbase, rrb);
-            pa[t] = rra * Gm::RS + c.sa[t];
-            pb[t] = rrb * Gm::RS + c.sb[t];
-            const uint32_t va = *reinterpret_cast<const uint16_t*>(tmap + oa), vb = *reinterpret_cast<const uint16_t*>(tmap + ob);
-            pa[t] += va * (uint32_t)Gm::TILE;
-            pb[t] += vb * (uint32_t)Gm::TILE;
-            MG_GATHER_BOUNDS(oa, pa[t]);
-            MG_GATHER_BOUNDS(ob, pb[t]);
+        for (int u = 0; u < SB; u++) on[u] = lane < Gm::lanes_of(t0 + u) && (!kTail || i0 + (uint32_t)((t0 + u) * Gm::LPT) < nfull);
+        uint32_t pa[SB], pb[SB];
+#pragma unroll
+        for (int u = 0; u < SB; u++) {
+            const int t = t0 + u;
+            pa[u] = pb[u] = 0;
+            if (!kTail || on[u]) {
+                uint32_t rra, rrb;
+                const uint32_t oa = gather_tmap_off<VS, TS>(c.ta[t], c.ra[t], tcyc, rowbase, rra);
+                const uint32_t ob = gather_tmap_off<VS, TS>(c.tb[t], c.rb[t], tcyc, rowbase, rrb);
+                pa[u] = rra * Gm::RS + c.sa[t];
+                pb[u] = rrb * Gm::RS + c.sb[t];
+                const uint32_t va = *reinterpret_cast<const uint16_t*>(tmap + oa), vb = *reinterpret_cast<const uint16_t*>(tmap + ob);
+                pa[u] += va * (uint32_t)Gm::TILE;
+                pb[u] += vb * (uint32_t)Gm::TILE;
+                MG_GATHER_BOUNDS(oa, pa[u]);
+                MG_GATHER_BOUNDS(ob, pb[u]);
+            }
         }
-    }
-    MG_SCHED_FENCE();
-    uint32_t wa[NT][5], wb[NT][5];
+        MG_SCHED_FENCE();
+        uint32_t wa[SB][5], wb[SB][5];
 #pragma unroll
-    for (int t = 0; t < NT; t++) {
-        const uint32_t* qa = reinterpret_cast<const uint32_t*>(atlas + pa[t]);
-        const uint32_t* qb = reinterpret_cast<const uint32_t*>(atlas + pb[t]);
+        for (int u = 0; u < SB; u++) {
+            const uint32_t* qa = reinterpret_cast<const uint32_t*>(atlas + pa[u]);
+            const uint32_t* qb = reinterpret_cast<const uint32_t*>(atlas + pb[u]);
 #pragma unroll
-        for (int j = 0; j < 5; j++) { wa[t][j] = qa[j]; wb[t][j] = qb[j]; }
-    }
-    MG_SCHED_FENCE();
-#pragma unroll
-    for (int t = 0; t < NT; t++) {
-        if (on[t]) {
-            GatherChunk v;
-            v.x = gather_align(wa[t][1], wa[t][0], c.ha[t]) | gather_align(wb[t][1], wb[t][0], c.hb[t]);
-            v.y = gather_align(wa[t][2], wa[t][1], c.ha[t]) | gather_align(wb[t][2], wb[t][1], c.hb[t]);
-            v.z = gather_align(wa[t][3], wa[t][2], c.ha[t]) | gather_align(wb[t][3], wb[t][2], c.hb[t]);
-            v.w = gather_align(wa[t][4], wa[t][3], c.ha[t]) | gather_align(wb[t][4], wb[t][3], c.hb[t]);
-            out[i0 + (uint32_t)(t * Gm::LPT)] = v;
+            for (int j = 0; j < 5; j++) { wa[u][j] = qa[j]; wb[u][j] = qb[j]; }
         }
+        MG_SCHED_FENCE();
+#pragma unroll
+        for (int u = 0; u < SB; u++) {
+            const int t = t0 + u;
+            if (on[u]) {
+                GatherChunk v;
+                v.x = gather_align(wa[u][1], wa[u][0], c.ha[t]) | gather_align(wb[u][1], wb[u][0], c.hb[t]);
+                v.y = gather_align(wa[u][2], wa[u][1], c.ha[t]) | gather_align(wb[u][2], wb[u][1], c.hb[t]);
+                v.z = gather_align(wa[u][3], wa[u][2], c.ha[t]) | gather_align(wb[u][3], wb[u][2], c.hb[t]);
+                v.w = gather_align(wa[u][4], wa[u][3], c.ha[t]) | gather_align(wb[u][4], wb[u][3], c.hb[t]);
+                out[i0 + (uint32_t)(t * Gm::LPT)] = v;
+            }
+        }
+        MG_SCHED_FENCE();
     }
 }
 

@@ -20,6 +20,8 @@ MG_RENDER_GROUP_C(MG_RENDER_EXTERN)
 MG_RENDER_GROUP_D(MG_RENDER_EXTERN)
 MG_RENDER_GROUP_E(MG_RENDER_EXTERN)
 MG_RENDER_GROUP_G(MG_RENDER_EXTERN)
+MG_RENDER_GROUP_H(MG_RENDER_EXTERN)
+MG_RENDER_GROUP_I(MG_RENDER_EXTERN)
 MG_RENDER_GROUP_V(MG_RENDER_EXTERN)
 #endif
 
@@ -126,11 +128,20 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
         if (ts == 32) return launch_render_t<0, 32, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
         return launch_render_t<0, 0, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
     }
-    if (mode == 2) {   // the gather raster: view 7 with 5- or 6-pixel tiles (GridAgentInterface's defaults, agents.py:21-22)
-        if (ts == 5) return wpb == 16 ? launch_render_t<7, 5, 16, 0, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)
-                                      : launch_render_t<7, 5, 4, 0, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
-        return wpb == 16 ? launch_render_t<7, 6, 16, 0, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)
-                         : launch_render_t<7, 6, 4, 0, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
+    if (mode == 2) {   // the gather raster: view 7 (GridAgentInterface's default, agents.py:21) with 5- .. 12-pixel tiles
+#define MG_RENDER_DISPATCH_G(TS)                                                                                     \
+    (wpb == 16 ? launch_render_t<7, TS, 16, 0, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)              \
+               : launch_render_t<7, TS, 4, 0, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs))
+        switch (ts) {
+        case 5: return MG_RENDER_DISPATCH_G(5);
+        case 6: return MG_RENDER_DISPATCH_G(6);
+        case 7: return MG_RENDER_DISPATCH_G(7);
+        case 9: return MG_RENDER_DISPATCH_G(9);
+        case 10: return MG_RENDER_DISPATCH_G(10);
+        case 11: return MG_RENDER_DISPATCH_G(11);
+        default: return MG_RENDER_DISPATCH_G(12);
+        }
+#undef MG_RENDER_DISPATCH_G
     }
     {   // atlas too large for LDS (next to 4 waves of scratch): read it from global memory instead
         const RenderScratch L = render_scratch_for(cfg, 4);
@@ -167,12 +178,7 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
     if (ts == 32 && vs == 7) return MG_RENDER_DISPATCH(7, 32, 0);
     if (ts == 16) return MG_RENDER_DISPATCH_RT(16, 0);
     if (ts == 32) return MG_RENDER_DISPATCH_RT(32, 0);
-    bool rt_ts = false;     // measurement build: MG_RENDER_RT_TS=1 takes the run-time-tile-size instantiation instead
-#if defined(MG_AB_VARIANTS)
-    if (const char* f = getenv("MG_RENDER_RT_TS")) rt_ts = atoi(f) != 0;
-#endif
-    if (vs == 7 && ts == 11 && !rt_ts) return MG_RENDER_DISPATCH(7, 11, 0);
-    if (vs == 7) return MG_RENDER_DISPATCH(7, 0, 0);        // the default view with any other tile size
+    if (vs == 7) return MG_RENDER_DISPATCH(7, 0, 0);        // the default view with any other tile size (or a gather atlas too large for LDS)
     return MG_RENDER_DISPATCH_RT(0, 0);                   // anything else
 #endif
 }

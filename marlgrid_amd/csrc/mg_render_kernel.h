@@ -1172,7 +1172,7 @@ hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_t* obs,
     X(7, 16, 16, 0, 0) X(7, 16, 4, 0, 0) X(7, 32, 16, 0, 0) X(7, 32, 4, 0, 0) X(0, 16, 8, 0, 0) X(0, 16, 4, 0, 0)               \
     X(0, 32, 8, 0, 0) X(0, 32, 4, 0, 0) X(0, 8, 4, 8, 0) X(0, 16, 4, 8, 0) X(0, 32, 4, 8, 0) X(0, 0, 4, 8, 0)
 #define MG_RENDER_GROUP_C(X) /* assemble-and-stream: any other tile size */                                                \
-    X(7, 11, 16, 0, 0) X(7, 11, 4, 0, 0) X(7, 0, 16, 0, 0) X(7, 0, 4, 0, 0) X(0, 0, 8, 0, 0) X(0, 0, 4, 0, 0)
+    X(7, 0, 16, 0, 0) X(7, 0, 4, 0, 0) X(0, 0, 8, 0, 0) X(0, 0, 4, 0, 0)
 #define MG_RENDER_GROUP_D(X) /* 'prestige': per-env recoloured tiles */                                                     \
     X(7, 8, 12, 9, 0) X(7, 8, 8, 9, 0) X(7, 8, 4, 9, 0) X(7, 11, 12, 9, 0) X(7, 11, 8, 9, 0) X(7, 11, 4, 9, 0)                  \
     X(0, 8, 4, 9, 0) X(0, 16, 4, 9, 0)
@@ -1181,6 +1181,10 @@ hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_t* obs,
     X(0, 8, 4, 12, 0) X(0, 16, 4, 12, 0) X(0, 32, 4, 12, 0) X(0, 0, 4, 12, 0)
 #define MG_RENDER_GROUP_G(X) /* the gather raster (mg_gather.h): view 7, 5- and 6-pixel tiles */                          \
     X(7, 5, 16, 0, 2) X(7, 5, 4, 0, 2) X(7, 6, 16, 0, 2) X(7, 6, 4, 0, 2)
+#define MG_RENDER_GROUP_H(X) /* ... 7-, 9- and 10-pixel tiles */                                                           \
+    X(7, 7, 16, 0, 2) X(7, 7, 4, 0, 2) X(7, 9, 16, 0, 2) X(7, 9, 4, 0, 2) X(7, 10, 16, 0, 2) X(7, 10, 4, 0, 2)
+#define MG_RENDER_GROUP_I(X) /* ... 11- and 12-pixel tiles */                                                              \
+    X(7, 11, 16, 0, 2) X(7, 11, 4, 0, 2) X(7, 12, 16, 0, 2) X(7, 12, 4, 0, 2)
 #if defined(MG_AB_VARIANTS)
 #define MG_RENDER_GROUP_V(X) /* measurement variants (tools/ab_render.py) */                                               \
     X(7, 8, 16, 2, 0) X(7, 8, 4, 2, 0) X(7, 8, 16, 3, 0) X(7, 8, 4, 3, 0) X(7, 8, 16, 4, 0) X(7, 8, 4, 4, 0)                     \

@@ -163,6 +163,13 @@ def test_rng_seeding_golden():
                                        ("Edge-3AgentCluttered15x15-tile6", 37, 30),
                                        ("Edge-5AgentEmpty9x9-tile5-offset3", 4133, 25),
                                        ("Edge-5AgentEmpty9x9-tile5-offset3", 9, 25),
+                                       ("Edge-3AgentCluttered11x11-tile7", 4101, 20),
+                                       ("Edge-3AgentCluttered11x11-tile9", 67, 20),
+                                       ("Edge-3AgentCluttered11x11-tile10", 4098, 20),
+                                       ("Edge-3AgentCluttered11x11-tile11", 4097, 20),
+                                       ("Edge-3AgentCluttered11x11-tile11", 11, 20),
+                                       ("Edge-3AgentCluttered11x11-tile12", 4103, 20),
+                                       ("Edge-3AgentCluttered11x11-tile13", 4099, 20),
                                        ("Test-3AgentCluttered9x9-prestige-mixed", 256, 160)])
 def test_batch_vs_oracle(name, B, T):
     """same seeds, same actions: HIP batch == B oracle envs, every step, full observations."""
