@@ -572,8 +572,9 @@ class MultiGridEnv(object):
         <= min(a quarter of the free memory, 32 GiB); 2 s at most; a kept buffer pins its whole candidate — 1.5 .. 3 x its
         size, outside torch's allocator (`env.obs_placement[g]["pinned_bytes"]`); buffers under 256 MiB are plain torch
         allocations.  "thorough" adds what round 4 found necessary on memory nobody had allocated before: larger block
-        pairs (a kept buffer may then pin up to 12 x its size), a second pass, and one big allocate-and-free (half of the
-        free memory, 64 GiB at most) that mixes the driver's free lists.  A released buffer of the fast class is
+        pairs (a kept buffer may then pin up to 12 x its size), a second pass, one big allocate-and-free (half of the
+        free memory, 64 GiB at most) that mixes the driver's free lists, and larger budgets (candidates up to half of the
+        free memory / 128 GiB, 6 s per pass).  A released buffer of the fast class is
         remembered by the library: the next env of the same size in this process takes it without a search
         (`release_obs_cache()` gives them back).  Without a candidate in the fast class the best seen is kept and
         `found` is False: try again later, or with place_obs="thorough"."""
@@ -583,6 +584,10 @@ class MultiGridEnv(object):
         if stir is None:
             stir = thorough
         flags = (N.PLACE_THOROUGH if thorough else 0) | (N.PLACE_STIR if stir else 0) | (0 if reuse else N.PLACE_NO_REUSE)
+        if thorough and not budget:         # the long search is for a process that owns its GPU: half of what is free, 6 s per pass
+            budget = min(torch.cuda.mem_get_info(self.device)[0] // 2, 128 << 30)
+        if thorough and not seconds:
+            seconds = 6.0
         tn = N.PlaceTuning(gain=gain, slow_alloc_s_per_gib=slow_alloc, min_bytes=min_bytes, stir_bytes=stir_cap,
                            max_candidates=max_candidates, iters=iters)
         threshold = min_bytes or (256 << 20)

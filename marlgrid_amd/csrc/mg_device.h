@@ -110,7 +110,9 @@ struct RenderScratch {
 // whole aligned dwords with zeros outside the row — no edge masks, no conditional reads.
 __host__ __device__ inline bool render_gather(const MgConfig& cfg) {
     const int ts = cfg.tile_size;
-    return cfg.view_size == 7 && (ts == 5 || ts == 6 || ts == 7 || ts == 9 || ts == 10 || ts == 11 || ts == 12) && cfg.prestige_mask == 0;
+    // ('prestige' agents — per-env recoloured tiles next to the atlas's —: the reference's example, 11-pixel tiles)
+    return cfg.view_size == 7 && (ts == 5 || ts == 6 || ts == 7 || ts == 9 || ts == 10 || ts == 11 || ts == 12) &&
+           (cfg.prestige_mask == 0 || ts == 11);
 }
 __host__ __device__ inline int render_gather_row_bytes(int ts) { return (16 + 3 * ts + 3) / 4 * 4; }
 __host__ __device__ inline int render_atlas_raw_bytes(const MgConfig& cfg) {
@@ -187,7 +189,8 @@ __host__ __device__ inline bool render_chunk_raster(const MgConfig& cfg, int mod
 __host__ __device__ inline RenderScratch render_scratch_for(const MgConfig& cfg, int wpb, int mode = 0) {
     const int n = cfg.n_agents, vs = cfg.view_size, ts = cfg.tile_size;
     const int nv = cfg.n_view ? cfg.n_view : n;
-    const int dyn = cfg.prestige_mask ? (cfg.any_hide ? 2 : 1) * n * 4 * ts * ts * 3 : 0;
+    // (the recoloured tiles of a 'prestige' env: as the atlas's — gather raster: in padded rows)
+    const int dyn = cfg.prestige_mask ? (cfg.any_hide ? 2 : 1) * n * 4 * ts * (mode == 2 ? render_gather_row_bytes(ts) : ts * 3) + (mode == 2 ? 32 : 0) : 0;
     // (`fixed`: what a workgroup holds besides its waves' scratch — exactly the launcher's sum, launch_render_t)
     const int atlas_b = render_atlas_lds_bytes(cfg, mode), fixed = kRenderShared;
     const bool gather = mode == 2;
@@ -207,7 +210,7 @@ __host__ __device__ inline RenderScratch render_scratch_for(const MgConfig& cfg,
     const int resident = (atlas_b + 4 * b.total + fixed <= 160 * 1024) ? atlas_b : 0;   // else the atlas is read in place
     // ('prestige' — 12-wave workgroups next to a large atlas —: fewer view slots before fewer staged envs or fewer waves)
     for (int slots = dyn ? 8 : 0; dyn && slots >= 1; slots >>= 1) {
-        const RenderScratch t = render_scratch_layout(cfg.cells_stride, n, nv, vs, 8, dyn, out, rows, cfg.any_hide != 0, slots);
+        const RenderScratch t = render_scratch_layout(cfg.cells_stride, n, nv, vs, 8, dyn, out, rows, cfg.any_hide != 0, slots, gather);
         if (resident + wpb * t.total + fixed <= 160 * 1024) return t;
     }
     int k = 8;

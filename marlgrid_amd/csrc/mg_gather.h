@@ -166,13 +166,17 @@ MG_HD uint32_t gather_tmap_off(uint32_t t_, uint32_t r_, uint32_t tcyc, uint32_t
 }
 
 // One byte of the group's stream, the slow way (the < 16 bytes in front of the first and behind the last whole chunk).
-template <int VS, int TS>
-MG_HD uint8_t gather_byte(const uint8_t* tmap, const uint8_t* atlas, uint32_t q) {
+// kDyn: virtual tiles >= dyn.first are not part of the atlas but a wave's own (the per-env recoloured 'prestige'
+// tiles, in the same padded layout): tile t of them lies at atlas + t * TILE + dyn.delta
+struct GatherDyn { uint32_t first, delta; };
+template <int VS, int TS, bool kDyn = false>
+MG_HD uint8_t gather_byte(const uint8_t* tmap, const uint8_t* atlas, uint32_t q, GatherDyn dyn = GatherDyn{0, 0}) {
     typedef GatherGeom<VS, TS> Gm;
     const uint32_t g = q / Gm::SEG, k = q - g * Gm::SEG, R = g / VS, col = g - R * VS, band = R / TS, rr = R - band * TS;
     const uint32_t vt = *reinterpret_cast<const uint16_t*>(tmap + (band * VS + col) * 2u);
-    MG_GATHER_BOUNDS((band * VS + col) * 2u, vt * Gm::TILE + rr * Gm::RS + Gm::FRONT + k - 16u);
-    return atlas[vt * Gm::TILE + rr * Gm::RS + Gm::FRONT + k];
+    const uint32_t a = vt * Gm::TILE + rr * Gm::RS + Gm::FRONT + k + ((kDyn && vt >= dyn.first) ? dyn.delta : 0u);
+    MG_GATHER_BOUNDS((band * VS + col) * 2u, a - 16u);
+    return atlas[a];
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -187,9 +191,9 @@ struct alignas(16) GatherChunk { uint32_t x, y, z, w; };     // one aligned 16-b
 // across them — all tmap look-ups, all window reads, then compose and store — for up to three sets at a time (four
 // sets: two and two; their forty window registers do not fit a 16-wave workgroup's 128).  kTail: the group's last,
 // incomplete cycle — chunks >= nfull are not touched (their tmap entries lie behind the group's).
-template <int VS, int TS, bool kTail>
+template <int VS, int TS, bool kTail, bool kDyn = false>
 MG_HD void gather_cycle(const GatherLane<GatherGeom<VS, TS>::NT>& c, int lane, uint32_t y, const uint8_t* tmap,
-                        const uint8_t* atlas, GatherChunk* out, uint32_t nfull) {
+                        const uint8_t* atlas, GatherChunk* out, uint32_t nfull, GatherDyn dyn = GatherDyn{0, 0}) {
     typedef GatherGeom<VS, TS> Gm;
     constexpr int NT = Gm::NT, SB = NT <= 3 ? NT : 2;           // sets per batch
     const uint32_t tcyc = y * (uint32_t)(Gm::CYC_BANDS * VS * 2), rowbase = y * (uint32_t)Gm::CYC_ROWS;
@@ -211,8 +215,8 @@ MG_HD void gather_cycle(const GatherLane<GatherGeom<VS, TS>::NT>& c, int lane, u
                 pa[u] = rra * Gm::RS + c.sa[t];
                 pb[u] = rrb * Gm::RS + c.sb[t];
                 const uint32_t va = *reinterpret_cast<const uint16_t*>(tmap + oa), vb = *reinterpret_cast<const uint16_t*>(tmap + ob);
-                pa[u] += va * (uint32_t)Gm::TILE;
-                pb[u] += vb * (uint32_t)Gm::TILE;
+                pa[u] += va * (uint32_t)Gm::TILE + ((kDyn && va >= dyn.first) ? dyn.delta : 0u);
+                pb[u] += vb * (uint32_t)Gm::TILE + ((kDyn && vb >= dyn.first) ? dyn.delta : 0u);
                 MG_GATHER_BOUNDS(oa, pa[u]);
                 MG_GATHER_BOUNDS(ob, pb[u]);
             }
@@ -246,18 +250,19 @@ MG_HD void gather_cycle(const GatherLane<GatherGeom<VS, TS>::NT>& c, int lane, u
 // The raster of a GROUP of envs by one wave: `stream_bytes` bytes at `dst` (any alignment) — whole aligned chunks by
 // gather_cycle, the bytes in front of the first and behind the last whole chunk one by one (the chunk they lie in is
 // shared with the wave, or the group, before / after: everybody stores its own bytes).
-template <int VS, int TS>
-MG_HD void gather_group(int lane, const uint8_t* tmap, const uint8_t* atlas, uint8_t* dst, uint32_t stream_bytes) {
+template <int VS, int TS, bool kDyn = false>
+MG_HD void gather_group(int lane, const uint8_t* tmap, const uint8_t* atlas, uint8_t* dst, uint32_t stream_bytes,
+                        GatherDyn dyn = GatherDyn{0, 0}) {
     typedef GatherGeom<VS, TS> Gm;
     const uint32_t qs = (16u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u)) & 15u;
     const uint32_t nfull = (stream_bytes - qs) >> 4, tail0 = qs + (nfull << 4);
-    if ((uint32_t)lane < qs) dst[lane] = gather_byte<VS, TS>(tmap, atlas, (uint32_t)lane);
-    if (lane < 16 && tail0 + (uint32_t)lane < stream_bytes) dst[tail0 + lane] = gather_byte<VS, TS>(tmap, atlas, tail0 + (uint32_t)lane);
+    if ((uint32_t)lane < qs) dst[lane] = gather_byte<VS, TS, kDyn>(tmap, atlas, (uint32_t)lane, dyn);
+    if (lane < 16 && tail0 + (uint32_t)lane < stream_bytes) dst[tail0 + lane] = gather_byte<VS, TS, kDyn>(tmap, atlas, tail0 + (uint32_t)lane, dyn);
     const GatherLane<Gm::NT> c = gather_lane<VS, TS>(lane, qs);
     GatherChunk* out = reinterpret_cast<GatherChunk*>(dst + qs);
     uint32_t y = 0;
-    for (; (y + 1u) * (uint32_t)Gm::CC <= nfull; y++) gather_cycle<VS, TS, false>(c, lane, y, tmap, atlas, out, nfull);
-    if (y * (uint32_t)Gm::CC < nfull) gather_cycle<VS, TS, true>(c, lane, y, tmap, atlas, out, nfull);
+    for (; (y + 1u) * (uint32_t)Gm::CC <= nfull; y++) gather_cycle<VS, TS, false, kDyn>(c, lane, y, tmap, atlas, out, nfull, dyn);
+    if (y * (uint32_t)Gm::CC < nfull) gather_cycle<VS, TS, true, kDyn>(c, lane, y, tmap, atlas, out, nfull, dyn);
 }
 
 }  // namespace mg

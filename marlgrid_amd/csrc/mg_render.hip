@@ -115,10 +115,13 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
 #if defined(MG_AB_VARIANTS)
         if (const char* f = getenv("MG_RENDER_RT_TS")) rt_ts = atoi(f) != 0;
 #endif
-        if (vs == 7 && ts == 11 && !rt_ts)     // examples/human_player.py's view_tile_size
-            return pw == 12 ? launch_render_t<7, 11, 12, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)
-                 : pw == 8 ? launch_render_t<7, 11, 8, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)
-                           : launch_render_t<7, 11, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
+        if (mode == 2 && !rt_ts) {             // examples/human_player.py's view_tile_size 11: the gather raster
+            int gw = wpb;
+            if (gw == 16) gw = render_lds_bytes(cfg, 12, 2) <= 160 * 1024 ? 12 : render_lds_bytes(cfg, 8, 2) <= 160 * 1024 ? 8 : 4;
+            return gw == 12 ? launch_render_t<7, 11, 12, 9, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)
+                 : gw == 8 ? launch_render_t<7, 11, 8, 9, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)
+                           : launch_render_t<7, 11, 4, 9, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
+        }
         if (vs == 7 && (ts % 8) != 0)
             return pw == 12 ? launch_render_t<7, 0, 12, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)
                  : pw == 8 ? launch_render_t<7, 0, 8, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     const int atlas_bytes = kGlobalAtlas ? 0 : lc.atlas_lds;       // in LDS (render_atlas_lds_bytes)
     // RM_ == 2: the gather raster (mg_gather.h) — tile rows padded with zeros in LDS: 16 zero bytes in front of every row
     constexpr bool kGather = RM_ == 2;
-    static_assert(!kGather || (VS_ > 0 && TS_ >= 5 && (TS_ % 8) != 0 && V_ == 0), "gather raster: compile-time view and tile size, static atlas in LDS");
+    static_assert(!kGather || (VS_ > 0 && TS_ >= 5 && (TS_ % 8) != 0 && (V_ == 0 || V_ == 9)), "gather raster: compile-time view and tile size, static atlas in LDS");
     typedef GatherGeom<kGather ? VS_ : 7, kGather ? TS_ : 5> Gm;
     constexpr bool kPadRows = kGather;                                // (the prologue pads the atlas as it copies it)
     constexpr int kRowB = kGather ? Gm::RS : 0, kRowW = kRowB / 4;
@@ -324,6 +324,10 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     int depth;
     {
         MG_REGION_LOCALS;
+        if constexpr (kGather && kPrestige) {       // the recoloured tiles' rows are padded like the atlas's: the zeros, once
+            for (int i = lane; i < (L.out - L.dyn) / 16; i += kWave) reinterpret_cast<uint4*>(w_dyn)[i] = make_uint4(0, 0, 0, 0);
+            wave_lds_sync();
+        }
         if constexpr (kStreamRaster) {
             const size_t a0 = (size_t)e0 * nv * img_bytes;
             head = (uint32_t)((reinterpret_cast<uintptr_t>(obs) + a0) & 15);
@@ -758,6 +762,12 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             //     agent); w_trow is free after the shadow cast.  Then per agent the tile in orientation
             //     0 (the only pass with per-pixel arithmetic) and three rotated byte copies of it.
             const int npx = TS * TS;
+            // byte offset of pixel p inside a tile, and the bytes of a tile: as in HBM, or — gather raster — in padded rows
+            auto px = [&](int p) -> int {
+                if constexpr (kGather) { const int r = p / TS_, c = p - r * TS_; return r * Gm::RS + Gm::FRONT + 3 * c; }
+                else return 3 * p;
+            };
+            const int tbytes = kGather ? Gm::TILE : tile_bytes;
             const uint8_t* abase = kGlobalAtlas ? cfg.atlas : s_atlas;
             const uint8_t* w_grid = w_stage_g + (size_t)ej * cfg.cells_stride;      // (here, per env: the recoloured tiles have ONE slot;
             const uint64_t* w_rec = w_stage_r + (size_t)ej * rec_stride;            //  the views of the group are done, w_trow is free)
@@ -788,13 +798,13 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                                        ((uint32_t)cfg.prestige_amax[2] << 16) | ((uint32_t)cfg.prestige_amax[3] << 24);
                 const uint32_t amax = (amax4 >> (8u * sdir)) & 0xFFu;   // (no indexed kernarg load: that is a VMEM load)
                 const uint32_t M = ((amax * col.r) >> 8) + ((amax * col.g) >> 8) + ((amax * col.b) >> 8);
-                const uint8_t* white = abase + (size_t)(cfg.prestige_sprite_tile + sdir) * tile_bytes;   // orientation 0, no border
-                const uint8_t* btile = base ? abase + (size_t)(1 + base) * tile_bytes : nullptr;
+                const uint8_t* white = abase + (size_t)(cfg.prestige_sprite_tile + sdir) * tbytes;   // orientation 0, no border
+                const uint8_t* btile = base ? abase + (size_t)(1 + base) * tbytes : nullptr;
                 const bool border = (s_oflags2[base] & 1) != 0;
-                const uint8_t* etile = abase + (size_t)tile_bytes;                                   // empty tile
-                uint8_t* t0 = w_dyn + (size_t)(Xh * 4) * npx * 3;
+                const uint8_t* etile = abase + (size_t)tbytes;                                   // empty tile
+                uint8_t* t0 = w_dyn + (size_t)(Xh * 4) * tbytes;
                 for (int p = lane; p < npx; p += kWave) {
-                    const int sp = p * 3;
+                    const int sp = px(p);
                     prestige_pixel(white[sp], col, M, btile ? btile + sp : nullptr, border ? etile + sp : nullptr, t0 + sp);
                 }
                 wave_lds_sync();
@@ -806,8 +816,8 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                         if (o == 3) { sr = c; sc = TS - 1 - r; }
                         else if (o == 1) { sr = TS - 1 - c; sc = r; }
                         else { sr = TS - 1 - r; sc = TS - 1 - c; }
-                        const uint8_t* src = t0 + (sr * TS + sc) * 3;
-                        uint8_t* dst = t0 + ((size_t)o * npx + p) * 3;
+                        const uint8_t* src = t0 + px(sr * TS + sc);
+                        uint8_t* dst = t0 + (size_t)o * tbytes + px(p);
                         dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
                     }
                 }
@@ -816,10 +826,15 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
         }
         // 6. raster: stream the env's n images out
         if constexpr (kGather) {
-            // the whole GROUP's images as one stream (mg_gather.h): when the group's first env comes up
-            if (ej == ej0) {
+            // the whole GROUP's images as one stream (mg_gather.h), when the group's first env comes up — or, 'prestige', env
+            // by env: the recoloured tiles (w_dyn: ONE slot, virtual tiles >= NT4) are this env's
+            if constexpr (kPrestige) {
+                gather_group<VS_, TS_, true>(lane, reinterpret_cast<const uint8_t*>(w_tmap), s_atlas, obs + (size_t)e * nv * img_bytes,
+                                             (uint32_t)(nv * img_bytes), GatherDyn{NT4, dyn_off - NT4 * (uint32_t)Gm::TILE});
+            } else if (ej == ej0) {
                 const int G = min(kb, ej0 + gd) - ej0;
-                gather_group<VS_, TS_>(lane, reinterpret_cast<const uint8_t*>(w_tmap0), s_atlas, obs + (size_t)e * nv * img_bytes, (uint32_t)((size_t)G * nv * img_bytes));
+                gather_group<VS_, TS_>(lane, reinterpret_cast<const uint8_t*>(w_tmap0), s_atlas, obs + (size_t)e * nv * img_bytes,
+                                       (uint32_t)((size_t)G * nv * img_bytes));
             }
         } else if constexpr (kChunkRaster) {
             // The env's n images are one contiguous run of 8-byte *pairs*: PR pairs per pixel row,
@@ -1174,7 +1189,7 @@ hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_t* obs,
 #define MG_RENDER_GROUP_C(X) /* assemble-and-stream: any other tile size */                                                \
     X(7, 0, 16, 0, 0) X(7, 0, 4, 0, 0) X(0, 0, 8, 0, 0) X(0, 0, 4, 0, 0)
 #define MG_RENDER_GROUP_D(X) /* 'prestige': per-env recoloured tiles */                                                     \
-    X(7, 8, 12, 9, 0) X(7, 8, 8, 9, 0) X(7, 8, 4, 9, 0) X(7, 11, 12, 9, 0) X(7, 11, 8, 9, 0) X(7, 11, 4, 9, 0)                  \
+    X(7, 8, 12, 9, 0) X(7, 8, 8, 9, 0) X(7, 8, 4, 9, 0)                                                                       \
     X(0, 8, 4, 9, 0) X(0, 16, 4, 9, 0)
 #define MG_RENDER_GROUP_E(X)                                                                                               \
     X(7, 0, 12, 9, 0) X(7, 0, 8, 9, 0) X(7, 0, 4, 9, 0) X(0, 32, 4, 9, 0) X(0, 0, 4, 9, 0)                                      \
@@ -1183,8 +1198,8 @@ hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_t* obs,
     X(7, 5, 16, 0, 2) X(7, 5, 4, 0, 2) X(7, 6, 16, 0, 2) X(7, 6, 4, 0, 2)
 #define MG_RENDER_GROUP_H(X) /* ... 7-, 9- and 10-pixel tiles */                                                           \
     X(7, 7, 16, 0, 2) X(7, 7, 4, 0, 2) X(7, 9, 16, 0, 2) X(7, 9, 4, 0, 2) X(7, 10, 16, 0, 2) X(7, 10, 4, 0, 2)
-#define MG_RENDER_GROUP_I(X) /* ... 11- and 12-pixel tiles */                                                              \
-    X(7, 11, 16, 0, 2) X(7, 11, 4, 0, 2) X(7, 12, 16, 0, 2) X(7, 12, 4, 0, 2)
+#define MG_RENDER_GROUP_I(X) /* ... 11- and 12-pixel tiles; 11 with 'prestige' agents (examples/human_player.py) */        \
+    X(7, 11, 16, 0, 2) X(7, 11, 4, 0, 2) X(7, 12, 16, 0, 2) X(7, 12, 4, 0, 2) X(7, 11, 12, 9, 2) X(7, 11, 8, 9, 2) X(7, 11, 4, 9, 2)
 #if defined(MG_AB_VARIANTS)
 #define MG_RENDER_GROUP_V(X) /* measurement variants (tools/ab_render.py) */                                               \
     X(7, 8, 16, 2, 0) X(7, 8, 4, 2, 0) X(7, 8, 16, 3, 0) X(7, 8, 4, 3, 0) X(7, 8, 16, 4, 0) X(7, 8, 4, 4, 0)                     \

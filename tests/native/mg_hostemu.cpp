@@ -100,14 +100,16 @@ namespace {
 // the kernel's prologue does (pad_source / pad_cut), then gather_group lane by lane (the lanes of the raster do not
 // talk to each other).  Returns the number of out-of-range LDS offsets formed (0 = none), -1 for bad arguments.
 template <int VS, int TS>
-int gather_emu(int n_vt, const uint8_t* atlas_raw, const uint16_t* tmap, int tmap_entries, uint8_t* dst, uint32_t stream_bytes) {
+int gather_emu(int n_vt, int n_dyn, const uint8_t* atlas_raw, const uint16_t* tmap, int tmap_entries, uint8_t* dst, uint32_t stream_bytes) {
     typedef mg::GatherGeom<VS, TS> Gm;
+    // virtual tiles [0, n_vt): the atlas, padded dword by dword as the kernel's prologue does; [n_vt, n_vt + n_dyn): a
+    // wave's own recoloured tiles, in the same padded layout somewhere else in LDS (here: behind a gap of garbage)
     const int rows = n_vt * TS, raw16 = (rows * Gm::SEG + 15) / 16 * 16;
     std::vector<uint8_t> raw(raw16, 0);
     memcpy(raw.data(), atlas_raw, (size_t)rows * Gm::SEG);
     constexpr int ROW_W = Gm::RS / 4;
-    const int npd = rows * ROW_W + Gm::TAIL / 4;
-    std::vector<uint32_t> padded(npd, 0xA5A5A5A5u);
+    const int npd = rows * ROW_W + Gm::TAIL / 4, gap = 37 * 4, dyn_w = n_dyn * TS * ROW_W + (n_dyn ? Gm::TAIL / 4 : 0);
+    std::vector<uint32_t> padded(npd + gap / 4 + dyn_w, 0xA5A5A5A5u);
     for (int d = 0; d < npd; d++) {
         uint32_t cut, keep;
         const int a = mg::pad_source<Gm::SEG, Gm::FRONT / 4, ROW_W>(d, rows, raw16, cut, keep);
@@ -115,11 +117,19 @@ int gather_emu(int n_vt, const uint8_t* atlas_raw, const uint16_t* tmap, int tma
         if (a >= 0) { memcpy(&lo, raw.data() + a, 4); memcpy(&hi, raw.data() + a + 4, 4); }
         padded[d] = a >= 0 ? mg::pad_cut(lo, hi, cut, keep) : 0u;
     }
+    uint8_t* dynp = reinterpret_cast<uint8_t*>(padded.data() + npd) + gap;
+    if (n_dyn) memset(dynp, 0, (size_t)dyn_w * 4);
+    for (int t = 0; t < n_dyn; t++)
+        for (int r = 0; r < TS; r++)
+            memcpy(dynp + (size_t)t * Gm::TILE + r * Gm::RS + Gm::FRONT, atlas_raw + ((size_t)(n_vt + t) * TS + r) * Gm::SEG, Gm::SEG);
+    const mg::GatherDyn dyn = {(uint32_t)n_vt, (uint32_t)(npd * 4 + gap) - (uint32_t)n_vt * Gm::TILE};
     g_gather_tmap_bytes = (uint32_t)tmap_entries * 2u;
-    g_gather_atlas_bytes = (uint32_t)npd * 4u;
+    g_gather_atlas_bytes = (uint32_t)padded.size() * 4u;
     g_gather_oob = 0;
-    for (int lane = 0; lane < 64; lane++)
-        mg::gather_group<VS, TS>(lane, reinterpret_cast<const uint8_t*>(tmap), reinterpret_cast<const uint8_t*>(padded.data()), dst, stream_bytes);
+    for (int lane = 0; lane < 64; lane++) {
+        if (n_dyn) mg::gather_group<VS, TS, true>(lane, reinterpret_cast<const uint8_t*>(tmap), reinterpret_cast<const uint8_t*>(padded.data()), dst, stream_bytes, dyn);
+        else mg::gather_group<VS, TS>(lane, reinterpret_cast<const uint8_t*>(tmap), reinterpret_cast<const uint8_t*>(padded.data()), dst, stream_bytes);
+    }
     return (int)g_gather_oob;
 }
 }  // namespace
@@ -127,14 +137,14 @@ int gather_emu(int n_vt, const uint8_t* atlas_raw, const uint16_t* tmap, int tma
 extern "C" {
 
 // geometry of (vs, ts) as the kernel sees it: out[0..7] = SEG, RS, PC, PR, C, NT, LPT, kConstBand
-int emu_gather(int vs, int ts, int n_vt, const uint8_t* atlas_raw, const uint16_t* tmap, int tmap_entries, uint8_t* dst,
+int emu_gather(int vs, int ts, int n_vt, int n_dyn, const uint8_t* atlas_raw, const uint16_t* tmap, int tmap_entries, uint8_t* dst,
                uint32_t stream_bytes, int32_t* geom) {
 #define MG_EMU_GATHER(VS, TS)                                                                                           \
     if (vs == VS && ts == TS) {                                                                                         \
         typedef mg::GatherGeom<VS, TS> Gm;                                                                              \
         if (geom) { const int32_t g[8] = {Gm::SEG, Gm::RS, Gm::PC, Gm::PR, Gm::C, Gm::NT, Gm::LPT, Gm::kConstBand};    \
                     memcpy(geom, g, sizeof(g)); }                                                                       \
-        return gather_emu<VS, TS>(n_vt, atlas_raw, tmap, tmap_entries, dst, stream_bytes);                              \
+        return gather_emu<VS, TS>(n_vt, n_dyn, atlas_raw, tmap, tmap_entries, dst, stream_bytes);                              \
     }
     MG_EMU_GATHER(7, 5) MG_EMU_GATHER(7, 6) MG_EMU_GATHER(7, 7) MG_EMU_GATHER(7, 9) MG_EMU_GATHER(7, 10) MG_EMU_GATHER(7, 11)
     MG_EMU_GATHER(7, 12) MG_EMU_GATHER(5, 5) MG_EMU_GATHER(9, 6) MG_EMU_GATHER(3, 5) MG_EMU_GATHER(6, 5) MG_EMU_GATHER(4, 6)

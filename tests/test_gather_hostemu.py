@@ -35,15 +35,16 @@ def test_gather_raster_equals_bytewise_raster(vs, ts):
         nv = int(rng.randint(1, 4))
         G = int(rng.choice([1, 2, 3, 4, 8]))
         phase = trial % 16
-        atlas = rng.randint(1, 256, size=(n_vt, ts, seg)).astype(np.uint8)       # (no zero bytes: a byte that is not ORed in shows)
+        n_dyn = int(rng.choice([0, 0, 4, 24]))            # a wave's own recoloured tiles ('prestige'): virtual tiles behind the atlas's
+        atlas = rng.randint(1, 256, size=(n_vt + n_dyn, ts, seg)).astype(np.uint8)       # (no zero bytes: a byte that is not ORed in shows)
         n_bands = G * nv * vs
-        tmap = rng.randint(0, n_vt, size=n_bands * vs).astype(np.uint16)
+        tmap = rng.randint(0, n_vt + n_dyn, size=n_bands * vs).astype(np.uint16)
         want = _naive(vs, ts, tmap, atlas, n_bands)
         assert want.size == G * nv * (vs * ts) * (vs * ts) * 3
         buf = np.full(want.size + 64 + 16, 0xEE, np.uint8)
         base = buf.ctypes.data
         off = (-base) % 16 + 16 + phase                                           # the stream starts `phase` bytes behind a 16-byte boundary
-        rc = L.emu_gather(vs, ts, n_vt, C.c_void_p(atlas.ctypes.data), C.c_void_p(tmap.ctypes.data), tmap.size,
+        rc = L.emu_gather(vs, ts, n_vt, n_dyn, C.c_void_p(atlas.ctypes.data), C.c_void_p(tmap.ctypes.data), tmap.size,
                           C.c_void_p(base + off), C.c_uint32(want.size), C.c_void_p(geom.ctypes.data))
         assert rc == 0, "out-of-range LDS offsets formed: %d (geometry %s)" % (rc, geom.tolist())
         got = buf[off:off + want.size]
