@@ -394,8 +394,17 @@ class MultiGridEnv(object):
         # big allocate-and-free: for a process that owns the GPU); False = plain torch allocations
         if place_obs is True:
             place_obs = DEFAULT_PLACE_OBS
+        # ... or a dict of the search's own knobs: {"budget": bytes of live candidates, "seconds": per pass, "thorough": bool,
+        # "stir": bool, "reuse": bool} (what `_place_obs_buffers` takes)
+        self._place_kw = {}
+        if isinstance(place_obs, dict):
+            unknown = set(place_obs) - {"budget", "seconds", "thorough", "stir", "reuse", "min_bytes"}
+            if unknown:
+                raise ValueError("place_obs: unknown keys %s" % sorted(unknown))
+            self._place_kw = dict(place_obs)
+            place_obs = "thorough" if place_obs.get("thorough") else "search"
         if place_obs not in ("search", "thorough", False):
-            raise ValueError("place_obs must be 'search' (= True), 'thorough' or False")
+            raise ValueError("place_obs must be 'search' (= True), 'thorough', a dict of budgets, or False")
         self.place_obs = place_obs
         self._dry = bool(_dry)
         if self.batch_size < 1:
@@ -437,7 +446,7 @@ class MultiGridEnv(object):
         self.reset()
         self.obs_placement = []
         if not self._dry and self.place_obs in ("search", "thorough"):
-            self._place_obs_buffers()
+            self._place_obs_buffers(**self._place_kw)
         self._spec_ctor = self._spec_last     # the constructor-time `_gen_grid` (base.py:369)
         self._retrace = True
 

@@ -138,6 +138,19 @@ def test_obs_buffer_placement_search():
     assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)
 
 
+def test_obs_buffer_placement_budgets_as_constructor_kwargs():
+    """place_obs={...}: the search's memory and time budgets as the caller states them"""
+    import gc
+    env = product_envs.build("MarlGrid-3AgentCluttered15x15-v0", batch_size=16384, place_obs={"budget": 8 << 30, "seconds": 1.0, "reuse": False})
+    pm = env.obs_placement[0]
+    assert pm["budget_bytes"] == 8 << 30 and pm["reused"] == 0 and pm["seconds"] < 4.0 and len(pm["kept"]) == 2
+    assert pm["pinned_bytes"] <= 8 << 30
+    with pytest.raises(ValueError):
+        product_envs.build("MarlGrid-3AgentCluttered15x15-v0", batch_size=64, place_obs={"megabytes": 5})
+    del env
+    gc.collect()
+
+
 def test_obs_buffer_placement_search_when_nothing_is_found():
     """The search's later stages, forced (no candidate can be 60 % under the median; every allocation counts as slow),
     with place_obs='thorough' semantics: twelve misses, the one big allocate-and-free that stirs the driver's free lists,
