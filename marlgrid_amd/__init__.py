@@ -10,6 +10,6 @@ in HBM, with every per-step operation a hand-written HIP kernel for gfx950 (see 
     obs, rew, done, _ = env.step(actions)              # actions: (B, 3) ints
 """
 from .agents import GridAgentInterface, IndependentLearners, LearningAgent  # noqa: F401
-from .base import MultiGrid, MultiGridEnv  # noqa: F401
+from .base import MultiGrid, MultiGridEnv, release_obs_cache  # noqa: F401
 
 __version__ = "0.1.0"

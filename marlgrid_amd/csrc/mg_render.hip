@@ -20,6 +20,7 @@ MG_RENDER_GROUP_C(MG_RENDER_EXTERN)
 MG_RENDER_GROUP_D(MG_RENDER_EXTERN)
 MG_RENDER_GROUP_E(MG_RENDER_EXTERN)
 MG_RENDER_GROUP_G(MG_RENDER_EXTERN)
+MG_RENDER_GROUP_X(MG_RENDER_EXTERN)
 MG_RENDER_GROUP_H(MG_RENDER_EXTERN)
 MG_RENDER_GROUP_I(MG_RENDER_EXTERN)
 MG_RENDER_GROUP_V(MG_RENDER_EXTERN)
@@ -170,6 +171,9 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
         if (getenv("MG_RENDER_RASTER") && atoi(getenv("MG_RENDER_RASTER")) == 1)   // assemble-and-stream at tile 8
             return wpb == 16 ? launch_render_t<7, 8, 16, 0, 1>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)
                              : launch_render_t<7, 8, 4, 0, 1>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
+#endif
+#if defined(MG_EXP) && (MG_EXP & 8)      // experiment build: 12-wave workgroups (3 waves per SIMD, a 168-VGPR budget) for the plain kernel
+        if (wpb == 16) return launch_render_t<7, 8, 12, 0, 0>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
 #endif
         return MG_RENDER_DISPATCH(7, 8, 0);
     }

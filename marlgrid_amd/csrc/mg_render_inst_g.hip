@@ -6,5 +6,6 @@
 namespace mg {
 #if !defined(MG_DEV_ONLY)
 MG_RENDER_GROUP_G(MG_RENDER_INSTANTIATE)
+MG_RENDER_GROUP_X(MG_RENDER_INSTANTIATE)
 #endif
 }  // namespace mg

@@ -1194,6 +1194,11 @@ hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_t* obs,
 #define MG_RENDER_GROUP_E(X)                                                                                               \
     X(7, 0, 12, 9, 0) X(7, 0, 8, 9, 0) X(7, 0, 4, 9, 0) X(0, 32, 4, 9, 0) X(0, 0, 4, 9, 0)                                      \
     X(0, 8, 4, 12, 0) X(0, 16, 4, 12, 0) X(0, 32, 4, 12, 0) X(0, 0, 4, 12, 0)
+#if defined(MG_EXP) && (MG_EXP & 8)
+#define MG_RENDER_GROUP_X(X) X(7, 8, 12, 0, 0)      /* experiment builds only (mg_render.hip) */
+#else
+#define MG_RENDER_GROUP_X(X)
+#endif
 #define MG_RENDER_GROUP_G(X) /* the gather raster (mg_gather.h): view 7, 5- and 6-pixel tiles */                          \
     X(7, 5, 16, 0, 2) X(7, 5, 4, 0, 2) X(7, 6, 16, 0, 2) X(7, 6, 4, 0, 2)
 #define MG_RENDER_GROUP_H(X) /* ... 7-, 9- and 10-pixel tiles */                                                           \
