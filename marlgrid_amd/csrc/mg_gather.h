@@ -1,6 +1,7 @@
 // mg_gather.h — the GATHER raster of the observation kernel (mg_render_kernel.h, RM_ == 2): tile sizes whose rows
-// are not whole 8-byte pairs — the reference's default view_tile_size 5 (agents.py:22) and 6 — rendered
-// OUTPUT-centric: a lane composes one aligned 16-byte chunk of the output stream in registers and stores it.
+// are not whole 8-byte pairs — the reference's default view_tile_size 5 (agents.py:22), 6, 7, 9, 10, 11, 12 at the
+// default view size 7 — rendered OUTPUT-centric: a lane composes one aligned 16-byte chunk of the output stream in
+// registers and stores it.
 //
 // What is rendered (MultiGrid.render, base.py:301-331): an env's n images are P = VS * TS pixel rows of RB = 3 * P bytes
 // each, back to back — i.e. ONE stream of SEGMENTS of SEG = 3 * TS bytes (one pixel row of one view cell's tile),
@@ -21,7 +22,9 @@
 // adds the row.  Tile 6: 63 chunks = 8 rows — 63 lanes, and three periods are four whole bands of tiles, so with three
 // sets of constants even the tile row inside the band is constant: a window is add, tmap look-up, multiply-add, five
 // dwords.  Tile 5: 105 chunks = 16 rows in two trips of 53 + 52 lanes; the band and the tile row are worked out
-// per trip (five periods of constants do not fit the registers).
+// per trip (five periods of constants do not fit the registers).  Tile 11: 231 chunks in four trips of 58 lanes, two
+// and two.  'prestige' agents (the reference's example, tile 11): their per-env recoloured tiles are virtual tiles
+// behind the atlas's, in the same padded layout in the wave's own scratch (GatherDyn).
 //
 // Plain inline functions over byte pointers: the same text compiles with g++ for tests/native (the index
 // arithmetic is checked on the host against a byte-by-byte raster; the product never loads that build).

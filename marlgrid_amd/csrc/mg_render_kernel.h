@@ -14,11 +14,12 @@
 //     (mg_core.h step_run, auto-reset included) before anything is drawn —, derives the view_size x view_size
 //     egocentric neighbourhoods (base object, shown agent, transparency) of a group of envs cooperatively, one
 //     lane per viewer runs the shadow-casting pass as row bit-masks (log-step floods), and the wave writes a
-//     per-view-cell atlas offset map (tmap) per env to LDS;
+//     per-view-cell atlas offset map (tmap) per env to LDS — the tile of a cell is selected where the cell is looked at,
+//     the shadow cast's result applied by view row;
 //   * the raster then emits the env's n*P*P*3 contiguous output bytes as 16-byte
 //     (global_store_dwordx4) chunks, consecutive lanes -> consecutive chunks.  Tile sizes that are a
 //     multiple of 8: each chunk is assembled in registers from two 8-byte LDS look-ups
-//     atlas[tmap[cell] + row*TD + k].  The reference's default view with 5- or 6-pixel tiles: the GATHER raster
+//     atlas[tmap[cell] + row*TD + k].  The reference's default view with 5- (its default), 6-, 7-, 9- … 12-pixel tiles: the GATHER raster
 //     (mg_gather.h) — a lane composes an aligned 16-byte chunk from the (at most two) tile rows it spans, which sit
 //     in LDS padded with zeros, with aligned dword reads and v_alignbyte, and stores it.  Any other tile size: a few
 //     KiB of whole pixel rows at a time are first ASSEMBLED in an LDS piece buffer — one lane per (row, view column)
