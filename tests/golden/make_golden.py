@@ -39,6 +39,11 @@ TRAJ = {  # scenario -> (n_seeds, n_steps, n_full_obs_seeds)
     "Test-4AgentEmpty5x5-crowded": (8, 150, 2),
     "Test-4AgentEmpty5x5-crowded-noghost": (8, 150, 1),
     "Test-2AgentCluttered9x9-offset2-ts5": (6, 120, 2),
+    # the gather raster's other geometries (round 5), pinned to the reference's own pixels: 6-pixel tiles (63-lane periods),
+    # 11-pixel tiles (four sets of lane constants), five viewers at 5 pixels (every env at another byte phase)
+    "Edge-3AgentCluttered15x15-tile6": (6, 100, 2),
+    "Edge-3AgentCluttered11x11-tile11": (4, 60, 1),
+    "Edge-5AgentEmpty9x9-tile5-offset3": (4, 60, 1),
     "Test-2AgentEmpty7x7-see-through": (4, 60, 2),
     "Test-3AgentCluttered9x9-respawn": (8, 200, 1),
     "Test-4AgentEmpty5x5-respawn-noghost": (8, 200, 1),
