@@ -97,7 +97,12 @@ def build(force=False):
             and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src),
                                                    os.path.getmtime(os.path.join(_HERE, "mg_oracle.h")))):
         return _LIB_PATH
-    subprocess.check_call(["make", "-C", _HERE, "-B", "-s"])
+    import fcntl
+    with open(os.path.join(_HERE, ".build.lock"), "w") as lock:      # (one builder at a time under pytest-xdist)
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if (force or not os.path.exists(_LIB_PATH)
+                or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "mg_oracle.h")))):
+            subprocess.check_call(["make", "-C", _HERE, "-B", "-s"])
     return _LIB_PATH
 
 

@@ -23,7 +23,12 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        subprocess.check_call(["make", "-s", "-C", HERE])
+        # (one builder at a time: pytest-xdist workers load this module concurrently, and two `make`s that both find the
+        # library out of date would write it at once)
+        import fcntl
+        with open(os.path.join(HERE, ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            subprocess.check_call(["make", "-s", "-C", HERE])
         L = C.CDLL(os.path.join(HERE, "libmg_hostemu.so"))
         for i, t in enumerate((N.Config, N.State, N.GenProgram, N.ObjDesc)):
             assert L.emu_sizeof(i) == C.sizeof(t), (t, L.emu_sizeof(i), C.sizeof(t))
