@@ -344,7 +344,7 @@ int32_t mg_obs_free(void* ptr);
 #define MG_PLACE_STOP_FOUND 1   /* MgPlaceStats.stopped: the kept set is `gain` under the median candidate */
 #define MG_PLACE_STOP_CAP 2     /* max_candidates measured */
 #define MG_PLACE_STOP_TIME 3
-#define MG_PLACE_STOP_MEMORY 4  /* the budget was reached twice */
+#define MG_PLACE_STOP_MEMORY 4  /* the budget does not hold another candidate (after the losers went back, up to six times) */
 #define MG_PLACE_STOP_OOM 5     /* hipMalloc failed */
 #define MG_PLACE_STOP_SMALL 6   /* buffers under min_bytes: plain allocations */
 typedef struct MgPlaceTuning {  /* 0 = the default of each */
@@ -352,7 +352,7 @@ typedef struct MgPlaceTuning {  /* 0 = the default of each */
     double slow_alloc_s_per_gib;/* MG_PLACE_STIR only when allocations took at least this long: 0.02; < 0: always */
     uint64_t min_bytes;         /* 256 MiB */
     uint64_t stir_bytes;        /* cap of the allocate-and-free: 64 GiB */
-    int32_t max_candidates;     /* per pass: 64 (at most MG_PLACE_ALL - MG_PLACE_MAX) */
+    int32_t max_candidates;     /* per pass: 192 (the first MG_PLACE_ALL are recorded in MgPlaceStats.all_ms) */
     int32_t iters;              /* raster launches per measurement: 3 */
 } MgPlaceTuning;
 typedef struct MgPlaceStats {
@@ -364,7 +364,7 @@ typedef struct MgPlaceStats {
     uint64_t buffer_bytes, candidate_bytes, alloc_bytes, pinned_bytes, stirred_bytes, budget_bytes;
     uint64_t window_offset[MG_PLACE_MAX];         /* of each kept buffer inside its allocation */
     uint64_t arena_bytes[MG_PLACE_MAX];           /* ... and that allocation's size */
-    float all_ms[MG_PLACE_ALL];                   /* every candidate measured, in order (the first n_buffers: plain allocations) */
+    float all_ms[MG_PLACE_ALL];                   /* the first MG_PLACE_ALL candidates measured, in order (the first n_buffers: plain allocations) */
 } MgPlaceStats;
 int32_t mg_obs_place(const MgConfig* cfg, const MgState* st, int32_t n_buffers, uint64_t budget_bytes, double seconds,
                      int32_t flags, const MgPlaceTuning* tuning, void** out, MgPlaceStats* stats, void* stream);

@@ -84,7 +84,9 @@ int32_t mg_obs_place(const MgConfig* cfg, const MgState* st, int32_t n_buffers, 
     MgPlaceTuning tn = {};
     if (tuning) tn = *tuning;
     const double gain = tn.gain > 0 ? tn.gain : 0.12;
-    const int max_cands = tn.max_candidates > 0 ? std::min(tn.max_candidates, (int)MG_PLACE_ALL - MG_PLACE_MAX) : 64;
+    // (a candidate costs 1-2 ms where memory has been used before: the time limit is the bound that matters; a box on which the
+    // default search drew its 64 candidates in 80 ms without a hit, and found its pair in the next 10, is why the default is 192)
+    const int max_cands = tn.max_candidates > 0 ? tn.max_candidates : 192;
     const int iters = tn.iters > 0 ? tn.iters : 3;
     const uint64_t min_bytes = tn.min_bytes ? tn.min_bytes : (256ull << 20);
     const double slow_alloc = tn.slow_alloc_s_per_gib > 0 ? tn.slow_alloc_s_per_gib : (tn.slow_alloc_s_per_gib < 0 ? 0.0 : 0.02);
@@ -179,7 +181,8 @@ int32_t mg_obs_place(const MgConfig* cfg, const MgState* st, int32_t n_buffers, 
             double t_end = now_s() + seconds;
             int misses = 0, level = 0;
             bool plain = cands.empty();         // the first `need` candidates: plain buffer-sized allocations (the baseline)
-            bool dropped = false, plain_stage = false;
+            bool plain_stage = false, drew_since_drop = false;
+            int drops = 0;
             int n_plain0 = 0;
             S.stopped = MG_PLACE_STOP_CAP;
             while ((int)cands.size() < need + max_cands * pass) {
@@ -215,9 +218,15 @@ int32_t mg_obs_place(const MgConfig* cfg, const MgState* st, int32_t n_buffers, 
                     continue;
                 }
                 if (is_short && !baseline) {
-                    if (dropped) { S.stopped = MG_PLACE_STOP_MEMORY; break; }
+                    // the budget is reached: the losers go back to the driver and the search goes on inside the same bound (what comes
+                    // back is handed out again, but in another order and cut differently: measured, the next few draws often hit) —
+                    // up to six times; a budget that does not hold one candidate next to the kept ones ends the search
+                    if (drops >= 6 || (drops > 0 && !drew_since_drop)) { S.stopped = MG_PLACE_STOP_MEMORY; break; }
                     drop_losers();
-                    dropped = true;
+                    drops++;
+                    drew_since_drop = false;
+                    plain = plain_stage = false;        // (back to the constructed candidates: they hit more often than plain ones)
+                    misses = level = 0;
                     continue;
                 }
                 const double t0 = now_s();
@@ -226,6 +235,7 @@ int32_t mg_obs_place(const MgConfig* cfg, const MgState* st, int32_t n_buffers, 
                 S.alloc_seconds += now_s() - t0;
                 S.alloc_bytes += arena;
                 alive += arena;
+                drew_since_drop = true;
                 const uint64_t centre = plain ? 0 : (2 * Pk - nbytes / 2) & ~4095ull;   // the window centred on the 2 P | P junction
                 Cand pick = {base, arena, centre, measure(base, centre)};
                 const float med = cands.empty() ? pick.ms : median_ms();

@@ -106,8 +106,9 @@ def test_obs_buffer_placement_search():
                 # the first env's ring was released when it died: taken back without a search
                 assert pm["reused"] == 2 and pm["candidates"] == 0 and pm["found"] and pm["seconds"] < 0.25
             elif pm["reused"] == 0:
-                assert 2 <= pm["candidates"] <= 66 and pm["passes"] == 1 and not pm["stirred"] and pm["block_pair_level"] == 0
-                assert sorted(pm["all"])[:2] == sorted(pm["kept"])          # the fastest two were kept
+                assert 2 <= pm["candidates"] <= 194 and pm["passes"] == 1 and not pm["stirred"] and pm["block_pair_level"] == 0
+                if pm["candidates"] <= N.PLACE_ALL:
+                    assert sorted(pm["all"])[:2] == sorted(pm["kept"])      # the fastest two were kept
                 if not pm["plain_stage"]:
                     # a candidate is a 2 P block followed by a P block, the buffer the window centred on their boundary
                     P = pm["candidate_bytes"] // 3
@@ -212,7 +213,7 @@ def test_obs_place_through_the_c_abi():
     rc, bufs, s1, dt = place()
     assert rc == 0 and all(b and b % 4096 == 0 for b in bufs) and bufs[0] != bufs[1]
     assert s1.buffer_bytes == nbytes and s1.reused == 0 and s1.passes == 1 and s1.level == 0 and s1.stirred_bytes == 0
-    assert s1.budget_bytes <= 32 << 30 and s1.seconds < 6.0 and 2 <= s1.candidates <= 66 and s1.windows >= s1.candidates
+    assert s1.budget_bytes <= 32 << 30 and s1.seconds < 6.0 and 2 <= s1.candidates <= 194 and s1.windows >= s1.candidates
     assert 2 * nbytes <= s1.pinned_bytes <= 6 * nbytes == 6 * s1.buffer_bytes
     assert free0 - torch.cuda.mem_get_info()[0] <= s1.pinned_bytes + (64 << 20)          # every other candidate is back
     for i in range(2):
