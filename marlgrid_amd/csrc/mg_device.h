@@ -104,15 +104,16 @@ struct RenderScratch {
 };
 // The atlas in LDS.  As it is in HBM ([4 orientations][n_tiles][ts][ts][3], rounded up to 16 bytes) — except for the
 // GATHER raster (mg_gather.h; the kernel's RM_ == 2, `mode` 2 below), which is instantiated for the reference's default
-// view with its default 5-pixel tiles (agents.py:21-22) and for 6-, 7-, 9-, 10-, 11- and 12-pixel tiles (the tile sizes
-// under 16 that the 16-byte-chunk raster does not take): there every tile ROW gets 16 zero bytes in
+// view with its default 5-pixel tiles (agents.py:21-22), for 6-, 7-, 9-, 10-, 11- and 12-pixel tiles (the tile sizes
+// under 16 that the 16-byte-chunk raster does not take) and for views 3, 5, 9 at 5-pixel tiles: there every tile ROW gets 16 zero bytes in
 // front (GatherGeom::RS bytes per row, 32 zero bytes behind the last), so that a 16-byte window anywhere around a row is
 // whole aligned dwords with zeros outside the row — no edge masks, no conditional reads.
 __host__ __device__ inline bool render_gather(const MgConfig& cfg) {
-    const int ts = cfg.tile_size;
+    const int vs = cfg.view_size, ts = cfg.tile_size;
     // ('prestige' agents — per-env recoloured tiles next to the atlas's —: the reference's example, 11-pixel tiles)
-    return cfg.view_size == 7 && (ts == 5 || ts == 6 || ts == 7 || ts == 9 || ts == 10 || ts == 11 || ts == 12) &&
-           (cfg.prestige_mask == 0 || ts == 11);
+    if (vs == 7) return (ts == 5 || ts == 6 || ts == 7 || ts == 9 || ts == 10 || ts == 11 || ts == 12) && (cfg.prestige_mask == 0 || ts == 11);
+    // the other view sizes the 16-byte-chunk raster is instantiated for, at GridAgentInterface's default tile size
+    return (vs == 3 || vs == 5 || vs == 9) && ts == 5 && cfg.prestige_mask == 0;
 }
 __host__ __device__ inline int render_gather_row_bytes(int ts) { return (16 + 3 * ts + 3) / 4 * 4; }
 __host__ __device__ inline int render_atlas_raw_bytes(const MgConfig& cfg) {

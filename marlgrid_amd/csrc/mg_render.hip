@@ -23,6 +23,7 @@ MG_RENDER_GROUP_G(MG_RENDER_EXTERN)
 MG_RENDER_GROUP_X(MG_RENDER_EXTERN)
 MG_RENDER_GROUP_H(MG_RENDER_EXTERN)
 MG_RENDER_GROUP_I(MG_RENDER_EXTERN)
+MG_RENDER_GROUP_J(MG_RENDER_EXTERN)
 MG_RENDER_GROUP_V(MG_RENDER_EXTERN)
 #endif
 
@@ -132,18 +133,21 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
         if (ts == 32) return launch_render_t<0, 32, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
         return launch_render_t<0, 0, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
     }
-    if (mode == 2) {   // the gather raster: view 7 (GridAgentInterface's default, agents.py:21) with 5- .. 12-pixel tiles
-#define MG_RENDER_DISPATCH_G(TS)                                                                                     \
-    (wpb == 16 ? launch_render_t<7, TS, 16, 0, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)              \
-               : launch_render_t<7, TS, 4, 0, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs))
+    if (mode == 2) {   // the gather raster: view 7 (GridAgentInterface's default, agents.py:21) with 5- .. 12-pixel tiles; views 3 / 5 / 9 at its default 5-pixel tiles
+#define MG_RENDER_DISPATCH_G(VS, TS)                                                                                 \
+    (wpb == 16 ? launch_render_t<VS, TS, 16, 0, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)             \
+               : launch_render_t<VS, TS, 4, 0, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs))
+        if (vs == 3) return MG_RENDER_DISPATCH_G(3, 5);
+        if (vs == 5) return MG_RENDER_DISPATCH_G(5, 5);
+        if (vs == 9) return MG_RENDER_DISPATCH_G(9, 5);
         switch (ts) {
-        case 5: return MG_RENDER_DISPATCH_G(5);
-        case 6: return MG_RENDER_DISPATCH_G(6);
-        case 7: return MG_RENDER_DISPATCH_G(7);
-        case 9: return MG_RENDER_DISPATCH_G(9);
-        case 10: return MG_RENDER_DISPATCH_G(10);
-        case 11: return MG_RENDER_DISPATCH_G(11);
-        default: return MG_RENDER_DISPATCH_G(12);
+        case 5: return MG_RENDER_DISPATCH_G(7, 5);
+        case 6: return MG_RENDER_DISPATCH_G(7, 6);
+        case 7: return MG_RENDER_DISPATCH_G(7, 7);
+        case 9: return MG_RENDER_DISPATCH_G(7, 9);
+        case 10: return MG_RENDER_DISPATCH_G(7, 10);
+        case 11: return MG_RENDER_DISPATCH_G(7, 11);
+        default: return MG_RENDER_DISPATCH_G(7, 12);
         }
 #undef MG_RENDER_DISPATCH_G
     }

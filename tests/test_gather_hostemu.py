@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "native"))
 import hostemu  # noqa: E402
 
-GEOMS = [(7, 5), (7, 6), (7, 7), (7, 9), (7, 10), (7, 11), (7, 12), (5, 5), (9, 6), (3, 5), (6, 5), (4, 6)]
+GEOMS = [(7, 5), (7, 6), (7, 7), (7, 9), (7, 10), (7, 11), (7, 12), (5, 5), (9, 5), (9, 6), (3, 5), (6, 5), (4, 6)]
 
 
 def _naive(vs, ts, tmap, atlas, n_bands):
@@ -55,5 +55,7 @@ def test_gather_raster_equals_bytewise_raster(vs, ts):
     assert geom[0] == seg
     if (vs, ts) == (7, 6):
         assert geom.tolist() == [18, 36, 63, 8, 3, 3, 63, 1]     # 63 lanes, three sets, tile rows constant
+    if (vs, ts) == (5, 5):
+        assert geom.tolist() == [15, 32, 75, 16, 3, 4, 57, 0]    # three periods in four trips of 57 lanes (one period: 38 of 64)
     if (vs, ts) == (7, 5):
         assert geom.tolist() == [15, 32, 105, 16, 1, 2, 53, 0]   # 53 + 52 lanes, bands per trip

@@ -170,6 +170,11 @@ def test_rng_seeding_golden():
                                        ("Edge-3AgentCluttered11x11-tile11", 11, 20),
                                        ("Edge-3AgentCluttered11x11-tile12", 4103, 20),
                                        ("Edge-3AgentCluttered11x11-tile13", 4099, 20),
+                                       ("Edge-3AgentCluttered11x11-view3-tile5", 4105, 20),
+                                       ("Edge-3AgentCluttered11x11-view5-tile5", 4102, 20),
+                                       ("Edge-3AgentCluttered11x11-view5-tile5", 13, 20),
+                                       ("Edge-3AgentCluttered11x11-view9-tile5", 4107, 20),
+                                       ("Edge-3AgentCluttered11x11-view9-tile5", 66, 20),
                                        ("Test-3AgentCluttered9x9-prestige-mixed", 256, 160)])
 def test_batch_vs_oracle(name, B, T):
     """same seeds, same actions: HIP batch == B oracle envs, every step, full observations."""

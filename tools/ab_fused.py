@@ -3,7 +3,7 @@
 build of an earlier commit next to the current one).  First a parity check of every build against the first one
 (two envs, same seeds and actions, 130 steps: observations, rewards, done, records, grids and the whole RNG state
 must be equal), then 9 interleaved rounds of 100 launches each, all into the SAME observation buffer.
-usage: [TILE=5 | PRESTIGE=3,8] [B=...] ab_fused.py path/to/ref.so path/to/new.so [...]"""
+usage: [TILE=5 [VIEW=9] | PRESTIGE=3,8] [B=...] ab_fused.py path/to/ref.so path/to/new.so [...]"""
 import ctypes as C
 import os
 import statistics
@@ -26,7 +26,7 @@ def build():
     if os.environ.get("TILE"):      # the bench scenario's shape with another view_tile_size (the instantiations off the fast path)
         from marlgrid_amd.agents import GridAgentInterface
         from marlgrid_amd.envs import ClutteredMultiGrid
-        return ClutteredMultiGrid(agents=[GridAgentInterface(color=c, view_size=7, view_tile_size=int(os.environ["TILE"])) for c in ("red", "blue", "purple")],
+        return ClutteredMultiGrid(agents=[GridAgentInterface(color=c, view_size=int(os.environ.get("VIEW", "7")), view_tile_size=int(os.environ["TILE"])) for c in ("red", "blue", "purple")],
                                   grid_size=15, clutter_density=0.15, batch_size=B, strict=False, auto_reset=True, place_obs=PLACE)
     if os.environ.get("PRESTIGE"):  # PRESTIGE=<agents>,<tile>: the goal-cycle scenario of tools/bench_cases.py ('prestige'-coloured agents)
         from marlgrid_amd.agents import GridAgentInterface
