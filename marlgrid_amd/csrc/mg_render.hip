@@ -24,6 +24,7 @@ MG_RENDER_GROUP_X(MG_RENDER_EXTERN)
 MG_RENDER_GROUP_H(MG_RENDER_EXTERN)
 MG_RENDER_GROUP_I(MG_RENDER_EXTERN)
 MG_RENDER_GROUP_J(MG_RENDER_EXTERN)
+MG_RENDER_GROUP_K(MG_RENDER_EXTERN)
 MG_RENDER_GROUP_V(MG_RENDER_EXTERN)
 #endif
 
@@ -138,7 +139,10 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
     (wpb == 16 ? launch_render_t<VS, TS, 16, 0, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)             \
                : launch_render_t<VS, TS, 4, 0, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs))
         if (vs == 3) return MG_RENDER_DISPATCH_G(3, 5);
+        if (vs == 4) return MG_RENDER_DISPATCH_G(4, 5);
         if (vs == 5) return MG_RENDER_DISPATCH_G(5, 5);
+        if (vs == 6) return MG_RENDER_DISPATCH_G(6, 5);
+        if (vs == 8) return MG_RENDER_DISPATCH_G(8, 5);
         if (vs == 9) return MG_RENDER_DISPATCH_G(9, 5);
         switch (ts) {
         case 5: return MG_RENDER_DISPATCH_G(7, 5);
@@ -184,6 +188,9 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
     if (ts == 8 && vs == 9) return MG_RENDER_DISPATCH(9, 8, 0);
     if (ts == 8 && vs == 5) return MG_RENDER_DISPATCH(5, 8, 0);
     if (ts == 8 && vs == 3) return MG_RENDER_DISPATCH(3, 8, 0);
+    if (ts == 8 && vs == 4) return MG_RENDER_DISPATCH(4, 8, 0);      // even views (agents.py:233-266 as it is written)
+    if (ts == 8 && vs == 6) return MG_RENDER_DISPATCH(6, 8, 0);
+    if (ts == 8 && vs == 8) return MG_RENDER_DISPATCH(8, 8, 0);
     if (ts == 8) return MG_RENDER_DISPATCH_RT(8, 0);      // other view sizes: run-time VS, same raster
     if (ts == 16 && vs == 7) return MG_RENDER_DISPATCH(7, 16, 0);
     if (ts == 32 && vs == 7) return MG_RENDER_DISPATCH(7, 32, 0);

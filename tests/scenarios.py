@@ -140,7 +140,8 @@ def ref_recipe(name):
         "Edge-3AgentCluttered15x15-tile6": ("ClutteredMultiGrid", dict(grid_size=15, n_clutter=10)),
         "Edge-5AgentEmpty9x9-tile5-offset3": ("EmptyMultiGrid", dict(grid_size=9)),
         **{"Edge-3AgentCluttered11x11-tile%d" % ts: ("ClutteredMultiGrid", dict(grid_size=11, n_clutter=9)) for ts in (7, 9, 10, 11, 12, 13)},
-        **{"Edge-3AgentCluttered11x11-view%d-tile5" % vs: ("ClutteredMultiGrid", dict(grid_size=11, n_clutter=9)) for vs in (3, 5, 9)},
+        **{"Edge-3AgentCluttered11x11-view%d-tile5" % vs: ("ClutteredMultiGrid", dict(grid_size=11, n_clutter=9)) for vs in (3, 4, 5, 6, 8, 9)},
+        **{"Edge-3AgentCluttered11x11-view%d-tile8" % vs: ("ClutteredMultiGrid", dict(grid_size=11, n_clutter=9)) for vs in (4, 6, 8)},
         "Test-3AgentEmpty7x11-nonsquare": ("EmptyMultiGrid", dict(width=7, height=11)),
         "Test-3AgentCluttered12x6-nonsquare": ("ClutteredMultiGrid", dict(width=12, height=6, n_clutter=7)),
         "Test-2AgentLateStatic10x10": ("LateStaticTestEnv", dict(grid_size=10, respawn=True, max_steps=50)),
@@ -319,7 +320,10 @@ def registered(name):   # noqa: F811  (extends the table above with test-only sc
            for ts in (7, 9, 10, 11, 12, 13)},
         # ... and for the other shipped view sizes at the default 5-pixel tiles
         **{"Edge-3AgentCluttered11x11-view%d-tile5" % vs: (lambda vs=vs: cluttered_spec(3, 11, vs, n_clutter=9, tile_size=5, view_offset=vs // 3))
-           for vs in (3, 5, 9)},
+           for vs in (3, 4, 5, 6, 8, 9)},
+        # even views with a compile-time size at the registered 8-pixel tiles (the chunk raster)
+        **{"Edge-3AgentCluttered11x11-view%d-tile8" % vs: (lambda vs=vs: cluttered_spec(3, 11, vs, n_clutter=9, view_offset=vs // 3))
+           for vs in (4, 6, 8)},
         # EVEN view sizes (agents.py:233-266 is written with view_size // 2: in an even view the agent sits at column
         # view_size // 2 when it faces up or right and one column to the left of it when it faces down or left, while
         # the shadow cast always starts from column view_size // 2 — upstream's geometry, reproduced as it is)

@@ -175,6 +175,14 @@ def test_rng_seeding_golden():
                                        ("Edge-3AgentCluttered11x11-view5-tile5", 13, 20),
                                        ("Edge-3AgentCluttered11x11-view9-tile5", 4107, 20),
                                        ("Edge-3AgentCluttered11x11-view9-tile5", 66, 20),
+                                       ("Edge-3AgentCluttered11x11-view4-tile5", 4104, 20),
+                                       ("Edge-3AgentCluttered11x11-view6-tile5", 4106, 20),
+                                       ("Edge-3AgentCluttered11x11-view6-tile5", 10, 20),
+                                       ("Edge-3AgentCluttered11x11-view8-tile5", 4108, 20),
+                                       ("Edge-3AgentCluttered11x11-view4-tile8", 4109, 20),
+                                       ("Edge-3AgentCluttered11x11-view6-tile8", 4110, 20),
+                                       ("Edge-3AgentCluttered11x11-view6-tile8", 12, 20),
+                                       ("Edge-3AgentCluttered11x11-view8-tile8", 4111, 20),
                                        ("Test-3AgentCluttered9x9-prestige-mixed", 256, 160)])
 def test_batch_vs_oracle(name, B, T):
     """same seeds, same actions: HIP batch == B oracle envs, every step, full observations."""

@@ -36,6 +36,11 @@ def build():
             agents=[GridAgentInterface(color="prestige", view_size=7, view_tile_size=ts, view_offset=1) for _ in range(k)],
             grid_size=13, clutter_density=0.15, n_bonus_tiles=3, max_steps=250, respawn=True, reward_decay=False,
             initial_reward=True, penalty=-1.5, batch_size=B, strict=False, auto_reset=True, place_obs=PLACE)
+    if os.environ.get("VIEW"):      # the bench scenario's shape with another view size at the registered 8-pixel tiles
+        from marlgrid_amd.agents import GridAgentInterface
+        from marlgrid_amd.envs import ClutteredMultiGrid
+        return ClutteredMultiGrid(agents=[GridAgentInterface(color=c, view_size=int(os.environ["VIEW"]), view_tile_size=8) for c in ("red", "blue", "purple")],
+                                  grid_size=15, clutter_density=0.15, batch_size=B, strict=False, auto_reset=True, place_obs=PLACE)
     return make(WL, batch_size=B, auto_reset=True, strict=False, place_obs=PLACE)
 
 
