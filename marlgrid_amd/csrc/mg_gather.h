@@ -1,6 +1,6 @@
 // mg_gather.h — the GATHER raster of the observation kernel (mg_render_kernel.h, RM_ == 2): tile sizes whose rows
 // are not whole 8-byte pairs — the reference's default view_tile_size 5 (agents.py:22), 6, 7, 9, 10, 11, 12 at the
-// default view size 7, and views 3 / 5 / 9 at 5-pixel tiles — rendered OUTPUT-centric: a lane composes one aligned 16-byte chunk of the output stream in
+// default view size 7, and views 3 .. 9 at 5-pixel tiles — rendered OUTPUT-centric: a lane composes one aligned 16-byte chunk of the output stream in
 // registers and stores it.
 //
 // What is rendered (MultiGrid.render, base.py:301-331): an env's n images are P = VS * TS pixel rows of RB = 3 * P bytes
