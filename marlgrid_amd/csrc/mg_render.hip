@@ -121,6 +121,10 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
         if (mode == 2 && !rt_ts) {             // examples/human_player.py's view_tile_size 11: the gather raster
             int gw = wpb;
             if (gw == 16) gw = render_lds_bytes(cfg, 12, 2) <= 160 * 1024 ? 12 : render_lds_bytes(cfg, 8, 2) <= 160 * 1024 ? 8 : 4;
+            if (ts == 5)                       // ... and GridAgentInterface's default tile size
+                return gw == 12 ? launch_render_t<7, 5, 12, 9, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)
+                     : gw == 8 ? launch_render_t<7, 5, 8, 9, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)
+                               : launch_render_t<7, 5, 4, 9, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
             return gw == 12 ? launch_render_t<7, 11, 12, 9, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)
                  : gw == 8 ? launch_render_t<7, 11, 8, 9, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)
                            : launch_render_t<7, 11, 4, 9, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);

@@ -126,6 +126,9 @@ def ref_recipe(name):
         "Test-1AgentGoalcycle11x11-prestige-ts11": ("ClutteredGoalCycleEnv", dict(grid_size=11, clutter_density=0.1,
                                                                                   n_bonus_tiles=3, max_steps=80)),
         "Test-3AgentCluttered9x9-prestige-mixed": ("ClutteredMultiGrid", dict(grid_size=9, n_clutter=5, respawn=True)),
+        "Edge-3AgentCluttered9x9-prestige-mixed-tile5": ("ClutteredMultiGrid", dict(grid_size=9, n_clutter=5, respawn=True)),
+        "Edge-2AgentGoalcycle9x9-prestige-tile5": ("ClutteredGoalCycleEnv", dict(grid_size=9, n_clutter=4, n_bonus_tiles=3,
+                                                                                 penalty=-1.5, max_steps=60)),
         # oracle-only edge shapes (no golden file): view sizes / tile sizes / agent counts / big grids
         "Edge-12AgentCluttered9x9-view3": ("ClutteredMultiGrid", dict(grid_size=9, n_clutter=5)),
         "Edge-2AgentCluttered40x40-view9-off3": ("ClutteredMultiGrid", dict(grid_size=40, clutter_density=0.2)),
@@ -296,6 +299,11 @@ def registered(name):   # noqa: F811  (extends the table above with test-only sc
                                                                           view_offset=1),
         "Test-3AgentCluttered9x9-prestige-mixed": lambda: cluttered_spec(3, 9, 7, n_clutter=5, respawn=True,
                                                                          colors=["prestige", "blue", "prestige"]),
+        # 'prestige' agents at GridAgentInterface's default tile size (the gather raster with per-env recoloured tiles)
+        "Edge-3AgentCluttered9x9-prestige-mixed-tile5": lambda: cluttered_spec(3, 9, 7, n_clutter=5, respawn=True, tile_size=5,
+                                                                               colors=["prestige", "blue", "prestige"]),
+        "Edge-2AgentGoalcycle9x9-prestige-tile5": lambda: goalcycle_spec(2, 9, 7, n_clutter=4, n_bonus_tiles=3, penalty=-1.5,
+                                                                         max_steps=60, colors=["prestige", "prestige"], tile_size=5),
         "Edge-12AgentCluttered9x9-view3": lambda: cluttered_spec(12, 9, 3, n_clutter=5, colors=_MANY[:12]),
         "Edge-2AgentCluttered40x40-view9-off3": lambda: cluttered_spec(2, 40, 9, clutter_density=0.2, view_offset=3),
         "Edge-3AgentCluttered13x13-view11": lambda: cluttered_spec(3, 13, 11, n_clutter=20),

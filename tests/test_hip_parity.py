@@ -183,7 +183,10 @@ def test_rng_seeding_golden():
                                        ("Edge-3AgentCluttered11x11-view6-tile8", 4110, 20),
                                        ("Edge-3AgentCluttered11x11-view6-tile8", 12, 20),
                                        ("Edge-3AgentCluttered11x11-view8-tile8", 4111, 20),
-                                       ("Test-3AgentCluttered9x9-prestige-mixed", 256, 160)])
+                                       ("Test-3AgentCluttered9x9-prestige-mixed", 256, 160),
+                                       ("Edge-3AgentCluttered9x9-prestige-mixed-tile5", 4101, 70),
+                                       ("Edge-3AgentCluttered9x9-prestige-mixed-tile5", 21, 120),
+                                       ("Edge-2AgentGoalcycle9x9-prestige-tile5", 300, 90)])
 def test_batch_vs_oracle(name, B, T):
     """same seeds, same actions: HIP batch == B oracle envs, every step, full observations."""
     import torch
