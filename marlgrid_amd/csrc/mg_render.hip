@@ -25,6 +25,7 @@ MG_RENDER_GROUP_H(MG_RENDER_EXTERN)
 MG_RENDER_GROUP_I(MG_RENDER_EXTERN)
 MG_RENDER_GROUP_J(MG_RENDER_EXTERN)
 MG_RENDER_GROUP_K(MG_RENDER_EXTERN)
+MG_RENDER_GROUP_L(MG_RENDER_EXTERN)
 MG_RENDER_GROUP_V(MG_RENDER_EXTERN)
 #endif
 
@@ -201,6 +202,14 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
     if (ts == 16) return MG_RENDER_DISPATCH_RT(16, 0);
     if (ts == 32) return MG_RENDER_DISPATCH_RT(32, 0);
     if (vs == 7) return MG_RENDER_DISPATCH(7, 0, 0);        // the default view with any other tile size (or a gather atlas too large for LDS)
+    // the other small views with any tile size: compile-time view (exact dividers, a shadow cast of VS rows, 16-wave workgroups),
+    // run-time tile size
+    if (vs == 3) return MG_RENDER_DISPATCH(3, 0, 0);
+    if (vs == 4) return MG_RENDER_DISPATCH(4, 0, 0);
+    if (vs == 5) return MG_RENDER_DISPATCH(5, 0, 0);
+    if (vs == 6) return MG_RENDER_DISPATCH(6, 0, 0);
+    if (vs == 8) return MG_RENDER_DISPATCH(8, 0, 0);
+    if (vs == 9) return MG_RENDER_DISPATCH(9, 0, 0);
     return MG_RENDER_DISPATCH_RT(0, 0);                   // anything else
 #endif
 }

@@ -183,6 +183,12 @@ def test_rng_seeding_golden():
                                        ("Edge-3AgentCluttered11x11-view6-tile8", 4110, 20),
                                        ("Edge-3AgentCluttered11x11-view6-tile8", 12, 20),
                                        ("Edge-3AgentCluttered11x11-view8-tile8", 4111, 20),
+                                       ("Edge-3AgentCluttered11x11-view5-tile6", 4112, 20),
+                                       ("Edge-3AgentCluttered11x11-view9-tile7", 4113, 20),
+                                       ("Edge-3AgentCluttered11x11-view3-tile13", 4114, 20),
+                                       ("Edge-3AgentCluttered11x11-view6-tile4", 4115, 20),
+                                       ("Edge-3AgentCluttered11x11-view8-tile11", 4116, 15),
+                                       ("Edge-3AgentCluttered11x11-view4-tile3", 14, 20),
                                        ("Test-3AgentCluttered9x9-prestige-mixed", 256, 160),
                                        ("Edge-3AgentCluttered9x9-prestige-mixed-tile5", 4101, 70),
                                        ("Edge-3AgentCluttered9x9-prestige-mixed-tile5", 21, 120),
