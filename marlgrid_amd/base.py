@@ -634,6 +634,12 @@ class MultiGridEnv(object):
                               "plain_stage": bool(st.plain_stage), "stirred": ({"bytes": st.stirred_bytes} if st.stirred_bytes else None),
                               "alloc_ms_per_GiB": 1e3 * st.alloc_seconds / max(st.alloc_bytes, 1) * (1 << 30)}
             self.obs_placement.append(g.placement_ms)
+            if not st.found and not thorough:
+                import warnings
+                warnings.warn("marlgrid_amd: the bounded placement search found no observation buffer in the fast class for %d-byte "
+                              "buffers (%d candidates, stopped: %s): the raster may run up to 20 %% below its best — "
+                              "place_obs='thorough' searches with larger budgets (env.obs_placement has the numbers)"
+                              % (nbytes, st.candidates, g.placement_ms["stopped"]), RuntimeWarning, stacklevel=3)
         for i, r in enumerate(self._ring):
             r["obs"] = self._groups[0].ring[i]
         self.obs = self._ring[self._ring_i]["obs"]
