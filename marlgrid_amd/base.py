@@ -637,8 +637,9 @@ class MultiGridEnv(object):
             if not st.found and not thorough:
                 import warnings
                 warnings.warn("marlgrid_amd: the bounded placement search found no observation buffer in the fast class for %d-byte "
-                              "buffers (%d candidates, stopped: %s): the raster may run up to 20 %% below its best — "
-                              "place_obs='thorough' searches with larger budgets (env.obs_placement has the numbers)"
+                              "buffers (%d candidates, stopped: %s): if this configuration's raster is bound by HBM writes it may run up to "
+                              "20 %% below its best — place_obs='thorough' searches with larger budgets (env.obs_placement has the "
+                              "numbers; a configuration that is not HBM-bound has no fast class to find)"
                               % (nbytes, st.candidates, g.placement_ms["stopped"]), RuntimeWarning, stacklevel=3)
         for i, r in enumerate(self._ring):
             r["obs"] = self._groups[0].ring[i]
