@@ -285,6 +285,9 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     uint8_t* s_vmap = reinterpret_cast<uint8_t*>(s_obj + MG_MAX_OBJ);             // [MG_MAX_AGENTS] viewer slot -> agent
     constexpr bool kChunkRaster = TS_ > 0 && (TS_ % 8) == 0 && RM_ == 0;
     constexpr bool kStreamRaster = !kChunkRaster && !kGather;     // assemble-and-stream
+    // the rasters bound by instruction issue run at a raised wave priority (phase 6); measured per instantiation: the gather
+    // raster at 11-pixel tiles without 'prestige' agents is close enough to the HBM bound to lose 0.6 % by it
+    constexpr bool kRasterPrio = (kGather && (TS_ <= 10 || V_ == 9)) || kStreamRaster;
     // The wave's scratch pointers (w_stage_g ... w_out), the launch's dimensions (VS, TS, n, nv: the viewers —
     // all n agents by default; a subset when the env's agents differ in view size / tile size / offset and are
     // rendered group by group, agents.py:19-35) and the dividers have ONE definition: MG_REGION_LOCALS, expanded
@@ -826,6 +829,11 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             wave_lds_sync();
         }
         // 6. raster: stream the env's n images out
+        // The rasters that are bound by instruction issue run at a raised wave priority: a wave that is storing gets its
+        // instructions before the SIMD's other waves' step / view instructions, so the launch's stores start earlier and stop
+        // less often (whole step: tile 5 -4.2 %, tile 6 -1.2 %, view 9 at tile 5 -3.8 %, tile 13 — assemble-and-stream — -4.7 %,
+        // the reference's example -1.8 %; tile 8, HBM-bound: +0.01 %, tile 11: +0.6 % — both left alone; profiles/r05).
+        if constexpr (kRasterPrio) __builtin_amdgcn_s_setprio(3);
         if constexpr (kGather) {
             // the whole GROUP's images as one stream (mg_gather.h), when the group's first env comes up — or, 'prestige', env
             // by env: the recoloured tiles (w_dyn: ONE slot, virtual tiles >= NT4) are this env's
@@ -1104,6 +1112,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             }
         }
         }
+        if constexpr (kRasterPrio) __builtin_amdgcn_s_setprio(0);
         wave_lds_sync();   // scratch is reused by the next env
         if (e == e0) MG_STAMP(pass == 0 ? 4 : 5);
     }
