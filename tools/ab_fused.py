@@ -61,9 +61,14 @@ for nm in names:
     print("%s: %s" % (nm, L.mg_build_info().decode()))
 
 
+RING = os.environ.get("RING", "0") != "0"      # RING=1: alternate between the env's two observation buffers, as env.step() does
+                                              # (one buffer rewritten every launch partly lives in the 256 MiB Infinity Cache)
+
+
 def launch(L, e, i):
+    obs = e._ring[i % len(e._ring)]["obs"] if RING else e.obs
     rc = L.mg_step_render(C.byref(e._cfg), C.byref(e._state), acts[i % 16].data_ptr(), 8, e.rewards.data_ptr(),
-                          C.byref(e._reset_prog), e.obs.data_ptr(), e._stream())
+                          C.byref(e._reset_prog), obs.data_ptr(), e._stream())
     assert rc == 0, rc
 
 
@@ -78,8 +83,11 @@ if os.environ.get("CHECK", "1") != "0":
             launch(libs[names[0]], ref, i)
             launch(libs[nm], env, i)
             if i % 10 == 9 or 95 < i < 130 or i % 100 in (98, 99, 0, 1):
-                for k in ("obs", "rewards", "done_t", "agent_state", "grid_state", "mt_state", "mt_pos", "mt_head", "step_count_t"):
+                for k in ("rewards", "done_t", "agent_state", "grid_state", "mt_state", "mt_pos", "mt_head", "step_count_t"):
                     assert torch.equal(getattr(env, k), getattr(ref, k)), ("%s differs from %s in %s at step %d" % (nm, names[0], k, i))
+                for j in range(len(env._ring) if RING else 1):
+                    k = "obs"
+                    assert torch.equal(env._ring[j]["obs"] if RING else env.obs, ref._ring[j]["obs"] if RING else ref.obs), ("%s differs from %s in %s at step %d" % (nm, names[0], k, i))
         env.check_errors()
         print("%s identical to %s over 130 steps (obs, rewards, done, records, grids, RNG state)" % (nm, names[0]), flush=True)
     del ref
