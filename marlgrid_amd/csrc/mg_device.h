@@ -112,8 +112,9 @@ __host__ __device__ inline bool render_gather(const MgConfig& cfg) {
     const int vs = cfg.view_size, ts = cfg.tile_size;
     // ('prestige' agents — per-env recoloured tiles next to the atlas's —: the reference's example, 11-pixel tiles, and the default 5)
     if (vs == 7) return (ts == 5 || ts == 6 || ts == 7 || ts == 9 || ts == 10 || ts == 11 || ts == 12) && (cfg.prestige_mask == 0 || ts == 11 || ts == 5);
-    // the other view sizes the 16-byte-chunk raster is instantiated for (3 .. 9, even ones included), at GridAgentInterface's default tile size
-    return (vs == 3 || vs == 4 || vs == 5 || vs == 6 || vs == 8 || vs == 9) && ts == 5 && cfg.prestige_mask == 0;
+    // the other view sizes the 16-byte-chunk raster is instantiated for (3 .. 9, even ones included) and the large odd views
+    // (11, 13, 15: 8-wave workgroups — their shadow-cast arrays need more than 128 VGPRs), at GridAgentInterface's default tile size
+    return (vs == 3 || vs == 4 || vs == 5 || vs == 6 || vs == 8 || vs == 9 || vs == 11 || vs == 13 || vs == 15) && ts == 5 && cfg.prestige_mask == 0;
 }
 __host__ __device__ inline int render_gather_row_bytes(int ts) { return (16 + 3 * ts + 3) / 4 * 4; }
 __host__ __device__ inline int render_atlas_raw_bytes(const MgConfig& cfg) {

@@ -26,6 +26,7 @@ MG_RENDER_GROUP_I(MG_RENDER_EXTERN)
 MG_RENDER_GROUP_J(MG_RENDER_EXTERN)
 MG_RENDER_GROUP_K(MG_RENDER_EXTERN)
 MG_RENDER_GROUP_L(MG_RENDER_EXTERN)
+MG_RENDER_GROUP_M(MG_RENDER_EXTERN)
 MG_RENDER_GROUP_V(MG_RENDER_EXTERN)
 #endif
 
@@ -143,6 +144,16 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
 #define MG_RENDER_DISPATCH_G(VS, TS)                                                                                 \
     (wpb == 16 ? launch_render_t<VS, TS, 16, 0, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)             \
                : launch_render_t<VS, TS, 4, 0, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs))
+        if (vs > 9) {      // views 11 / 13 / 15: 8-wave workgroups where their scratch fits, else 4
+            const int w8 = (cfg.B >= 4096 && render_lds_bytes(cfg, 8, 2) <= 160 * 1024) ? 8 : 4;
+#define MG_RENDER_DISPATCH_G8(VS)                                                                                    \
+    (w8 == 8 ? launch_render_t<VS, 5, 8, 0, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)                 \
+             : launch_render_t<VS, 5, 4, 0, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs))
+            if (vs == 11) return MG_RENDER_DISPATCH_G8(11);
+            if (vs == 13) return MG_RENDER_DISPATCH_G8(13);
+            return MG_RENDER_DISPATCH_G8(15);
+#undef MG_RENDER_DISPATCH_G8
+        }
         if (vs == 3) return MG_RENDER_DISPATCH_G(3, 5);
         if (vs == 4) return MG_RENDER_DISPATCH_G(4, 5);
         if (vs == 5) return MG_RENDER_DISPATCH_G(5, 5);

@@ -1213,6 +1213,8 @@ hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_t* obs,
     X(7, 5, 16, 0, 2) X(7, 5, 4, 0, 2) X(7, 6, 16, 0, 2) X(7, 6, 4, 0, 2)
 #define MG_RENDER_GROUP_H(X) /* ... 7-, 9- and 10-pixel tiles */                                                           \
     X(7, 7, 16, 0, 2) X(7, 7, 4, 0, 2) X(7, 9, 16, 0, 2) X(7, 9, 4, 0, 2) X(7, 10, 16, 0, 2) X(7, 10, 4, 0, 2)
+#define MG_RENDER_GROUP_M(X) /* the gather raster for views 11, 13, 15 at 5-pixel tiles (8-wave workgroups) */                  \
+    X(11, 5, 8, 0, 2) X(11, 5, 4, 0, 2) X(13, 5, 8, 0, 2) X(13, 5, 4, 0, 2) X(15, 5, 8, 0, 2) X(15, 5, 4, 0, 2)
 #define MG_RENDER_GROUP_L(X) /* assemble-and-stream with a compile-time view: views 3 .. 9 at any tile size */                    \
     X(3, 0, 16, 0, 0) X(3, 0, 4, 0, 0) X(4, 0, 16, 0, 0) X(4, 0, 4, 0, 0) X(5, 0, 16, 0, 0) X(5, 0, 4, 0, 0)                       \
     X(6, 0, 16, 0, 0) X(6, 0, 4, 0, 0) X(8, 0, 16, 0, 0) X(8, 0, 4, 0, 0) X(9, 0, 16, 0, 0) X(9, 0, 4, 0, 0)

@@ -147,7 +147,7 @@ int emu_gather(int vs, int ts, int n_vt, int n_dyn, const uint8_t* atlas_raw, co
         return gather_emu<VS, TS>(n_vt, n_dyn, atlas_raw, tmap, tmap_entries, dst, stream_bytes);                              \
     }
     MG_EMU_GATHER(7, 5) MG_EMU_GATHER(7, 6) MG_EMU_GATHER(7, 7) MG_EMU_GATHER(7, 9) MG_EMU_GATHER(7, 10) MG_EMU_GATHER(7, 11)
-    MG_EMU_GATHER(7, 12) MG_EMU_GATHER(5, 5) MG_EMU_GATHER(9, 6) MG_EMU_GATHER(3, 5) MG_EMU_GATHER(6, 5) MG_EMU_GATHER(4, 6) MG_EMU_GATHER(9, 5) MG_EMU_GATHER(4, 5) MG_EMU_GATHER(8, 5)
+    MG_EMU_GATHER(7, 12) MG_EMU_GATHER(5, 5) MG_EMU_GATHER(9, 6) MG_EMU_GATHER(3, 5) MG_EMU_GATHER(6, 5) MG_EMU_GATHER(4, 6) MG_EMU_GATHER(9, 5) MG_EMU_GATHER(4, 5) MG_EMU_GATHER(8, 5) MG_EMU_GATHER(11, 5) MG_EMU_GATHER(13, 5) MG_EMU_GATHER(15, 5)
 #undef MG_EMU_GATHER
     return -1;
 }

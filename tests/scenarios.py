@@ -145,6 +145,7 @@ def ref_recipe(name):
         **{"Edge-3AgentCluttered11x11-tile%d" % ts: ("ClutteredMultiGrid", dict(grid_size=11, n_clutter=9)) for ts in (7, 9, 10, 11, 12, 13)},
         **{"Edge-3AgentCluttered11x11-view%d-tile5" % vs: ("ClutteredMultiGrid", dict(grid_size=11, n_clutter=9)) for vs in (3, 4, 5, 6, 8, 9)},
         **{"Edge-3AgentCluttered11x11-view%d-tile8" % vs: ("ClutteredMultiGrid", dict(grid_size=11, n_clutter=9)) for vs in (4, 6, 8)},
+        **{"Edge-3AgentCluttered15x15-view%d-tile5" % vs: ("ClutteredMultiGrid", dict(grid_size=15, n_clutter=12)) for vs in (11, 13, 15)},
         **{"Edge-3AgentCluttered11x11-view%d-tile%d" % vt: ("ClutteredMultiGrid", dict(grid_size=11, n_clutter=9))
            for vt in ((5, 6), (9, 7), (3, 13), (6, 4), (8, 11), (4, 3))},
         "Test-3AgentEmpty7x11-nonsquare": ("EmptyMultiGrid", dict(width=7, height=11)),
@@ -334,6 +335,9 @@ def registered(name):   # noqa: F811  (extends the table above with test-only sc
         # compile-time views with run-time tile sizes (assemble-and-stream, 16-wave workgroups)
         **{"Edge-3AgentCluttered11x11-view%d-tile%d" % vt: (lambda vt=vt: cluttered_spec(3, 11, vt[0], n_clutter=9, tile_size=vt[1], view_offset=vt[0] // 4))
            for vt in ((5, 6), (9, 7), (3, 13), (6, 4), (8, 11), (4, 3))},
+        # the large odd views at the default 5-pixel tiles (gather raster, 8-wave workgroups)
+        **{"Edge-3AgentCluttered15x15-view%d-tile5" % vs: (lambda vs=vs: cluttered_spec(3, 15, vs, n_clutter=12, tile_size=5, view_offset=vs // 5))
+           for vs in (11, 13, 15)},
         # even views with a compile-time size at the registered 8-pixel tiles (the chunk raster)
         **{"Edge-3AgentCluttered11x11-view%d-tile8" % vs: (lambda vs=vs: cluttered_spec(3, 11, vs, n_clutter=9, view_offset=vs // 3))
            for vs in (4, 6, 8)},

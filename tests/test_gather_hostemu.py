@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "native"))
 import hostemu  # noqa: E402
 
-GEOMS = [(7, 5), (7, 6), (7, 7), (7, 9), (7, 10), (7, 11), (7, 12), (5, 5), (9, 5), (9, 6), (3, 5), (6, 5), (4, 6), (4, 5), (8, 5)]
+GEOMS = [(7, 5), (7, 6), (7, 7), (7, 9), (7, 10), (7, 11), (7, 12), (5, 5), (9, 5), (9, 6), (3, 5), (6, 5), (4, 6), (4, 5), (8, 5), (11, 5), (13, 5), (15, 5)]
 
 
 def _naive(vs, ts, tmap, atlas, n_bands):

@@ -189,6 +189,10 @@ def test_rng_seeding_golden():
                                        ("Edge-3AgentCluttered11x11-view6-tile4", 4115, 20),
                                        ("Edge-3AgentCluttered11x11-view8-tile11", 4116, 15),
                                        ("Edge-3AgentCluttered11x11-view4-tile3", 14, 20),
+                                       ("Edge-3AgentCluttered15x15-view11-tile5", 4117, 15),
+                                       ("Edge-3AgentCluttered15x15-view13-tile5", 4118, 15),
+                                       ("Edge-3AgentCluttered15x15-view13-tile5", 17, 15),
+                                       ("Edge-3AgentCluttered15x15-view15-tile5", 4119, 12),
                                        ("Test-3AgentCluttered9x9-prestige-mixed", 256, 160),
                                        ("Edge-3AgentCluttered9x9-prestige-mixed-tile5", 4101, 70),
                                        ("Edge-3AgentCluttered9x9-prestige-mixed-tile5", 21, 120),
