@@ -316,7 +316,8 @@ int32_t mg_obs_free(void* ptr);
  * the buffer — the driver builds it from a 2 P' block and a P' block), the buffer the window centred on the junction;
  * candidates are timed with the raster itself (the state `st` as it is: HIP events around `iters` mg_render_obs launches on
  * `stream`, blocking) and kept alive until `n_buffers` of them run 12 % under the median candidate, then all the others
- * go back to the driver.  Buffers under 256 MiB are plain allocations (the effect needs thousands of streams).
+ * go back to the driver.  Buffers under 256 MiB are plain allocations (the effect needs thousands of streams), and so are
+ * the buffers of a configuration whose raster writes them at under 3.5 TB/s (it is bound by something else than HBM).
  *   budget_bytes  bytes of candidates alive at any time; 0 = min(a quarter of the free memory, 32 GiB)
  *   seconds       time limit of a pass; <= 0 = 2 s
  *   flags         MG_PLACE_THOROUGH: larger block pairs (candidates of 6 P' and 12 P' bytes — a kept buffer then pins up
@@ -347,6 +348,7 @@ int32_t mg_obs_free(void* ptr);
 #define MG_PLACE_STOP_MEMORY 4  /* the budget does not hold another candidate (after the losers went back, up to six times) */
 #define MG_PLACE_STOP_OOM 5     /* hipMalloc failed */
 #define MG_PLACE_STOP_SMALL 6   /* buffers under min_bytes: plain allocations */
+#define MG_PLACE_STOP_UNBOUND 7 /* the raster writes the plain buffers at under 3.5 TB/s: not bound by HBM writes, nothing to place */
 typedef struct MgPlaceTuning {  /* 0 = the default of each */
     double gain;                /* 0.12 */
     double slow_alloc_s_per_gib;/* MG_PLACE_STIR only when allocations took at least this long: 0.02; < 0: always */

@@ -69,7 +69,7 @@ class GenProgram(C.Structure):
 
 PLACE_MAX, PLACE_ALL = 8, 136
 PLACE_STIR, PLACE_THOROUGH, PLACE_NO_REUSE = 1, 2, 4
-PLACE_STOP = {0: "", 1: "found", 2: "cap", 3: "time", 4: "memory", 5: "out of memory", 6: "small"}
+PLACE_STOP = {0: "", 1: "found", 2: "cap", 3: "time", 4: "memory", 5: "out of memory", 6: "small", 7: "not HBM-bound"}
 E_NOMEM = -103
 
 

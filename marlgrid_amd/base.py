@@ -634,7 +634,7 @@ class MultiGridEnv(object):
                               "plain_stage": bool(st.plain_stage), "stirred": ({"bytes": st.stirred_bytes} if st.stirred_bytes else None),
                               "alloc_ms_per_GiB": 1e3 * st.alloc_seconds / max(st.alloc_bytes, 1) * (1 << 30)}
             self.obs_placement.append(g.placement_ms)
-            if not st.found and not thorough:
+            if not st.found and not thorough and st.stopped != 7:       # (7: not bound by HBM writes — nothing to find, nothing to say)
                 import warnings
                 warnings.warn("marlgrid_amd: the bounded placement search found no observation buffer in the fast class for %d-byte "
                               "buffers (%d candidates, stopped: %s): if this configuration's raster is bound by HBM writes it may run up to "

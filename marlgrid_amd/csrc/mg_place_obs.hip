@@ -271,7 +271,15 @@ int32_t mg_obs_place(const MgConfig* cfg, const MgState* st, int32_t n_buffers, 
                     }
                 }
                 cands.push_back(pick);
-                if (baseline && ++n_plain0 >= need) plain = false;     // the baseline is in: on to the constructed candidates
+                if (baseline && ++n_plain0 >= need) {
+                    plain = false;                                     // the baseline is in: on to the constructed candidates
+                    // ... unless this configuration's raster is nowhere near what HBM takes even inside a block (5.3 TB/s): a
+                    // launch that writes its buffer at under 3.5 TB/s is bound by something else — instruction issue, latency —
+                    // and no placement changes that (measured: views 11 / 13 at 5-pixel tiles, 194 candidates without a class)
+                    float best0 = 1e30f;
+                    for (const Cand& k : cands) best0 = std::min(best0, k.ms);
+                    if ((double)nbytes / ((double)best0 * 1e-3) < 3.5e12) { S.stopped = MG_PLACE_STOP_UNBOUND; break; }
+                }
                 if (err != hipSuccess) break;
                 const float m2 = median_ms();
                 misses = pick.ms <= (1.0 - gain) * m2 ? 0 : misses + 1;
@@ -281,6 +289,7 @@ int32_t mg_obs_place(const MgConfig* cfg, const MgState* st, int32_t n_buffers, 
                     break;
                 }
             }
+            if (S.stopped == MG_PLACE_STOP_UNBOUND) break;     // (nothing to find: no second pass either)
             if (!fast && pass < passes) drop_losers();   // (a second pass starts from the best of the first: the free lists are in another order now)
         }
         // the best `need` of what is still allocated are kept; the rest goes back to the driver
