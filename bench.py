@@ -30,6 +30,11 @@ How the line is measured (one self-consistent measurement, not a collage):
   * `extra.pipelined_shards`: the per-GPU batch (and twice it) as TWO envs on two streams, stepped without a join
     (marlgrid_amd.sharding.ShardPipeline): what overlapping launches of independent shards are worth, next to the
     same number of envs as one env.  The contract line itself is ONE env on one stream.
+  * `parity_after_timed`: when the timed region is over, eight envs of the rank's batch are REPLAYED on the CPU oracle
+    (child process; the checker, never the thing measured) with the very actions the bench fed them — reset, the W
+    warm-up steps and every timed step, auto-reset on `done` — and grid, agent records (stack order included), step
+    counter, MT19937 state, the last step's rewards / done and the last observations are compared: the state the
+    timed ~60 000 steps per env end in is the reference's (marlgrid/base.py:501-653 over ~600 episodes per env).
   * the interpreter's garbage is collected (and the survivors frozen) before every timed region: a full collection in
     the middle of a 20-step block is a 50 ms host stall (settle_interpreter).
 The run refuses to start if an MG_* / MARLGRID_* environment variable is set, and echoes the
@@ -422,7 +427,29 @@ def build_env(wl, B, dev, seeds, fused=True):
     return make(wl, batch_size=B, device=dev, seeds=seeds, auto_reset=True, fused_step=fused)
 
 
-def measure(wl, B, dev, ctl, seeds, K, Wm, min_seconds, max_blocks, action_seed, fused=True, shared=False):
+def parity_ids(B):
+    """the envs of a rank's batch that are replayed on the oracle after the timed region: both ends, a wave boundary,
+    the middle (eight, fewer for tiny batches)"""
+    return sorted({b for b in (0, 1, 63, 64, B // 2, B // 2 + 1, B - 2, B - 1) if 0 <= b < B})
+
+
+def parity_snapshot(env, wl, seeds, pool, steps, last):
+    """what the oracle replay needs, as host arrays: the sampled envs' seeds, their column of the action pool, and the
+    state / last outputs the HIP path ended in (taken right after the timed region, before anything else touches the env)"""
+    import numpy as np
+    import torch
+    ids = parity_ids(env.batch_size)
+    ix = torch.as_tensor(ids, device=env.device)
+    W, H = env.width, env.height
+    return {"workload": wl, "ids": np.array(ids), "seeds": np.array([int(seeds[b]) for b in ids], dtype=np.int64),
+            "pool": np.stack([a[ix].cpu().numpy() for a in pool]).astype(np.int32), "steps": int(steps),
+            "grid": env.grid_state[ix][:, :W * H].reshape(len(ids), W, H).cpu().numpy(),
+            "agents": env.agent_state[ix].cpu().numpy(), "step_count": env.step_count_t[ix].cpu().numpy(),
+            "mt": env.mt_state[ix].cpu().numpy().view(np.uint32), "mt_pos": env.mt_pos[ix].cpu().numpy(),
+            "obs": last[0][ix].cpu().numpy(), "rewards": last[1][ix].cpu().numpy(), "done": last[2][ix].cpu().numpy()}
+
+
+def measure(wl, B, dev, ctl, seeds, K, Wm, min_seconds, max_blocks, action_seed, fused=True, shared=False, snapshot=False):
     import torch
     env = build_env(wl, B, dev, seeds, fused)
     env.placement_retries = ensure_placed(env, shared)
@@ -432,13 +459,19 @@ def measure(wl, B, dev, ctl, seeds, K, Wm, min_seconds, max_blocks, action_seed,
     pool = [torch.randint(0, 7, (B, n), generator=g).to(dev) for _ in range(64)]
     probes = Probes(env, K)
     env._probe = probes
+    last = [None]
+
+    def step(i):            # global step i of the run takes pool[i % 64] (the warm-up and the timed blocks: one sequence)
+        last[0] = env.step(pool[i % 64])
     for i in range(Wm):
-        env.step(pool[i % 64])
+        step(i)
     settle_interpreter()
-    blocks = timed_blocks(lambda i: env.step(pool[(Wm + i) % 64]), lambda: torch.cuda.synchronize(dev), ctl, K,
+    blocks = timed_blocks(lambda i: step(Wm + i), lambda: torch.cuda.synchronize(dev), ctl, K,
                           min_seconds, max_blocks, probes)
     env._probe = None
     env.check_errors()
+    if snapshot:
+        env.parity_snapshot = parity_snapshot(env, wl, seeds, pool, Wm + len(blocks) * K, last[0])
     return env, summarise(blocks, K), blocks
 
 
@@ -538,6 +571,8 @@ def main():
                     help="barriers over RCCL (one rank per GPU: the default) or gloo (--oversubscribe's default); either "
                          "way the gathers run over gloo, and a RCCL group that does not come up on every rank falls "
                          "back to gloo (timing.control_plane.fallback says why)")
+    ap.add_argument("--no-parity", action="store_true", help="skip parity_after_timed (the oracle replay of eight envs of the timed run)")
+    ap.add_argument("--parity-replay", default=None, help=argparse.SUPPRESS)               # (parity_after_timed's child)
     ap.add_argument("--no-pin", action="store_true", help="do not pin the rank to the CPUs of its GPU's NUMA node")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="run the distributed measurement skeleton with a sleep() in place of the engine (gloo, no GPU)")
@@ -546,6 +581,8 @@ def main():
     args = ap.parse_args()
     if args.cpu_baseline_only:
         return cpu_baseline_child(args.cpu_seconds, args.workload)
+    if args.parity_replay:
+        return parity_replay_child(args.parity_replay)
 
     bad = sorted(k for k in os.environ if k.startswith("MG_") or k.startswith("MARLGRID_")
                  or (k.startswith("BENCH_TEST_") and not args.selftest_cpu))      # (test hooks: the CPU skeleton only)
@@ -599,8 +636,12 @@ def main():
     assert len(seeds) == B
     clocks_before = smi.sample(dev_index) if rank == 0 else None
     fused = not args.unfused
-    env, summary, blocks = measure(wl, B, dev, ctl, seeds, K, Wm, args.min_seconds, args.max_blocks, rank, fused, shared)
+    env, summary, blocks = measure(wl, B, dev, ctl, seeds, K, Wm, args.min_seconds, args.max_blocks, rank, fused, shared,
+                                   snapshot=not args.no_parity)
     clocks_after = smi.sample(dev_index) if rank == 0 else None
+    # every rank replays eight envs of ITS shard on the CPU oracle (a child process each, a few seconds, GPUs idle)
+    parity = None if args.no_parity else parity_after_timed(env.parity_snapshot)
+    parity_by_rank = ctl.gather_objects(parity)
     raster_ms = raster_only_ms(env) if rank == 0 else None
     # who ran what: every rank's device and its own K-step times (a straggler, or two ranks on one GPU, shows)
     own = robust([b["per_rank_s"][rank] / K * 1e3 for b in blocks if not b["instrumented"]])
@@ -660,6 +701,12 @@ def main():
             "obs_placement_found_by_rank": [r["obs_placement"].get("found") for r in ranks_info],
             "placement_retries_by_rank": [r["placement_retries"] for r in ranks_info],
         }
+        if not args.no_parity:
+            p0 = parity_by_rank[0] or {}
+            out["parity_after_timed"] = dict(p0, ok=all(bool(p and p.get("ok")) for p in parity_by_rank),
+                                             ok_by_rank=[bool(p and p.get("ok")) for p in parity_by_rank],
+                                             errors_by_rank=[(p or {}).get("error") for p in parity_by_rank]
+                                             if any((p or {}).get("error") for p in parity_by_rank) else None)
     del env
     torch.cuda.empty_cache()
 
@@ -797,6 +844,77 @@ def selftest_cpu(args, rank, local_rank, world, K, Wm):
                 out["errors"] = {"cpu_baseline": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(out), flush=True)
     ctl.close()
+
+
+def parity_after_timed(snap):
+    """Replay the sampled envs of the timed run on the CPU oracle and compare where they ended (see the module docstring).
+    The oracle is the CHECKER here — loaded in a child process only, after the timed region, never on the measured path.
+    Returns {"envs", "steps", "ok", ...}; never raises (a failure of the leg itself is reported as ok = False + error)."""
+    import subprocess
+    import tempfile
+    import numpy as np
+    path = None
+    try:
+        fd, path = tempfile.mkstemp(suffix=".npz", prefix="mg_parity_")
+        os.close(fd)
+        np.savez(path, **snap)
+        env = {k: v for k, v in os.environ.items()
+               if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "BENCH_SELF_LAUNCHED")}
+        env["OMP_NUM_THREADS"] = "1"
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--parity-replay", path], env=env, capture_output=True,
+                           text=True, timeout=1200)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"envs": len(snap["ids"]), "steps": snap["steps"], "ok": False,
+                    "error": "replay child failed (rc %d): %s" % (r.returncode, r.stderr[-400:])}
+        return json.loads(lines[-1])
+    except Exception as e:      # noqa: BLE001
+        return {"envs": len(snap["ids"]), "steps": snap["steps"], "ok": False, "error": "%s: %s" % (type(e).__name__, e)}
+    finally:
+        if path and os.path.exists(path):
+            os.unlink(path)
+
+
+def parity_replay_child(path):
+    """the oracle side of parity_after_timed: same seeds, same actions (global step s takes pool[s % 64]), reset on `done`"""
+    import numpy as np
+    import canon
+    import product_envs
+    import scenarios
+    from marlgrid_amd import seeding
+    from oracle import oracle as O
+    z = np.load(path)
+    wl, ids, T = str(z["workload"]), z["ids"], int(z["steps"])
+    spec = scenarios.registered(wl)
+    t0 = time.perf_counter()
+    orc = O.OracleBatch(spec, z["seeds"])
+    orc.reset()
+    pool = z["pool"]
+    episodes = np.zeros(len(ids), np.int64)
+    obs = rew = done = None
+    for s in range(T):
+        obs, rew, done, _ = orc.step(pool[s % 64], render=(s == T - 1), auto_reset=True, threads=1)
+        episodes += done
+    bad = []
+    st = product_envs.canonical_arrays(spec, z["grid"], z["agents"], z["step_count"])
+    for j, b in enumerate(ids):
+        try:
+            canon.assert_same(st[j], canon.oracle_canonical(orc.envs[j]), "env %d" % b)
+        except AssertionError as e:
+            bad.append("state: " + str(e)[:200])
+        if not seeding.same_stream(seeding.numpy_form(z["mt"][j], z["mt_pos"][j], 16), orc.envs[j].mt_state()):
+            bad.append("env %d: MT19937 state differs" % b)
+    if T > 0 and "obs" in z.files:
+        if not np.array_equal(z["obs"], obs):
+            bad.append("last observations differ in envs %s" % [int(ids[j]) for j in range(len(ids)) if not np.array_equal(z["obs"][j], obs[j])])
+        if np.abs(z["rewards"].astype(np.float64) - rew).max() > 1e-6:
+            bad.append("last rewards differ")
+        if not np.array_equal(z["done"].astype(bool), done):
+            bad.append("last done flags differ")
+    print(json.dumps({"envs": int(len(ids)), "env_ids": [int(b) for b in ids], "steps": T, "ok": not bad,
+                      "episodes_per_env_min": int(episodes.min()), "compared": ["grid", "agent records + stack order", "step_count",
+                      "MT19937 state (numpy form)", "last rewards (1e-6)", "last done", "last observations (bit-exact)"],
+                      "oracle_seconds": time.perf_counter() - t0, "mismatches": bad[:8] or None}), flush=True)
 
 
 def physical_cores(cpus):

@@ -95,3 +95,30 @@ def test_core_bodies_vs_oracle(name, B, T, auto):
         if t % 7 == 0 or t == T - 1:
             _same_state(emu, orc, what)
     assert not emu.error.any()
+
+
+@pytest.mark.parametrize("name,B,T", [("MarlGrid-3AgentCluttered15x15-v0", 16, 6000),
+                                       ("Custom-8AgentCluttered30x30", 4, 3000),
+                                       ("Test-3AgentCluttered9x9-respawn", 16, 6000)])
+def test_core_bodies_long_horizon(name, B, T):
+    """what bench.py times is ~60 000 steps per env: the lane-per-env bodies over MANY episodes (auto-reset inside the
+    step, >= 25 wraps of the 624-word MT19937 state through the lazy regeneration) against the oracle — rewards / done
+    every step, canonical state + RNG every 250 steps.  The GPU twin (LDS staging, LDS-DMA head refills, observations):
+    tests/test_hip_soak.py."""
+    import hostemu
+    seeds = 515000 + np.arange(B)
+    emu = hostemu.HostEmu(name, B, seeds, auto_reset=True)
+    orc = O.OracleBatch(scenarios.registered(name), seeds)
+    emu.reset()
+    orc.reset()
+    rng = np.random.RandomState(17)
+    episodes = np.zeros(B, np.int64)
+    for t in range(1, T + 1):
+        a = rng.randint(0, 7, size=(B, emu.n))
+        r, d = emu.step(a)
+        _o, r2, d2, _ = orc.step(a, render=False, auto_reset=True)
+        assert np.abs(r.astype(np.float64) - r2).max() <= REW_TOL and np.array_equal(d, d2), (name, t)
+        episodes += d2
+        if t % 250 == 0 or t == T:
+            _same_state(emu, orc, "%s step %d" % (name, t))
+    assert episodes.min() >= T // 100 and not emu.error.any()

@@ -417,7 +417,9 @@ def test_shard_invariance_and_idempotence():
     big = product_envs.build(name, batch_size=B, strict=False)
     sub_ids = np.array([0, 1, 63, 64, 4095, 20000, B - 1])
     small = product_envs.build(name, batch_size=len(sub_ids), seeds=1337 + sub_ids)
+    orc = O.OracleBatch(scenarios.registered(name), 1337 + sub_ids)      # the chain to the oracle, closed in this run
     big.reset(); small.reset()
+    assert np.array_equal(big.obs[sub_ids].cpu().numpy(), orc.reset())
     g = torch.Generator().manual_seed(0)
     for t in range(30):
         a = torch.randint(0, 7, (B, 3), generator=g)
@@ -425,6 +427,9 @@ def test_shard_invariance_and_idempotence():
         o2, r2, d2, _ = small.step(a[sub_ids])
         assert torch.equal(o1[sub_ids].cpu(), o2.cpu())
         assert torch.equal(r1[sub_ids].cpu(), r2.cpu()) and torch.equal(d1[sub_ids].cpu(), d2.cpu())
+        o3, r3, d3, _ = orc.step(a[sub_ids].numpy())
+        assert np.array_equal(o2.cpu().numpy(), o3) and np.array_equal(d2.cpu().numpy(), d3), t
+        assert np.abs(r2.cpu().numpy().astype(np.float64) - r3).max() <= REW_TOL
     first = big.gen_obs().clone()
     assert torch.equal(first, big.gen_obs())
     big.check_errors()
@@ -567,7 +572,9 @@ def test_full_headline_batch_properties():
     env = make("MarlGrid-3AgentCluttered15x15-v0", batch_size=B, strict=False, obs_buffers=1)
     ids = np.array([0, 1, 65535, 65536, 131071, 200000, B - 1])
     small = make("MarlGrid-3AgentCluttered15x15-v0", batch_size=len(ids), seeds=1337 + ids)
+    orc = O.OracleBatch(scenarios.registered("MarlGrid-3AgentCluttered15x15-v0"), 1337 + ids)   # ... and the oracle on the same ids
     env.reset(); small.reset()
+    assert np.array_equal(env.obs[ids].cpu().numpy(), orc.reset())
     g = torch.Generator().manual_seed(0)
     for t in range(12):
         a = torch.randint(0, 7, (B, 3), generator=g)
@@ -575,6 +582,9 @@ def test_full_headline_batch_properties():
         o2, r2, d2, _ = small.step(a[ids])
         assert torch.equal(o[ids].cpu(), o2.cpu()) and torch.equal(r[ids].cpu(), r2.cpu())
         assert torch.equal(d[ids].cpu(), d2.cpu())
+        o3, r3, d3, _ = orc.step(a[ids].numpy())
+        assert np.array_equal(o[ids].cpu().numpy(), o3) and np.array_equal(d[ids].cpu().numpy(), d3), t
+        assert np.abs(r[ids].cpu().numpy().astype(np.float64) - r3).max() <= REW_TOL
     env.check_errors()
     tiles = env.obs[-64:].reshape(64, 3, 7, 8, 7, 8, 3).permute(0, 1, 2, 4, 3, 5, 6).reshape(-1, 192).cpu().numpy()
     known = {bytes(x) for x in env.atlas.reshape(-1, 192)}
@@ -929,14 +939,18 @@ def test_agents_with_their_own_views_vs_oracle(shared):
 
 def _full_size_properties(name, B, n, vs, ts, steps, **kw):
     """size-independent properties at a BASELINE batch: shard invariance against a 7-env twin holding the same
-    global env ids, no runtime errors, every tile-sized block of the last envs' images is an atlas tile"""
+    global env ids — and, so that the run closes its own chain, the ORACLE on those seven seeds, stepped with the same
+    actions (it resets on `done`, as the launch does): observations, rewards, done every step, canonical state and RNG
+    at the end —, no runtime errors, every tile-sized block of the last envs' images is an atlas tile"""
     import torch
     env = product_envs.build(name, batch_size=B, strict=False, obs_buffers=1, auto_reset=True, **kw)
     ids = np.array([0, 1, B // 4 - 1, B // 4, B // 2 + 5, B - 2, B - 1])
     small = product_envs.build(name, batch_size=len(ids), seeds=1337 + ids, auto_reset=True)
+    orc = O.OracleBatch(scenarios.registered(name), 1337 + ids)
     assert env.view_size == vs and env.tile_size == ts and env.num_agents == n
     o, o2 = env.reset(), small.reset()
     assert torch.equal(o[ids].cpu(), o2.cpu())
+    assert np.array_equal(o2.cpu().numpy(), orc.reset())
     g = torch.Generator().manual_seed(1)
     for t in range(steps):
         a = torch.randint(0, 7, (B, n), generator=g)
@@ -944,7 +958,15 @@ def _full_size_properties(name, B, n, vs, ts, steps, **kw):
         o2, r2, d2, _ = small.step(a[ids])
         assert torch.equal(o[ids].cpu(), o2.cpu()) and torch.equal(r[ids].cpu(), r2.cpu()), (name, t)
         assert torch.equal(d[ids].cpu(), d2.cpu())
+        o3, r3, d3, _ = orc.step(a[ids].numpy(), auto_reset=True)
+        assert np.array_equal(o[ids].cpu().numpy(), o3) and np.array_equal(d[ids].cpu().numpy(), d3), (name, t)
+        assert np.abs(r[ids].cpu().numpy().astype(np.float64) - r3).max() <= REW_TOL, (name, t)
     env.check_errors()
+    st = product_envs.canonical_arrays(env.scenario_spec(), env.grid.grid[ids].cpu().numpy(), env.agent_state[ids].cpu().numpy(),
+                                       env.step_count[ids].cpu().numpy())
+    for j, b in enumerate(ids):
+        canon.assert_same(st[j], canon.oracle_canonical(orc.envs[j]), "%s env %d" % (name, b))
+        assert seeding.same_stream(env.numpy_rng_state(int(b)), orc.envs[j].mt_state()), (name, b)
     tb = ts * ts * 3
     tiles = env.obs[-32:].reshape(32, n, vs, ts, vs, ts, 3).permute(0, 1, 2, 4, 3, 5, 6).reshape(-1, tb).cpu().numpy()
     known = {bytes(x) for x in env.atlas.reshape(-1, tb)}

@@ -1,0 +1,84 @@
+"""Long-horizon GPU parity: what bench.py times is ~60 000 steps per env (600 episodes, ~290 wraps of the 624-word
+MT19937 state), so the HIP path is stepped against the CPU oracle over MANY episodes here, with `auto_reset=True` (the
+reset of a finished episode runs inside the step launch; the oracle resets on `done`): >= 6 000 steps, >= 60 episodes
+per env, >= 25 wraps of the lazy MT regeneration and its LDS-DMA head refills.  Every step: rewards (<= 1e-6) and done;
+every `obs_every`-th step: the full observations; every 500th step and at the end: canonical state of every env (grid,
+agent records incl. stack order, step counter) and the numpy form of the RNG state.
+Reference: marlgrid/base.py:501-653 (step), :402-416 (reset), over many episodes."""
+import numpy as np
+import pytest
+
+import canon
+import product_envs
+import scenarios
+from marlgrid_amd import seeding
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+REW_TOL = 1e-6
+
+
+def soak(name, B, T, obs_every=50, seed0=424200, action_seed=5, p=None, **kw):
+    import torch
+    seeds = seed0 + np.arange(B)
+    env = product_envs.build(name, batch_size=B, seeds=seeds, auto_reset=True, **kw)
+    spec = scenarios.registered(name)
+    orc = O.OracleBatch(spec, seeds)
+    assert np.array_equal(env.reset().cpu().numpy(), orc.reset())
+    n = env.num_agents
+    rng = np.random.RandomState(action_seed)
+    episodes = np.zeros(B, np.int64)
+    # RNG words drawn per env, counted on the device (mt_pos runs modulo 624; no step draws 624 words)
+    draws = torch.zeros(B, dtype=torch.int64, device=env.device)
+    last_pos = env.mt_pos.clone()
+
+    def deep(t):
+        st = product_envs.canonical(env)
+        for b in range(B):
+            canon.assert_same(st[b], canon.oracle_canonical(orc.envs[b]), "%s env %d step %d" % (name, b, t))
+        for b in (0, B - 1) if t < T else range(B):
+            assert seeding.same_stream(env.numpy_rng_state(b), orc.envs[b].mt_state()), (name, b, t)
+
+    for t in range(1, T + 1):
+        a = rng.randint(0, 7, size=(B, n)) if p is None else rng.choice(len(p), size=(B, n), p=p)
+        look = t % obs_every == 0 or t == T
+        o, r, dn, _ = env.step(torch.from_numpy(a))
+        o2, r2, dn2, _ = orc.step(a, render=look, auto_reset=True)
+        assert np.array_equal(dn.cpu().numpy(), dn2), "%s done step %d" % (name, t)
+        assert np.abs(r.cpu().numpy().astype(np.float64) - r2).max() <= REW_TOL, "%s rewards step %d" % (name, t)
+        episodes += dn2
+        if look:
+            assert np.array_equal(o.cpu().numpy(), o2), "%s obs step %d" % (name, t)
+        draws += (env.mt_pos - last_pos).long() % 624
+        last_pos = env.mt_pos.clone()
+        if t % 500 == 0 or t == T:
+            deep(t)
+    env.check_errors()
+    return dict(episodes=episodes, wraps=draws.cpu().numpy() / 624.0)
+
+
+def test_soak_headline_3agent_cluttered15x15():
+    """the bench workload: 64 envs x 6 000 steps, >= 60 episodes per env, >= 25 MT wraps"""
+    s = soak("MarlGrid-3AgentCluttered15x15-v0", 64, 6000)
+    assert s["episodes"].min() >= 60, s["episodes"].min()
+    assert s["wraps"].min() >= 25, s["wraps"]
+
+
+def test_soak_config4_8agent_cluttered30x30():
+    """BASELINE.json configs[4]: 16 envs x 6 000 steps (eight agents: ~10 shuffle draws per step)"""
+    s = soak("Custom-8AgentCluttered30x30", 16, 6000, seed0=77000, action_seed=6)
+    assert s["episodes"].min() >= 60 and s["wraps"].min() >= 25, (s["episodes"].min(), s["wraps"])
+
+
+def test_soak_goalcycle_demo_solo():
+    """ClutteredGoalCycleEnv (BonusTile cycle, reward_decay False): one agent draws nothing in the shuffle, so the RNG
+    only moves in the resets — 6 000 steps are 60 episodes of ~32 placements each"""
+    s = soak("Goalcycle-demo-solo-v0", 64, 6000, seed0=9100, action_seed=7, p=[.2, .2, .6])
+    assert s["episodes"].min() >= 60, s["episodes"].min()
+
+
+def test_soak_respawn_3agent_cluttered9x9():
+    """respawn=True (base.py:627-646): agents that reach the goal are re-placed by rejection sampling inside the step,
+    episodes end at max_steps only — 6 000 steps, forward-heavy actions so that respawns are frequent"""
+    s = soak("Test-3AgentCluttered9x9-respawn", 64, 6000, seed0=31337, action_seed=8, p=[.15, .15, .5, .05, .05, .05, .05])
+    assert s["episodes"].min() >= 60 and s["wraps"].min() >= 25, (s["episodes"].min(), s["wraps"])

@@ -2,6 +2,7 @@
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -442,3 +443,46 @@ def test_late_static_edits_are_rectangle_fills_and_visible_to_get():
 
     with pytest.raises(NotImplementedError, match=r"1 groups of random placements and \d+ rectangle fills"):
         TooMany(agents=[dict(color="red")], grid_size=11, _dry=True)
+
+
+def test_bench_parity_after_timed_replay(tmp_path):
+    """bench.py's parity_after_timed leg without a GPU: the engine's lane-per-env bodies (tests/native host build) play the
+    bench's part — reset, then global step s takes pool[s % 64] — and the replay child (the oracle) must agree with the
+    state they end in; a corrupted record, a shifted action pool and a wrong step count must each be caught"""
+    import json
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "tests", "native"))
+    import hostemu
+    import bench
+    wl, B, T = "MarlGrid-3AgentCluttered15x15-v0", 70, 450
+    seeds = [1337 + b for b in range(B)]
+    emu = hostemu.HostEmu(wl, B, seeds, auto_reset=True)
+    emu.reset()
+    rng = np.random.RandomState(0)
+    pool = [rng.randint(0, 7, size=(B, 3)) for _ in range(64)]
+    for s in range(T):
+        rew, done = emu.step(pool[s % 64])
+    ids = bench.parity_ids(B)
+    assert ids == [0, 1, 35, 36, 63, 64, 68, 69]
+    W, H = emu.env.width, emu.env.height
+    snap = {"workload": wl, "ids": np.array(ids), "seeds": np.array([seeds[b] for b in ids], dtype=np.int64),
+            "pool": np.stack([a[ids] for a in pool]).astype(np.int32), "steps": T,
+            "grid": emu.grid[ids][:, :W * H].reshape(len(ids), W, H), "agents": emu.rec[ids].view(np.int64),
+            "step_count": emu.step_count[ids], "mt": emu.mt[ids], "mt_pos": emu.mt_pos[ids],
+            "rewards": rew[ids], "done": done[ids]}
+
+    def replay(sn):
+        path = str(tmp_path / "snap.npz")
+        np.savez(path, **sn)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--parity-replay", path], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-500:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    res = replay(snap)
+    assert res["ok"] and res["steps"] == T and res["envs"] == 8 and res["episodes_per_env_min"] >= 4, res
+    bad = dict(snap, agents=snap["agents"].copy())
+    bad["agents"][3, 1] ^= 1                                # one agent of one env one cell off
+    assert not replay(bad)["ok"]
+    assert not replay(dict(snap, pool=np.roll(snap["pool"], 1, axis=0)))["ok"]
+    assert not replay(dict(snap, steps=T - 1))["ok"]
+    # and through the parent-side wrapper (temp file, clean child environment)
+    assert bench.parity_after_timed(snap)["ok"]
