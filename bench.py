@@ -220,7 +220,7 @@ OBS_BUFFERS_NOTE = {
     False: "plain torch allocations"}
 
 
-def ensure_placed(env, shared=False):
+def ensure_placed(env, share=1):
     """A rank whose observation buffers are not in the fast class places them once more before anything is timed — the
     long search (larger candidates, a second pass, one big allocate-and-free: this process owns its GPU) — and says so:
     with MAX-over-ranks timing one rank's plain-speed buffers would cost the whole N-GPU point a fifth.  Returns the
@@ -231,7 +231,8 @@ def ensure_placed(env, shared=False):
         if pm is not None and not pm.get("found") and pm.get("stopped") != "out of memory":
             first = {k: pm.get(k) for k in ("kept", "candidates", "stopped", "seconds")}
             free = torch.cuda.mem_get_info(env.device)[0]
-            env._place_obs_buffers(thorough=True, stir=not shared, seconds=6.0, budget=min(free // (4 if shared else 2), 128 << 30))
+            # (ranks that share a GPU — --oversubscribe — count on their part of what is free, and do not stir each other's free lists)
+            env._place_obs_buffers(thorough=True, stir=share == 1, seconds=6.0, budget=min(free // (2 * share), 128 << 30), share=share)
             retries = 1
             for pm2 in env.obs_placement:
                 if pm2 is not None:
@@ -414,17 +415,18 @@ def summarise(blocks, K):
     return out
 
 
-def build_env(wl, B, dev, seeds, fused=True):
+def build_env(wl, B, dev, seeds, fused=True, share=1):
     from marlgrid_amd.envs import make
+    place = {"share": share} if share > 1 else True
     if wl == "Custom-8AgentCluttered30x30":     # BASELINE.json configs[4]; not a registered id upstream
         from marlgrid_amd.agents import GridAgentInterface
         from marlgrid_amd.envs import ClutteredMultiGrid
         cols = ["red", "blue", "purple", "orange", "olive", "pink", "cyan", "yellow"]
         return ClutteredMultiGrid(agents=[GridAgentInterface(color=c, view_size=9, view_tile_size=8) for c in cols],
                                   grid_size=30, clutter_density=0.15, batch_size=B, device=dev, seeds=seeds,
-                                  auto_reset=True, fused_step=fused)
+                                  auto_reset=True, fused_step=fused, place_obs=place)
     # everything else at its default — strict=True included (errors are polled, not synchronised on)
-    return make(wl, batch_size=B, device=dev, seeds=seeds, auto_reset=True, fused_step=fused)
+    return make(wl, batch_size=B, device=dev, seeds=seeds, auto_reset=True, fused_step=fused, place_obs=place)
 
 
 def parity_ids(B):
@@ -449,10 +451,10 @@ def parity_snapshot(env, wl, seeds, pool, steps, last):
             "obs": last[0][ix].cpu().numpy(), "rewards": last[1][ix].cpu().numpy(), "done": last[2][ix].cpu().numpy()}
 
 
-def measure(wl, B, dev, ctl, seeds, K, Wm, min_seconds, max_blocks, action_seed, fused=True, shared=False, snapshot=False):
+def measure(wl, B, dev, ctl, seeds, K, Wm, min_seconds, max_blocks, action_seed, fused=True, share=1, snapshot=False):
     import torch
-    env = build_env(wl, B, dev, seeds, fused)
-    env.placement_retries = ensure_placed(env, shared)
+    env = build_env(wl, B, dev, seeds, fused, share)
+    env.placement_retries = ensure_placed(env, share)
     env.reset()
     n = env.num_agents
     g = torch.Generator(device="cpu").manual_seed(action_seed)
@@ -488,7 +490,10 @@ def measure_pipeline(wl, B, parts, dev, ctl, K, Wm, min_seconds, max_blocks, act
     # the public path: make(id, pipeline=P) and the sampler's own call, step_part(k, actions), part after part
     pipe = make(wl, pipeline=parts, batch_size=B, device=dev, seed=1337, auto_reset=True, fused_step=fused,
                 streams=_PIPE_STREAMS[parts])
-    retries = sum(ensure_placed(e) for e in pipe.envs)
+    retries = 0
+    for k in range(parts):          # (a retry launches — the search's rasters, the re-render — on the part's own stream, like its steps)
+        with pipe.on(k):
+            retries += ensure_placed(pipe.envs[k])
     pipe.reset()
     n = pipe.envs[0].num_agents
     g = torch.Generator(device="cpu").manual_seed(action_seed)
@@ -532,7 +537,7 @@ def roofline_of(env, B, summary, traffic, raster_ms=None):
     fused = dom == "step_render_interval_ms"
     ms, st = k[dom], k[dom + "_stats"]
     ach = B * n * alg / (ms * 1e-3) / 1e9
-    kname = "mg::render_kernel<%d, %d, %d, 0>" % (vs, ts, 16 if B >= 4096 else 4)
+    kname = getattr(env, "kernel_name", None) or "mg::render_kernel (name not recorded)"      # the launcher's own (mg_render_kernel_name)
     return {"bound": "hbm", "kernel": kname + (" launched by mg_step_render (the env step fused in front of the raster)"
                                                   if fused else ""),
             "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
@@ -620,6 +625,7 @@ def main():
               "ranks onto fewer GPUs for a plumbing check)" % (world, ndev), file=sys.stderr)
         sys.exit(3)
     shared = args.oversubscribe and world > ndev
+    share = (world + ndev - 1) // ndev if shared else 1          # ranks per GPU: each counts on its part of the free memory
     dev_index = local_rank % ndev if args.oversubscribe else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -636,7 +642,7 @@ def main():
     assert len(seeds) == B
     clocks_before = smi.sample(dev_index) if rank == 0 else None
     fused = not args.unfused
-    env, summary, blocks = measure(wl, B, dev, ctl, seeds, K, Wm, args.min_seconds, args.max_blocks, rank, fused, shared,
+    env, summary, blocks = measure(wl, B, dev, ctl, seeds, K, Wm, args.min_seconds, args.max_blocks, rank, fused, share,
                                    snapshot=not args.no_parity)
     clocks_after = smi.sample(dev_index) if rank == 0 else None
     # every rank replays eight envs of ITS shard on the CPU oracle (a child process each, a few seconds, GPUs idle)
@@ -656,6 +662,7 @@ def main():
                                      "placement_retries": getattr(env, "placement_retries", 0)})
     n, vs, ts = env.num_agents, env.view_size, env.tile_size
     P = vs * ts
+    kname0 = env.kernel_name
 
     out = None
     if rank == 0:
@@ -740,7 +747,7 @@ def main():
     if rank == 0:
         # roofline needs the env's geometry only
         class _Geo(object):
-            view_size, tile_size, num_agents = vs, ts, n
+            view_size, tile_size, num_agents, kernel_name = vs, ts, n, kname0
         out["roofline"] = roofline_of(_Geo, B, summary, traffic if n_gpus == 1 else None, raster_ms)
         out["pmc"] = traffic
 

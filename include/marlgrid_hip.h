@@ -24,6 +24,7 @@
  *   mg_place        MultiGridEnv.place_obj / try_place_obj outside _gen_grid (base.py:664-708)
  *   mg_render_frame MultiGridEnv.render's whole-grid image: MultiGrid.render(top_agent=None) +
  *                   visibility highlight         (base.py:714-759, 301-331)
+ *   mg_render_kernel_name  (no reference counterpart: names the launch for profiles and warns of generic instantiations)
  *   mg_obs_place    the observation arrays MultiGridEnv's constructor / gen_obs allocate (base.py:334-347, 453-474),
  *                   for a batch: where in HBM they lie (construction time; mg_obs_release, mg_obs_trim)
  *
@@ -58,7 +59,7 @@
 extern "C" {
 #endif
 
-#define MG_ABI_VERSION 5
+#define MG_ABI_VERSION 6
 #define MG_MAX_AGENTS 16
 #define MG_MAX_OBJ 64
 #define MG_MAX_GEN 32
@@ -283,6 +284,14 @@ int32_t mg_render_frame(const MgConfig* cfg, const MgState* st, const int32_t* e
  * (no device access; obj / atlas may still be NULL). */
 int32_t mg_render_obs_lds_bytes(const MgConfig* cfg);
 
+/* Which instantiation of the observation kernel `cfg` gets from the launcher (mg_render_obs and mg_step_render launch the
+ * same one), as rocprofv3 prints it: "mg::render_kernel<VS, TS, WPB, V, RM>" — view size, tile size (0: read from cfg at
+ * run time), waves per workgroup, variant (0 plain, 8 atlas read in place, 9 'prestige' recolouring, 12 both), raster (0 by
+ * tile size: 16-byte chunks at 8 / 16 / 32, assemble-and-stream otherwise; 2 gather).  No device access, nothing is launched
+ * (obj / atlas may be NULL).  Returns a bit mask >= 0: 1 = the view size, 2 = the tile size is a run-time value — 3 is the
+ * fully generic instantiation, 2-2.4x slower than a specialised one (hosts warn) — or MG_E_ARG / MG_E_LAUNCH (does not fit LDS). */
+int32_t mg_render_kernel_name(const MgConfig* cfg, char* out, int32_t cap);
+
 /* timing helper for bench.py: average duration (ms) of `iters` back-to-back mg_render_obs
  * launches on `stream`, bracketed by HIP events recorded on that same stream. */
 int32_t mg_time_render_obs(const MgConfig* cfg, const MgState* st, uint8_t* obs, int32_t iters,
@@ -318,8 +327,11 @@ int32_t mg_obs_free(void* ptr);
  * `stream`, blocking) and kept alive until `n_buffers` of them run 12 % under the median candidate, then all the others
  * go back to the driver.  Buffers under 256 MiB are plain allocations (the effect needs thousands of streams), and so are
  * the buffers of a configuration whose raster writes them at under 3.5 TB/s (it is bound by something else than HBM).
- *   budget_bytes  bytes of candidates alive at any time; 0 = min(a quarter of the free memory, 32 GiB)
- *   seconds       time limit of a pass; <= 0 = 2 s
+ *   budget_bytes  bytes of candidates alive at any time; 0 = min(a quarter of the free memory, 32 GiB), raised to the kept
+ *                 buffers + three first-level candidates while that is within half of the free memory (large buffers: a
+ *                 16 GB buffer's candidates are 24 GiB each)
+ *   seconds       time limit of a pass (not applied before the plain baseline allocations are in); <= 0 = 2 s, more for
+ *                 candidates above 12 GiB (0.16 s per GiB of candidate, 8 s at most)
  *   flags         MG_PLACE_THOROUGH: larger block pairs (candidates of 6 P' and 12 P' bytes — a kept buffer then pins up
  *                 to 12x its size) and a second pass when the first found nothing; MG_PLACE_STIR: when nothing was found
  *                 and allocations were slow (memory nobody had before is cleared as it is handed out, front to back, all in
@@ -356,6 +368,9 @@ typedef struct MgPlaceTuning {  /* 0 = the default of each */
     uint64_t stir_bytes;        /* cap of the allocate-and-free: 64 GiB */
     int32_t max_candidates;     /* per pass: 192 (the first MG_PLACE_ALL are recorded in MgPlaceStats.all_ms) */
     int32_t iters;              /* raster launches per measurement: 3 */
+    int32_t share;              /* processes that share this device's memory (ranks of an oversubscribed launch): the default
+                                 * budget is worked out from 1 / share of what is free.  0 / 1: this process counts on all of it */
+    int32_t reserved1;
 } MgPlaceTuning;
 typedef struct MgPlaceStats {
     int32_t found, reused, candidates, windows;   /* windows: positions measured (>= candidates) */

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 MAX_AGENTS, MAX_OBJ, MAX_GEN, MAX_VIEW, KEY_WORDS, MT_N, MT_HEAD = 16, 64, 32, 15, 2, 624, 16
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 OK = 0
 ERR_VALUE, ERR_RECURSION, ERR_TYPE, ERR_ASSERT, ERR_ATTRIBUTE = 1, 2, 3, 4, 5
@@ -75,7 +75,8 @@ E_NOMEM = -103
 
 class PlaceTuning(C.Structure):
     _fields_ = [("gain", C.c_double), ("slow_alloc_s_per_gib", C.c_double), ("min_bytes", C.c_uint64),
-                ("stir_bytes", C.c_uint64), ("max_candidates", C.c_int32), ("iters", C.c_int32)]
+                ("stir_bytes", C.c_uint64), ("max_candidates", C.c_int32), ("iters", C.c_int32),
+                ("share", C.c_int32), ("reserved1", C.c_int32)]
 
 
 class PlaceStats(C.Structure):
@@ -95,7 +96,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "lib
 SYMBOLS = ["mg_abi_version", "mg_struct_sizes", "mg_host_flag_alloc", "mg_host_flag_free", "mg_obs_alloc", "mg_obs_free", "mg_obs_place", "mg_obs_release", "mg_obs_trim", "mg_build_info", "mg_error_string", "mg_mt_seed", "mg_reset", "mg_step", "mg_step_render",
            "mg_render_obs",
            "mg_encode", "mg_put_obj", "mg_place", "mg_render_frame", "mg_time_render_obs",
-           "mg_render_obs_lds_bytes"]
+           "mg_render_obs_lds_bytes", "mg_render_kernel_name"]
 
 _lib = None
 _path = LIB_PATH
@@ -168,6 +169,7 @@ def lib():
     L.mg_put_obj.argtypes = [C.POINTER(Config), C.POINTER(State), i32, i32, i32, vp, vp]
     L.mg_place.argtypes = [C.POINTER(Config), C.POINTER(State), i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]
     L.mg_render_frame.argtypes = [C.POINTER(Config), C.POINTER(State), vp, i32, vp, i32, i32, C.c_uint32, vp, vp]
+    L.mg_render_kernel_name.argtypes = [C.POINTER(Config), C.c_char_p, i32]
     L.mg_time_render_obs.argtypes = [C.POINTER(Config), C.POINTER(State), vp, i32, C.POINTER(C.c_float), vp]
     for f in SYMBOLS:
         getattr(L, f)
@@ -180,3 +182,12 @@ def lib():
 def check(rc):
     if rc != 0:
         raise RuntimeError("libmarlgrid_hip: %s (%d)" % (lib().mg_error_string(rc).decode(), rc))
+
+
+def render_kernel_name(cfg):
+    """(name, generic bits) of the observation-kernel instantiation the launcher picks for `cfg` (mg_render_kernel_name)"""
+    buf = C.create_string_buffer(96)
+    rc = lib().mg_render_kernel_name(C.byref(cfg), buf, len(buf))
+    if rc < 0:
+        check(rc)
+    return buf.value.decode(), rc

@@ -143,6 +143,9 @@ class MultiGrid(object):
         # what `_gen_grid` itself has drawn so far — the template plus the static edits made after a place_obj (which go
         # into the reset program, not the template): what get() answers while `_gen_grid` runs
         self._shadow = np.zeros((self.width, self.height), np.uint8)
+        # cells a recorded random placement may have filled since `_gen_grid` last drew on them (place_obj only takes empty
+        # cells of its sampling rectangle; a later static edit of a cell decides it again)
+        self._maybe = np.zeros((self.width, self.height), bool)
         env._tr_begin(self)
 
     # ---- layout recording / live edits --------------------------------------------------------
@@ -155,6 +158,7 @@ class MultiGrid(object):
             if env._tr_static(("put", key, int(i), int(j)), key, [(int(i), int(j), int(i) + 1, int(j) + 1)]):
                 self._template[i, j] = key
             self._shadow[i, j] = key
+            self._maybe[i, j] = False
         else:
             env.put_obj(obj, i, j)
 
@@ -192,6 +196,7 @@ class MultiGrid(object):
                     self._template[i, j] = key
             for (i, j) in cells:
                 self._shadow[i, j] = key
+                self._maybe[i, j] = False
         else:
             for (i, j) in cells:
                 self.set(i, j, obj_type())
@@ -208,6 +213,15 @@ class MultiGrid(object):
         assert i >= 0 and i < self.width
         assert j >= 0 and j < self.height
         if self._env._tracing:      # inside `_gen_grid`: what it has drawn so far (random placements are per env: not in here)
+            if self._maybe[i, j]:
+                # upstream's grid.get() here sees what an earlier place_obj put into THIS env's cell; the recorder cannot —
+                # the draw happens later, on the device, per env.  Layout code that branches on the answer would be recorded
+                # with a layout the reference would not produce: say so instead of answering "empty" silently.
+                import warnings
+                warnings.warn("marlgrid_amd: grid.get(%d, %d) inside _gen_grid reads a cell an earlier random place_obj may "
+                              "have filled — placements are drawn per env on the device, the recorder answers with the static "
+                              "layout only (%s); a layout that branches on this value is not recorded faithfully"
+                              % (i, j, "empty" if self._shadow[i, j] == 0 else "the object drawn there"), RuntimeWarning, stacklevel=2)
             return self.obj_reg.obj_of_key(int(self._shadow[i, j]))
         return self.obj_reg.obj_of_key(int(self.grid[env, i, j].item()))
 
@@ -344,6 +358,36 @@ def release_obs_cache(device=None):
     return N.lib().mg_obs_trim(idx)
 
 
+_GENERIC_WARNED = set()
+
+
+def _warn_generic_kernel(g, generic, prestige):
+    """mg_render_kernel_name's bits 1 | 2: view size AND tile size are run-time values of the launch — the fully generic
+    instantiation of the observation kernel (assemble-and-stream raster, run-time dividers, a 15-row shadow cast, 8- / 4-wave
+    workgroups), measured 2-2.4x slower than a specialised one (profiles/r05: view 9 at 5-pixel tiles 0.3136 -> 0.1360 ms
+    when it got its own).  Said once per configuration and process, naming what is specialised nearby."""
+    if generic != 3:
+        return
+    key = (g.view_size, g.tile_size, prestige, g.kernel_name)
+    if key in _GENERIC_WARNED:
+        return
+    _GENERIC_WARNED.add(key)
+    import warnings
+    near = []
+    if prestige:
+        near.append("'prestige' agents: view_size 7 with any view_tile_size (5, 8 and 11 fastest), or view_tile_size 8 / 16 / 32 with any view")
+    else:
+        if g.view_size > 9:
+            near.append("view_size %d with view_tile_size 8, 16 or 32%s" % (g.view_size, ", or 5" if g.view_size in (11, 13, 15) else ""))
+        near.append("view_size 3 ... 9 with this view_tile_size (%d)" % g.tile_size)
+        if g.view_size not in (11, 13, 15):
+            near.append("view_size 11 / 13 / 15 with view_tile_size 5")
+    warnings.warn("marlgrid_amd: view_size=%d, view_tile_size=%d%s takes the fully run-time instantiation of the observation "
+                  "kernel (%s): correct, but 2-2.4x slower than a specialised one.  Specialised nearby: %s."
+                  % (g.view_size, g.tile_size, " with 'prestige' agents" if prestige else "", g.kernel_name, "; ".join(near)),
+                  RuntimeWarning, stacklevel=4)
+
+
 class _ViewGroup(object):
     """agents that share one view geometry: their launch config, atlas and observation buffers"""
 
@@ -395,10 +439,11 @@ class MultiGridEnv(object):
         if place_obs is True:
             place_obs = DEFAULT_PLACE_OBS
         # ... or a dict of the search's own knobs: {"budget": bytes of live candidates, "seconds": per pass, "thorough": bool,
-        # "stir": bool, "reuse": bool} (what `_place_obs_buffers` takes)
+        # "stir": bool, "reuse": bool, "share": processes that share this device's memory — each counts on 1 / share of what
+        # is free} (what `_place_obs_buffers` takes)
         self._place_kw = {}
         if isinstance(place_obs, dict):
-            unknown = set(place_obs) - {"budget", "seconds", "thorough", "stir", "reuse", "min_bytes"}
+            unknown = set(place_obs) - {"budget", "seconds", "thorough", "stir", "reuse", "min_bytes", "share"}
             if unknown:
                 raise ValueError("place_obs: unknown keys %s" % sorted(unknown))
             self._place_kw = dict(place_obs)
@@ -517,6 +562,13 @@ class MultiGridEnv(object):
         return len(self.agents)
 
     @property
+    def kernel_name(self):
+        """the instantiation of the observation kernel a step launches (first view group), as the launcher names it
+        (mg_render_kernel_name) and as rocprofv3 prints it"""
+        self._sync_tables()
+        return self._groups[0].kernel_name
+
+    @property
     def action_space(self):
         return spaces.Tuple([agent.action_space for agent in self.agents])
 
@@ -566,7 +618,7 @@ class MultiGridEnv(object):
 
     @_on_device
     def _place_obs_buffers(self, budget=0, seconds=0.0, thorough=None, stir=None, reuse=True, min_bytes=0, gain=0.0, max_candidates=0,
-                           slow_alloc=0.0, stir_cap=0, iters=0):
+                           slow_alloc=0.0, stir_cap=0, iters=0, share=1):
         """place_obs="search" (default) / "thorough": choose WHERE in HBM the observation buffers live — mg_obs_place
         (include/marlgrid_hip.h; marlgrid_amd/csrc/mg_place_obs.hip) does the work, this is its caller.
 
@@ -578,9 +630,12 @@ class MultiGridEnv(object):
         2 P | P junction), times the raster into each and keeps the fastest `obs_buffers` once they run 12 % under the median.
 
         What it costs (the defaults are meant to be survivable for whoever shares the GPU): candidates alive at any time
-        <= min(a quarter of the free memory, 32 GiB); 2 s at most; a kept buffer pins its whole candidate — 1.5 .. 3 x its
-        size, outside torch's allocator (`env.obs_placement[g]["pinned_bytes"]`); buffers under 256 MiB are plain torch
-        allocations.  "thorough" adds what round 4 found necessary on memory nobody had allocated before: larger block
+        <= min(a quarter of the free memory, 32 GiB) — for buffers of several GB raised to the kept buffers plus three
+        candidates, while that is within half of the free memory (a 16 GB buffer's candidates are 24 GiB each: round 5's
+        flat 32 GiB could not hold one) —; 2 s at most (0.16 s per GiB of candidate above 12 GiB, 8 s at most); a kept buffer
+        pins its whole candidate — 1.5 .. 3 x its size, outside torch's allocator (`env.obs_placement[g]["pinned_bytes"]`);
+        buffers under 256 MiB are plain torch allocations; at most MG_PLACE_MAX (8) buffers of a ring are placed (the
+        rest stay torch allocations); `share` = k: k processes share this device, each counts on 1 / k of what is free.  "thorough" adds what round 4 found necessary on memory nobody had allocated before: larger block
         pairs (a kept buffer may then pin up to 12 x its size), a second pass, one big allocate-and-free (half of the
         free memory, 64 GiB at most) that mixes the driver's free lists, and larger budgets (candidates up to half of the
         free memory / 128 GiB, 6 s per pass).  A released buffer of the fast class is
@@ -593,33 +648,44 @@ class MultiGridEnv(object):
         if stir is None:
             stir = thorough
         flags = (N.PLACE_THOROUGH if thorough else 0) | (N.PLACE_STIR if stir else 0) | (0 if reuse else N.PLACE_NO_REUSE)
+        share = max(1, int(share))
         if thorough and not budget:         # the long search is for a process that owns its GPU: half of what is free, 6 s per pass
-            budget = min(torch.cuda.mem_get_info(self.device)[0] // 2, 128 << 30)
+            budget = min(torch.cuda.mem_get_info(self.device)[0] // (2 * share), 128 << 30)
         if thorough and not seconds:
             seconds = 6.0
         tn = N.PlaceTuning(gain=gain, slow_alloc_s_per_gib=slow_alloc, min_bytes=min_bytes, stir_bytes=stir_cap,
-                           max_candidates=max_candidates, iters=iters)
+                           max_candidates=max_candidates, iters=iters, share=share)
         threshold = min_bytes or (256 << 20)
         any_replaced = False
+        previous = list(getattr(self, "obs_placement", None) or [])
         self.obs_placement = []
-        for g in self._groups:
+        for gi, g in enumerate(self._groups):
             nbytes = g.ring[0].numel()
             if nbytes < threshold:
                 self.obs_placement.append(None)
                 continue
-            keep = len(g.ring)
+            # (a call places at most MG_PLACE_MAX buffers: a longer ring keeps torch allocations for the rest — the ring
+            # rotates through all of them, `kept` says which are placed)
+            keep = min(len(g.ring), N.PLACE_MAX)
             out = (C.c_void_p * keep)()
             st = N.PlaceStats()
             rc = self._lib.mg_obs_place(C.byref(g.cfg), C.byref(self._state), keep, int(budget), float(seconds), flags, C.byref(tn),
                                         out, C.byref(st), self._stream())
             if rc == N.E_NOMEM:
-                g.placement_ms = {"found": False, "stopped": "out of memory", "kept": [], "candidates": st.candidates,
-                                  "seconds": st.seconds, "buffer_bytes": nbytes, "pinned_bytes": 0}
+                # nothing was handed out: the ring stays what it was — torch allocations, or the buffers an earlier call
+                # placed (whose record then stays too: they are still pinned)
+                was = previous[gi] if gi < len(previous) else None
+                failed = {"found": False, "stopped": N.PLACE_STOP.get(st.stopped, str(st.stopped)) or "out of memory", "kept": [],
+                          "candidates": st.candidates, "seconds": st.seconds, "buffer_bytes": nbytes, "pinned_bytes": 0}
+                if was and was.get("pinned_bytes"):
+                    g.placement_ms = dict(was, retry_failed=failed)
+                else:
+                    g.placement_ms = failed
                 self.obs_placement.append(g.placement_ms)
-                continue                                            # the torch allocations stay
+                continue
             N.check(rc)
-            g.ring = [_PlacedBuffer(self._lib, out[i], nbytes, self.device).tensor(g.shape) for i in range(keep)]
-            for t in g.ring:
+            g.ring = [_PlacedBuffer(self._lib, out[i], nbytes, self.device).tensor(g.shape) for i in range(keep)] + list(g.ring[keep:])
+            for t in g.ring[:keep]:
                 t.zero_()
             g.obs = g.ring[self._ring_i]
             any_replaced = True
@@ -632,6 +698,7 @@ class MultiGridEnv(object):
                               "kept_window_offsets": [st.window_offset[i] for i in range(keep)],
                               "pinned_bytes": st.pinned_bytes, "budget_bytes": st.budget_bytes, "block_pair_level": st.level,
                               "plain_stage": bool(st.plain_stage), "stirred": ({"bytes": st.stirred_bytes} if st.stirred_bytes else None),
+                              "placed_buffers": keep, "ring_buffers": len(g.ring), "share": share,
                               "alloc_ms_per_GiB": 1e3 * st.alloc_seconds / max(st.alloc_bytes, 1) * (1 << 30)}
             self.obs_placement.append(g.placement_ms)
             if not st.found and not thorough and st.stopped != 7:       # (7: not bound by HBM writes — nothing to find, nothing to say)
@@ -830,6 +897,11 @@ class MultiGridEnv(object):
         region = self._place_region(top, size)
         rej = self._reject_table(reject_fn, region)
         op = (key, 1, max_tries) + region + (None if rej is None else rej.tobytes(),)
+        x0, y0, x1, y1 = region
+        may = self._tr_grid._shadow[x0:x1, y0:y1] == 0          # (only empty cells accept a placement, base.py:672-679)
+        if rej is not None:
+            may &= rej[x0:x1, y0:y1] == 0
+        self._tr_grid._maybe[x0:x1, y0:y1] |= may
         if self._tr_ops and self._tr_ops[-1][0] == key and self._tr_ops[-1][2:] == op[2:] and self._tr_ops[-1][2] > 0:
             self._tr_ops[-1] = (key, self._tr_ops[-1][1] + 1) + op[2:]
         else:
@@ -1024,6 +1096,10 @@ class MultiGridEnv(object):
             g.atlas = atlas
             cfg.obj, cfg.atlas = g.obj_dev.data_ptr(), g.atlas_dev.data_ptr()
             g.cfg = cfg
+            # which instantiation of the observation kernel the launcher picks for this group (what rocprofv3 will call the
+            # launch) — and a warning, once per configuration, when it is the fully generic one
+            g.kernel_name, generic = N.render_kernel_name(cfg)
+            _warn_generic_kernel(g, generic, bool(cfg.prestige_mask))
         g0 = self._groups[0]
         self._cfg, self.atlas, self._obj_dev, self._atlas_dev = g0.cfg, g0.atlas, g0.obj_dev, g0.atlas_dev
         self._tables_version = self.obj_reg.version

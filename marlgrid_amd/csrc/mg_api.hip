@@ -1,6 +1,8 @@
 // mg_api.hip — the C ABI of libmarlgrid_hip.so (include/marlgrid_hip.h): argument checks and
 // launches only; every buffer is caller-owned device memory, every call is asynchronous on the
 // caller's stream.
+#include <stdio.h>
+
 #include "mg_device.h"
 #include "mg_launch.h"
 
@@ -208,6 +210,18 @@ int32_t mg_render_obs_lds_bytes(const MgConfig* cfg) {
         cfg->tile_size < 1 || cfg->tile_size > 64 || cfg->cells_stride < 0 || cfg->n_tiles < 0)
         return MG_E_ARG;
     return mg::render_min_lds_bytes(*cfg);
+}
+
+int32_t mg_render_kernel_name(const MgConfig* cfg, char* out, int32_t cap) {
+    if (!cfg || !out || cap < 1 || cfg->B < 1 || cfg->n_agents < 1 || cfg->n_agents > MG_MAX_AGENTS || cfg->view_size < 1 ||
+        cfg->view_size > MG_MAX_VIEW || cfg->tile_size < 1 || cfg->tile_size > 64 || cfg->cells_stride < 0 || cfg->n_tiles < 0)
+        return MG_E_ARG;
+    mg::RenderPick pick = {0, 0, 0, 0, 0, 0};
+    MgState none = {};
+    const hipError_t e = mg::launch_render(*cfg, none, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &pick);
+    if (e != hipSuccess) { out[0] = 0; return MG_E_LAUNCH; }      // (the configuration does not fit LDS: mg_render_obs_lds_bytes)
+    snprintf(out, (size_t)cap, "mg::render_kernel<%d, %d, %d, %d, %d>", pick.vs, pick.ts, pick.wpb, pick.v, pick.rm);
+    return (pick.vs == 0 ? 1 : 0) | (pick.ts == 0 ? 2 : 0);
 }
 
 int32_t mg_time_render_obs(const MgConfig* cfg, const MgState* st, uint8_t* obs, int32_t iters, float* avg_ms,

@@ -1,49 +1,54 @@
-// mg_encode.hip — batched MultiGrid.encode (marlgrid/base.py:196-214): per cell the
-// (type_idx, colour_idx, state) triple of the cell's *top object* (WorldObj.encode,
-// objects.py:90-99); agents stacked on another object are not reflected, an agent that is the
-// cell object encodes as (13, colour, dir).
+// mg_encode.hip — batched MultiGrid.encode (marlgrid/base.py:196-214): per cell the (type_idx, colour_idx, state) triple
+// of the cell's *top object* (WorldObj.encode, objects.py:90-99); agents stacked on another object are not reflected, an
+// agent that is the cell object encodes as (13, colour, dir).  out: uint8 [B][W][H][3].
 //
-// One lane per cell; a wave covers 64 consecutive cells of the flattened [B][W*H] space, so the
-// grid read and the 3-byte-per-cell write are both contiguous across the wave.
+// Roofline: HBM.  Algorithmic bytes per env = cells_stride + 8 n (in) + 3 W H (out): 939 B at 15x15 with three agents.
+//
+// The output of a batch is ONE flat byte stream (3 bytes per cell, cells of consecutive envs back to back — an env's
+// 675 bytes are not a multiple of anything), so the kernel is written from the output's side: a PIECE is PC consecutive
+// cells of the flat [B * W*H] cell space (PC a multiple of 16: a piece's 3 PC bytes are whole aligned 16-byte chunks) and
+// belongs to one workgroup of PC / 16 threads:
+//   A. the piece's slice of `grid` — one contiguous run of HBM, the 15 padding bytes between envs included — goes to LDS
+//      as it is (aligned dwords, every load in flight before the first wait), the (type, colour, state) table of the
+//      object kinds (one dword per kind) next to it;
+//   B. one lane per (env, agent) of the envs the piece touches: an agent that is the FIRST of its cell (lowest arrival
+//      rank: `obj.agents[0]` / the cell object, base.py:547-552) marks the cell — in the grid bytes themselves where object
+//      ids and agent codes share a byte (n_obj + 4 n <= 256), in a second byte plane otherwise;
+//   C. a lane per 16-byte chunk of output: the six cells the chunk spans (the second half of them possibly in the next
+//      env: two aligned LDS windows merged by a 64-bit shift), six table look-ups, the 18 bytes packed with v_perm_b32
+//      and cut at the chunk's phase with v_alignbyte, one global_store_dwordx4.
+// Nothing per cell but a table look-up; no division per cell (one per chunk); every store 16 bytes and aligned.
+// (Round 2's kernel — a lane per cell, a 64-bit divide, a 32-byte descriptor gather and n record loads per empty cell,
+// three byte stores — ran at 0.11 of the HBM roofline: profiles/r02/README.md.)
 #include "mg_device.h"
+#include "mg_encode_core.h"
 #include "mg_launch.h"
 
 namespace mg {
 
-__global__ __launch_bounds__(kBlock) void encode_kernel(MgConfig cfg, MgState st, const uint8_t* __restrict__ vis,
-                                                        uint8_t* __restrict__ out) {
-    const int cells = cfg.W * cfg.H;
-    const long long idx = (long long)blockIdx.x * kBlock + threadIdx.x;
-    if (idx >= (long long)cfg.B * cells) return;
-    const int b = (int)(idx / cells), c = (int)(idx - (long long)b * cells);
-    uint32_t e0 = 0, e1 = 0, e2 = 0;
-    if (!vis || vis[idx]) {
-        const uint32_t base = st.grid[(size_t)b * cfg.cells_stride + c];
-        if (base) {
-            const MgObjDesc od = cfg.obj[base];
-            e0 = od.type_idx; e1 = od.color_idx; e2 = od.state;
-        } else {
-            const uint32_t xy = (uint32_t)(c / cfg.H) | ((uint32_t)(c % cfg.H) << 8);
-            uint32_t best = 0xFFFF;
-            for (int k = 0; k < cfg.n_agents; k++) {
-                const uint64_t r = st.agents[(size_t)b * cfg.n_agents + k];
-                if ((rec_byte(r, MG_AG_FLAGS) & MG_AF_PLACED) && rec_xy(r) == xy && rec_byte(r, MG_AG_RANK) < best) {
-                    best = rec_byte(r, MG_AG_RANK);
-                    e0 = (uint32_t)cfg.agent_type_idx; e1 = cfg.agent_color_idx[k]; e2 = rec_byte(r, MG_AG_DIR);
-                }
-            }
-        }
-    }
-    uint8_t* o = out + (size_t)idx * 3;
-    o[0] = (uint8_t)e0; o[1] = (uint8_t)e1; o[2] = (uint8_t)e2;
+template <int PC>
+__global__ __launch_bounds__(PC / 16) void encode_kernel(MgConfig cfg, MgState st, const uint8_t* __restrict__ vis,
+                                                         uint8_t* __restrict__ out, EncodeLaunch lc) {
+    constexpr int T = PC / 16;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x;
+    const EncodePiece P = encode_piece(cfg, lc, (long long)blockIdx.x, PC);
+    encode_stage(cfg, st, lc, P, smem, tid, T);
+    __syncthreads();
+    encode_agents(cfg, st, lc, P, smem, tid, T);
+    __syncthreads();
+    encode_chunks(cfg, lc, P, vis, out, smem, tid, T, PC);
 }
 
 hipError_t launch_encode(const MgConfig& cfg, const MgState& st, const uint8_t* vis_mask, uint8_t* out,
                          hipStream_t s) {
     if (cfg.B <= 0) return hipSuccess;
-    long long total = (long long)cfg.B * cfg.W * cfg.H;
-    hipLaunchKernelGGL(encode_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, cfg, st,
-                       vis_mask, out);
+    int PC = 0;
+    const EncodeLaunch lc = encode_launch(cfg, out, PC);
+    const size_t lds = kEncTab + (size_t)lc.nraw * (lc.two ? 2 : 1);
+    const unsigned pieces = (unsigned)((lc.total + PC - 1) / PC);
+    if (PC == 4096) hipLaunchKernelGGL((encode_kernel<4096>), dim3(pieces), dim3(256), lds, s, cfg, st, vis_mask, out, lc);
+    else hipLaunchKernelGGL((encode_kernel<1024>), dim3(pieces), dim3(64), lds, s, cfg, st, vis_mask, out, lc);
     return hipGetLastError();
 }
 

@@ -1,0 +1,252 @@
+// mg_encode_core.h — the phases of mg_encode.hip's kernel as plain inline functions (thread `tid` of a workgroup of T; LDS as a
+// pointer), so that the same text compiles with g++ for tests/native, which runs a piece phase by phase, thread by thread,
+// against a cell-by-cell encode on the host before any GPU sees it.
+//
+// mg_encode — batched MultiGrid.encode (marlgrid/base.py:196-214): per cell the (type_idx, colour_idx, state) triple
+// of the cell's *top object* (WorldObj.encode, objects.py:90-99); agents stacked on another object are not reflected, an
+// agent that is the cell object encodes as (13, colour, dir).  out: uint8 [B][W][H][3].
+//
+// Roofline: HBM.  Algorithmic bytes per env = cells_stride + 8 n (in) + 3 W H (out): 939 B at 15x15 with three agents.
+//
+// The output of a batch is ONE flat byte stream (3 bytes per cell, cells of consecutive envs back to back — an env's
+// 675 bytes are not a multiple of anything), so the kernel is written from the output's side: a PIECE is PC consecutive
+// cells of the flat [B * W*H] cell space (PC a multiple of 16: a piece's 3 PC bytes are whole aligned 16-byte chunks) and
+// belongs to one workgroup of PC / 16 threads:
+//   A. the piece's slice of `grid` — one contiguous run of HBM, the 15 padding bytes between envs included — goes to LDS
+//      as it is (aligned dwords, every load in flight before the first wait), the (type, colour, state) table of the
+//      object kinds (one dword per kind) next to it;
+//   B. one lane per (env, agent) of the envs the piece touches: an agent that is the FIRST of its cell (lowest arrival
+//      rank: `obj.agents[0]` / the cell object, base.py:547-552) marks the cell — in the grid bytes themselves where object
+//      ids and agent codes share a byte (n_obj + 4 n <= 256), in a second byte plane otherwise;
+//   C. a lane per 16-byte chunk of output: the six cells the chunk spans (the second half of them possibly in the next
+//      env: two aligned LDS windows merged by a 64-bit shift), six table look-ups, the 18 bytes packed with v_perm_b32
+//      and cut at the chunk's phase with v_alignbyte, one global_store_dwordx4.
+// Nothing per cell but a table look-up; no division per cell (one per chunk); every store 16 bytes and aligned.
+// (Round 2's kernel — a lane per cell, a 64-bit divide, a 32-byte descriptor gather and n record loads per empty cell,
+// three byte stores — ran at 0.11 of the HBM roofline: profiles/r02/README.md.)
+#pragma once
+#include "mg_core.h"
+
+namespace mg {
+
+struct EncodeLaunch {
+    long long total;          // B * W * H cells
+    int cells, nraw;          // W * H; bytes of the raw grid plane in LDS (a multiple of 16)
+    uint32_t m_cells, m_n;    // divide-by-multiply constants (32-bit mul_hi): ceil(2^32 / cells), ceil(2^32 / n)
+    int two, aligned;         // agent marks in their own byte plane; `out` is 16-byte aligned
+};
+
+MG_HD uint32_t enc_mulhi(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * b) >> 32);
+#endif
+}
+MG_HD uint32_t enc_align(uint32_t hi, uint32_t lo, uint32_t sh) {     // bytes [sh, sh + 4) of lo | hi << 32, sh = 0..3
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbyte(hi, lo, sh);
+#else
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * sh));
+#endif
+}
+MG_HD uint32_t enc_perm(uint32_t hi, uint32_t lo, uint32_t sel) {     // v_perm_b32: selector byte 0..3 = lo's bytes, 4..7 = hi's, 12 = 0x00
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(hi, lo, sel);
+#else
+    uint32_t out = 0;
+    for (int i = 0; i < 4; i++) {
+        const uint32_t s = (sel >> (8 * i)) & 0xFFu;
+        const uint32_t b = s < 4 ? (lo >> (8 * s)) & 0xFFu : s < 8 ? (hi >> (8 * (s - 4))) & 0xFFu : 0u;
+        out |= b << (8 * i);
+    }
+    return out;
+#endif
+}
+MG_HD uint32_t enc_div(uint32_t x, uint32_t d, uint32_t m) {     // x / d, m = ceil(2^32 / d): exact for every 32-bit x
+    if (d == 1) return x;                       // (m would be 2^32)
+    uint32_t q = enc_mulhi(x, m);
+    q -= (q * d > x) ? 1u : 0u;
+    return q;
+}
+
+// the piece of workgroup `block`: where it starts, what it spans
+struct EncodePiece {
+    long long g0, b0;         // first cell (flat), its env
+    int len, c0, c0a;         // cells; the first cell within its env, rounded down to a dword
+    int el, nd;               // the last cell lies in env b0 + el; dwords of the slice
+};
+MG_HD EncodePiece encode_piece(const MgConfig& cfg, const EncodeLaunch& lc, long long block, int PC) {
+    EncodePiece P;
+    P.g0 = block * PC;
+    P.len = (int)(lc.total - P.g0 < (long long)PC ? lc.total - P.g0 : (long long)PC);
+    P.b0 = P.g0 / lc.cells;                                                 // (uniform: one 64-bit division per workgroup)
+    P.c0 = (int)(P.g0 - P.b0 * lc.cells);
+    P.c0a = P.c0 & ~3;
+    P.el = (int)enc_div((uint32_t)(P.c0 + P.len - 1), (uint32_t)lc.cells, lc.m_cells);
+    const int cl = P.c0 + P.len - 1 - P.el * lc.cells;
+    P.nd = (P.el * cfg.cells_stride + cl + 1 - P.c0a + 3) >> 2;
+    return P;
+}
+constexpr int kEncTab = 2048;     // bytes of the two look-up tables in front of the planes
+
+// A. the slice of `grid` and the tables -> LDS.  (The kernel issues its first 8 dwords per thread before anything else.)
+MG_HD void encode_stage(const MgConfig& cfg, const MgState& st, const EncodeLaunch& lc, const EncodePiece& P, uint8_t* smem, int tid, int T) {
+    uint32_t* tab = reinterpret_cast<uint32_t*>(smem);                     // [256] object id (or agent code) -> triple
+    uint32_t* tab2 = tab + 256;                                             // [256] two planes: agent code -> triple (0: none)
+    uint8_t* raw = smem + kEncTab;                                          // the piece's slice of `grid`, HBM layout
+    uint8_t* ag = raw + lc.nraw;                                            // (two planes) agent marks, same layout
+    const int n = cfg.n_agents;
+    const uint32_t* gsrc = reinterpret_cast<const uint32_t*>(st.grid + (size_t)P.b0 * cfg.cells_stride + P.c0a);
+    constexpr int R = 8;
+    uint32_t v[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) v[r] = (tid + r * T < P.nd) ? gsrc[tid + r * T] : 0u;
+    for (int o = tid; o < 256; o += T) {                                    // (T >= 64: at most four trips; one for T = 256)
+        uint32_t e = 0;
+        if (o > 0 && o < cfg.n_obj) {                                       // type, colour, state
+            const MgObjDesc* d = cfg.obj + o;
+            e = (uint32_t)d->type_idx | ((uint32_t)d->color_idx << 8) | ((uint32_t)d->state << 16);
+        }
+        // agent codes: agent k facing d -> (agent_type_idx, colour of k, d)
+        const int code = lc.two ? o - 1 : o - cfg.n_obj;
+        uint32_t a = 0;
+        if (code >= 0 && code < 4 * n) a = (uint32_t)cfg.agent_type_idx | ((uint32_t)cfg.agent_color_idx[code >> 2] << 8) | ((uint32_t)(code & 3) << 16);
+        if (lc.two) { tab[o] = e; tab2[o] = a; }
+        else tab[o] = (o < cfg.n_obj) ? e : a;
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++)
+        if (tid + r * T < P.nd) reinterpret_cast<uint32_t*>(raw)[tid + r * T] = v[r];
+    for (int i = tid + R * T; i < P.nd; i += T) reinterpret_cast<uint32_t*>(raw)[i] = gsrc[i];
+    if (lc.two)
+        for (int i = tid; i < lc.nraw / 4; i += T) reinterpret_cast<uint32_t*>(ag)[i] = 0u;
+}
+
+// B. the first agent of every occupied cell
+MG_HD void encode_agents(const MgConfig& cfg, const MgState& st, const EncodeLaunch& lc, const EncodePiece& P, uint8_t* smem, int tid, int T) {
+    uint8_t* raw = smem + kEncTab;
+    uint8_t* ag = raw + lc.nraw;
+    const int n = cfg.n_agents, cells = lc.cells, stride = cfg.cells_stride;
+    const int items = (P.el + 1) * n;
+    for (int it = tid; it < items; it += T) {
+        const uint32_t e = enc_div((uint32_t)it, (uint32_t)n, lc.m_n);
+        const int k = it - (int)e * n;
+        const uint64_t* recs = st.agents + (size_t)(P.b0 + e) * n;
+        const uint64_t r = recs[k];
+        if (!(rec_byte(r, MG_AG_FLAGS) & MG_AF_PLACED)) continue;
+        const int c = (int)rec_byte(r, MG_AG_X) * cfg.H + (int)rec_byte(r, MG_AG_Y);
+        const int f = (int)e * cells + c - P.c0;                            // the cell, piece-relative
+        if (f < 0 || f >= P.len) continue;
+        const uint32_t xy = rec_xy(r), rank = rec_byte(r, MG_AG_RANK);
+        bool first = true;
+        for (int j = 0; j < n; j++) {
+            const uint64_t rj = recs[j];
+            if ((rec_byte(rj, MG_AG_FLAGS) & MG_AF_PLACED) && rec_xy(rj) == xy && rec_byte(rj, MG_AG_RANK) < rank) first = false;
+        }
+        if (!first) continue;
+        const int addr = (int)e * stride + c - P.c0a;
+        const uint32_t code = 4u * (uint32_t)k + rec_byte(r, MG_AG_DIR);
+        if (lc.two) ag[addr] = (uint8_t)(1u + code);
+        else if (raw[addr] == 0) raw[addr] = (uint8_t)((uint32_t)cfg.n_obj + code);     // (only an empty cell's object is the agent)
+    }
+}
+
+// C. 16-byte chunks of output
+#if !defined(MG_ENC_BOUNDS)
+#define MG_ENC_BOUNDS(off, bytes) do {} while (0)
+#endif
+MG_HD void encode_chunks(const MgConfig& cfg, const EncodeLaunch& lc, const EncodePiece& P, const uint8_t* vis, uint8_t* out,
+                         const uint8_t* smem, int tid, int T, int PC) {
+    const uint32_t* tab = reinterpret_cast<const uint32_t*>(smem);
+    const uint32_t* tab2 = tab + 256;
+    const uint8_t* raw = smem + kEncTab;
+    const uint8_t* ag = raw + lc.nraw;
+    const int cells = lc.cells, stride = cfg.cells_stride;
+    uint8_t* dst = out + (size_t)P.g0 * 3;
+    const int nbytes = P.len * 3;
+    const int NQ = 3 * PC / 16;
+    for (int q = tid; q < NQ; q += T) {
+        if (16 * q >= nbytes) break;
+        const uint32_t qd = ((uint32_t)q * 21846u) >> 16;                   // q / 3 (q < 32768)
+        const uint32_t p = (uint32_t)q - 3u * qd;                           // the chunk's first byte is byte p of its first cell
+        const int f = 16 * (int)qd + (p == 0 ? 0 : p == 1 ? 5 : 10);        // ... which is cell f of the piece
+        const uint32_t cc = (uint32_t)(P.c0 + f);
+        const uint32_t e = enc_div(cc, (uint32_t)cells, lc.m_cells);
+        const int c = (int)cc - (int)e * cells;
+        const int nA = cells - c;                                           // cells left in this env, this one included
+        const int addrA = (int)e * stride + c - P.c0a;
+        // six consecutive cells: a window of the env's bytes, continued — where the env ends inside it — by the next env's first
+        const bool needB = nA < 6 && f + nA < P.len;
+        const int addrB = needB ? ((int)e + 1) * stride - P.c0a : 0;        // (4-byte aligned: stride is a multiple of 16)
+        MG_ENC_BOUNDS(addrA & ~3, 12);
+        MG_ENC_BOUNDS(addrB, 8);
+        uint64_t X, Y = 0;
+        {
+            const uint32_t sh = (uint32_t)addrA & 3u, s8 = 8u * (uint32_t)(nA < 7 ? nA : 7);
+            const uint32_t* w = reinterpret_cast<const uint32_t*>(raw + (addrA & ~3));
+            const uint32_t* wb = reinterpret_cast<const uint32_t*>(raw + addrB);
+            const uint64_t A = (uint64_t)enc_align(w[1], w[0], sh) | ((uint64_t)enc_align(w[2], w[1], sh) << 32);
+            const uint64_t Bv = (uint64_t)wb[0] | ((uint64_t)wb[1] << 32);
+            X = needB ? ((A & ~(~0ull << s8)) | (Bv << s8)) : A;
+            if (lc.two) {
+                const uint32_t* u = reinterpret_cast<const uint32_t*>(ag + (addrA & ~3));
+                const uint32_t* ub = reinterpret_cast<const uint32_t*>(ag + addrB);
+                const uint64_t A2 = (uint64_t)enc_align(u[1], u[0], sh) | ((uint64_t)enc_align(u[2], u[1], sh) << 32);
+                const uint64_t B2 = (uint64_t)ub[0] | ((uint64_t)ub[1] << 32);
+                Y = needB ? ((A2 & ~(~0ull << s8)) | (B2 << s8)) : A2;
+            }
+        }
+        uint32_t t[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const uint32_t b = (uint32_t)(X >> (8 * i)) & 0xFFu;
+            t[i] = tab[b];
+            if (lc.two && b == 0) t[i] = tab2[(uint32_t)(Y >> (8 * i)) & 0xFFu];
+        }
+        if (vis) {      // vis_mask (base.py:205-206): cells that are not visible encode as (0, 0, 0); flat [B][W][H]
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+                if (f + i < P.len && !vis[(size_t)P.g0 + f + i]) t[i] = 0;
+        }
+        // 18 bytes = 6 x 3, as five dwords; the chunk is bytes p .. p + 15 of them
+        const uint32_t d0 = enc_perm(t[1], t[0], 0x04020100u);      // t0.0 t0.1 t0.2 t1.0
+        const uint32_t d1 = enc_perm(t[2], t[1], 0x05040201u);      // t1.1 t1.2 t2.0 t2.1
+        const uint32_t d2 = enc_perm(t[3], t[2], 0x06050402u);      // t2.2 t3.0 t3.1 t3.2
+        const uint32_t d3 = enc_perm(t[5], t[4], 0x04020100u);      // t4.0 t4.1 t4.2 t5.0
+        const uint32_t d4 = enc_perm(0u, t[5], 0x0C0C0201u);        // t5.1 t5.2 0 0
+        uint32_t w4[4] = {enc_align(d1, d0, p), enc_align(d2, d1, p), enc_align(d3, d2, p), enc_align(d4, d3, p)};
+        if (lc.aligned && 16 * q + 16 <= nbytes) {
+            typedef struct { uint32_t v[4]; } __attribute__((aligned(16))) q16;
+            q16 o4 = {{w4[0], w4[1], w4[2], w4[3]}};
+            *reinterpret_cast<q16*>(dst + 16 * q) = o4;
+        } else {        // the batch's last < 16 bytes, or a caller's `out` that is not 16-byte aligned
+            for (int i = 0; i < 16 && 16 * q + i < nbytes; i++) dst[16 * q + i] = (uint8_t)(w4[i >> 2] >> (8 * (i & 3)));
+        }
+    }
+}
+
+// bytes of the raw plane a piece of PC cells can span in HBM layout (+ slack for the window reads past its end)
+inline int encode_raw_bytes(int cells, int stride, int PC) {
+    const long long envs = cells >= PC ? 2 : (PC + cells - 2) / cells + 1;      // envs a piece can touch
+    long long span = cells >= PC ? (long long)PC + (stride - cells) + 8 : envs * stride;
+    span += stride < 64 ? stride : 64;                                          // the window of the env after the last
+    return (int)((span + 16 + 15) / 16 * 16);
+}
+
+// everything the launch derives from the config on the host
+inline EncodeLaunch encode_launch(const MgConfig& cfg, const void* out, int& PC) {
+    EncodeLaunch lc;
+    lc.cells = cfg.W * cfg.H;
+    lc.total = (long long)cfg.B * lc.cells;
+    lc.m_cells = (uint32_t)((0x100000000ull + (uint32_t)lc.cells - 1) / (uint32_t)lc.cells);
+    lc.m_n = (uint32_t)((0x100000000ull + (uint32_t)cfg.n_agents - 1) / (uint32_t)cfg.n_agents);
+    lc.two = cfg.n_obj + 4 * cfg.n_agents > 256 ? 1 : 0;
+    lc.aligned = (reinterpret_cast<uintptr_t>(out) & 15) == 0 ? 1 : 0;
+    // pieces of 4096 cells (256 threads) where that makes a thousand workgroups, else of 1024 cells (one wave each)
+    if (PC == 0) PC = lc.total / 4096 >= 1024 ? 4096 : 1024;
+    lc.nraw = encode_raw_bytes(lc.cells, cfg.cells_stride, PC);
+    return lc;
+}
+
+}  // namespace mg

@@ -12,8 +12,12 @@ hipError_t launch_reset(const MgConfig& cfg, const MgState& st, const MgGenProgr
 hipError_t launch_step(const MgConfig& cfg, const MgState& st, const void* actions, int action_bytes,
                        float* rewards, const MgGenProgram* auto_reset, hipStream_t s);
 struct FusedStep;
+// which instantiation of mg::render_kernel<VS, TS, WPB, V, RM> a configuration gets (0 = the value is read from the
+// config at run time) and the LDS bytes of one of its workgroups: filled in INSTEAD of launching when handed to launch_render
+struct RenderPick { int vs, ts, wpb, v, rm, lds; };
 hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, uint8_t* view_cells,
-                         uint8_t* view_agent, uint8_t* vis_mask, hipStream_t s, const FusedStep* fused_step = nullptr);
+                         uint8_t* view_agent, uint8_t* vis_mask, hipStream_t s, const FusedStep* fused_step = nullptr,
+                         RenderPick* pick = nullptr);
 int render_min_lds_bytes(const MgConfig& cfg);
 hipError_t launch_encode(const MgConfig& cfg, const MgState& st, const uint8_t* vis_mask, uint8_t* out,
                          hipStream_t s);

@@ -34,6 +34,7 @@ struct Arena {
     int device;
     float ms;              // the raster into it when it was chosen
     bool fast;             // it was chosen as one of the fast class (found = 1)
+    int32_t geom[5];       // the raster it was timed with: B, viewers, view_size, tile_size, n_agents — `ms` means nothing to another
 };
 
 std::mutex g_mu;
@@ -91,7 +92,9 @@ int32_t mg_obs_place(const MgConfig* cfg, const MgState* st, int32_t n_buffers, 
     const uint64_t min_bytes = tn.min_bytes ? tn.min_bytes : (256ull << 20);
     const double slow_alloc = tn.slow_alloc_s_per_gib > 0 ? tn.slow_alloc_s_per_gib : (tn.slow_alloc_s_per_gib < 0 ? 0.0 : 0.02);
     const uint64_t stir_cap = tn.stir_bytes ? tn.stir_bytes : (64ull << 30);
-    if (seconds <= 0) seconds = 2.0;
+    const bool default_seconds = seconds <= 0;
+    if (default_seconds) seconds = 2.0;
+    const uint64_t share = tn.share > 1 ? (uint64_t)tn.share : 1;     // this process counts on 1 / share of what is free
     int device = 0;
     if (hipGetDevice(&device) != hipSuccess) return MG_E_LAUNCH;
     MgPlaceStats S = {};
@@ -101,6 +104,7 @@ int32_t mg_obs_place(const MgConfig* cfg, const MgState* st, int32_t n_buffers, 
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return MG_E_LAUNCH;
 
     const int keep = n_buffers;
+    const int32_t geom[5] = {cfg->B, nv, cfg->view_size, cfg->tile_size, cfg->n_agents};
     std::vector<Cand> kept;                 // what goes to the caller
     bool fast = false;
     hipError_t err = hipSuccess;
@@ -111,7 +115,10 @@ int32_t mg_obs_place(const MgConfig* cfg, const MgState* st, int32_t n_buffers, 
         {
             std::lock_guard<std::mutex> lk(g_mu);
             for (size_t i = 0; i < g_spare.size() && (int)mine.size() < keep;)
-                if (g_spare[i].device == device && g_spare[i].buffer_bytes == nbytes) { mine.push_back(g_spare[i]); g_spare.erase(g_spare.begin() + i); }
+                // (same size AND same raster: an arena's `ms` was measured under the configuration that released it — another view /
+                // tile / agent split of the same byte count writes another pattern at another speed, and neither "still as fast
+                // as it was" nor "fast class" would mean anything for it)
+                if (g_spare[i].device == device && g_spare[i].buffer_bytes == nbytes && std::equal(geom, geom + 5, g_spare[i].geom)) { mine.push_back(g_spare[i]); g_spare.erase(g_spare.begin() + i); }
                 else i++;
         }
         for (const Arena& a : mine) {
@@ -142,6 +149,9 @@ int32_t mg_obs_place(const MgConfig* cfg, const MgState* st, int32_t n_buffers, 
         uint64_t P0 = 1ull << 21;
         while (P0 < half) P0 <<= 1;                                   // the power of two >= half the buffer (>= 2 MiB)
         S.candidate_bytes = 3 * P0;
+        // (the default time limit follows the candidate: memory nobody had before is cleared as it is handed out, ~0.02 s per GiB —
+        // a 24 GiB candidate of BASELINE configs[4] is half a second of hipMalloc, and 2 s would end the search after four)
+        if (default_seconds) seconds = std::min(8.0, std::max(2.0, 0.16 * (double)(3 * P0) / (double)(1ull << 30)));
         const int max_level = (flags & MG_PLACE_THOROUGH) ? 2 : 0;
         const int passes = (flags & MG_PLACE_THOROUGH) ? 2 : 1;
         std::vector<Cand> cands;              // every candidate measured (base == nullptr: gone back to the driver)
@@ -186,14 +196,20 @@ int32_t mg_obs_place(const MgConfig* cfg, const MgState* st, int32_t n_buffers, 
             int n_plain0 = 0;
             S.stopped = MG_PLACE_STOP_CAP;
             while ((int)cands.size() < need + max_cands * pass) {
-                if (now_s() > t_end) { S.stopped = MG_PLACE_STOP_TIME; break; }
                 const bool baseline = plain && !plain_stage;
+                // (no time limit before the baseline is in: the `need` plain allocations are what is kept when nothing else is found)
+                if (!baseline && now_s() > t_end) { S.stopped = MG_PLACE_STOP_TIME; break; }
                 const uint64_t Pk = P0 << level;
                 const uint64_t arena = plain ? nbytes : 3 * Pk;
                 size_t fr = 0, total = 0;
                 if (hipMemGetInfo(&fr, &total) != hipSuccess) { err = hipErrorUnknown; break; }
-                // live candidates: a quarter of what is free (and was free before this search took its share), 32 GiB at most
-                const uint64_t budget = budget_bytes ? budget_bytes : std::min<uint64_t>(((uint64_t)fr + alive) / 4, 32ull << 30);
+                // live candidates: a quarter of what is free (and was free before this search took its share), 32 GiB at most — but
+                // never less than the kept buffers plus THREE first-level candidates while that is within half of what is free: a
+                // bound that cannot hold one candidate next to the baseline (16 GB buffers: 24 GiB candidates; round 5's 32 GiB) is
+                // not a bounded search, it is no search.  `share` (MgPlaceTuning): ranks that share a device count on their part.
+                const uint64_t fs = ((uint64_t)fr + alive) / share;
+                const uint64_t budget = budget_bytes ? budget_bytes
+                    : std::max<uint64_t>(std::min<uint64_t>(fs / 4, 32ull << 30), std::min<uint64_t>(fs / 2, (uint64_t)need * nbytes + 3 * (3 * P0)));
                 S.budget_bytes = budget;
                 const bool is_short = alive + arena > std::max<uint64_t>(budget, (uint64_t)need * nbytes) || arena + (256ull << 20) > fr;
                 if (!baseline && (misses >= 12 || is_short) && !plain_stage) {
@@ -321,7 +337,8 @@ int32_t mg_obs_place(const MgConfig* cfg, const MgState* st, int32_t n_buffers, 
             S.window_offset[i] = k.offset;
             S.arena_bytes[i] = k.bytes;
             S.pinned_bytes += k.bytes;
-            g_out.push_back({k.base, k.bytes, k.offset, nbytes, device, k.ms, fast && k.ms > 0.f});
+            Arena a = {k.base, k.bytes, k.offset, nbytes, device, k.ms, fast && k.ms > 0.f, {geom[0], geom[1], geom[2], geom[3], geom[4]}};
+            g_out.push_back(a);
         }
     }
     S.seconds = now_s() - t_begin;

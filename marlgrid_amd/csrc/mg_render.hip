@@ -66,16 +66,16 @@ static int choose_wpb(const MgConfig& cfg, int mode) {
 }
 
 #define MG_RENDER_DISPATCH(VS, TS, V)                                                                      \
-    (wpb == 16 ? launch_render_t<VS, TS, 16, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)           \
-               : launch_render_t<VS, TS, 4, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs))
+    (wpb == 16 ? launch_render_t<VS, TS, 16, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick)           \
+               : launch_render_t<VS, TS, 4, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick))
 // run-time view size: its MG_MAX_VIEW-entry shadow-cast arrays need more than the 128 VGPRs a 16-wave
 // workgroup leaves per lane (spills would be VMEM traffic in the middle of the run): 8-wave workgroups
 #define MG_RENDER_DISPATCH_RT(TS, V)                                                                       \
-    (wpb == 16 ? launch_render_t<0, TS, 8, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)             \
-               : launch_render_t<0, TS, 4, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs))
+    (wpb == 16 ? launch_render_t<0, TS, 8, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick)             \
+               : launch_render_t<0, TS, 4, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick))
 // The kernel launch of mg_render_obs / mg_step_render.
 hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, uint8_t* view_cells,
-                         uint8_t* view_agent, uint8_t* vis_mask, hipStream_t s, const FusedStep* fs) {
+                         uint8_t* view_agent, uint8_t* vis_mask, hipStream_t s, const FusedStep* fs, RenderPick* pick) {
     if (cfg.B <= 0) return hipSuccess;
 
     FusedStep none;
@@ -90,7 +90,7 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
     if ((view_cells || view_agent || vis_mask) && !(view_cells && view_agent && vis_mask)) return hipErrorInvalidValue;
 #if defined(MG_DEV_ONLY)   // development: compile ONE instantiation (register / ISA checks without the other sixty),
     // e.g. -DMG_DEV_ONLY="7,5,16,0,0"
-    return launch_render_t<MG_DEV_ONLY>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
+    return launch_render_t<MG_DEV_ONLY>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick);
 #else
     const int vs = cfg.view_size, ts = cfg.tile_size;
     const int mode = render_mode_for(cfg);
@@ -100,10 +100,10 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
         const size_t lds4 = (size_t)render_atlas_lds_bytes(cfg, 0) + kRenderShared +
                             4 * (size_t)L.total;
         if (lds4 > 160 * 1024) {   // the static atlas stays in global memory
-            if (ts == 8) return launch_render_t<0, 8, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
-            if (ts == 16) return launch_render_t<0, 16, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
-            if (ts == 32) return launch_render_t<0, 32, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
-            return launch_render_t<0, 0, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
+            if (ts == 8) return launch_render_t<0, 8, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick);
+            if (ts == 16) return launch_render_t<0, 16, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick);
+            if (ts == 32) return launch_render_t<0, 32, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick);
+            return launch_render_t<0, 0, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick);
         }
         // the shipped view: compile-time size; 8-wave workgroups when they fit (the recolouring code needs
         // more than the 128 VGPRs a 16-wave workgroup leaves per lane)
@@ -113,9 +113,9 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
         int pw = wpb;
         if (pw == 16) pw = render_lds_bytes(cfg, 12) <= 160 * 1024 ? 12 : 8;
         if (vs == 7 && ts == 8)
-            return pw == 12 ? launch_render_t<7, 8, 12, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)
-                 : pw == 8 ? launch_render_t<7, 8, 8, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)
-                           : launch_render_t<7, 8, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
+            return pw == 12 ? launch_render_t<7, 8, 12, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick)
+                 : pw == 8 ? launch_render_t<7, 8, 8, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick)
+                           : launch_render_t<7, 8, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick);
         bool rt_ts = false;
 #if defined(MG_AB_VARIANTS)
         if (const char* f = getenv("MG_RENDER_RT_TS")) rt_ts = atoi(f) != 0;
@@ -124,31 +124,31 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
             int gw = wpb;
             if (gw == 16) gw = render_lds_bytes(cfg, 12, 2) <= 160 * 1024 ? 12 : render_lds_bytes(cfg, 8, 2) <= 160 * 1024 ? 8 : 4;
             if (ts == 5)                       // ... and GridAgentInterface's default tile size
-                return gw == 12 ? launch_render_t<7, 5, 12, 9, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)
-                     : gw == 8 ? launch_render_t<7, 5, 8, 9, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)
-                               : launch_render_t<7, 5, 4, 9, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
-            return gw == 12 ? launch_render_t<7, 11, 12, 9, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)
-                 : gw == 8 ? launch_render_t<7, 11, 8, 9, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)
-                           : launch_render_t<7, 11, 4, 9, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
+                return gw == 12 ? launch_render_t<7, 5, 12, 9, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick)
+                     : gw == 8 ? launch_render_t<7, 5, 8, 9, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick)
+                               : launch_render_t<7, 5, 4, 9, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick);
+            return gw == 12 ? launch_render_t<7, 11, 12, 9, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick)
+                 : gw == 8 ? launch_render_t<7, 11, 8, 9, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick)
+                           : launch_render_t<7, 11, 4, 9, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick);
         }
         if (vs == 7 && (ts % 8) != 0)
-            return pw == 12 ? launch_render_t<7, 0, 12, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)
-                 : pw == 8 ? launch_render_t<7, 0, 8, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)
-                           : launch_render_t<7, 0, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
-        if (ts == 8) return launch_render_t<0, 8, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
-        if (ts == 16) return launch_render_t<0, 16, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
-        if (ts == 32) return launch_render_t<0, 32, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
-        return launch_render_t<0, 0, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
+            return pw == 12 ? launch_render_t<7, 0, 12, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick)
+                 : pw == 8 ? launch_render_t<7, 0, 8, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick)
+                           : launch_render_t<7, 0, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick);
+        if (ts == 8) return launch_render_t<0, 8, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick);
+        if (ts == 16) return launch_render_t<0, 16, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick);
+        if (ts == 32) return launch_render_t<0, 32, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick);
+        return launch_render_t<0, 0, 4, 9>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick);
     }
     if (mode == 2) {   // the gather raster: view 7 (GridAgentInterface's default, agents.py:21) with 5- .. 12-pixel tiles; views 3 / 5 / 9 at its default 5-pixel tiles
 #define MG_RENDER_DISPATCH_G(VS, TS)                                                                                 \
-    (wpb == 16 ? launch_render_t<VS, TS, 16, 0, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)             \
-               : launch_render_t<VS, TS, 4, 0, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs))
+    (wpb == 16 ? launch_render_t<VS, TS, 16, 0, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick)             \
+               : launch_render_t<VS, TS, 4, 0, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick))
         if (vs > 9) {      // views 11 / 13 / 15: 8-wave workgroups where their scratch fits, else 4
             const int w8 = (cfg.B >= 4096 && render_lds_bytes(cfg, 8, 2) <= 160 * 1024) ? 8 : 4;
 #define MG_RENDER_DISPATCH_G8(VS)                                                                                    \
-    (w8 == 8 ? launch_render_t<VS, 5, 8, 0, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)                 \
-             : launch_render_t<VS, 5, 4, 0, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs))
+    (w8 == 8 ? launch_render_t<VS, 5, 8, 0, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick)                 \
+             : launch_render_t<VS, 5, 4, 0, 2>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick))
             if (vs == 11) return MG_RENDER_DISPATCH_G8(11);
             if (vs == 13) return MG_RENDER_DISPATCH_G8(13);
             return MG_RENDER_DISPATCH_G8(15);
@@ -176,10 +176,10 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
         const size_t lds4 = (size_t)render_atlas_lds_bytes(cfg, 0) + kRenderShared +
                             4 * (size_t)L.total;
         if (lds4 > 160 * 1024) {
-            if (ts == 8) return launch_render_t<0, 8, 4, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
-            if (ts == 16) return launch_render_t<0, 16, 4, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
-            if (ts == 32) return launch_render_t<0, 32, 4, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
-            return launch_render_t<0, 0, 4, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
+            if (ts == 8) return launch_render_t<0, 8, 4, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick);
+            if (ts == 16) return launch_render_t<0, 16, 4, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick);
+            if (ts == 32) return launch_render_t<0, 32, 4, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick);
+            return launch_render_t<0, 0, 4, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick);
         }
     }
     if (ts == 8 && vs == 7) {
@@ -193,11 +193,11 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
         default: break;
         }
         if (getenv("MG_RENDER_RASTER") && atoi(getenv("MG_RENDER_RASTER")) == 1)   // assemble-and-stream at tile 8
-            return wpb == 16 ? launch_render_t<7, 8, 16, 0, 1>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs)
-                             : launch_render_t<7, 8, 4, 0, 1>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
+            return wpb == 16 ? launch_render_t<7, 8, 16, 0, 1>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick)
+                             : launch_render_t<7, 8, 4, 0, 1>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick);
 #endif
 #if defined(MG_EXP) && (MG_EXP & 8)      // experiment build: 12-wave workgroups (3 waves per SIMD, a 168-VGPR budget) for the plain kernel
-        if (wpb == 16) return launch_render_t<7, 8, 12, 0, 0>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs);
+        if (wpb == 16) return launch_render_t<7, 8, 12, 0, 0>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick);
 #endif
         return MG_RENDER_DISPATCH(7, 8, 0);
     }

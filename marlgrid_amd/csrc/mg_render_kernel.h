@@ -1136,12 +1136,16 @@ inline int device_cus() {
 
 template <int VS_, int TS_, int WPB, int V_ = 0, int RM_ = 0>
 hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_t* obs, uint8_t* c, uint8_t* a,
-                                  uint8_t* v, hipStream_t s, const FusedStep* fs) {
+                                  uint8_t* v, hipStream_t s, const FusedStep* fs, RenderPick* pick) {
     static_assert(RM_ == 1 || TS_ == 0 || (TS_ % 8) != 0 || TS_ == 8 || TS_ == 16 || TS_ == 32, "see render_chunk_raster");
     const RenderScratch L = render_scratch_for(cfg, WPB, RM_);
     const size_t atlas_lds = (V_ == 8 || V_ == 12) ? 0 : (size_t)render_atlas_lds_bytes(cfg, RM_);
     size_t lds = atlas_lds + kRenderShared + WPB * (size_t)L.total;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (pick) {     // mg_render_kernel_name: which instantiation this configuration gets — nothing is launched
+        pick->vs = VS_; pick->ts = TS_; pick->wpb = WPB; pick->v = V_; pick->rm = RM_; pick->lds = (int)lds;
+        return hipSuccess;
+    }
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<VS_, TS_, WPB, V_, RM_>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1235,9 +1239,9 @@ hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_t* obs,
 #endif
 #define MG_RENDER_EXTERN(VS, TS, WPB, V, RM)                                                                               \
     extern template hipError_t launch_render_t<VS, TS, WPB, V, RM>(const MgConfig&, const MgState&, uint8_t*, uint8_t*,     \
-                                                                 uint8_t*, uint8_t*, hipStream_t, const FusedStep*);
+                                                                 uint8_t*, uint8_t*, hipStream_t, const FusedStep*, RenderPick*);
 #define MG_RENDER_INSTANTIATE(VS, TS, WPB, V, RM)                                                                          \
     template hipError_t launch_render_t<VS, TS, WPB, V, RM>(const MgConfig&, const MgState&, uint8_t*, uint8_t*, uint8_t*,  \
-                                                          uint8_t*, hipStream_t, const FusedStep*);
+                                                          uint8_t*, hipStream_t, const FusedStep*, RenderPick*);
 
 }  // namespace mg

@@ -19,6 +19,14 @@ static uint32_t g_gather_tmap_bytes = 0, g_gather_atlas_bytes = 0, g_gather_oob 
     } while (0)
 #include "mg_gather.h"
 
+// mg_encode's phases (mg_encode_core.h), every LDS offset its chunk phase forms checked against the planes
+static uint32_t g_enc_plane_bytes = 0, g_enc_oob = 0;
+#define MG_ENC_BOUNDS(off, bytes)                                                                           \
+    do {                                                                                                    \
+        if ((off) < 0 || (uint32_t)(off) + (uint32_t)(bytes) > g_enc_plane_bytes) g_enc_oob++;              \
+    } while (0)
+#include "mg_encode_core.h"
+
 namespace {
 struct Scratch {
     std::vector<uint64_t> rec;
@@ -150,6 +158,31 @@ int emu_gather(int vs, int ts, int n_vt, int n_dyn, const uint8_t* atlas_raw, co
     MG_EMU_GATHER(7, 12) MG_EMU_GATHER(5, 5) MG_EMU_GATHER(9, 6) MG_EMU_GATHER(3, 5) MG_EMU_GATHER(6, 5) MG_EMU_GATHER(4, 6) MG_EMU_GATHER(9, 5) MG_EMU_GATHER(4, 5) MG_EMU_GATHER(8, 5) MG_EMU_GATHER(11, 5) MG_EMU_GATHER(13, 5) MG_EMU_GATHER(15, 5)
 #undef MG_EMU_GATHER
     return -1;
+}
+
+// mg_encode as its kernel runs it: piece by piece, phase by phase (a barrier between phases), thread by thread; the LDS
+// of a workgroup is a buffer of exactly the size the launcher asks for, filled with garbage first.  pc: 0 = the launcher's
+// choice, or 4096 / 1024.  Returns the number of out-of-range LDS offsets formed (0 = none), -1 for bad arguments.
+int emu_encode(const MgConfig* cfg, const MgState* st, const uint8_t* vis, uint8_t* out, int pc) {
+    if (pc != 0 && pc != 4096 && pc != 1024) return -1;
+    int PC = pc;
+    const mg::EncodeLaunch lc = mg::encode_launch(*cfg, out, PC);
+    const int T = PC / 16;
+    const size_t lds = mg::kEncTab + (size_t)lc.nraw * (lc.two ? 2 : 1);
+    g_enc_plane_bytes = (uint32_t)lc.nraw;
+    g_enc_oob = 0;
+    const long long pieces = (lc.total + PC - 1) / PC;
+    std::vector<uint8_t> smem(lds + 16);
+    uint8_t* sm = smem.data() + ((16 - (reinterpret_cast<uintptr_t>(smem.data()) & 15)) & 15);
+    for (long long b = 0; b < pieces; b++) {
+        memset(sm, 0xA5, lds);
+        const mg::EncodePiece P = mg::encode_piece(*cfg, lc, b, PC);
+        if ((size_t)P.nd * 4 > (size_t)lc.nraw) return -2;
+        for (int tid = 0; tid < T; tid++) mg::encode_stage(*cfg, *st, lc, P, sm, tid, T);
+        for (int tid = 0; tid < T; tid++) mg::encode_agents(*cfg, *st, lc, P, sm, tid, T);
+        for (int tid = 0; tid < T; tid++) mg::encode_chunks(*cfg, lc, P, vis, out, sm, tid, T, PC);
+    }
+    return (int)g_enc_oob;
 }
 
 int emu_sizeof(int which) {

@@ -382,3 +382,96 @@ def test_pipeline_public_path_alternating_loop_equals_one_env():
                     obs[k] = nxt
     pipe2.check_errors()
     assert Rand.seen == 12 * 2 * 32 * 2
+
+
+def _encode_reference_torch(env):
+    """MultiGrid.encode (base.py:196-214) for the whole batch in torch: the base object's triple; on an empty cell the triple
+    of the lowest-rank placed agent standing there (agents written in descending rank order: the lowest rank lands last)"""
+    import torch
+    from marlgrid_amd import _native as N
+    B, W, H, n = env.batch_size, env.width, env.height, env.num_agents
+    table = torch.tensor([[0, 0, 0]] + [list(o.encode()) for o in env.obj_reg.objs[1:]], dtype=torch.uint8, device=env.device)
+    base = env.grid_state[:, :W * H].long()
+    enc = table[base]                                                     # (B, W*H, 3)
+    rec = env.agent_state
+    by = lambda i: (rec >> (8 * i)) & 0xFF                                 # noqa: E731
+    x, y, d, fl, rk = by(N.AG_X), by(N.AG_Y), by(N.AG_DIR), by(N.AG_FLAGS), by(N.AG_RANK)
+    cell = (x * H + y).clamp(max=W * H - 1)
+    colors = torch.tensor([env._cfg.agent_color_idx[k] for k in range(n)], device=env.device)
+    rows = torch.arange(B, device=env.device)
+    for want_rank in range(n - 1, -1, -1):
+        for k in range(n):
+            m = ((fl[:, k] & N.AF_PLACED) != 0) & (rk[:, k] == want_rank) & (base[rows, cell[:, k]] == 0)
+            tri = torch.stack([torch.full((B,), 13, device=env.device), colors[k].expand(B), d[:, k]], dim=1).to(torch.uint8)
+            enc[rows[m], cell[m, k]] = tri[m]
+    return enc.view(B, W, H, 3)
+
+
+@pytest.mark.parametrize("name,B", [("MarlGrid-3AgentCluttered15x15-v0", 32768), ("MarlGrid-3AgentCluttered11x11-v0", 4096),
+                                    ("Test-4AgentEmpty5x5-crowded", 1000), ("Custom-8AgentCluttered30x30", 4099),
+                                    ("Edge-2AgentCluttered40x40-view9-off3", 700), ("Edge-16AgentEmpty6x6-view7", 333),
+                                    ("MarlGrid-2AgentEmpty9x9-v0", 1)])
+def test_encode_whole_batch_and_through_the_c_abi(name, B):
+    """mg_encode (MultiGrid.encode, base.py:196-214) for the WHOLE batch against a torch restatement — the kernel works on
+    pieces of the flat output stream that do not know about envs, so every env boundary, chunk phase and piece boundary is
+    in here (4 096-cell pieces at the bench shard, 1 024-cell ones below) —, against the oracle on sampled envs, with a
+    vis_mask, and into a caller's buffer that is NOT 16-byte aligned (pure C ABI: byte stores instead of 16-byte ones)."""
+    import torch
+    import scenarios
+    from marlgrid_amd import _native as N
+    from oracle import oracle as O
+    seeds = 2024 + np.arange(B)
+    env = product_envs.build(name, batch_size=B, seeds=seeds, place_obs=False)
+    env.reset()
+    rng = np.random.RandomState(1)
+    n = env.num_agents
+    for t in range(12):
+        env.step(torch.from_numpy(rng.randint(0, 3, size=(B, n))))
+    got = env.grid.encode()
+    want = _encode_reference_torch(env)
+    assert torch.equal(got, want), torch.nonzero((got != want).any(dim=-1))[:5]
+    ids = sorted({0, 1, B // 3, B // 2, B - 2, B - 1} & set(range(B)))
+    orc = O.OracleBatch(scenarios.registered(name), seeds[ids])
+    orc.reset()
+    rng = np.random.RandomState(1)
+    for t in range(12):
+        orc.step(rng.randint(0, 3, size=(B, n))[ids], render=False)
+    for j, b in enumerate(ids):
+        assert np.array_equal(got[b].cpu().numpy(), orc.envs[j].encode()), b
+    # vis_mask: (B, W, H) — cells that are not visible encode as zeros
+    vm = torch.from_numpy(np.random.RandomState(2).rand(B, env.width, env.height) < 0.6).to(env.device)
+    masked = env.grid.encode(vm)
+    assert torch.equal(masked, want * vm[..., None].to(torch.uint8))
+    # a misaligned output buffer through the C ABI
+    nb = B * env.width * env.height * 3
+    buf = torch.full((nb + 32,), 0x5A, dtype=torch.uint8, device=env.device)
+    for shift in (1, 7):
+        N.check(env._lib.mg_encode(C.byref(env._cfg), C.byref(env._state), None, C.c_void_p(buf.data_ptr() + shift), env._stream()))
+        assert torch.equal(buf[shift:shift + nb].view_as(want), want)
+        assert bool((buf[:shift] == 0x5A).all()) and bool((buf[shift + nb:] == 0x5A).all())
+
+
+def test_obs_ring_longer_than_a_placement_call():
+    """obs_buffers > MG_PLACE_MAX (8): the first eight buffers of the ring are placed by the library, the rest stay torch
+    allocations, the ring rotates through all of them (the constructor used to fail with 'invalid argument')"""
+    import gc
+    import torch
+    from marlgrid_amd import _native as N
+    B = 12288                                         # 347 MB per buffer: above the 256 MiB threshold
+    env = product_envs.build("MarlGrid-3AgentCluttered15x15-v0", batch_size=B, obs_buffers=9)
+    twin = product_envs.build("MarlGrid-3AgentCluttered15x15-v0", batch_size=B, place_obs=False)
+    pm = env.obs_placement[0]
+    assert pm["placed_buffers"] == N.PLACE_MAX == 8 and pm["ring_buffers"] == 9 and len(pm["kept"]) == 8
+    assert len({t.data_ptr() for t in env._groups[0].ring}) == 9
+    env.reset(); twin.reset()
+    g = torch.Generator().manual_seed(4)
+    seen = set()
+    for t in range(20):
+        a = torch.randint(0, 7, (B, 3), generator=g)
+        o, r, d, _ = env.step(a)
+        o2, r2, d2, _ = twin.step(a)
+        seen.add(o.data_ptr())
+        assert torch.equal(o, o2) and torch.equal(r, r2) and torch.equal(d, d2)
+    assert len(seen) == 9
+    del env, twin
+    gc.collect()

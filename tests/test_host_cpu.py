@@ -82,7 +82,7 @@ def test_production_library_has_no_measurement_switches():
     L = ctypes.CDLL(so)
     L.mg_build_info.restype = ctypes.c_char_p
     info = L.mg_build_info().decode()
-    assert info.startswith("libmarlgrid_hip gfx950 abi5 src-") and "variants" not in info
+    assert info.startswith("libmarlgrid_hip gfx950 abi6 src-") and "variants" not in info
 
 
 def test_product_never_imports_the_oracle():
@@ -423,7 +423,10 @@ def test_late_static_edits_are_rectangle_fills_and_visible_to_get():
             seen["none"] = self.grid.get(4, 4)
             self.place_agents = None
 
-    env = Late(agents=[dict(color="red")], grid_size=11, _dry=True)
+    # (grid.get(4, 4): an empty cell inside the goal's sampling rectangle — the recorder answers "empty" and says that it
+    # cannot know: upstream's get() there sees what THIS env's earlier place_obj drew)
+    with pytest.warns(RuntimeWarning, match=r"grid.get\(4, 4\) inside _gen_grid reads a cell an earlier random place_obj"):
+        env = Late(agents=[dict(color="red")], grid_size=11, _dry=True)
     template, ops = env._dry_trace
     fills = [o for o in ops if o[2] == 0]
     assert [(o[3], o[4], o[5], o[6]) for o in fills][:2] == [(2, 3, 7, 4), (2, 5, 7, 6)]
@@ -486,3 +489,41 @@ def test_bench_parity_after_timed_replay(tmp_path):
     assert not replay(dict(snap, steps=T - 1))["ok"]
     # and through the parent-side wrapper (temp file, clean child environment)
     assert bench.parity_after_timed(snap)["ok"]
+
+
+def test_render_kernel_name_and_generic_warning():
+    """mg_render_kernel_name: the launcher's own pick for a configuration (no device access) — what bench.py prints as
+    roofline.kernel and rocprofv3 prints as the kernel — and the RuntimeWarning for a configuration that falls off the
+    dispatch table onto the fully run-time instantiation."""
+    import warnings
+    import product_envs
+    from marlgrid_amd import _native as N
+    from marlgrid_amd import base as MB
+    from marlgrid_amd.agents import GridAgentInterface
+    from marlgrid_amd.envs import ClutteredMultiGrid, make
+
+    def name_of(env):
+        cfg, _raw, _flat, _atlas = env._host_tables()
+        return N.render_kernel_name(cfg)
+    assert name_of(make("MarlGrid-3AgentCluttered15x15-v0", batch_size=32768, _dry=True)) == ("mg::render_kernel<7, 8, 16, 0, 0>", 0)
+    assert name_of(make("MarlGrid-3AgentCluttered15x15-v0", batch_size=1024, _dry=True)) == ("mg::render_kernel<7, 8, 4, 0, 0>", 0)
+
+    def cl(vs, ts, B=8192, color="red"):
+        return ClutteredMultiGrid(agents=[GridAgentInterface(color=color, view_size=vs, view_tile_size=ts)], grid_size=15,
+                                  n_clutter=5, batch_size=B, _dry=True)
+    assert name_of(cl(7, 5)) == ("mg::render_kernel<7, 5, 16, 0, 2>", 0)              # the reference's class defaults: gather
+    assert name_of(cl(9, 8)) == ("mg::render_kernel<9, 8, 16, 0, 0>", 0)
+    assert name_of(cl(11, 8)) == ("mg::render_kernel<0, 8, 8, 0, 0>", 1)               # run-time view, chunk raster
+    assert name_of(cl(5, 6)) == ("mg::render_kernel<5, 0, 16, 0, 0>", 2)               # compile-time view, run-time tile
+    assert name_of(cl(11, 6)) == ("mg::render_kernel<0, 0, 8, 0, 0>", 3)               # the fully generic one
+    assert name_of(cl(7, 11, color="prestige"))[0] == "mg::render_kernel<7, 11, 12, 9, 2>"
+    # the warning, once per configuration
+    MB._GENERIC_WARNED.clear()
+    g = cl(11, 6)._groups[0]
+    g.kernel_name = "mg::render_kernel<0, 0, 8, 0, 0>"
+    with pytest.warns(RuntimeWarning, match="fully run-time instantiation.*view_size 3 ... 9 with this view_tile_size"):
+        MB._warn_generic_kernel(g, 3, False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        MB._warn_generic_kernel(g, 3, False)          # said once
+        MB._warn_generic_kernel(g, 1, False)          # a run-time view alone is not the generic instantiation

@@ -3,7 +3,9 @@
 (place_obs="thorough": this tool owns the GPU and measures kernels, not the placement search's bounded default): the other BASELINE.json configs at their per-GPU batch, the tile / view sizes off the fast path,
 the 'prestige' cases and the reference's one runnable example.  Per case one JSON line: the raster alone
 (mg_render_obs, HIP events inside the library) and the whole env.step() (HIP events around 30 steps), both as a
-fraction of 8 TB/s on the observation bytes.  usage: bench_cases.py [substring of a case label ...]"""
+fraction of 8 TB/s on the observation bytes, and mg_encode (MultiGrid.encode for the batch) alone against ITS algorithmic
+bytes (grid + records in, 3 bytes per cell out).  usage: bench_cases.py [--place=default|thorough] [substring of a case label ...]
+--place=default: the constructor's own bounded placement search (what a user gets out of the box) instead of "thorough"."""
 import ctypes as C
 import json
 import os
@@ -18,7 +20,13 @@ from marlgrid_amd.agents import GridAgentInterface  # noqa: E402
 from marlgrid_amd.envs import ClutteredGoalCycleEnv, ClutteredMultiGrid, make  # noqa: E402
 
 COLS = ["red", "blue", "purple", "orange", "olive", "pink", "cyan", "yellow"]
-KW = dict(strict=False, auto_reset=True, place_obs="thorough")
+PLACE = "thorough"
+for a in list(sys.argv[1:]):
+    if a.startswith("--place="):
+        PLACE = a.split("=", 1)[1]
+        sys.argv.remove(a)
+assert PLACE in ("default", "thorough")
+KW = dict(strict=False, auto_reset=True, place_obs="thorough" if PLACE == "thorough" else True)
 
 
 def agents(n, vs, ts, **kw):
@@ -76,6 +84,19 @@ for label, mk in cases:
             b.record()
             b.synchronize()
             step.append(a.elapsed_time(b) / 30)
+        enc_out = torch.empty((B, env.width, env.height, 3), dtype=torch.uint8, device=env.device)
+        enc = []
+        for rep in range(5):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            N.check(env._lib.mg_encode(C.byref(env._cfg), C.byref(env._state), None, enc_out.data_ptr(), env._stream()))
+            a.record()
+            for i in range(50):
+                N.check(env._lib.mg_encode(C.byref(env._cfg), C.byref(env._state), None, enc_out.data_ptr(), env._stream()))
+            b.record()
+            b.synchronize()
+            enc.append(a.elapsed_time(b) / 50)
+        del enc_out
+        enc_bytes = B * (env.cells_stride + 8 * env.num_agents + 3 * env.width * env.height)
         env.check_errors()
         nb = env.obs.numel()
         pm = getattr(env._groups[0], "placement_ms", None) or {}
@@ -83,7 +104,11 @@ for label, mk in cases:
         print(json.dumps({"case": label, "B": B, "n": env.num_agents, "view": env.view_size, "tile": env.tile_size, "obs_bytes": nb,
                           "raster_ms": r, "raster_frac_of_8TBps": nb / r / 1e6 / 8000, "step_ms": s,
                           "step_frac_of_8TBps": nb / s / 1e6 / 8000, "agent_steps_per_s": B * env.num_agents / s * 1e3,
-                          "obs_placement": {k: pm.get(k) for k in ("found", "kept", "candidates", "stopped", "seconds", "pinned_bytes")}}), flush=True)
+                          "kernel": env.kernel_name, "place_obs": PLACE,
+                          "encode_ms": statistics.median(enc), "encode_bytes": enc_bytes,
+                          "encode_frac_of_8TBps": enc_bytes / statistics.median(enc) / 1e6 / 8000,
+                          "obs_placement": {k: pm.get(k) for k in ("found", "kept", "candidates", "stopped", "seconds", "pinned_bytes",
+                                                                   "budget_bytes", "median_ms", "candidate_bytes")}}), flush=True)
         del env
     except Exception as e:      # noqa: BLE001 — one case must not cost the others
         print(json.dumps({"case": label, "error": "%s: %s" % (type(e).__name__, e)}), flush=True)
