@@ -654,11 +654,13 @@ def main():
     place = getattr(env._groups[0], "placement_ms", None) or {}
     ranks_info = ctl.gather_objects({"rank": rank, "local_rank": local_rank, "device_index": dev_index,
                                      "device": device_identity(dev_index), "affinity": affinity,
+                                     # the slice of the global env batch this rank stepped: [lo, hi), seeds 1337 + id
+                                     "global_envs": [seeds[0] - 1337, seeds[-1] - 1337 + 1], "ranks_on_this_gpu": share,
                                      "ms_per_step_own": own["mean"], "ms_per_step_own_median": own["median"],
                                      # which observation buffers this rank drew (ms per raster launch into each kept
                                      # buffer): the MAX over ranks is the unluckiest rank's
                                      "obs_placement": {k: place.get(k) for k in ("found", "reused", "kept", "candidates", "stopped", "seconds",
-                                                                                 "pinned_bytes", "first_attempt")},
+                                                                                 "pinned_bytes", "budget_bytes", "share", "first_attempt")},
                                      "placement_retries": getattr(env, "placement_retries", 0)})
     n, vs, ts = env.num_agents, env.view_size, env.tile_size
     P = vs * ts

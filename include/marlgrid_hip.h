@@ -354,7 +354,8 @@ int32_t mg_obs_free(void* ptr);
 #define MG_PLACE_STIR 1
 #define MG_PLACE_THOROUGH 2
 #define MG_PLACE_NO_REUSE 4
-#define MG_PLACE_STOP_FOUND 1   /* MgPlaceStats.stopped: the kept set is `gain` under the median candidate */
+#define MG_PLACE_STOP_FOUND 1   /* MgPlaceStats.stopped: the kept set is `gain` under the median candidate — or takes the raster's bytes
+                                 * at 5.9 TB/s and more, the rate of the fast class (buffers of several GB: wherever they lie) */
 #define MG_PLACE_STOP_CAP 2     /* max_candidates measured */
 #define MG_PLACE_STOP_TIME 3
 #define MG_PLACE_STOP_MEMORY 4  /* the budget does not hold another candidate (after the losers went back, up to six times) */

@@ -61,4 +61,47 @@ def test_bench_two_ranks_on_one_gpu_through_the_drivers_launch_line():
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["one_thread"] > 0
     rf = out["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and 0 < rf["frac"] < 1 and rf["traffic"] is None
+    par = out["parity_after_timed"]
+    assert par["ok"] is True and par["ok_by_rank"] == [True, True] and par["steps"] >= 25
+    assert [q["global_envs"] for q in ranks] == [[0, 32768], [32768, 65536]]
+    assert "errors" not in out or set(out["errors"]) <= {"pmc"}, out.get("errors")
+
+
+def test_bench_eight_ranks_rehearsal_on_one_gpu():
+    """The 8-rank launch the driver's SCALE run will make, rehearsed on the one GPU (`--gpus 8 --oversubscribe`, the
+    driver's own torch.distributed.run line): no 1 -> 8 curve can be measured on this pool, so what the curve will depend
+    on is exercised instead — eight ranks come up, agree on a control plane, shard the global env batch into eight
+    distinct contiguous ranges, each places its observation buffers inside ITS share of the device's free memory (the
+    default budget is worked out from free / ranks-on-this-GPU: eight searches of a quarter of what is free each would be
+    twice the device), each replays eight of its envs on the oracle after the timed region, and rank 0 prints ONE line."""
+    env = {k: v for k, v in os.environ.items()
+           if not (k.startswith("MG_") or k.startswith("MARLGRID_") or k.startswith("BENCH_TEST_")
+                   or k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"))}
+    Bp = 12288                                          # 347 MB of observations per buffer: above the placement threshold
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5",
+           "--oversubscribe", "--batch-per-gpu", str(Bp), "--min-seconds", "0.5", "--no-strong", "--no-pipeline", "--cpu-seconds", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["config"]["global_batch"] == 8 * Bp and out["scaling"] == "weak"
+    t = out["timing"]
+    ranks = t["per_rank"]
+    assert [q["rank"] for q in ranks] == list(range(8)) and t["ranks_share_a_gpu"] is True
+    assert [q["global_envs"] for q in ranks] == [[k * Bp, (k + 1) * Bp] for k in range(8)]       # distinct, contiguous, complete
+    pinned = 0
+    for q in ranks:
+        assert q["ranks_on_this_gpu"] == 8 and q["ms_per_step_own"] > 0
+        pl = q["obs_placement"]
+        assert pl["kept"] and len(pl["kept"]) == 2 and pl["share"] == 8
+        assert pl["budget_bytes"] <= (288 << 30) // 8 // 2                                          # its share, not the device
+        pinned += pl["pinned_bytes"]
+    assert pinned <= 64 << 30
+    assert len(out["obs_placement_found_by_rank"]) == 8 and len(out["placement_retries_by_rank"]) == 8
+    assert abs(out["value"] - 8 * Bp * 3 / (out["ms_per_step"] * 1e-3)) <= 1e-6 * out["value"]
+    par = out["parity_after_timed"]
+    assert par["ok"] is True and par["ok_by_rank"] == [True] * 8 and par["envs"] == 8 and par["steps"] >= 25
+    assert out["cpu_baseline"]["value"] > 0 and out["roofline"]["traffic"] is None
     assert "errors" not in out or set(out["errors"]) <= {"pmc"}, out.get("errors")

@@ -223,7 +223,8 @@ def test_obs_place_through_the_c_abi():
     N.check(L.mg_time_render_obs(C.byref(cfg), C.byref(st), bufs[0], 5, C.byref(ms), stream))
     assert abs(ms.value - s1.kept_ms[0]) <= 0.12 * s1.kept_ms[0], (ms.value, s1.kept_ms[0])
     if s1.found:
-        assert s1.kept_ms[1] <= 0.88 * s1.median_ms * 1.001
+        # (found: the kept pair is 12 % under the median candidate, or takes the raster's bytes at the fast class's 5.9 TB/s)
+        assert s1.kept_ms[1] <= 0.88 * s1.median_ms * 1.001 or nbytes / (s1.kept_ms[1] * 1e-3) >= 5.9e12
     assert L.mg_obs_release(C.c_void_p(bufs[0] + 4096)) == -100                           # not a placed buffer
     for b in bufs:
         assert L.mg_obs_release(C.c_void_p(b)) == 0
@@ -444,8 +445,8 @@ def test_encode_whole_batch_and_through_the_c_abi(name, B):
     assert torch.equal(masked, want * vm[..., None].to(torch.uint8))
     # a misaligned output buffer through the C ABI
     nb = B * env.width * env.height * 3
-    buf = torch.full((nb + 32,), 0x5A, dtype=torch.uint8, device=env.device)
     for shift in (1, 7):
+        buf = torch.full((nb + 32,), 0x5A, dtype=torch.uint8, device=env.device)
         N.check(env._lib.mg_encode(C.byref(env._cfg), C.byref(env._state), None, C.c_void_p(buf.data_ptr() + shift), env._stream()))
         assert torch.equal(buf[shift:shift + nb].view_as(want), want)
         assert bool((buf[:shift] == 0x5A).all()) and bool((buf[shift + nb:] == 0x5A).all())
