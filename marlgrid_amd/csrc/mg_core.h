@@ -159,6 +159,8 @@ struct Mt {
     int used;               // draws taken since the kernel started
     uint32_t* dma = nullptr;   // the obs kernel's fused step: the wave's LDS landing zone for mt_generate16_dma (null: none) ...
     int dcol = 0;              // ... and this lane's column in it
+    bool ahead_regs = true;    // mt_ahead may keep its operands in registers (false — the obs kernel, which runs at its register
+                               // limit —: through the landing zone or not at all)
 
     // The head is consumed as a ring: draw number `used` is head[used % 16]; when a whole head has
     // been consumed and more is needed (placements, resets) the next 16 outputs are generated into it
@@ -204,6 +206,10 @@ constexpr int kMtAhead = 4;     // (mt_ahead's loads are written for exactly 4)
 struct MtAhead {
     uint32_t a[kMtAhead + 1], c[kMtAhead];
     int pos, used;          // the state these operands belong to (used == 0: nothing requested)
+    bool in_lds;            // the obs kernel: the operands were sent to the wave's LDS landing zone (LDS-DMA: rows 0 - 2 of Mt::dma,
+                            // 16 / 4 / 16 bytes per stepping lane) instead of nine registers that would stay live — and, at the
+                            // kernel's 128-register limit, be spilled with a full wait right after the request — across the
+                            // agents' resolution; mt_ahead_fetch collects them when they are used
 };
 MG_HD MtAhead mt_ahead(const Mt& mt) {
     // (three loads — 16 + 4 + 16 bytes — and nothing else: the step is a chain of dependent instructions in which
@@ -215,12 +221,49 @@ MG_HD MtAhead mt_ahead(const Mt& mt) {
     if (pm >= MG_MT_N) pm -= MG_MT_N;
     ah.pos = p;
     ah.used = (mt.used >= 1 && mt.used <= kMtAhead && p + kMtAhead < MG_MT_N && pm + kMtAhead <= MG_MT_N) ? mt.used : 0;
+    ah.in_lds = false;
     if (ah.used) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (mt.dma) {
+            typedef const __attribute__((address_space(1))) void* gptr;
+            typedef __attribute__((address_space(3))) void* lptr;
+            __builtin_amdgcn_global_load_lds((gptr)(mt.w + p), (lptr)(mt.dma), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr)(mt.w + p + 4), (lptr)(mt.dma + 32), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr)(mt.w + pm), (lptr)(mt.dma + 64), 16, 0, 0);
+            ah.in_lds = true;
+            return ah;
+        }
+#endif
+        if (!mt.ahead_regs) { ah.used = 0; return ah; }
         __builtin_memcpy(&ah.a[0], mt.w + p, 16);
         ah.a[4] = mt.w[p + 4];
         __builtin_memcpy(&ah.c[0], mt.w + pm, 16);
     }
     return ah;
+}
+// the operands as mt_finish uses them: the registers mt_ahead filled, or — after ONE wait for the wave's outstanding
+// loads — what it sent to the LDS landing zone
+MG_HD MtAhead mt_ahead_fetch(const Mt& mt, const MtAhead& ah) {
+    MtAhead r = ah;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (ah.in_lds) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t* z = mt.dma + 4 * mt.dcol;
+#pragma unroll
+        for (int i = 0; i < kMtAhead; i++) {
+            // (opaque: as plain loads the compiler merges "this LDS word or that field of *ah" into a load through a phi of
+            // POINTERS — and a struct whose fields' addresses flow into a phi lives in scratch memory, all of StepCtx with it)
+            uint32_t va = z[i], vc = z[64 + i];
+            MG_OPAQUE32(va); MG_OPAQUE32(vc);
+            r.a[i] = va; r.c[i] = vc;
+        }
+        uint32_t v4 = mt.dma[32 + mt.dcol];
+        MG_OPAQUE32(v4);
+        r.a[kMtAhead] = v4;
+    }
+#endif
+    (void)mt;
+    return r;
 }
 
 // After the env's last draw of the kernel: what is left of the current head slides down to the front,
@@ -234,10 +277,11 @@ MG_HD void mt_finish(Mt& mt, uint32_t* head_out, const MtAhead* ah = nullptr) {
     for (int j = 0; j < keep; j++) head_out[j] = mt.head[(j + k) * mt.hstride];
     if (ah && ah->used && ah->used == mt.used && ah->pos == mt.pos) {      // (k == used <= kMtAhead)
         int p = mt.pos;
+        const MtAhead got = mt_ahead_fetch(mt, *ah);
 #pragma unroll
         for (int i = 0; i < kMtAhead; i++) {
             if (i < k) {
-                uint32_t a0 = ah->a[i], a1 = ah->a[i + 1], c0 = ah->c[i];
+                uint32_t a0 = got.a[i], a1 = got.a[i + 1], c0 = got.c[i];
                 MG_OPAQUE32(a0); MG_OPAQUE32(a1); MG_OPAQUE32(c0);      // (used HERE, not where they were requested)
                 const uint32_t x = mt_twist(a0, a1, c0);
                 mt.w[p] = x;
@@ -270,10 +314,11 @@ MG_HD int mt_finish_ring(Mt& mt, const MtAhead* ah = nullptr) {
     const int k = r ? r : MG_MT_HEAD;           // words consumed from the current head: slots 0 .. k-1
     if (ah && ah->used && ah->used == mt.used && ah->pos == mt.pos) {      // (k == used <= kMtAhead)
         int p = mt.pos;
+        const MtAhead got = mt_ahead_fetch(mt, *ah);
 #pragma unroll
         for (int i = 0; i < kMtAhead; i++) {
             if (i < k) {
-                uint32_t a0 = ah->a[i], a1 = ah->a[i + 1], c0 = ah->c[i];
+                uint32_t a0 = got.a[i], a1 = got.a[i + 1], c0 = got.c[i];
                 MG_OPAQUE32(a0); MG_OPAQUE32(a1); MG_OPAQUE32(c0);
                 const uint32_t x = mt_twist(a0, a1, c0);
                 mt.w[p] = x;
@@ -457,6 +502,13 @@ struct StepScratch {        // per-workgroup arrays, this env is column `col`, e
     int S, col;
     bool defer_writeback = false;   // the caller writes records and RNG head back itself (StepOut::head_k; the obs kernel)
     uint32_t* dma = nullptr;        // the obs kernel: the wave's LDS landing zone for one-round-trip head refills (mt_generate16_dma)
+    // the obs kernel's agent-parallel resolution (step_par_*, S = 8): [n][8] flags / turns, the envs' step counts, and
+    // where step_par_commit puts the settled records (a second [n][8] column set: the sequential loop of an env that
+    // needs it still reads the old ones in `rec`)
+    uint8_t* pflag = nullptr;
+    uint8_t* ordp = nullptr;
+    int32_t* psc = nullptr;
+    uint64_t* rec_out = nullptr;
 #if defined(MG_AB_VARIANTS)
     unsigned long long* stamp = nullptr;   // measurement build: 5 words, wall_clock64 at the section ends of step_run (or null)
 #endif
@@ -491,19 +543,69 @@ MG_HD StepEnv step_load(const MgConfig& cfg, const MgState& st, const void* acti
     return e;
 }
 
+// What entering the cell object `fbase` does to the agent that just moved onto it (base.py:576-585): the reward of a Goal
+// / BonusTile (hasattr(fwd_cell, 'get_reward'); float64, decayed like base.py:579), the agent's bonus state, done on a
+// Goal / Lava.  `r`: the mover's record with its new position; returns it with bonus state and flags updated.
+struct MoveEffect { float rew; bool rewarded; double rwd_applied; };
+MG_HD uint64_t enter_cell(const MgConfig& cfg, const MgObjDesc* obj, uint32_t fbase, uint32_t fflags, uint64_t r, uint32_t flags,
+                          int step_count, MoveEffect& fx) {
+    const MgObjDesc od = obj[fbase];
+    if (od.reward_kind) {                 // hasattr(fwd_cell,'get_reward') :576-581
+        double rwd;
+        if (od.reward_kind == 1) {
+            rwd = od.reward;              // Goal.get_reward objects.py:219-220
+        } else {                          // BonusTile.get_reward objects.py:180-206
+            int bs = (int)rec_byte(r, MG_AG_BONUS);
+            bool first_bonus = false;
+            const int nb = od.n_bonus ? od.n_bonus : 1;
+            if (bs == 0xFF) { bs = ((int)od.bonus_id - 1 + nb) % nb; first_bonus = true; }
+            if (bs == od.bonus_id) rwd = -fabs(od.penalty);
+            else if ((bs + 1) % nb == od.bonus_id) { bs = od.bonus_id; rwd = od.reward; }
+            else rwd = -fabs(od.penalty);
+            if (od.bonus_flags & 2) bs = od.bonus_id;
+            if (first_bonus && !(od.bonus_flags & 1)) rwd = 0.0;
+            r = rec_set(r, MG_AG_BONUS, (uint32_t)bs);
+        }
+        // reward decay factor, float64 like the reference (base.py:579) — worked out where a reward is paid (a float64
+        // division: a hundred dependent cycles that most steps of most envs do not need)
+        int t = step_count;
+        MG_OPAQUE32(t);
+        const double decay = cfg.reward_decay ? (1.0 - 0.9 * ((double)t / (double)cfg.max_steps)) : 1.0;
+        fx.rwd_applied = rwd * decay;
+        fx.rewarded = true;
+        fx.rew = (float)fx.rwd_applied;
+    }
+    if (fflags & MG_OF_ENDS_EPISODE) r = rec_set(r, MG_AG_FLAGS, flags | MG_AF_DONE);  // :584-585
+    return r;
+}
+
 // auto_reset: an env whose episode ends in this step starts its next one right away (`prog`; reset
 // fused into the step: the done flag still reports the end).
 // `g`: the env's grid slice — its home in HBM (st.grid + b * cells_stride), or a staged copy of it (the obs
 // kernel steps the envs it is about to render on their LDS copies: no dependent HBM round trip per grid
 // look-up); returns whether the slice was written (the owner of a staged copy then writes it back).
-MG_HD StepOut step_run(const MgConfig& cfg, const MgState& st, const MgGenProgram& prog, bool auto_reset, float* rewards,
-                       int b, const StepEnv& env, const StepScratch& sc, uint8_t* g) {
+//
+// A step in three parts, so that the obs kernel can put its agent-parallel resolution (step_par_*, below) between the
+// first and the last: step_begin (late spawns, step_count, the shuffle), step_agents (the sequential action loop),
+// step_end (done agents, respawn, episode end, auto-reset, write-back).  step_run = the three in a row.
+struct StepCtx {            // what an env's step carries from part to part (one lane's registers)
+    Mt mt;
+    uint64_t order;         // iter_order: agent of turn i in nibble i
+    int err, step_count;
+    MtAhead ahead;
+    bool grid_dirty;
+};
+
+MG_HD StepCtx step_begin(const MgConfig& cfg, const MgState& st, int b, const StepEnv& env, const StepScratch& sc, uint8_t* g) {
     const int n = cfg.n_agents, W = cfg.W, H = cfg.H, S = sc.S, col = sc.col;
     uint64_t* s_rec = sc.rec;
-    Mt mt{st.mt + (size_t)b * MG_MT_N, env.pos0, sc.head + col, S, 0};
-    mt.dma = sc.dma;
-    mt.dcol = col;
-    int err = 0;
+    StepCtx c;
+    c.mt = Mt{st.mt + (size_t)b * MG_MT_N, env.pos0, sc.head + col, S, 0};
+    c.mt.dma = sc.dma;
+    c.mt.dcol = col;
+    c.mt.ahead_regs = !sc.defer_writeback;       // (defer_writeback: the obs kernel's fused step)
+    c.err = 0;
+    c.grid_dirty = false;
     MG_STEP_STAMP(0);
 
     // late spawns (base.py:503-506), before step_count is incremented and before the shuffle: any agent
@@ -512,7 +614,7 @@ MG_HD StepOut step_run(const MgConfig& cfg, const MgState& st, const MgGenProgra
     for (int k = 0; k < n; k++) {
         const uint32_t f = rec_byte(s_rec[k * S + col], MG_AG_FLAGS);
         if (!(f & (MG_AF_ACTIVE | MG_AF_DONE)) && env.sc0 >= cfg.spawn_delay[k])
-            if (!place_agent(cfg, sc.oflags, g, mt, s_rec, S, col, k, 0)) err = err ? err : MG_ERR_RECURSION;
+            if (!place_agent(cfg, sc.oflags, g, c.mt, s_rec, S, col, k, 0)) c.err = c.err ? c.err : MG_ERR_RECURSION;
     }
 
     // round trip 2: every agent's front cell.  An agent's position and heading are only ever changed
@@ -528,36 +630,38 @@ MG_HD StepOut step_run(const MgConfig& cfg, const MgState& st, const MgGenProgra
             const bool ok = (rec_byte(r, MG_AG_FLAGS) & MG_AF_ACTIVE) && fx >= 0 && fx < W && fy >= 0 && fy < H;
             sc.fb[k * S + col] = ok ? g[fx * H + fy] : (uint8_t)0;
         }
-    const bool direct = !sc.fb;     // (no pre-loaded front cells: the action loop reads `g`)
-    bool grid_dirty = false;
 
-    int step_count = env.sc0 + 1;   // base.py:512
-    // reward decay factor, float64 like the reference (base.py:579) — worked out where a reward is paid (a float64
-    // division: a hundred dependent cycles that most steps of most envs do not need)
-    auto decay_now = [&]() -> double {
-        int t = step_count;
-        MG_OPAQUE32(t);
-        return cfg.reward_decay ? (1.0 - 0.9 * ((double)t / (double)cfg.max_steps)) : 1.0;
-    };
+    c.step_count = env.sc0 + 1;   // base.py:512
 
     // iter_order = arange(n); np_random.shuffle(iter_order)  (base.py:514-516): legacy Fisher-Yates
     // over numpy's masked-rejection bounded draws — served from the look-ahead head
     // (the permutation as sixteen nibbles of one register: a swap is four shifts instead of four LDS round trips)
     static_assert(MG_MAX_AGENTS <= 16, "iter_order: one nibble per agent");
-    uint64_t order = 0xFEDCBA9876543210ull;
+    // (the identity, made HERE: as a loop invariant of the obs kernel's env loop it is hoisted, spilled at the kernel's
+    // register limit and fetched back from scratch memory in front of every shuffle)
+    uint32_t id_lo = 0x76543210u, id_hi = 0xFEDCBA98u;
+    MG_OPAQUE32(id_lo); MG_OPAQUE32(id_hi);
+    uint64_t order = (uint64_t)id_lo | ((uint64_t)id_hi << 32);
     for (int i = n - 1; i >= 1; i--) {
-        const int j = (int)mt.bounded((uint32_t)i);
+        const int j = (int)c.mt.bounded((uint32_t)i);
         const uint64_t oi_ = (order >> (4 * i)) & 0xFull, oj_ = (order >> (4 * j)) & 0xFull;
         order = (order & ~((0xFull << (4 * i)) | (0xFull << (4 * j)))) | (oj_ << (4 * i)) | (oi_ << (4 * j));
     }
-
-    const MtAhead ahead = mt_ahead(mt);
+    c.order = order;
+    c.ahead = mt_ahead(c.mt);
     MG_STEP_STAMP(1);
+    return c;
+}
+
+MG_HD void step_agents(const MgConfig& cfg, const MgState& st, float* rewards, int b, const StepScratch& sc, uint8_t* g, StepCtx& c) {
+    const int n = cfg.n_agents, W = cfg.W, H = cfg.H, S = sc.S, col = sc.col;
+    uint64_t* s_rec = sc.rec;
+    const bool direct = !sc.fb;     // (no pre-loaded front cells: the action loop reads `g`)
+    int err = c.err;
+    bool grid_dirty = c.grid_dirty;
     for (int oi = 0; oi < n; oi++) {
-        const int k = (int)((order >> (4 * oi)) & 0xFull);
-        float rew = 0.0f;
-        bool rewarded = false;      // agent.reward(rwd) was called (prestige bookkeeping)
-        double rwd_applied = 0.0;
+        const int k = (int)((c.order >> (4 * oi)) & 0xFull);
+        MoveEffect fxm = {0.0f, false, 0.0};      // agent.reward(rwd) was called: `rewarded` (prestige bookkeeping)
         uint64_t r = s_rec[k * S + col];
         const uint32_t flags = rec_byte(r, MG_AG_FLAGS);
         if (flags & MG_AF_ACTIVE) {   // base.py:521
@@ -595,30 +699,7 @@ MG_HD StepOut step_run(const MgConfig& cfg, const MgState& st, const MgGenProgra
                             r = arrive(s_rec, S, col, n, r);
                             r = rec_set(r, MG_AG_X, (uint32_t)fx);
                             r = rec_set(r, MG_AG_Y, (uint32_t)fy);
-                            if (fbase) {
-                                const MgObjDesc od = sc.obj[fbase];
-                                if (od.reward_kind) {                 // hasattr(fwd_cell,'get_reward') :576-581
-                                    double rwd;
-                                    if (od.reward_kind == 1) {
-                                        rwd = od.reward;              // Goal.get_reward objects.py:219-220
-                                    } else {                          // BonusTile.get_reward objects.py:180-206
-                                        int bs = (int)rec_byte(r, MG_AG_BONUS);
-                                        bool first_bonus = false;
-                                        const int nb = od.n_bonus ? od.n_bonus : 1;
-                                        if (bs == 0xFF) { bs = ((int)od.bonus_id - 1 + nb) % nb; first_bonus = true; }
-                                        if (bs == od.bonus_id) rwd = -fabs(od.penalty);
-                                        else if ((bs + 1) % nb == od.bonus_id) { bs = od.bonus_id; rwd = od.reward; }
-                                        else rwd = -fabs(od.penalty);
-                                        if (od.bonus_flags & 2) bs = od.bonus_id;
-                                        if (first_bonus && !(od.bonus_flags & 1)) rwd = 0.0;
-                                        r = rec_set(r, MG_AG_BONUS, (uint32_t)bs);
-                                    }
-                                    rwd_applied = rwd * decay_now();
-                                    rewarded = true;
-                                    rew = (float)rwd_applied;
-                                }
-                                if (fflags & MG_OF_ENDS_EPISODE) r = rec_set(r, MG_AG_FLAGS, flags | MG_AF_DONE);  // :584-585
-                            }
+                            if (fbase) r = enter_cell(cfg, sc.obj, fbase, fflags, r, flags, c.step_count, fxm);
                         }
                     } else {
                         // drop: `if not fwd_cell and agent.carrying`
@@ -664,14 +745,24 @@ MG_HD StepOut step_run(const MgConfig& cfg, const MgState& st, const MgGenProgra
                 // agent.reward(rwd) then agent.on_step(): agents.py:141-153 (allow_negative_prestige=False)
                 double* pp = st.prestige + (size_t)b * n + k;
                 double p = *pp;
-                if (rewarded) p = (rwd_applied >= 0) ? p + rwd_applied : 0.0;
+                if (fxm.rewarded) p = (fxm.rwd_applied >= 0) ? p + fxm.rwd_applied : 0.0;
                 *pp = p * cfg.prestige_beta[k];
             }
         }
-        rewards[(size_t)b * n + k] = rew;
+        rewards[(size_t)b * n + k] = fxm.rew;
     }
-
+    c.err = err;
+    c.grid_dirty = grid_dirty;
     MG_STEP_STAMP(2);
+}
+
+MG_HD StepOut step_end(const MgConfig& cfg, const MgState& st, const MgGenProgram& prog, bool auto_reset, int b,
+                       const StepScratch& sc, uint8_t* g, StepCtx& c) {
+    const int n = cfg.n_agents, S = sc.S, col = sc.col;
+    uint64_t* s_rec = sc.rec;
+    Mt& mt = c.mt;
+    int err = c.err, step_count = c.step_count;
+    bool grid_dirty = c.grid_dirty;
     // done agents (base.py:627-646), in index order: without respawn they are deactivated but stay
     // where they are; with respawn they leave their cell (an agent only ever becomes done on a Goal /
     // Lava, i.e. inside that object's stack, so nothing is left behind), drop what they carry
@@ -703,10 +794,10 @@ MG_HD StepOut step_run(const MgConfig& cfg, const MgState& st, const MgGenProgra
     MG_STEP_STAMP(3);
     int head_k = -1;
     if (sc.defer_writeback) {
-        head_k = mt_finish_ring(mt, &ahead);
+        head_k = mt_finish_ring(mt, &c.ahead);
     } else {
         for (int k = 0; k < n; k++) st.agents[(size_t)b * n + k] = s_rec[k * S + col];
-        mt_finish(mt, st.mt_head + (size_t)b * MG_MT_HEAD, &ahead);
+        mt_finish(mt, st.mt_head + (size_t)b * MG_MT_HEAD, &c.ahead);
     }
     st.step_count[b] = step_count;
     st.mt_pos[b] = mt.pos;
@@ -715,6 +806,138 @@ MG_HD StepOut step_run(const MgConfig& cfg, const MgState& st, const MgGenProgra
     MG_STEP_STAMP(4);
     StepOut out = {grid_dirty, head_k};
     return out;
+}
+
+MG_HD StepOut step_run(const MgConfig& cfg, const MgState& st, const MgGenProgram& prog, bool auto_reset, float* rewards,
+                       int b, const StepEnv& env, const StepScratch& sc, uint8_t* g) {
+    StepCtx c = step_begin(cfg, st, b, env, sc, g);
+    step_agents(cfg, st, rewards, b, sc, g, c);
+    return step_end(cfg, st, prog, auto_reset, b, sc, g, c);
+}
+
+// ---- the action loop resolved by ONE LANE PER AGENT (the obs kernel's fused step) ---------------------------------------
+// The reference's loop is sequential per env (base.py:517-622), and so is step_agents: ~1 700 dependent instructions at
+// three agents — LDS round trips, mostly — on ONE lane, at the head of every wave of the obs kernel.  But what an agent does
+// rarely depends on what the agents before it did: a turn never does; a forward move with ghost_mode (the default) depends
+// on the cell OBJECT in front — which only a pickup / drop / toggle changes — and not on who stands there; the only thing
+// the order always decides is the arrival RANK (who lies on top of whom), and that has a closed form: the agents that did
+// not move keep their relative order at the bottom, the movers follow in the order they moved (= `arrive` applied in turn).
+// So, between step_begin and step_end, the wave resolves the agents of its (<= 8) staged envs with one lane per (agent,
+// env): lane l = 8 k + j is agent k of staged env j (S = 8 columns, n <= 8 agents).
+//   step_par_resolve  reads the PRE-step state and either settles the agent's action or asks for the sequential loop for
+//                     its env — conservatively: anything that writes the grid (a pickup, drop or toggle that would take
+//                     effect), any error (front cell outside the grid, an unknown action, an evicted agent that moves),
+//                     and, without ghost_mode, a forward move onto an empty cell that another agent occupies or also
+//                     moves onto;
+//   step_par_commit   works out the ranks and, unless some agent of the env asked for the loop, writes the records, the
+//                     rewards and 'prestige' — else it writes nothing and the env's lane runs step_agents as before.
+// Bit-exact by construction: an env either takes a path on which no agent's outcome depends on the order (ranks aside,
+// and those are computed from the order), or it takes the sequential loop.  Both halves are plain functions of `lane` that
+// talk through the step's LDS columns only (no cross-lane builtins), so that tests/native runs them lane by lane on the host.
+struct ParLane {            // what a lane carries from step_par_resolve to step_par_commit
+    uint64_t r;             // the agent's record after its action (rank not yet)
+    MoveEffect fx;
+    bool live, active, moved;
+};
+// sc.pflag [n][8] u8: bit 0 the agent moved, bit 1 its env needs the sequential loop; sc.ordp [n][8] u8: the agent's turn;
+// sc.psc [8] i32: the env's step_count (after the increment)
+MG_HD void step_par_publish(const MgConfig& cfg, const StepScratch& sc, const StepCtx& c) {      // the env's lane, after step_begin
+    const int n = cfg.n_agents, col = sc.col;
+    for (int i = 0; i < n; i++) sc.ordp[(int)((c.order >> (4 * i)) & 0xFull) * 8 + col] = (uint8_t)i;
+    sc.psc[col] = c.step_count;
+}
+MG_HD ParLane step_par_resolve(const MgConfig& cfg, const StepScratch& sc, const uint8_t* grids, int kb, int lane) {
+    const int n = cfg.n_agents, W = cfg.W, H = cfg.H;
+    const int j = lane & 7, k = lane >> 3;
+    ParLane P;
+    P.fx = MoveEffect{0.0f, false, 0.0};
+    P.live = k < n && j < kb;
+    P.active = P.moved = false;
+    P.r = 0;
+    if (!P.live) return P;
+    const uint8_t* g = grids + (size_t)j * cfg.cells_stride;
+    uint64_t r = sc.rec[k * 8 + j];
+    const uint32_t flags = rec_byte(r, MG_AG_FLAGS);
+    bool serial = false;
+    if (flags & MG_AF_ACTIVE) {
+        P.active = true;
+        const int action = (int)sc.act[k * 8 + j];
+        const int cx = (int)rec_byte(r, MG_AG_X), cy = (int)rec_byte(r, MG_AG_Y), dir = (int)rec_byte(r, MG_AG_DIR);
+        const int fx = cx + dir_dx(dir), fy = cy + dir_dy(dir);
+        if (fx < 0 || fx >= W || fy < 0 || fy >= H || action > 6) {
+            serial = true;                                            // AssertionError / ValueError: the loop records them
+        } else {
+            const uint32_t fbase = g[fx * H + fy], fflags = sc.oflags[fbase];
+            const uint32_t fxy = (uint32_t)fx | ((uint32_t)fy << 8);
+            if (action == 0) r = rec_set(r, MG_AG_DIR, (uint32_t)((dir + 3) & 3));
+            else if (action == 1) r = rec_set(r, MG_AG_DIR, (uint32_t)((dir + 1) & 3));
+            else if (action == 2) {
+                const bool can_move = fbase ? (fflags & MG_OF_CAN_OVERLAP) != 0 : true;
+                if (can_move && (flags & MG_AF_EVICTED)) serial = true;
+                if (can_move && !(cfg.ghost_mode & 1) && fbase == 0) {
+                    // blocked iff an agent stands there WHEN THIS AGENT ACTS (base.py:541-542): nobody there now and nobody
+                    // heading there -> free whatever the order; anything else is the loop's business
+                    for (int i = 0; i < n; i++) {
+                        if (i == k) continue;
+                        const uint64_t ri = sc.rec[i * 8 + j];
+                        const uint32_t fi = rec_byte(ri, MG_AG_FLAGS);
+                        if ((fi & MG_AF_PLACED) && rec_xy(ri) == fxy) serial = true;
+                        if ((fi & MG_AF_ACTIVE) && sc.act[i * 8 + j] == 2) {
+                            const int di = (int)rec_byte(ri, MG_AG_DIR);
+                            const uint32_t txy = (uint32_t)((int)rec_byte(ri, MG_AG_X) + dir_dx(di)) | ((uint32_t)((int)rec_byte(ri, MG_AG_Y) + dir_dy(di)) << 8);
+                            if (txy == fxy) serial = true;
+                        }
+                    }
+                }
+                if (can_move && !serial) {
+                    P.moved = true;
+                    r = rec_set(r, MG_AG_X, (uint32_t)fx);
+                    r = rec_set(r, MG_AG_Y, (uint32_t)fy);
+                    if (fbase) r = enter_cell(cfg, sc.obj, fbase, fflags, r, flags, sc.psc[j], P.fx);
+                }
+            } else if (action == 3) {
+                if (fbase && (fflags & MG_OF_CAN_PICKUP) && rec_byte(r, MG_AG_CARRY) == 0) serial = true;
+            } else if (action == 4) {
+                if (fbase == 0 && rec_byte(r, MG_AG_CARRY)) serial = true;       // (whoever stands there: the loop decides)
+            } else if (action == 5) {
+                if (fbase && (fflags & (MG_OF_IS_BOX | MG_OF_IS_DOOR))) serial = true;
+            }
+        }
+    }
+    P.r = r;
+    sc.pflag[k * 8 + j] = (uint8_t)((P.moved ? 1 : 0) | (serial ? 2 : 0));
+    return P;
+}
+// returns whether the lane's env needs the sequential loop (the same answer in every lane of the env)
+MG_HD bool step_par_commit(const MgConfig& cfg, const MgState& st, float* rewards, int b0, const StepScratch& sc, const ParLane& P, int lane) {
+    const int n = cfg.n_agents;
+    const int j = lane & 7, k = lane >> 3;
+    if (!P.live) return false;
+    // ranks (`arrive`, base.py:547-552 / 684-686, applied in turn order): non-movers keep their order at the bottom, the
+    // movers lie on top of them in the order of their turns
+    const uint32_t my_rank = rec_byte(sc.rec[k * 8 + j], MG_AG_RANK), my_turn = sc.ordp[k * 8 + j];
+    uint32_t serial = 0, below = 0, stay = 0, before = 0;
+    for (int i = 0; i < n; i++) {
+        const uint32_t f = sc.pflag[i * 8 + j];
+        serial |= f & 2u;
+        const bool mv = (f & 1u) != 0;
+        const uint32_t ri = (uint32_t)reinterpret_cast<const uint8_t*>(sc.rec + i * 8 + j)[MG_AG_RANK];
+        stay += mv ? 0u : 1u;
+        below += (!mv && ri < my_rank) ? 1u : 0u;
+        before += (mv && sc.ordp[i * 8 + j] < my_turn) ? 1u : 0u;
+    }
+    if (serial) return true;
+    const size_t at = (size_t)(b0 + j) * n + k;
+    uint64_t r = rec_set(P.r, MG_AG_RANK, P.moved ? stay + before : below);
+    if (P.active && cfg.prestige_mask) {
+        // agent.reward(rwd) then agent.on_step(): agents.py:141-153 (allow_negative_prestige=False)
+        double p = st.prestige[at];
+        if (P.fx.rewarded) p = (P.fx.rwd_applied >= 0) ? p + P.fx.rwd_applied : 0.0;
+        st.prestige[at] = p * cfg.prestige_beta[k];
+    }
+    rewards[at] = P.fx.rew;
+    sc.rec_out[k * 8 + j] = r;
+    return false;
 }
 
 // ---- MultiGridEnv.reset for one env (explicit reset; the auto-reset runs inside step_run) ---------

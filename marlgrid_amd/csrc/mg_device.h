@@ -173,8 +173,9 @@ __host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride,
     s.out = o;   o += round_up(out_bytes, 16);   // assemble-and-stream raster: the piece being assembled
     s.piece_rows = piece_rows;
     s.out_chunks = round_up(out_bytes, 16) / 16;
-    // fused step (mg_step_render): lane j < stage_envs steps staged env j; its [item][8] columns
-    s.step = o;  o += round_up(n * 8 * 8 + MG_MT_HEAD * 8 * 4 + 3 * n * 8, 16);
+    // fused step (mg_step_render): lane j < stage_envs steps staged env j; its [item][8] columns: records, RNG look-ahead,
+    // actions, the agent-parallel resolution's flags and turns (step_par_*, mg_core.h), the envs' step counts
+    s.step = o;  o += round_up(n * 8 * 8 + MG_MT_HEAD * 8 * 4 + 3 * n * 8 + 8 * 4, 16);
     s.total = o;
     return s;
 }

@@ -146,6 +146,10 @@ __device__ __forceinline__ StepScratch fused_step_scratch(const MgConfig& cfg, i
     sc.rec = reinterpret_cast<uint64_t*>(sp);                                   // [n][8]
     sc.head = reinterpret_cast<uint32_t*>(sp + n * 8 * 8);                      // [MG_MT_HEAD][8]
     sc.act = sp + n * 8 * 8 + MG_MT_HEAD * 8 * 4;                               // [n][8]
+    sc.pflag = sc.act + n * 8;                                                  // [n][8]  step_par_*: moved / needs the loop
+    sc.ordp = sc.pflag + n * 8;                                                 // [n][8]  ... the agent's turn
+    sc.psc = reinterpret_cast<int32_t*>(sc.ordp + n * 8);                       // [8]     ... the env's step count
+    sc.rec_out = sc.rec;                                                        // (in place: the lanes of a wave run in lockstep)
     sc.fb = nullptr;                                                            // (the grid is a staged LDS copy: no pre-load)
     sc.obj = s_obj;
     sc.oflags = s_oflags;
@@ -525,9 +529,26 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 // one-round-trip head refills through LDS-DMA (mt_generate16_dma): their landing zone, 9 rows of 128 bytes,
                 // is the tmap area — the views have not begun
                 sc.dma = (size_t)L.tmap_slots * L.tmap_stride >= kMtDmaBufDwords * 4 ? reinterpret_cast<uint32_t*>(w_tmap0) : nullptr;
+                // The step in three parts (mg_core.h): step_begin on the env's lane (late spawns, the shuffle); the agents
+                // resolved by ONE LANE PER (agent, env) on the pre-step state — lane 8 k + j: agent k of staged env j, up
+                // to 8 agents — instead of a sequential loop of ~1 700 dependent instructions on the env's lane, which then
+                // only runs for an env whose agents' actions do depend on their order (step_par_commit says which);
+                // step_end on the env's lane (done agents, respawn, the episode's end and the reset that follows it).
+                StepCtx ctx;
+                uint8_t* const g_mine = w_stage_g + (size_t)(lane & 7) * cfg.cells_stride;
+                if (lane < kb) ctx = step_begin(cfg, st, eb + lane, se, sc, g_mine);
+                bool loop = true;                       // this env's agents take the sequential loop
+                if (n <= 8) {
+                    if (lane < kb) step_par_publish(cfg, sc, ctx);
+                    wave_lds_sync();
+                    const ParLane P = step_par_resolve(cfg, sc, w_stage_g, kb, lane);
+                    wave_lds_sync();
+                    loop = step_par_commit(cfg, st, fs.rewards, eb, sc, P, lane);
+                    wave_lds_sync();
+                }
                 if (lane < kb) {
-                    const StepOut so = step_run(cfg, st, fs.prog, fs.has_prog != 0, fs.rewards, eb + lane, se, sc,
-                                                w_stage_g + (size_t)lane * cfg.cells_stride);
+                    if (loop) step_agents(cfg, st, fs.rewards, eb + lane, sc, g_mine, ctx);
+                    const StepOut so = step_end(cfg, st, fs.prog, fs.has_prog != 0, eb + lane, sc, g_mine, ctx);
                     wrote = so.wrote;
                     head_k = so.head_k;
                     if constexpr (kPrestige) {

@@ -41,9 +41,11 @@ def _ptr(a):
 
 
 class HostEmu(object):
-    def __init__(self, name, B, seeds, auto_reset=False, **kw):
+    def __init__(self, name, B, seeds, auto_reset=False, par=False, **kw):
         import product_envs
         self.L = lib()
+        self.par = par                                  # step as the obs kernel's fused step does: agents resolved lane-parallel
+        self.n_serial = C.c_int64(0)                    # ... and how many env-steps still took the sequential loop
         self.env = env = product_envs.build(name, batch_size=B, seeds=[int(s) for s in seeds], _dry=True, **kw)
         self.B, self.n = B, env.num_agents
         self.auto_reset = auto_reset
@@ -120,8 +122,12 @@ class HostEmu(object):
             self.env.reset()
             self._last_prog = self._prog(self.env._dry_trace)
             prog = C.byref(self._last_prog)
-        rc = self.L.emu_step(C.byref(self._cfg()), C.byref(self.state), _ptr(a), 8, _ptr(self.rewards), prog)
-        assert rc == 0
+        if self.par:
+            rc = self.L.emu_step_par(C.byref(self._cfg()), C.byref(self.state), _ptr(a), 8, _ptr(self.rewards), prog,
+                                     C.byref(self.n_serial))
+        else:
+            rc = self.L.emu_step(C.byref(self._cfg()), C.byref(self.state), _ptr(a), 8, _ptr(self.rewards), prog)
+        assert rc == 0, rc
         return self.rewards.copy(), self.done.astype(bool)
 
     def place(self, what, region, max_tries=100000, fixed_pos=None, mask=None, reject=None):

@@ -90,6 +90,64 @@ int emu_step(const MgConfig* cfg, const MgState* st, const void* actions, int ac
     return 0;
 }
 
+// The obs kernel's fused step as a wave runs it (mg_render_kernel.h): batches of up to 8 staged envs in S = 8 columns,
+// step_begin on the env's lane, the agents resolved by one lane per (agent, env) — step_par_publish / _resolve / _commit,
+// here lane after lane with the phases in the kernel's order —, the sequential loop only for the envs that asked for it,
+// step_end.  *n_serial counts those envs.  More than 8 agents: the sequential step, as in the kernel.
+int emu_step_par(const MgConfig* cfg, const MgState* st, const void* actions, int action_bytes, float* rewards,
+                 const MgGenProgram* auto_reset, int64_t* n_serial) {
+    if (cfg->n_agents > 8) return emu_step(cfg, st, actions, action_bytes, rewards, auto_reset);
+    if (action_bytes != 1 && action_bytes != 4 && action_bytes != 8) return -100;
+    const int n = cfg->n_agents, stride = cfg->cells_stride;
+    MgGenProgram none;
+    memset(&none, 0, sizeof(none));
+    const MgGenProgram& prog = auto_reset ? *auto_reset : none;
+    std::vector<uint64_t> rec(n * 8), rec_out(n * 8);
+    std::vector<uint32_t> head(MG_MT_HEAD * 8);
+    std::vector<uint8_t> act(n * 8), pflag(n * 8), ordp(n * 8), oflags(MG_MAX_OBJ, 0), grids((size_t)8 * stride);
+    std::vector<int32_t> psc(8);
+    for (int i = 1; i < cfg->n_obj; i++) oflags[i] = cfg->obj[i].flags;
+    for (int b0 = 0; b0 < cfg->B; b0 += 8) {
+        const int kb = cfg->B - b0 < 8 ? cfg->B - b0 : 8;
+        mg::StepScratch sc;
+        sc.rec = rec.data(); sc.head = head.data(); sc.act = act.data(); sc.fb = nullptr;
+        sc.obj = cfg->obj; sc.oflags = oflags.data(); sc.S = 8; sc.col = 0;
+        sc.pflag = pflag.data(); sc.ordp = ordp.data(); sc.psc = psc.data(); sc.rec_out = rec_out.data();
+        sc.defer_writeback = true;
+        memset(pflag.data(), 0xEE, pflag.size());
+        memset(ordp.data(), 0xEE, ordp.size());
+        mg::StepCtx ctx[8];
+        for (int j = 0; j < kb; j++) {
+            sc.col = j;
+            memcpy(grids.data() + (size_t)j * stride, st->grid + (size_t)(b0 + j) * stride, stride);
+            const mg::StepEnv e = mg::step_load(*cfg, *st, actions, action_bytes, b0 + j, sc);
+            ctx[j] = mg::step_begin(*cfg, *st, b0 + j, e, sc, grids.data() + (size_t)j * stride);
+            mg::step_par_publish(*cfg, sc, ctx[j]);
+        }
+        mg::ParLane P[64];
+        bool serial[64];
+        for (int lane = 0; lane < 64; lane++) P[lane] = mg::step_par_resolve(*cfg, sc, grids.data(), kb, lane);
+        for (int lane = 0; lane < 64; lane++) serial[lane] = mg::step_par_commit(*cfg, *st, rewards, b0, sc, P[lane], lane);
+        for (int lane = 0; lane < 64; lane++)
+            if (P[lane].live && !serial[lane]) rec[lane] = rec_out[lane];        // (on the GPU rec_out IS rec: the lanes run in lockstep)
+        for (int j = 0; j < kb; j++) {
+            const int b = b0 + j;
+            sc.col = j;
+            uint8_t* g = grids.data() + (size_t)j * stride;
+            for (int k = 1; k < n; k++)
+                if (serial[k * 8 + j] != serial[j]) return -102;                      // every lane of an env gives the same answer
+            if (serial[j]) { mg::step_agents(*cfg, *st, rewards, b, sc, g, ctx[j]); if (n_serial) (*n_serial)++; }
+            const mg::StepOut out = mg::step_end(*cfg, *st, prog, auto_reset != nullptr, b, sc, g, ctx[j]);
+            for (int k = 0; k < n; k++) st->agents[(size_t)b * n + k] = rec[k * 8 + j];
+            for (int i = 0; i < MG_MT_HEAD; i++) st->mt_head[(size_t)b * MG_MT_HEAD + i] = head[((i + out.head_k) & (MG_MT_HEAD - 1)) * 8 + j];
+            uint8_t* home = st->grid + (size_t)b * stride;
+            if (out.wrote) memcpy(home, g, stride);
+            else if (memcmp(home, g, stride) != 0) return -101;
+        }
+    }
+    return 0;
+}
+
 int emu_place(const MgConfig* cfg, const MgState* st, int what, int x0, int y0, int x1, int y1, int max_tries,
               const int32_t* fixed_pos, const uint8_t* mask, const uint8_t* reject, int32_t* out_pos, uint8_t* out_ok) {
     Scratch s(cfg);

@@ -70,10 +70,13 @@ def test_numpy_form_round_trip():
     ("Test-2AgentLateStatic10x10", 16, 110, False),
     ("Test-3AgentCluttered9x9-view6", 16, 70, True),
 ])
-def test_core_bodies_vs_oracle(name, B, T, auto):
+@pytest.mark.parametrize("par", [False, True])
+def test_core_bodies_vs_oracle(name, B, T, auto, par):
+    """par: the step as the obs kernel's fused step runs it — batches of 8 envs, the agents resolved by one lane per
+    (agent, env) on the pre-step state (step_par_*), the sequential loop only for envs that ask for it"""
     import hostemu
     seeds = 4200 + np.arange(B)
-    emu = hostemu.HostEmu(name, B, seeds, auto_reset=auto)
+    emu = hostemu.HostEmu(name, B, seeds, auto_reset=auto, par=par)
     orc = O.OracleBatch(scenarios.registered(name), seeds)
     _same_state(emu, orc, "%s ctor" % name)
     emu.reset()
@@ -100,14 +103,15 @@ def test_core_bodies_vs_oracle(name, B, T, auto):
 @pytest.mark.parametrize("name,B,T", [("MarlGrid-3AgentCluttered15x15-v0", 16, 6000),
                                        ("Custom-8AgentCluttered30x30", 4, 3000),
                                        ("Test-3AgentCluttered9x9-respawn", 16, 6000)])
-def test_core_bodies_long_horizon(name, B, T):
+@pytest.mark.parametrize("par", [False, True])
+def test_core_bodies_long_horizon(name, B, T, par):
     """what bench.py times is ~60 000 steps per env: the lane-per-env bodies over MANY episodes (auto-reset inside the
     step, >= 25 wraps of the 624-word MT19937 state through the lazy regeneration) against the oracle — rewards / done
     every step, canonical state + RNG every 250 steps.  The GPU twin (LDS staging, LDS-DMA head refills, observations):
     tests/test_hip_soak.py."""
     import hostemu
     seeds = 515000 + np.arange(B)
-    emu = hostemu.HostEmu(name, B, seeds, auto_reset=True)
+    emu = hostemu.HostEmu(name, B, seeds, auto_reset=True, par=par)
     orc = O.OracleBatch(scenarios.registered(name), seeds)
     emu.reset()
     orc.reset()
@@ -122,3 +126,35 @@ def test_core_bodies_long_horizon(name, B, T):
         if t % 250 == 0 or t == T:
             _same_state(emu, orc, "%s step %d" % (name, t))
     assert episodes.min() >= T // 100 and not emu.error.any()
+    if par and emu.n <= 8:      # ghost_mode, nothing to pick up or toggle: no env-step of these scenarios needs the sequential loop
+        assert emu.n_serial.value == 0, emu.n_serial.value
+
+
+@pytest.mark.parametrize("name,B,T", [("Test-3AgentCluttered11x11-noghost", 64, 400), ("Test-4AgentEmpty5x5-crowded-noghost", 64, 300),
+                                       ("Test-4AgentEmpty5x5-respawn-noghost", 64, 300), ("Test-4AgentEmpty5x5-ghost0", 64, 200),
+                                       ("Test-4AgentEmpty5x5-crowded", 64, 300), ("Fuzz-3", 40, 120), ("Fuzz-8", 40, 120),
+                                       ("Fuzz-21", 40, 120), ("Fuzz-27", 40, 120), ("Fuzz-33", 40, 120)])
+def test_parallel_resolution_conflicts(name, B, T):
+    """the agent-parallel resolution where it has to give way: without ghost_mode agents block each other (a forward move
+    onto a cell somebody occupies or also heads for goes to the sequential loop), crowded rooms stack agents (ranks by turn
+    order) — some env-steps take the loop, most do not, and every one equals the oracle"""
+    import hostemu
+    seeds = 90210 + np.arange(B)
+    emu = hostemu.HostEmu(name, B, seeds, auto_reset=True, par=True)
+    orc = O.OracleBatch(scenarios.registered(name), seeds)
+    emu.reset()
+    orc.reset()
+    rng = np.random.RandomState(23)
+    for t in range(T):
+        a = rng.choice(7, size=(B, emu.n), p=[.15, .15, .5, .05, .05, .05, .05])
+        r, d = emu.step(a)
+        _o, r2, d2, _ = orc.step(a, render=False, auto_reset=True)
+        assert np.abs(r.astype(np.float64) - r2).max() <= REW_TOL and np.array_equal(d, d2), (name, t)
+        if t % 5 == 0 or t == T - 1:
+            _same_state(emu, orc, "%s step %d" % (name, t))
+    assert not emu.error.any()
+    if emu.n <= 8:
+        frac = emu.n_serial.value / float(B * T)
+        assert frac < 0.9, frac                      # (the loop is the exception even in a crowded 5x5 room)
+        if "noghost" in name:                        # (ghost_mode=0 `is not False`: moves may enter occupied cells, base.py:541)
+            assert emu.n_serial.value > 0            # ... but it is taken
