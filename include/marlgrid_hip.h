@@ -372,6 +372,7 @@ typedef struct MgPlaceTuning {  /* 0 = the default of each */
     int32_t share;              /* processes that share this device's memory (ranks of an oversubscribed launch): the default
                                  * budget is worked out from 1 / share of what is free.  0 / 1: this process counts on all of it */
     int32_t reserved1;
+    double fast_rate;           /* bytes per second at which a kept set counts as found whatever the median says: 5.9e12; < 0: never */
 } MgPlaceTuning;
 typedef struct MgPlaceStats {
     int32_t found, reused, candidates, windows;   /* windows: positions measured (>= candidates) */

@@ -76,7 +76,7 @@ E_NOMEM = -103
 class PlaceTuning(C.Structure):
     _fields_ = [("gain", C.c_double), ("slow_alloc_s_per_gib", C.c_double), ("min_bytes", C.c_uint64),
                 ("stir_bytes", C.c_uint64), ("max_candidates", C.c_int32), ("iters", C.c_int32),
-                ("share", C.c_int32), ("reserved1", C.c_int32)]
+                ("share", C.c_int32), ("reserved1", C.c_int32), ("fast_rate", C.c_double)]
 
 
 class PlaceStats(C.Structure):

@@ -618,7 +618,7 @@ class MultiGridEnv(object):
 
     @_on_device
     def _place_obs_buffers(self, budget=0, seconds=0.0, thorough=None, stir=None, reuse=True, min_bytes=0, gain=0.0, max_candidates=0,
-                           slow_alloc=0.0, stir_cap=0, iters=0, share=1):
+                           slow_alloc=0.0, stir_cap=0, iters=0, share=1, fast_rate=0.0):
         """place_obs="search" (default) / "thorough": choose WHERE in HBM the observation buffers live — mg_obs_place
         (include/marlgrid_hip.h; marlgrid_amd/csrc/mg_place_obs.hip) does the work, this is its caller.
 
@@ -654,7 +654,7 @@ class MultiGridEnv(object):
         if thorough and not seconds:
             seconds = 6.0
         tn = N.PlaceTuning(gain=gain, slow_alloc_s_per_gib=slow_alloc, min_bytes=min_bytes, stir_bytes=stir_cap,
-                           max_candidates=max_candidates, iters=iters, share=share)
+                           max_candidates=max_candidates, iters=iters, share=share, fast_rate=fast_rate)
         threshold = min_bytes or (256 << 20)
         any_replaced = False
         previous = list(getattr(self, "obs_placement", None) or [])

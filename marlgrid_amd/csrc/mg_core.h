@@ -207,7 +207,7 @@ struct MtAhead {
     uint32_t a[kMtAhead + 1], c[kMtAhead];
     int pos, used;          // the state these operands belong to (used == 0: nothing requested)
     bool in_lds;            // the obs kernel: the operands were sent to the wave's LDS landing zone (LDS-DMA: rows 0 - 2 of Mt::dma,
-                            // 16 / 4 / 16 bytes per stepping lane) instead of nine registers that would stay live — and, at the
+                            // 16 bytes each per stepping lane) instead of nine registers that would stay live — and, at the
                             // kernel's 128-register limit, be spilled with a full wait right after the request — across the
                             // agents' resolution; mt_ahead_fetch collects them when they are used
 };
@@ -227,8 +227,11 @@ MG_HD MtAhead mt_ahead(const Mt& mt) {
         if (mt.dma) {
             typedef const __attribute__((address_space(1))) void* gptr;
             typedef __attribute__((address_space(3))) void* lptr;
+            // (three 16-byte rows like mt_generate16_dma's: w[p .. p+3], w[p+4 .. p+7] — only its first word is an operand —,
+            // w[pm .. pm+3]; a 4-byte LDS-DMA load for the one word landed somewhere else on gfx950: measured, one env in 30 000)
+            if (p + 8 > MG_MT_N) { ah.used = 0; return ah; }
             __builtin_amdgcn_global_load_lds((gptr)(mt.w + p), (lptr)(mt.dma), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr)(mt.w + p + 4), (lptr)(mt.dma + 32), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr)(mt.w + p + 4), (lptr)(mt.dma + 32), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr)(mt.w + pm), (lptr)(mt.dma + 64), 16, 0, 0);
             ah.in_lds = true;
             return ah;
@@ -257,7 +260,7 @@ MG_HD MtAhead mt_ahead_fetch(const Mt& mt, const MtAhead& ah) {
             MG_OPAQUE32(va); MG_OPAQUE32(vc);
             r.a[i] = va; r.c[i] = vc;
         }
-        uint32_t v4 = mt.dma[32 + mt.dcol];
+        uint32_t v4 = z[32];
         MG_OPAQUE32(v4);
         r.a[kMtAhead] = v4;
     }

@@ -23,6 +23,9 @@
 #include "mg_device.h"
 #include "mg_encode_core.h"
 #include "mg_launch.h"
+#if defined(MG_AB_VARIANTS)
+#include <stdlib.h>
+#endif
 
 namespace mg {
 
@@ -44,10 +47,18 @@ hipError_t launch_encode(const MgConfig& cfg, const MgState& st, const uint8_t* 
                          hipStream_t s) {
     if (cfg.B <= 0) return hipSuccess;
     int PC = 0;
+#if defined(MG_AB_VARIANTS)
+    if (const char* f = getenv("MG_ENCODE_PC")) PC = atoi(f);      // measurement build: 1024 / 2048 / 4096 / 8192
+#endif
     const EncodeLaunch lc = encode_launch(cfg, out, PC);
     const size_t lds = kEncTab + (size_t)lc.nraw * (lc.two ? 2 : 1);
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
     const unsigned pieces = (unsigned)((lc.total + PC - 1) / PC);
     if (PC == 4096) hipLaunchKernelGGL((encode_kernel<4096>), dim3(pieces), dim3(256), lds, s, cfg, st, vis_mask, out, lc);
+#if defined(MG_AB_VARIANTS)
+    else if (PC == 2048) hipLaunchKernelGGL((encode_kernel<2048>), dim3(pieces), dim3(128), lds, s, cfg, st, vis_mask, out, lc);
+    else if (PC == 8192) hipLaunchKernelGGL((encode_kernel<8192>), dim3(pieces), dim3(512), lds, s, cfg, st, vis_mask, out, lc);
+#endif
     else hipLaunchKernelGGL((encode_kernel<1024>), dim3(pieces), dim3(64), lds, s, cfg, st, vis_mask, out, lc);
     return hipGetLastError();
 }

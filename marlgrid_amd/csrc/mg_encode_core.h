@@ -88,12 +88,14 @@ MG_HD EncodePiece encode_piece(const MgConfig& cfg, const EncodeLaunch& lc, long
     P.nd = (P.el * cfg.cells_stride + cl + 1 - P.c0a + 3) >> 2;
     return P;
 }
-constexpr int kEncTab = 2048;     // bytes of the two look-up tables in front of the planes
+constexpr int kEncRecCap = 512;    // agent records of a piece's envs staged in LDS (more — tiny grids with many agents —: read in place)
+constexpr int kEncTab = 2048 + kEncRecCap * 8;     // bytes of the two look-up tables and the staged records in front of the planes
 
 // A. the slice of `grid` and the tables -> LDS.  (The kernel issues its first 8 dwords per thread before anything else.)
 MG_HD void encode_stage(const MgConfig& cfg, const MgState& st, const EncodeLaunch& lc, const EncodePiece& P, uint8_t* smem, int tid, int T) {
     uint32_t* tab = reinterpret_cast<uint32_t*>(smem);                     // [256] object id (or agent code) -> triple
     uint32_t* tab2 = tab + 256;                                             // [256] two planes: agent code -> triple (0: none)
+    uint64_t* lrec = reinterpret_cast<uint64_t*>(smem + 2048);              // [kEncRecCap] the records of the piece's envs
     uint8_t* raw = smem + kEncTab;                                          // the piece's slice of `grid`, HBM layout
     uint8_t* ag = raw + lc.nraw;                                            // (two planes) agent marks, same layout
     const int n = cfg.n_agents;
@@ -102,23 +104,50 @@ MG_HD void encode_stage(const MgConfig& cfg, const MgState& st, const EncodeLaun
     uint32_t v[R];
 #pragma unroll
     for (int r = 0; r < R; r++) v[r] = (tid + r * T < P.nd) ? gsrc[tid + r * T] : 0u;
-    for (int o = tid; o < 256; o += T) {                                    // (T >= 64: at most four trips; one for T = 256)
-        uint32_t e = 0;
+    // the records of the envs the piece touches ride the same round trip (one contiguous run; the agents' phase then reads
+    // LDS only: as global loads behind the barrier they were a second dependent round trip of every workgroup)
+    const int nrec = (P.el + 1) * n;
+    const uint64_t* rsrc = st.agents + (size_t)P.b0 * n;
+    uint64_t rv[2] = {0ull, 0ull};
+    if (nrec <= kEncRecCap) {
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+            if (tid + r * T < nrec) rv[r] = rsrc[tid + r * T];
+    }
+    // the tables: at most four entries per thread (T >= 64), every load requested before the first is used (as a loop of
+    // load-then-store trips the one-wave workgroups of small batches made four dependent round trips of it)
+    uint32_t te[4], ta[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int o = tid + q * T;
+        uint32_t e = 0, a = 0;
         if (o > 0 && o < cfg.n_obj) {                                       // type, colour, state
             const MgObjDesc* d = cfg.obj + o;
             e = (uint32_t)d->type_idx | ((uint32_t)d->color_idx << 8) | ((uint32_t)d->state << 16);
         }
         // agent codes: agent k facing d -> (agent_type_idx, colour of k, d)
         const int code = lc.two ? o - 1 : o - cfg.n_obj;
-        uint32_t a = 0;
-        if (code >= 0 && code < 4 * n) a = (uint32_t)cfg.agent_type_idx | ((uint32_t)cfg.agent_color_idx[code >> 2] << 8) | ((uint32_t)(code & 3) << 16);
-        if (lc.two) { tab[o] = e; tab2[o] = a; }
-        else tab[o] = (o < cfg.n_obj) ? e : a;
+        if (o < 256 && code >= 0 && code < 4 * n) a = (uint32_t)cfg.agent_type_idx | ((uint32_t)cfg.agent_color_idx[code >> 2] << 8) | ((uint32_t)(code & 3) << 16);
+        te[q] = e; ta[q] = a;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int o = tid + q * T;
+        if (o < 256) {
+            if (lc.two) { tab[o] = te[q]; tab2[o] = ta[q]; }
+            else tab[o] = (o < cfg.n_obj) ? te[q] : ta[q];
+        }
     }
 #pragma unroll
     for (int r = 0; r < R; r++)
         if (tid + r * T < P.nd) reinterpret_cast<uint32_t*>(raw)[tid + r * T] = v[r];
     for (int i = tid + R * T; i < P.nd; i += T) reinterpret_cast<uint32_t*>(raw)[i] = gsrc[i];
+    if (nrec <= kEncRecCap) {
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+            if (tid + r * T < nrec) lrec[tid + r * T] = rv[r];
+        for (int i = tid + 2 * T; i < nrec; i += T) lrec[i] = rsrc[i];
+    }
     if (lc.two)
         for (int i = tid; i < lc.nraw / 4; i += T) reinterpret_cast<uint32_t*>(ag)[i] = 0u;
 }
@@ -127,12 +156,14 @@ MG_HD void encode_stage(const MgConfig& cfg, const MgState& st, const EncodeLaun
 MG_HD void encode_agents(const MgConfig& cfg, const MgState& st, const EncodeLaunch& lc, const EncodePiece& P, uint8_t* smem, int tid, int T) {
     uint8_t* raw = smem + kEncTab;
     uint8_t* ag = raw + lc.nraw;
+    const uint64_t* lrec = reinterpret_cast<const uint64_t*>(smem + 2048);
     const int n = cfg.n_agents, cells = lc.cells, stride = cfg.cells_stride;
     const int items = (P.el + 1) * n;
+    const bool staged = items <= kEncRecCap;
     for (int it = tid; it < items; it += T) {
         const uint32_t e = enc_div((uint32_t)it, (uint32_t)n, lc.m_n);
         const int k = it - (int)e * n;
-        const uint64_t* recs = st.agents + (size_t)(P.b0 + e) * n;
+        const uint64_t* recs = staged ? lrec + (size_t)e * n : st.agents + (size_t)(P.b0 + e) * n;
         const uint64_t r = recs[k];
         if (!(rec_byte(r, MG_AG_FLAGS) & MG_AF_PLACED)) continue;
         const int c = (int)rec_byte(r, MG_AG_X) * cfg.H + (int)rec_byte(r, MG_AG_Y);
@@ -245,6 +276,7 @@ inline EncodeLaunch encode_launch(const MgConfig& cfg, const void* out, int& PC)
     lc.aligned = (reinterpret_cast<uintptr_t>(out) & 15) == 0 ? 1 : 0;
     // pieces of 4096 cells (256 threads) where that makes a thousand workgroups, else of 1024 cells (one wave each)
     if (PC == 0) PC = lc.total / 4096 >= 1024 ? 4096 : 1024;
+    if (PC < 1024) PC = 1024;
     lc.nraw = encode_raw_bytes(lc.cells, cfg.cells_stride, PC);
     return lc;
 }

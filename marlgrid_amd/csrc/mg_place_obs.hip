@@ -94,6 +94,7 @@ int32_t mg_obs_place(const MgConfig* cfg, const MgState* st, int32_t n_buffers, 
     const uint64_t min_bytes = tn.min_bytes ? tn.min_bytes : (256ull << 20);
     const double slow_alloc = tn.slow_alloc_s_per_gib > 0 ? tn.slow_alloc_s_per_gib : (tn.slow_alloc_s_per_gib < 0 ? 0.0 : 0.02);
     const uint64_t stir_cap = tn.stir_bytes ? tn.stir_bytes : (64ull << 30);
+    const double fast_rate = tn.fast_rate > 0 ? tn.fast_rate : (tn.fast_rate < 0 ? 1e30 : kFastRate);
     const bool default_seconds = seconds <= 0;
     if (default_seconds) seconds = 2.0;
     const uint64_t share = tn.share > 1 ? (uint64_t)tn.share : 1;     // this process counts on 1 / share of what is free
@@ -310,7 +311,7 @@ int32_t mg_obs_place(const MgConfig* cfg, const MgState* st, int32_t n_buffers, 
                 // the bench shard's 925 MB against 0.188 inside a block): buffers of several GB span the driver's blocks wherever
                 // they lie — every candidate is "fast", none is 12 % under the median, and there is nothing left to look for
                 // (measured: BASELINE configs[2] 2.5 GB buffers at 6.4-6.5 TB/s, configs[4] 16 GB at 6.2-6.4, plain or constructed)
-                if ((int)cands.size() >= need && (double)nbytes / ((double)nth_ms(need - 1) * 1e-3) >= kFastRate) {
+                if ((int)cands.size() >= need && (double)nbytes / ((double)nth_ms(need - 1) * 1e-3) >= fast_rate) {
                     S.stopped = MG_PLACE_STOP_FOUND;
                     fast = true;
                     break;

@@ -166,7 +166,7 @@ def test_obs_buffer_placement_search_when_nothing_is_found():
     twin.reset()
     free0 = torch.cuda.mem_get_info()[0]
     env._place_obs_buffers(thorough=True, stir=True, reuse=False, gain=0.6, slow_alloc=-1.0, stir_cap=4 << 30, seconds=60.0,
-                           max_candidates=40, budget=128 << 30)
+                           max_candidates=40, budget=128 << 30, fast_rate=-1.0)
     pm = env._groups[0].placement_ms
     assert pm["found"] is False and pm["stopped"] == "cap" and pm["candidates"] == 82        # 2 + 2 passes of 40 (12 + 12 + 12 by level, 4 plain)
     assert pm["passes"] == 2                                         # nothing found: a second pass, from the best two of the first
@@ -245,9 +245,12 @@ def test_obs_place_through_the_c_abi():
     assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)
     # too little memory allowed for even one candidate: the plain buffers are still handed out (found = 0), nothing leaks
     rc, bufs4, s4, _ = place(budget=1 << 20, seconds=0.5)
-    assert rc == 0 and s4.found == 0 and s4.stopped in (2, 3, 4) and s4.pinned_bytes == 2 * nbytes
+    # (found = 1 only if the plain pair happens to take the raster's bytes at the fast class's 5.9 TB/s)
+    assert rc == 0 and s4.pinned_bytes == 2 * nbytes
+    assert (s4.found == 0 and s4.stopped in (2, 3, 4)) or (s4.found == 1 and nbytes / (max(s4.kept_ms[0], s4.kept_ms[1]) * 1e-3) >= 5.9e12)
     for b in bufs4:
         assert L.mg_obs_release(C.c_void_p(b)) == 0
+    L.mg_obs_trim(-1)                                   # (a pair that counted as found is remembered when it is released)
     assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)
 
 
