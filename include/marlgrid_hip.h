@@ -60,9 +60,9 @@ extern "C" {
 #endif
 
 #define MG_ABI_VERSION 6
-#define MG_MAX_AGENTS 16
-#define MG_MAX_OBJ 64
-#define MG_MAX_GEN 32
+#define MG_MAX_AGENTS 32  /* agents per env (the reference: any number, base.py:335-369; register_marl_env asserts <= 6) */
+#define MG_MAX_OBJ 256    /* object kinds incl. id 0 = None: the ids are uint8, as the reference's registry keys are (base.py:25,91) */
+#define MG_MAX_GEN 1024   /* ops of a reset program (device memory: a sanity bound, not a buffer size) */
 #define MG_MAX_VIEW 15
 #define MG_KEY_WORDS 2
 #define MG_MT_N 624
@@ -159,8 +159,8 @@ typedef struct MgConfig {
     double prestige_beta[MG_MAX_AGENTS], prestige_scale[MG_MAX_AGENTS];   /* agents.py:31-32, 141-153 */
     int32_t any_hide;                                             /* 1 if any mask below is non-zero */
     uint32_t hide_agent_mask;                                     /* bit k: agent k hides type 'Agent' */
-    uint64_t hide_obj_mask[MG_MAX_AGENTS];                        /* bit o: agent k hides object id o
-                                                                   * (hide_item_types, base.py:441-449) */
+    const uint32_t* hide_by_obj; /* device uint32 [n_obj] or NULL (nobody hides an object): bit k of entry o = agent k hides
+                             * object id o (hide_item_types, base.py:441-449) */
     const MgObjDesc* obj;   /* device, [n_obj] */
     const uint8_t* atlas;   /* device, [4 orientations][n_tiles][tile_size*tile_size*3], pre-rotated.
                              * tile 0 = shadow; 1+o = object o alone (o=0: empty tile);
@@ -203,7 +203,11 @@ typedef struct MgGenOp {
 typedef struct MgGenProgram {
     const uint8_t* template_grid; /* device, [cells_stride] */
     int32_t n_ops;
-    MgGenOp ops[MG_MAX_GEN];      /* placements and late static edits, in `_gen_grid` order */
+    const MgGenOp* ops;           /* DEVICE, [n_ops]: placements and late static edits, in `_gen_grid` order — upstream's `_gen_grid`
+                                   * is free Python of any length (marlgrid/envs); the program lives in device memory, not in the
+                                   * launch arguments.  The library cannot look into it from the host: the caller hands over ops
+                                   * with 0 <= obj < n_obj (>= 1 for placements), a non-empty rectangle inside the grid, count >= 0,
+                                   * max_tries >= 0 and reject in [-1, n_reject) */
     const uint8_t* reject;        /* device, [n_reject][cells_stride], index x*H + y, != 0 = rejected; NULL if no op
                                    * has a reject table */
     int32_t n_reject;

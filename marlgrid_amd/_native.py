@@ -7,7 +7,7 @@ this module raises.  Build it with `python -c "import __graft_entry__ as g; g.bu
 import ctypes as C
 import os
 
-MAX_AGENTS, MAX_OBJ, MAX_GEN, MAX_VIEW, KEY_WORDS, MT_N, MT_HEAD = 16, 64, 32, 15, 2, 624, 16
+MAX_AGENTS, MAX_OBJ, MAX_GEN, MAX_VIEW, KEY_WORDS, MT_N, MT_HEAD = 32, 256, 1024, 15, 2, 624, 16
 ABI_VERSION = 6
 
 OK = 0
@@ -47,7 +47,7 @@ class Config(C.Structure):
                 ("any_spawn_delay", C.c_int32), ("spawn_delay", C.c_int32 * MAX_AGENTS),
                 ("prestige_mask", C.c_uint32), ("prestige_amax", C.c_uint8 * 4), ("prestige_sprite_tile", C.c_int32),
                 ("prestige_beta", C.c_double * MAX_AGENTS), ("prestige_scale", C.c_double * MAX_AGENTS),
-                ("any_hide", C.c_int32), ("hide_agent_mask", C.c_uint32), ("hide_obj_mask", C.c_uint64 * MAX_AGENTS),
+                ("any_hide", C.c_int32), ("hide_agent_mask", C.c_uint32), ("hide_by_obj", C.c_void_p),
                 ("obj", C.c_void_p), ("atlas", C.c_void_p), ("spawn_reject", C.c_void_p)]
 
 
@@ -63,7 +63,7 @@ class GenOp(C.Structure):
 
 
 class GenProgram(C.Structure):
-    _fields_ = [("template_grid", C.c_void_p), ("n_ops", C.c_int32), ("ops", GenOp * MAX_GEN),
+    _fields_ = [("template_grid", C.c_void_p), ("n_ops", C.c_int32), ("ops", C.c_void_p),      # ops: DEVICE memory, GenOp [n_ops]
                 ("reject", C.c_void_p), ("n_reject", C.c_int32)]
 
 

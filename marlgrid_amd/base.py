@@ -806,8 +806,9 @@ class MultiGridEnv(object):
         if len(self._tr_ops) > N.MAX_GEN:
             fills = sum(1 for op in self._tr_ops if op[2] == 0)
             raise NotImplementedError("_gen_grid records %d reset-program ops — %d groups of random placements and %d rectangle "
-                                      "fills for static edits made after the first place_obj — and the device program holds %d "
-                                      "(MG_MAX_GEN): draw the static layout before the first place_obj (it then costs nothing)"
+                                      "fills for static edits made after the first place_obj — and a device program holds at most "
+                                      "%d (MG_MAX_GEN: a sanity bound — every env replays the whole program at every reset): draw the "
+                                      "static layout before the first place_obj (it then costs nothing)"
                                       % (len(self._tr_ops), len(self._tr_ops) - fills, fills, N.MAX_GEN))
         self._spec_last = dict(sym=list(self._tr_sym), ops=list(self._tr_ops), late=dict(self._tr_late))
         return g._template, list(self._tr_ops)
@@ -1003,16 +1004,17 @@ class MultiGridEnv(object):
             cfg.prestige_sprite_tile = atlas.shape[1] - 4
             for d in range(4):      # max alpha of the (white) sprite per dir = max of blend_tiles' alpha map
                 cfg.prestige_amax[d] = int(atlas[0, atlas.shape[1] - 4 + d][..., 0].max())
-        # hide_item_types (base.py:441-449): per viewer, the object ids / 'Agent' whose type is hidden
+        # hide_item_types (base.py:441-449): per object id the agents that hide its type (bit k = agent k; a device table,
+        # uploaded by _sync_tables), and the agents that hide 'Agent'
+        hide_by = np.zeros(len(objs), np.uint32)
         for k, a in enumerate(self.agents):
-            m = 0
             for i, o in enumerate(objs):
                 if o is not None and o.type in a.hide_item_types:
-                    m |= 1 << i
-            cfg.hide_obj_mask[k] = m
+                    hide_by[i] |= np.uint32(1 << k)
             if "Agent" in a.hide_item_types:
                 cfg.hide_agent_mask |= 1 << k
-        cfg.any_hide = int(cfg.hide_agent_mask != 0 or any(cfg.hide_obj_mask[k] for k in range(len(self.agents))))
+        grp.hide_by = hide_by if hide_by.any() else None
+        cfg.any_hide = int(cfg.hide_agent_mask != 0 or bool(hide_by.any()))
         self._refresh_cfg(cfg)
         return cfg, raw, flat, atlas
 
@@ -1095,6 +1097,8 @@ class MultiGridEnv(object):
             g.atlas_dev = torch.from_numpy(flat).to(self.device)
             g.atlas = atlas
             cfg.obj, cfg.atlas = g.obj_dev.data_ptr(), g.atlas_dev.data_ptr()
+            g.hide_dev = None if g.hide_by is None else torch.from_numpy(g.hide_by.view(np.int32)).to(self.device)
+            cfg.hide_by_obj = None if g.hide_dev is None else g.hide_dev.data_ptr()
             g.cfg = cfg
             # which instantiation of the observation kernel the launcher picks for this group (what rocprofv3 will call the
             # launch) — and a warning, once per configuration, when it is the fully generic one
@@ -1120,8 +1124,12 @@ class MultiGridEnv(object):
         prog.template_grid = prog._template_dev.data_ptr()
         prog.n_ops = len(ops)
         tables = []                   # place_obj(reject_fn=) tables, one row of cells_stride bytes each
+        host_ops = (N.GenOp * max(1, len(ops)))()
         for i, (obj, count, max_tries, x0, y0, x1, y1, rej) in enumerate(ops):
-            o = prog.ops[i]
+            # (the library cannot look into device memory from the host: what the kernels rely on is checked here)
+            assert (1 if max_tries > 0 else 0) <= obj < len(self.obj_reg.objs) and count >= 0 and max_tries >= 0
+            assert 0 <= x0 < x1 <= self.width and 0 <= y0 < y1 <= self.height
+            o = host_ops[i]
             o.obj, o.count, o.max_tries, o.x0, o.y0, o.x1, o.y1 = obj, count, max_tries, x0, y0, x1, y1
             o.reject = -1
             if rej is not None:
@@ -1129,6 +1137,9 @@ class MultiGridEnv(object):
                 row[:self.width * self.height] = np.frombuffer(rej, np.uint8)
                 o.reject = len(tables)
                 tables.append(row)
+        # the ops live in device memory (MgGenProgram::ops), kept alive on the struct like the template
+        prog._ops_dev = torch.from_numpy(np.frombuffer(bytes(host_ops), np.uint8).copy()).to(self.device)
+        prog.ops = prog._ops_dev.data_ptr()
         prog.n_reject = len(tables)
         if tables:
             prog._reject_dev = torch.from_numpy(np.stack(tables)).to(self.device)

@@ -32,13 +32,11 @@ int check_cfg(const MgConfig* c) {
 }
 
 int check_prog(const MgConfig* cfg, const MgGenProgram* prog) {
+    // (the ops themselves are device memory — MgGenProgram::ops —: what they must satisfy is the caller's to guarantee)
+    (void)cfg;
     if (!prog || !prog->template_grid || prog->n_ops < 0 || prog->n_ops > MG_MAX_GEN) return MG_E_ARG;
-    for (int i = 0; i < prog->n_ops; i++) {
-        const MgGenOp& op = prog->ops[i];
-        if (op.max_tries < 0 || op.obj < (op.max_tries == 0 ? 0 : 1) || op.obj >= cfg->n_obj || op.count < 0) return MG_E_ARG;   // (a static edit may put None)
-        if (op.x0 < 0 || op.y0 < 0 || op.x1 > cfg->W || op.y1 > cfg->H || op.x1 <= op.x0 || op.y1 <= op.y0) return MG_E_ARG;
-        if (op.reject < -1 || op.reject >= prog->n_reject || (op.reject >= 0 && !prog->reject)) return MG_E_ARG;
-    }
+    if (prog->n_ops > 0 && !prog->ops) return MG_E_ARG;
+    if (prog->n_reject < 0 || (prog->n_reject > 0 && !prog->reject)) return MG_E_ARG;
     return MG_OK;
 }
 

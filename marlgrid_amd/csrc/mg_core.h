@@ -501,13 +501,14 @@ struct StepScratch {        // per-workgroup arrays, this env is column `col`, e
     uint8_t* act;           // [n][S] action (0xFF: invalid)
     uint8_t* fb;            // [n][S] front-cell base id, pre-loaded (null: `g` is cheap to read, no pre-load)
     const MgObjDesc* obj;   // [n_obj] object table (shared)
-    const uint8_t* oflags;  // [MG_MAX_OBJ] object flags (shared)
+    const uint8_t* oflags;  // [n_obj] object flags (shared)
     int S, col;
     bool defer_writeback = false;   // the caller writes records and RNG head back itself (StepOut::head_k; the obs kernel)
     uint32_t* dma = nullptr;        // the obs kernel: the wave's LDS landing zone for one-round-trip head refills (mt_generate16_dma)
     // the obs kernel's agent-parallel resolution (step_par_*, S = 8): [n][8] flags / turns, the envs' step counts, and
     // where step_par_commit puts the settled records (a second [n][8] column set: the sequential loop of an env that
     // needs it still reads the old ones in `rec`)
+    uint8_t* ord = nullptr;         // [n][S] iter_order of an env with more than 16 agents (step_begin)
     uint8_t* pflag = nullptr;
     uint8_t* ordp = nullptr;
     int32_t* psc = nullptr;
@@ -638,17 +639,28 @@ MG_HD StepCtx step_begin(const MgConfig& cfg, const MgState& st, int b, const St
 
     // iter_order = arange(n); np_random.shuffle(iter_order)  (base.py:514-516): legacy Fisher-Yates
     // over numpy's masked-rejection bounded draws — served from the look-ahead head
-    // (the permutation as sixteen nibbles of one register: a swap is four shifts instead of four LDS round trips)
-    static_assert(MG_MAX_AGENTS <= 16, "iter_order: one nibble per agent");
+    // (up to 16 agents the permutation is sixteen nibbles of one register: a swap is four shifts instead of four LDS round
+    // trips; with more agents — up to MG_MAX_AGENTS — it lives in the step's scratch column sc.ord)
+    static_assert(MG_MAX_AGENTS <= 256, "iter_order: one byte per agent in sc.ord");
     // (the identity, made HERE: as a loop invariant of the obs kernel's env loop it is hoisted, spilled at the kernel's
     // register limit and fetched back from scratch memory in front of every shuffle)
     uint32_t id_lo = 0x76543210u, id_hi = 0xFEDCBA98u;
     MG_OPAQUE32(id_lo); MG_OPAQUE32(id_hi);
     uint64_t order = (uint64_t)id_lo | ((uint64_t)id_hi << 32);
-    for (int i = n - 1; i >= 1; i--) {
-        const int j = (int)c.mt.bounded((uint32_t)i);
-        const uint64_t oi_ = (order >> (4 * i)) & 0xFull, oj_ = (order >> (4 * j)) & 0xFull;
-        order = (order & ~((0xFull << (4 * i)) | (0xFull << (4 * j)))) | (oj_ << (4 * i)) | (oi_ << (4 * j));
+    if (n <= 16) {
+        for (int i = n - 1; i >= 1; i--) {
+            const int j = (int)c.mt.bounded((uint32_t)i);
+            const uint64_t oi_ = (order >> (4 * i)) & 0xFull, oj_ = (order >> (4 * j)) & 0xFull;
+            order = (order & ~((0xFull << (4 * i)) | (0xFull << (4 * j)))) | (oj_ << (4 * i)) | (oi_ << (4 * j));
+        }
+    } else {
+        for (int i = 0; i < n; i++) sc.ord[i * S + col] = (uint8_t)i;
+        for (int i = n - 1; i >= 1; i--) {
+            const int j = (int)c.mt.bounded((uint32_t)i);
+            const uint8_t t = sc.ord[i * S + col];
+            sc.ord[i * S + col] = sc.ord[j * S + col];
+            sc.ord[j * S + col] = t;
+        }
     }
     c.order = order;
     c.ahead = mt_ahead(c.mt);
@@ -663,7 +675,7 @@ MG_HD void step_agents(const MgConfig& cfg, const MgState& st, float* rewards, i
     int err = c.err;
     bool grid_dirty = c.grid_dirty;
     for (int oi = 0; oi < n; oi++) {
-        const int k = (int)((c.order >> (4 * oi)) & 0xFull);
+        const int k = n <= 16 ? (int)((c.order >> (4 * oi)) & 0xFull) : (int)sc.ord[oi * S + col];
         MoveEffect fxm = {0.0f, false, 0.0};      // agent.reward(rwd) was called: `rewarded` (prestige bookkeeping)
         uint64_t r = s_rec[k * S + col];
         const uint32_t flags = rec_byte(r, MG_AG_FLAGS);

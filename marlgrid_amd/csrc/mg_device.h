@@ -61,8 +61,28 @@ struct FusedStep {
     MgGenProgram prog;        // auto-reset program (has_prog)
 };
 
-// block-shared LDS of the obs-render kernel after the atlas: object flags, overlap slots, hide masks, prestige scales, flags2
-constexpr int kRenderShared = 3 * MG_MAX_OBJ + 2 * MG_MAX_AGENTS * 8 + MG_MAX_OBJ * 32 + MG_MAX_AGENTS;   // ... + the object table (fused step), the viewer map
+// Block-shared LDS of the obs-render kernel behind the atlas, sized by the configuration (object kinds in sixteens): per
+// object kind its flags, overlap slot, flags2 and — with hide_item_types — the mask of the agents that hide it; per agent
+// its prestige scale and the viewer map; for the fused step the object table (32 B per kind) and the first kOpsLds ops of
+// the reset program (the rest, if any, is read in place).  Offsets in bytes from the end of the atlas.
+constexpr int kOpsLds = 32;
+struct RenderShared { int no, oflags, oslot, oflags2, hideby, pscale, vmap, obj, ops, total; };
+__host__ __device__ inline RenderShared render_shared_layout(const MgConfig& cfg) {
+    RenderShared h;
+    h.no = ((cfg.n_obj < 1 ? 1 : cfg.n_obj) + 15) & ~15;
+    int o = 0;
+    h.oflags = o;  o += h.no;
+    h.oslot = o;   o += h.no;
+    h.oflags2 = o; o += h.no;
+    h.hideby = o;  o += cfg.any_hide ? h.no * 4 : 0;          // uint32 [no]
+    h.pscale = o;  o += MG_MAX_AGENTS * 8;                    // double [MG_MAX_AGENTS]
+    h.vmap = o;    o += MG_MAX_AGENTS;                        // uint8 [MG_MAX_AGENTS]
+    o = (o + 15) & ~15;
+    h.obj = o;     o += h.no * 32;                            // MgObjDesc [no]
+    h.ops = o;     o += kOpsLds * 32;                         // MgGenOp [kOpsLds]
+    h.total = o;
+    return h;
+}
 
 // x / d for small operands (x * d < 2^32) by multiply-high with ceil(2^32 / d): item index -> (slot, rest)
 struct SmallDiv {
@@ -135,6 +155,7 @@ struct RenderLaunch {
     uint32_t m_n, m_nv, m_nvVV, m_VV, m_VS, m_nvVS;   // Div20 multipliers of n, nv, nv * VS^2, VS^2, VS, nv * VS
     int depth_mode;                             // measurement builds: look-ahead depth forced for all waves (0: by wave)
     int atlas_lds;                              // bytes the atlas takes in LDS (render_atlas_lds_bytes; 0: read in place)
+    RenderShared sh;                            // the block-shared tables behind it (render_shared_layout)
 #if defined(MG_AB_VARIANTS)
     unsigned long long* stamps;                 // measurement build: phase stamps of every wave (tools/phase_stamps.py), or null
 #endif
@@ -195,7 +216,7 @@ __host__ __device__ inline RenderScratch render_scratch_for(const MgConfig& cfg,
     // (the recoloured tiles of a 'prestige' env: as the atlas's — gather raster: in padded rows)
     const int dyn = cfg.prestige_mask ? (cfg.any_hide ? 2 : 1) * n * 4 * ts * (mode == 2 ? render_gather_row_bytes(ts) : ts * 3) + (mode == 2 ? 32 : 0) : 0;
     // (`fixed`: what a workgroup holds besides its waves' scratch — exactly the launcher's sum, launch_render_t)
-    const int atlas_b = render_atlas_lds_bytes(cfg, mode), fixed = kRenderShared;
+    const int atlas_b = render_atlas_lds_bytes(cfg, mode), fixed = render_shared_layout(cfg).total;
     const bool gather = mode == 2;
     int rows = 0, out = 0;
     if (!gather && !render_chunk_raster(cfg, mode)) {
@@ -211,12 +232,15 @@ __host__ __device__ inline RenderScratch render_scratch_for(const MgConfig& cfg,
     // made right before the env's raster)
     const RenderScratch b = render_scratch_layout(cfg.cells_stride, n, nv, vs, 1, dyn, out, rows, true, 0, gather);
     const int resident = (atlas_b + 4 * b.total + fixed <= 160 * 1024) ? atlas_b : 0;   // else the atlas is read in place
+    // (a wave stages its batch's records with two per lane — mg_render_kernel.h, step_load_issue —: up to 8 envs of up to
+    // 16 agents, 4 envs of more)
+    const int kmax = n > 16 ? 4 : 8;
     // ('prestige' — 12-wave workgroups next to a large atlas —: fewer view slots before fewer staged envs or fewer waves)
-    for (int slots = dyn ? 8 : 0; dyn && slots >= 1; slots >>= 1) {
-        const RenderScratch t = render_scratch_layout(cfg.cells_stride, n, nv, vs, 8, dyn, out, rows, cfg.any_hide != 0, slots, gather);
+    for (int slots = dyn ? kmax : 0; dyn && slots >= 1; slots >>= 1) {
+        const RenderScratch t = render_scratch_layout(cfg.cells_stride, n, nv, vs, kmax, dyn, out, rows, cfg.any_hide != 0, slots, gather);
         if (resident + wpb * t.total + fixed <= 160 * 1024) return t;
     }
-    int k = 8;
+    int k = kmax;
     while (k > 1 && resident + wpb * render_scratch_layout(cfg.cells_stride, n, nv, vs, k, dyn, out, rows, cfg.any_hide != 0, dyn ? 1 : 0, gather).total + fixed > 160 * 1024) k >>= 1;
     return render_scratch_layout(cfg.cells_stride, n, nv, vs, k, dyn, out, rows, cfg.any_hide != 0, dyn ? 1 : 0, gather);
 }

@@ -35,20 +35,20 @@ MG_RENDER_GROUP_V(MG_RENDER_EXTERN)
 static int render_mode_for(const MgConfig& cfg) {
     if (!render_gather(cfg)) return 0;
     const RenderScratch L = render_scratch_for(cfg, 4, 2);
-    return (size_t)render_atlas_lds_bytes(cfg, 2) + kRenderShared + 4 * (size_t)L.total <= 160 * 1024 ? 2 : 0;
+    return (size_t)render_atlas_lds_bytes(cfg, 2) + (size_t)render_shared_layout(cfg).total + 4 * (size_t)L.total <= 160 * 1024 ? 2 : 0;
 }
 
 int render_min_lds_bytes(const MgConfig& cfg) {
     const int mode = render_mode_for(cfg);
     const RenderScratch L = render_scratch_for(cfg, 4, mode);
     const int atlas_b = render_atlas_lds_bytes(cfg, mode);
-    const int rest = kRenderShared + 4 * L.total;
+    const int rest = render_shared_layout(cfg).total + 4 * L.total;
     return atlas_b + rest <= 160 * 1024 ? atlas_b + rest : rest;   // else the atlas is read in place
 }
 
 static size_t render_lds_bytes(const MgConfig& cfg, int wpb, int mode = 0) {
     const RenderScratch L = render_scratch_for(cfg, wpb, mode);
-    return (size_t)render_atlas_lds_bytes(cfg, mode) + kRenderShared + (size_t)wpb * L.total;
+    return (size_t)render_atlas_lds_bytes(cfg, mode) + (size_t)render_shared_layout(cfg).total + (size_t)wpb * L.total;
 }
 
 // Workgroup shape.  16 waves per workgroup walk 16 *adjacent* envs at a time (a 450 KB contiguous
@@ -86,6 +86,9 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
     none.action_bytes = 8;
     none.prog.template_grid = nullptr;
     none.prog.n_ops = 0;
+    none.prog.ops = nullptr;
+    none.prog.reject = nullptr;
+    none.prog.n_reject = 0;
     if (!fs) fs = &none;
     if ((view_cells || view_agent || vis_mask) && !(view_cells && view_agent && vis_mask)) return hipErrorInvalidValue;
 #if defined(MG_DEV_ONLY)   // development: compile ONE instantiation (register / ISA checks without the other sixty),
@@ -97,7 +100,7 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
     const int wpb = choose_wpb(cfg, mode);
     if (cfg.prestige_mask) {   // per-env recoloured agent tiles (LDS), 4-wave workgroups
         const RenderScratch L = render_scratch_for(cfg, 4);
-        const size_t lds4 = (size_t)render_atlas_lds_bytes(cfg, 0) + kRenderShared +
+        const size_t lds4 = (size_t)render_atlas_lds_bytes(cfg, 0) + (size_t)render_shared_layout(cfg).total +
                             4 * (size_t)L.total;
         if (lds4 > 160 * 1024) {   // the static atlas stays in global memory
             if (ts == 8) return launch_render_t<0, 8, 4, 12>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick);
@@ -173,7 +176,7 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
     }
     {   // atlas too large for LDS (next to 4 waves of scratch): read it from global memory instead
         const RenderScratch L = render_scratch_for(cfg, 4);
-        const size_t lds4 = (size_t)render_atlas_lds_bytes(cfg, 0) + kRenderShared +
+        const size_t lds4 = (size_t)render_atlas_lds_bytes(cfg, 0) + (size_t)render_shared_layout(cfg).total +
                             4 * (size_t)L.total;
         if (lds4 > 160 * 1024) {
             if (ts == 8) return launch_render_t<0, 8, 4, 8>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick);

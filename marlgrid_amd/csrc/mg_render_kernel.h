@@ -101,7 +101,7 @@ __device__ __forceinline__ const T& kernarg_again(size_t offset) {
     const MgConfig& cfg = kernarg_again<MgConfig>(offsetof(RenderKernargs, cfg));                              \
     const RenderLaunch& lc = kernarg_again<RenderLaunch>(offsetof(RenderKernargs, lc));                        \
     const RenderScratch& L = lc.L;                                                                             \
-    uint8_t* const ws = smem + (kGlobalAtlas ? 0 : lc.atlas_lds) + kRenderShared + (size_t)wave * L.total;     \
+    uint8_t* const ws = smem + (kGlobalAtlas ? 0 : lc.atlas_lds) + lc.sh.total + (size_t)wave * L.total;       \
     uint8_t* const w_stage_g = ws + L.grid;                                                                    \
     uint64_t* const w_stage_r = reinterpret_cast<uint64_t*>(ws + L.rec);                                       \
     double* const w_stage_p = reinterpret_cast<double*>(ws + L.pres);                                          \
@@ -148,6 +148,7 @@ __device__ __forceinline__ StepScratch fused_step_scratch(const MgConfig& cfg, i
     sc.act = sp + n * 8 * 8 + MG_MT_HEAD * 8 * 4;                               // [n][8]
     sc.pflag = sc.act + n * 8;                                                  // [n][8]  step_par_*: moved / needs the loop
     sc.ordp = sc.pflag + n * 8;                                                 // [n][8]  ... the agent's turn
+    sc.ord = sc.ordp;                                                           // (more than 16 agents — no lane-parallel resolution —: iter_order)
     sc.psc = reinterpret_cast<int32_t*>(sc.ordp + n * 8);                       // [8]     ... the env's step count
     sc.rec_out = sc.rec;                                                        // (in place: the lanes of a wave run in lockstep)
     sc.fb = nullptr;                                                            // (the grid is a staged LDS copy: no pre-load)
@@ -280,13 +281,17 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     constexpr bool kSplit = (V_ == 12);        // static tiles in global memory, recoloured ones in LDS
     constexpr uint32_t kInLds = 0x80000000u;   // kSplit: marks a source offset as relative to the LDS base
     uint8_t* s_atlas = smem;
-    uint8_t* s_oflags = smem + atlas_bytes;             // [MG_MAX_OBJ]
-    uint8_t* s_oslot = s_oflags + MG_MAX_OBJ;           // [MG_MAX_OBJ]
-    uint64_t* s_hide = reinterpret_cast<uint64_t*>(s_oslot + MG_MAX_OBJ);   // [MG_MAX_AGENTS] hide_obj_mask
-    double* s_pscale = reinterpret_cast<double*>(s_hide + MG_MAX_AGENTS);     // [MG_MAX_AGENTS] prestige_scale
-    uint8_t* s_oflags2 = reinterpret_cast<uint8_t*>(s_pscale + MG_MAX_AGENTS); // [MG_MAX_OBJ]
-    MgObjDesc* s_obj = reinterpret_cast<MgObjDesc*>(s_oflags2 + MG_MAX_OBJ);      // [MG_MAX_OBJ] (fused step only)
-    uint8_t* s_vmap = reinterpret_cast<uint8_t*>(s_obj + MG_MAX_OBJ);             // [MG_MAX_AGENTS] viewer slot -> agent
+    // the block-shared tables (render_shared_layout: sized by the configuration's object kinds, in sixteens)
+    uint8_t* const s_shared = smem + atlas_bytes;
+    const int NO = lc.sh.no;                                                            // object kinds, padded
+    uint8_t* s_oflags = s_shared + lc.sh.oflags;                                        // [NO]
+    uint8_t* s_oslot = s_shared + lc.sh.oslot;                                          // [NO]
+    uint8_t* s_oflags2 = s_shared + lc.sh.oflags2;                                      // [NO]
+    uint32_t* s_hideby = reinterpret_cast<uint32_t*>(s_shared + lc.sh.hideby);          // [NO] who hides the kind (any_hide only)
+    double* s_pscale = reinterpret_cast<double*>(s_shared + lc.sh.pscale);              // [MG_MAX_AGENTS] prestige_scale
+    uint8_t* s_vmap = s_shared + lc.sh.vmap;                                            // [MG_MAX_AGENTS] viewer slot -> agent
+    MgObjDesc* s_obj = reinterpret_cast<MgObjDesc*>(s_shared + lc.sh.obj);              // [NO] (fused step only)
+    MgGenOp* s_ops = reinterpret_cast<MgGenOp*>(s_shared + lc.sh.ops);                  // [kOpsLds] the reset program's first ops (fused step)
     constexpr bool kChunkRaster = TS_ > 0 && (TS_ % 8) == 0 && RM_ == 0;
     constexpr bool kStreamRaster = !kChunkRaster && !kGather;     // assemble-and-stream
     // the rasters bound by instruction issue run at a raised wave priority (phase 6); measured per instantiation: the gather
@@ -414,10 +419,11 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             }
             const uint4* asrc = reinterpret_cast<const uint4*>(cfg.atlas);
             const int na = kGlobalAtlas ? 0 : render_atlas_raw_bytes(cfg) / 16;   // (0 when the atlas is read in place)
-            const int no = fs.enabled ? cfg.n_obj * 2 : 0;                  // object table (fused step): <= 128 chunks
-            uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0, o0 = a0;
+            const int no = fs.enabled ? cfg.n_obj * 2 : 0;                  // object table (fused step): <= 512 16-byte pieces
+            const int nops = fs.enabled && fs.has_prog ? min(fs.prog.n_ops, kOpsLds) * 2 : 0;   // ... and the reset program's first ops
+            uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0, o0 = a0, o1 = a0, p0 = a0;
             uint8_t f = 0, sl = 0xFF, f2 = 0, vmap0 = 0;
-            uint64_t hide0 = 0;
+            uint32_t hide0 = 0;
             double pscale0 = 0.;
             // padded tile rows (kPadRows): LDS dword d is 4 bytes of row d / kRowW, read as the 8 aligned bytes of the
             // atlas around them (pad_source, mg_gather.h) and cut out when they are stored
@@ -439,9 +445,13 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                     if (tidl + T < na) a1 = asrc[tidl + T];
                 }
                 if (tidl < no) o0 = reinterpret_cast<const uint4*>(cfg.obj)[tidl];
-                if (tidl < cfg.n_obj) { f = cfg.obj[tidl].flags; sl = cfg.obj[tidl].ovl_slot; f2 = cfg.obj[tidl].flags2; }
+                if (tidl + T < no) o1 = reinterpret_cast<const uint4*>(cfg.obj)[tidl + T];      // (more than 128 kinds at 4 waves)
+                if (tidl < nops) p0 = reinterpret_cast<const uint4*>(fs.prog.ops)[tidl];
+                if (tidl < cfg.n_obj) {         // (T >= 256 >= n_obj: one trip)
+                    f = cfg.obj[tidl].flags; sl = cfg.obj[tidl].ovl_slot; f2 = cfg.obj[tidl].flags2;
+                    if (cfg.any_hide && cfg.hide_by_obj) hide0 = cfg.hide_by_obj[tidl];
+                }
                 if (tidl < MG_MAX_AGENTS) {     // the per-agent tables of the launch struct, requested with the rest
-                    hide0 = cfg.hide_obj_mask[tidl];
                     pscale0 = cfg.prestige_scale[tidl];
                     vmap0 = cfg.view_agent[tidl];
                 }
@@ -494,16 +504,18 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 for (int i = tidl + 2 * T; i < na; i += T) adst[i] = asrc[i];    // (larger atlases: the rest, a second trip)
                 }
                 if (tidl < no) reinterpret_cast<uint4*>(s_obj)[tidl] = o0;
+                if (tidl + T < no) reinterpret_cast<uint4*>(s_obj)[tidl + T] = o1;
+                if (tidl < nops) reinterpret_cast<uint4*>(s_ops)[tidl] = p0;
                 // (anything computed on a loaded value goes here, behind the round trip: in front of the step's loads
                 // it was a wait for the first half of the requests before the second half was issued)
                 if (tidl == 0) { f = MG_OF_SEE_BEHIND | MG_OF_CAN_OVERLAP; sl = 0; f2 = 1; }   // empty cell
-                if (tidl < MG_MAX_OBJ) {
+                if (tidl < NO) {
                     s_oflags[tidl] = f;
                     s_oslot[tidl] = sl;
                     s_oflags2[tidl] = f2;
+                    if (cfg.any_hide) s_hideby[tidl] = hide0;
                 }
                 if (tidl < MG_MAX_AGENTS) {
-                    s_hide[tidl] = hide0;
                     s_pscale[tidl] = pscale0;
                     s_vmap[tidl] = cfg.n_view ? vmap0 : (uint8_t)tidl;
                 }
@@ -545,10 +557,17 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                     wave_lds_sync();
                     loop = step_par_commit(cfg, st, fs.rewards, eb, sc, P, lane);
                     wave_lds_sync();
+#if defined(MG_AB_VARIANTS)
+                    if (sc.stamp && !loop) sc.stamp[2] = wall_clock64();      // (the stamp step_agents sets when it runs)
+#endif
                 }
                 if (lane < kb) {
                     if (loop) step_agents(cfg, st, fs.rewards, eb + lane, sc, g_mine, ctx);
-                    const StepOut so = step_end(cfg, st, fs.prog, fs.has_prog != 0, eb + lane, sc, g_mine, ctx);
+                    // (the reset program's ops from their LDS copy when all of them are there — the prologue staged the first
+                    // kOpsLds —, else in place)
+                    MgGenProgram prog = fs.prog;
+                    if (prog.n_ops <= kOpsLds) prog.ops = s_ops;
+                    const StepOut so = step_end(cfg, st, prog, fs.has_prog != 0, eb + lane, sc, g_mine, ctx);
                     wrote = so.wrote;
                     head_k = so.head_k;
                     if constexpr (kPrestige) {
@@ -702,7 +721,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 // replaced by the first agent standing on it (or nothing) and that agent is drawn as
                 // a plain cell object — the "viewer is in the stack" rule no longer applies to it
                 const uint32_t first = w_first[gcell + cell];
-                if (base && ((s_hide[k] >> base) & 1ull)) { base = 0; show = first; }
+                if (base && ((s_hideby[base] >> k) & 1u)) { base = 0; show = first; }
                 else if (base == 0 && first != 0xFF && first != k && ((cfg.hide_agent_mask >> k) & 1u))
                     show = w_second[gcell + cell];
             }
@@ -1161,7 +1180,8 @@ hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_t* obs,
     static_assert(RM_ == 1 || TS_ == 0 || (TS_ % 8) != 0 || TS_ == 8 || TS_ == 16 || TS_ == 32, "see render_chunk_raster");
     const RenderScratch L = render_scratch_for(cfg, WPB, RM_);
     const size_t atlas_lds = (V_ == 8 || V_ == 12) ? 0 : (size_t)render_atlas_lds_bytes(cfg, RM_);
-    size_t lds = atlas_lds + kRenderShared + WPB * (size_t)L.total;
+    const RenderShared sh = render_shared_layout(cfg);
+    size_t lds = atlas_lds + sh.total + WPB * (size_t)L.total;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (pick) {     // mg_render_kernel_name: which instantiation this configuration gets — nothing is launched
         pick->vs = VS_; pick->ts = TS_; pick->wpb = WPB; pick->v = V_; pick->rm = RM_; pick->lds = (int)lds;
@@ -1202,6 +1222,7 @@ hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_t* obs,
     lc.m_nvVS = Div20(nv * vs).m;
     lc.depth_mode = 0;
     lc.atlas_lds = (int)atlas_lds;
+    lc.sh = sh;
 #if defined(MG_AB_VARIANTS)
     lc.stamps = g_ab_stamps;
 #endif

@@ -35,7 +35,8 @@ __global__ __launch_bounds__(BS) void step_kernel(MgConfig cfg, MgState st, MgGe
     sc.head = reinterpret_cast<uint32_t*>(s_obj + MG_MAX_OBJ);               // [MG_MT_HEAD][BS] u32
     sc.act = reinterpret_cast<uint8_t*>(sc.head + MG_MT_HEAD * BS);          // [n][BS]
     sc.fb = sc.act + (size_t)n * BS;                                         // [n][BS]
-    uint8_t* s_oflags = sc.fb + (size_t)n * BS;                              // [MG_MAX_OBJ]
+    sc.ord = sc.fb + (size_t)n * BS;                                         // [n][BS] iter_order (more than 16 agents)
+    uint8_t* s_oflags = sc.ord + (size_t)n * BS;                             // [MG_MAX_OBJ]
     sc.obj = s_obj;
     sc.oflags = s_oflags;
     sc.S = BS;
@@ -62,11 +63,14 @@ template <int BS>
 static hipError_t launch_step_bs(const MgConfig& cfg, const MgState& st, const void* actions, int action_bytes,
                                  float* rewards, const MgGenProgram* prog, hipStream_t s) {
     dim3 grid((cfg.B + BS - 1) / BS), block(BS);
-    const size_t lds = (size_t)cfg.n_agents * BS * (sizeof(uint64_t) + 3) + MG_MAX_OBJ * sizeof(MgObjDesc) +
+    const size_t lds = (size_t)cfg.n_agents * BS * (sizeof(uint64_t) + 4) + MG_MAX_OBJ * sizeof(MgObjDesc) +
                        (size_t)MG_MT_HEAD * BS * sizeof(uint32_t) + MG_MAX_OBJ;
     MgGenProgram none;
     none.template_grid = nullptr;
     none.n_ops = 0;
+    none.ops = nullptr;
+    none.reject = nullptr;
+    none.n_reject = 0;
     const MgGenProgram& p = prog ? *prog : none;
     const int has = prog ? 1 : 0;
     if (action_bytes != 1 && action_bytes != 4 && action_bytes != 8) return hipErrorInvalidValue;
@@ -80,6 +84,8 @@ hipError_t launch_step(const MgConfig& cfg, const MgState& st, const void* actio
     // One lane per env: spread the envs over as many CUs as possible with single-wave workgroups
     // until the batch alone fills the chip several times over.
     int bs = cfg.B > 256 * 8 * 64 ? 256 : 64;
+    // (256-lane workgroups of many agents would need more than the 64 KiB of LDS a launch gets without asking)
+    if ((size_t)cfg.n_agents * 256 * (sizeof(uint64_t) + 4) + MG_MAX_OBJ * (sizeof(MgObjDesc) + 1) + (size_t)MG_MT_HEAD * 256 * 4 > 64 * 1024) bs = 64;
 #if defined(MG_AB_VARIANTS)
     if (const char* f = getenv("MG_STEP_BLOCK")) { const int v = atoi(f); if (v == 64 || v == 256) bs = v; }
 #endif

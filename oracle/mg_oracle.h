@@ -24,10 +24,10 @@
 extern "C" {
 #endif
 
-#define MGO_MAX_AGENTS 16
-#define MGO_MAX_OBJ 64
+#define MGO_MAX_AGENTS 32
+#define MGO_MAX_OBJ 256
 #define MGO_MAX_FILL 8
-#define MGO_MAX_GEN 48
+#define MGO_MAX_GEN 192
 #define MGO_MAX_VIEW 15
 #define MGO_AGENT_BASE 1000 /* cell value >= this: the cell object is agent (value - base) */
 

@@ -23,7 +23,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libmgoracle.so")
 
-MAX_AGENTS, MAX_OBJ, MAX_FILL, MAX_GEN = 16, 64, 8, 48
+MAX_AGENTS, MAX_OBJ, MAX_FILL, MAX_GEN = 32, 256, 8, 192
 
 # objects.py:11-29
 COLORS = {

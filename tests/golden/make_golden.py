@@ -64,7 +64,16 @@ TRAJ = {  # scenario -> (n_seeds, n_steps, n_full_obs_seeds)
     "Test-3AgentCluttered9x9-view6": (8, 150, 2),
     "Test-2AgentEmpty8x8-view4-ts5": (6, 100, 2),
     "Test-2AgentLateStatic10x10": (8, 120, 1),
+    # the limits lifted in round 6: 24 agents (iter_order beyond 16 nibbles), 115 object kinds (ids beyond 64, the atlas read in
+    # place), a reset program of 61 ops (beyond the 32 a launch struct held)
+    "Limit-24AgentEmpty20x20-view5": (4, 60, 1),
+    "Limit-3Agent100Kinds24x24": (4, 80, 1),
+    "Limit-2Agent60Groups16x16": (4, 80, 1),
 }
+# action distributions: navigation mostly, all 7 ids present — except where the reference cannot go: toggling a Box raises
+# TypeError (objects.py:381-382) and a closed Door's sprite NameError (objects.py:370), so the scenarios that hold Boxes and open
+# Doors never toggle (pickup / drop of a Box are fine)
+ACT_P = {"Limit-3Agent100Kinds24x24": [.18, .18, .44, .08, .07, 0., .05], "Limit-2Agent60Groups16x16": [.18, .18, .44, .08, .07, 0., .05]}
 CANON = ("base_enc", "pos", "dir", "active", "done", "carry_enc", "ordinal")
 
 
@@ -173,7 +182,7 @@ def gen_traj(name, out):
     seeds = 1337 + np.arange(S)
     arng = np.random.RandomState(4242)
     # mostly navigation, all 7 ids present (pickup/drop/toggle/done are no-ops in these scenes)
-    actions = arng.choice(7, size=(S, T, n), p=[.2, .2, .4, .05, .05, .05, .05]).astype(np.int8)
+    actions = arng.choice(7, size=(S, T, n), p=ACT_P.get(name, [.2, .2, .4, .05, .05, .05, .05])).astype(np.int8)
     d = dict(seeds=seeds, actions=actions)
     rec = {k: [] for k in CANON}
     ctor = {k: [] for k in CANON}

@@ -33,7 +33,50 @@ def make_ref_env(spec, recipe, seed=1337):
         return _reject_env_class()(agents=agents, **kw)
     if cls_name == "LateStaticTestEnv":
         return _late_static_env_class()(agents=agents, **kw)
+    if cls_name == "KindsTestEnv":
+        return _kinds_env_class()(agents=agents, **kw)
+    if cls_name == "GroupsTestEnv":
+        return _groups_env_class()(agents=agents, **kw)
     return getattr(E, cls_name)(agents=agents, **kw)
+
+
+def _kinds_env_class():
+    """A test-only scenario ON TOP OF the reference's classes: a hundred objects of 115 kinds (scenarios.kinds_list) put on a
+    lattice of odd cells, six random walls after them — the registry beyond 64 entries (base.py:19-64: keys are uint8)."""
+    from marlgrid.base import MultiGridEnv, MultiGrid
+    from marlgrid import objects as RO
+    import scenarios
+
+    class KindsTestEnv(MultiGridEnv):
+        mission = ""
+        metadata = {}
+
+        def _gen_grid(self, width, height):
+            self.grid = MultiGrid((width, height))
+            self.grid.wall_rect(0, 0, width, height)
+            for i, (cls, color, kw) in enumerate(scenarios.kinds_list()):
+                self.put_obj(getattr(RO, cls)(color=color, **kw), 1 + 2 * (i % 11), 1 + 2 * (i // 11))
+            for _ in range(6):
+                self.place_obj(RO.Wall(), max_tries=100)
+    return KindsTestEnv
+
+
+def _groups_env_class():
+    """A test-only scenario ON TOP OF the reference's classes: sixty random placements of alternating kinds (upstream's
+    `_gen_grid` is free Python of any length, base.py:690-708)."""
+    from marlgrid.base import MultiGridEnv, MultiGrid
+    from marlgrid.objects import Box, Wall
+
+    class GroupsTestEnv(MultiGridEnv):
+        mission = ""
+        metadata = {}
+
+        def _gen_grid(self, width, height):
+            self.grid = MultiGrid((width, height))
+            self.grid.wall_rect(0, 0, width, height)
+            for i in range(60):
+                self.place_obj(Wall() if i % 2 == 0 else Box(("red", "blue", "green")[(i // 2) % 3]), max_tries=100)
+    return GroupsTestEnv
 
 
 def _spawn_rect_env_class():

@@ -72,6 +72,8 @@ class HostEmu(object):
         if self._tables_version != env.obj_reg.version:
             self.cfg, self._obj_raw, _, _ = env._host_tables()
             self.cfg.obj = self._obj_raw.ctypes.data
+            self._hide_by = env._groups[0].hide_by
+            self.cfg.hide_by_obj = None if self._hide_by is None else self._hide_by.ctypes.data
             self._tables_version = env.obj_reg.version
         else:
             env._refresh_cfg(self.cfg)
@@ -91,8 +93,10 @@ class HostEmu(object):
         prog.template_grid = t.ctypes.data
         prog.n_ops = len(ops)
         tables = []
+        prog._keep_ops = host_ops = (N.GenOp * max(1, len(ops)))()      # ("device" memory is host memory here)
+        prog.ops = C.cast(host_ops, C.c_void_p).value
         for i, (obj, count, max_tries, x0, y0, x1, y1, rej) in enumerate(ops):
-            o = prog.ops[i]
+            o = host_ops[i]
             o.obj, o.count, o.max_tries, o.x0, o.y0, o.x1, o.y1 = obj, count, max_tries, x0, y0, x1, y1
             o.reject = -1
             if rej is not None:                          # place_obj(reject_fn=), tabulated (base.py:_reject_table)

@@ -31,12 +31,12 @@ namespace {
 struct Scratch {
     std::vector<uint64_t> rec;
     std::vector<uint32_t> head;
-    std::vector<uint8_t> act, fb, oflags;
+    std::vector<uint8_t> act, fb, oflags, ord;
     mg::StepScratch sc;
     Scratch(const MgConfig* cfg) : rec(MG_MAX_AGENTS), head(MG_MT_HEAD), act(MG_MAX_AGENTS),
-                                   fb(MG_MAX_AGENTS), oflags(MG_MAX_OBJ, 0) {
+                                   fb(MG_MAX_AGENTS), oflags(MG_MAX_OBJ, 0), ord(MG_MAX_AGENTS) {
         for (int i = 1; i < cfg->n_obj; i++) oflags[i] = cfg->obj[i].flags;
-        sc.rec = rec.data(); sc.head = head.data(); sc.act = act.data(); sc.fb = fb.data();
+        sc.rec = rec.data(); sc.head = head.data(); sc.act = act.data(); sc.fb = fb.data(); sc.ord = ord.data();
         sc.obj = cfg->obj; sc.oflags = oflags.data(); sc.S = 1; sc.col = 0;
     }
 };

@@ -29,7 +29,42 @@ def build(name, **kw):
         return _reject_env_class()(agents=agents, **{**kwargs, **kw})
     if cls_name == "LateStaticTestEnv":
         return _late_static_env_class()(agents=agents, **{**kwargs, **kw})
+    if cls_name == "KindsTestEnv":
+        return _kinds_env_class()(agents=agents, **{**kwargs, **kw})
+    if cls_name == "GroupsTestEnv":
+        return _groups_env_class()(agents=agents, **{**kwargs, **kw})
     return getattr(E, cls_name)(agents=agents, **{**kwargs, **kw})
+
+
+def _kinds_env_class():
+    """the product-side twin of tests/golden/refstate.py:_kinds_env_class (same _gen_grid text)"""
+    from marlgrid_amd.base import MultiGridEnv, MultiGrid
+    from marlgrid_amd import objects as RO
+    import scenarios
+
+    class KindsTestEnv(MultiGridEnv):
+        def _gen_grid(self, width, height):
+            self.grid = MultiGrid((width, height))
+            self.grid.wall_rect(0, 0, width, height)
+            for i, (cls, color, kw) in enumerate(scenarios.kinds_list()):
+                self.put_obj(getattr(RO, cls)(color=color, **kw), 1 + 2 * (i % 11), 1 + 2 * (i // 11))
+            for _ in range(6):
+                self.place_obj(RO.Wall(), max_tries=100)
+    return KindsTestEnv
+
+
+def _groups_env_class():
+    """the product-side twin of tests/golden/refstate.py:_groups_env_class (same _gen_grid text)"""
+    from marlgrid_amd.base import MultiGridEnv, MultiGrid
+    from marlgrid_amd.objects import Box, Wall
+
+    class GroupsTestEnv(MultiGridEnv):
+        def _gen_grid(self, width, height):
+            self.grid = MultiGrid((width, height))
+            self.grid.wall_rect(0, 0, width, height)
+            for i in range(60):
+                self.place_obj(Wall() if i % 2 == 0 else Box(("red", "blue", "green")[(i // 2) % 3]), max_tries=100)
+    return GroupsTestEnv
 
 
 def _region_env_class():

@@ -151,6 +151,9 @@ def ref_recipe(name):
         "Test-3AgentEmpty7x11-nonsquare": ("EmptyMultiGrid", dict(width=7, height=11)),
         "Test-3AgentCluttered12x6-nonsquare": ("ClutteredMultiGrid", dict(width=12, height=6, n_clutter=7)),
         "Test-2AgentLateStatic10x10": ("LateStaticTestEnv", dict(grid_size=10, respawn=True, max_steps=50)),
+        "Limit-24AgentEmpty20x20-view5": ("EmptyMultiGrid", dict(grid_size=20, max_steps=60)),
+        "Limit-3Agent100Kinds24x24": ("KindsTestEnv", dict(grid_size=24, max_steps=80)),
+        "Limit-2Agent60Groups16x16": ("GroupsTestEnv", dict(grid_size=16, max_steps=60)),
         "Test-3AgentCluttered9x9-view6": ("ClutteredMultiGrid", dict(grid_size=9, n_clutter=7, max_steps=60)),
         "Test-2AgentEmpty8x8-view4-ts5": ("EmptyMultiGrid", dict(grid_size=8, max_steps=50)),
         # the reference's examples/human_player.py configuration (examples/human_player.py:35-55)
@@ -235,6 +238,74 @@ def late_static_spec():
     return s
 
 
+# ---- the limits round 6 lifted: more than 16 agents, more than 64 object kinds, more than 32 ops ----
+ALL_COLORS = ["red", "orange", "green", "blue", "cyan", "purple", "yellow", "olive", "grey", "worst", "pink", "white",
+              "prestige", "shadow"]                                   # objects.py:11-29, in key order
+
+
+def kinds_list():
+    """the hundred objects of the kinds scenario, in the order its `_gen_grid` puts them (plain data: the reference-side and
+    the product-side twin build their own objects from it): (class name, colour, kwargs)"""
+    out = [("Box", c, {}) for c in ALL_COLORS]
+    out += [("Door", c, dict(state=1)) for c in ALL_COLORS]           # open
+    out += [("Door", c, dict(state=3)) for c in ALL_COLORS]           # locked
+    out += [("Goal", c, dict(reward=1)) for c in ALL_COLORS] + [("Goal", "green", dict(reward=2)), ("Goal", "red", dict(reward=0.5))]
+    out += [("BonusTile", c, dict(reward=1, penalty=-0.5, bonus_id=b, n_bonus=3)) for c in ALL_COLORS for b in range(3)]
+    assert len(out) == 100
+    return out
+
+
+def kinds_spec():
+    """test-only scenario with a hundred objects of 115 kinds on one 24 x 24 board (ids beyond 64; an atlas of ~1 000 tiles that
+    is read in place): see tests/golden/refstate.py:_kinds_env_class.  The object list is in the order the product's registry
+    fills (a Door brings its other two states along)."""
+    s = _base(3, 24, 7, max_steps=80)
+    W = H = 24
+    objs = [None, WALL]
+    index = {}
+    prog = [("wall_rect", 0, 0, W, H)]
+    for i, (cls, color, kw) in enumerate(kinds_list()):
+        if cls == "Door":
+            key = (cls, color, kw["state"])
+            if key not in index:
+                for st in [kw["state"]] + [x for x in (1, 2, 3) if x != kw["state"]]:
+                    index[(cls, color, st)] = len(objs)
+                    objs.append(dict(type="Door", color=color, state=st))
+        elif cls == "Box":
+            key = (cls, color)
+            index[key] = len(objs)
+            objs.append(dict(type="Box", color=color, state=0))
+        elif cls == "Goal":
+            key = (cls, color, kw["reward"])
+            index[key] = len(objs)
+            objs.append(dict(type="Goal", color=color, state=0, reward=kw["reward"]))
+        else:
+            key = (cls, color, kw["bonus_id"])
+            index[key] = len(objs)
+            objs.append(dict(type="BonusTile", color=color, state=kw["bonus_id"], reward=kw["reward"], penalty=kw["penalty"],
+                             bonus_id=kw["bonus_id"], n_bonus=kw["n_bonus"], initial_reward=True, reset_on_mistake=False))
+        prog.append(("put", index[key], 1 + 2 * (i % 11), 1 + 2 * (i // 11)))
+    prog.append(("place", 1, 6, 100))
+    s["objects"] = objs
+    s["wall_obj"] = 1
+    s["gen_ctor"], s["gen_reset"] = prog, prog
+    return s
+
+
+def groups_spec():
+    """test-only scenario whose `_gen_grid` makes SIXTY random placements of alternating kinds — no two neighbours merge, the
+    reset program has sixty ops (a launch struct held 32 until round 5): see tests/golden/refstate.py:_groups_env_class"""
+    s = _base(2, 16, 7, max_steps=60)
+    W = H = 16
+    s["objects"] = [None, WALL] + [dict(type="Box", color=c, state=0) for c in ("red", "blue", "green")]
+    s["wall_obj"] = 1
+    prog = [("wall_rect", 0, 0, W, H)]
+    for i in range(60):
+        prog.append(("place", 1 if i % 2 == 0 else 2 + (i // 2) % 3, 1, 100))
+    s["gen_ctor"], s["gen_reset"] = prog, prog
+    return s
+
+
 def _with_views(spec, views):
     """per-agent view geometry (agents.py:19-35); spec-level view_size / tile_size / ... stay the first agent's"""
     for a, v in zip(spec["agents"], views):
@@ -284,6 +355,9 @@ def registered(name):   # noqa: F811  (extends the table above with test-only sc
         "Test-3AgentSpawnRect9x9": lambda: spawn_rect_spec(),
         "Test-2AgentReject9x9": lambda: reject_spec(),
         "Test-2AgentLateStatic10x10": lambda: late_static_spec(),
+        "Limit-24AgentEmpty20x20-view5": lambda: empty_spec(24, 20, 5, colors=[ALL_COLORS[k % 12] for k in range(24)], max_steps=60),
+        "Limit-3Agent100Kinds24x24": lambda: kinds_spec(),
+        "Limit-2Agent60Groups16x16": lambda: groups_spec(),
         # every agent its own view (agents.py:19-35): a 5x5 view at 8 px, a 7x7 view at 5 px looking through walls,
         # a 5x5 view at 8 px again (same group as the first) with the agent one row up
         "Test-3AgentCluttered9x9-hetero-views": lambda: _with_views(

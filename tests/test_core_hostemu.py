@@ -158,3 +158,28 @@ def test_parallel_resolution_conflicts(name, B, T):
         assert frac < 0.9, frac                      # (the loop is the exception even in a crowded 5x5 room)
         if "noghost" in name:                        # (ghost_mode=0 `is not False`: moves may enter occupied cells, base.py:541)
             assert emu.n_serial.value > 0            # ... but it is taken
+
+
+@pytest.mark.parametrize("par", [False, True])
+@pytest.mark.parametrize("name,B,T", [("Limit-24AgentEmpty20x20-view5", 12, 150), ("Limit-3Agent100Kinds24x24", 12, 200),
+                                       ("Limit-2Agent60Groups16x16", 12, 200)])
+def test_core_bodies_beyond_the_old_limits(name, B, T, par):
+    """24 agents (iter_order in the step's scratch column instead of sixteen nibbles), 115 object kinds (ids beyond 64), a reset
+    program of 61 ops in "device" memory — the scenarios whose reference trajectories are tests/golden/traj_Limit-*.npz —
+    against the oracle, Boxes picked up and dropped on the way (no toggles: a Box's raises TypeError upstream)"""
+    import hostemu
+    seeds = 77100 + np.arange(B)
+    emu = hostemu.HostEmu(name, B, seeds, auto_reset=True, par=par)
+    orc = O.OracleBatch(scenarios.registered(name), seeds)
+    _same_state(emu, orc, "%s ctor" % name)
+    emu.reset()
+    orc.reset()
+    rng = np.random.RandomState(29)
+    for t in range(T):
+        a = rng.choice(7, size=(B, emu.n), p=[.15, .15, .45, .1, .1, 0., .05])
+        r, d = emu.step(a)
+        _o, r2, d2, _ = orc.step(a, render=False, auto_reset=True)
+        assert np.abs(r.astype(np.float64) - r2).max() <= REW_TOL and np.array_equal(d, d2), (name, t)
+        if t % 10 == 0 or t == T - 1:
+            _same_state(emu, orc, "%s step %d" % (name, t))
+    assert not emu.error.any()

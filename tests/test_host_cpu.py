@@ -444,8 +444,17 @@ def test_late_static_edits_are_rectangle_fills_and_visible_to_get():
             for k in range(40):
                 self.grid.set(1 + (k * 2) % 9, 1 + (k * 4) // 9 * 2 % 9, Wall() if k % 2 else Floor())
 
-    with pytest.raises(NotImplementedError, match=r"1 groups of random placements and \d+ rectangle fills"):
-        TooMany(agents=[dict(color="red")], grid_size=11, _dry=True)
+    # forty-one ops: more than the 32 a launch struct held until round 5 — the program lives in device memory now
+    many = TooMany(agents=[dict(color="red")], grid_size=11, _dry=True)
+    assert len(many._dry_trace[1]) > 32
+    from marlgrid_amd import _native as N
+    old = N.MAX_GEN
+    N.MAX_GEN = 8                                        # (the sanity bound's message, without recording a thousand ops)
+    try:
+        with pytest.raises(NotImplementedError, match=r"1 groups of random placements and \d+ rectangle fills"):
+            TooMany(agents=[dict(color="red")], grid_size=11, _dry=True)
+    finally:
+        N.MAX_GEN = old
 
 
 def test_bench_parity_after_timed_replay(tmp_path):
