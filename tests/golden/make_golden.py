@@ -69,6 +69,7 @@ TRAJ = {  # scenario -> (n_seeds, n_steps, n_full_obs_seeds)
     "Limit-24AgentEmpty20x20-view5": (4, 60, 1),
     "Limit-3Agent100Kinds24x24": (4, 80, 1),
     "Limit-2Agent60Groups16x16": (4, 80, 1),
+    "Limit-2AgentCluttered128x128": (3, 60, 1),        # a grid of 16 KiB per env (two of them per wave in LDS: grid + first-agent map)
 }
 # action distributions: navigation mostly, all 7 ids present — except where the reference cannot go: toggling a Box raises
 # TypeError (objects.py:381-382) and a closed Door's sprite NameError (objects.py:370), so the scenarios that hold Boxes and open

@@ -153,6 +153,7 @@ def ref_recipe(name):
         "Test-2AgentLateStatic10x10": ("LateStaticTestEnv", dict(grid_size=10, respawn=True, max_steps=50)),
         "Limit-24AgentEmpty20x20-view5": ("EmptyMultiGrid", dict(grid_size=20, max_steps=60)),
         "Limit-3Agent100Kinds24x24": ("KindsTestEnv", dict(grid_size=24, max_steps=80)),
+        "Limit-2AgentCluttered128x128": ("ClutteredMultiGrid", dict(grid_size=128, n_clutter=600, max_steps=40)),
         "Limit-2Agent60Groups16x16": ("GroupsTestEnv", dict(grid_size=16, max_steps=60)),
         "Test-3AgentCluttered9x9-view6": ("ClutteredMultiGrid", dict(grid_size=9, n_clutter=7, max_steps=60)),
         "Test-2AgentEmpty8x8-view4-ts5": ("EmptyMultiGrid", dict(grid_size=8, max_steps=50)),
@@ -357,6 +358,7 @@ def registered(name):   # noqa: F811  (extends the table above with test-only sc
         "Test-2AgentLateStatic10x10": lambda: late_static_spec(),
         "Limit-24AgentEmpty20x20-view5": lambda: empty_spec(24, 20, 5, colors=[ALL_COLORS[k % 12] for k in range(24)], max_steps=60),
         "Limit-3Agent100Kinds24x24": lambda: kinds_spec(),
+        "Limit-2AgentCluttered128x128": lambda: cluttered_spec(2, 128, 7, n_clutter=600, max_steps=40),
         "Limit-2Agent60Groups16x16": lambda: groups_spec(),
         # every agent its own view (agents.py:19-35): a 5x5 view at 8 px, a 7x7 view at 5 px looking through walls,
         # a 5x5 view at 8 px again (same group as the first) with the agent one row up
