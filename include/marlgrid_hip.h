@@ -335,7 +335,7 @@ int32_t mg_obs_free(void* ptr);
  *                 buffers + three first-level candidates while that is within half of the free memory (large buffers: a
  *                 16 GB buffer's candidates are 24 GiB each)
  *   seconds       time limit of a pass (not applied before the plain baseline allocations are in); <= 0 = 2 s, more for
- *                 candidates above 12 GiB (0.16 s per GiB of candidate, 8 s at most)
+ *                 candidates above 6 GiB (0.33 s per GiB of candidate, 12 s at most)
  *   flags         MG_PLACE_THOROUGH: larger block pairs (candidates of 6 P' and 12 P' bytes — a kept buffer then pins up
  *                 to 12x its size) and a second pass when the first found nothing; MG_PLACE_STIR: when nothing was found
  *                 and allocations were slow (memory nobody had before is cleared as it is handed out, front to back, all in

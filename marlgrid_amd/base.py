@@ -632,7 +632,7 @@ class MultiGridEnv(object):
         What it costs (the defaults are meant to be survivable for whoever shares the GPU): candidates alive at any time
         <= min(a quarter of the free memory, 32 GiB) — for buffers of several GB raised to the kept buffers plus three
         candidates, while that is within half of the free memory (a 16 GB buffer's candidates are 24 GiB each: round 5's
-        flat 32 GiB could not hold one) —; 2 s at most (0.16 s per GiB of candidate above 12 GiB, 8 s at most); a kept buffer
+        flat 32 GiB could not hold one) —; 2 s at most (0.33 s per GiB of candidate above 6 GiB, 12 s at most); a kept buffer
         pins its whole candidate — 1.5 .. 3 x its size, outside torch's allocator (`env.obs_placement[g]["pinned_bytes"]`);
         buffers under 256 MiB are plain torch allocations; at most MG_PLACE_MAX (8) buffers of a ring are placed (the
         rest stay torch allocations); `share` = k: k processes share this device, each counts on 1 / k of what is free.  "thorough" adds what round 4 found necessary on memory nobody had allocated before: larger block
@@ -1092,7 +1092,8 @@ class MultiGridEnv(object):
             if need < 0 or need > 160 * 1024:
                 raise NotImplementedError(
                     "this configuration needs %d KiB of LDS per workgroup for 4 waves of per-env scratch; the obs "
-                    "kernel has 160 KiB — reduce the grid size (or the tile size of 'prestige' agents)" % (need // 1024))
+                    "kernel has 160 KiB — with 'prestige' agents reduce the grid (their recolouring has no grid-in-place variant) "
+                    "or the tile size; otherwise the number of agents / the view size" % (need // 1024))
             g.obj_dev = torch.from_numpy(raw).to(self.device)
             g.atlas_dev = torch.from_numpy(flat).to(self.device)
             g.atlas = atlas
@@ -1574,6 +1575,12 @@ class MultiGridEnv(object):
                 for d in range(4):
                     self._frame_amax |= int(fa[0, fa.shape[1] - 4 + d][..., 0].max()) << (8 * d)
         Hp, Wp = self.height * tile_size, self.width * tile_size
+        # (the frame kernel keeps the env's grid, its per-cell agent maps and the visibility highlight in one workgroup's LDS:
+        # 5 bytes per cell — grids up to ~180 x 180; the step path has no such limit, see mg_render_obs' grid-in-place variant)
+        if 3 * self.cells_stride + 2 * ((self.width * self.height + 7) // 8 * 8) + 4096 > 160 * 1024:
+            raise NotImplementedError("render(): the whole-grid image of a %d x %d grid needs more than the 160 KiB of LDS of a "
+                                      "workgroup (5 bytes per cell); observations, step() and encode() have no such limit"
+                                      % (self.width, self.height))
         img = torch.empty((K, Hp, Wp, 3), dtype=torch.uint8, device=self.device)
         N.check(self._lib.mg_render_frame(C.byref(self._cfg), C.byref(self._state), ids.data_ptr(), K,
                                           self._frame_atlas.data_ptr(), tile_size, int(bool(highlight)),

@@ -140,8 +140,10 @@ __host__ __device__ inline int render_gather_row_bytes(int ts) { return (16 + 3 
 __host__ __device__ inline int render_atlas_raw_bytes(const MgConfig& cfg) {
     return (4 * cfg.n_tiles * cfg.tile_size * cfg.tile_size * 3 + 15) / 16 * 16;
 }
-// `mode`: the kernel's RM_ (0: by tile size, 1: assemble-and-stream forced — measurement builds —, 2: gather)
+// `mode`: the kernel's RM_ (0: by tile size, 1: assemble-and-stream forced — measurement builds —, 2: gather, 3: assemble-and-
+// stream with the grid AND the atlas read in place — grids that do not fit LDS)
 __host__ __device__ inline int render_atlas_lds_bytes(const MgConfig& cfg, int mode) {
+    if (mode == 3) return 0;
     if (mode == 2) return (4 * cfg.n_tiles * cfg.tile_size * render_gather_row_bytes(cfg.tile_size) + 32 + 15) / 16 * 16;
     return render_atlas_raw_bytes(cfg);
 }
@@ -163,12 +165,15 @@ struct RenderLaunch {
 // n: the env's agents (records, who stands where); nv: the viewers this launch renders (view-sized arrays)
 __host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride, int n, int nv, int vs, int stage_envs = 1,
                                                                int dyn_bytes = 0, int out_bytes = 0, int piece_rows = 0,
-                                                               bool any_hide = true, int max_view_slots = 0, bool gather = false) {
+                                                               bool any_hide = true, int max_view_slots = 0, bool gather = false,
+                                                               bool big = false) {
     RenderScratch s;
     int o = 0;
     s.stage_envs = stage_envs;
     s.rec_stride = round_up(n * 8, 16) / 8;
-    s.grid = o;  o += stage_envs * round_up(cells_stride, 16);
+    // (big: a grid too large for LDS — the kernel's RM_ == 3 — is read in place, and who stands on a view cell is searched among
+    // the env's agents instead of looked up in per-cell maps: no `grid`, `first`, `second`)
+    s.grid = o;  o += big ? 0 : stage_envs * round_up(cells_stride, 16);
     s.rec = o;   o += stage_envs * s.rec_stride * 8;
     s.pres = o;  o += dyn_bytes ? stage_envs * s.rec_stride * 8 : 0;   // agent.prestige of the staged envs
     s.pcol = o;  o += dyn_bytes ? round_up(stage_envs * s.rec_stride * 4, 16) : 0;   // ... and the sprite colours it gives them (fused step)
@@ -184,8 +189,8 @@ __host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride,
     // (trow doubles as the per-agent colour words of the 'prestige' recolouring: at least n dwords)
     s.trow_stride = round_up((nv * vs > n ? nv * vs : n) * 4, 16) / 4;
     s.vaff = o;  o += round_up(s.view_slots * nv * 8, 16);   // per viewer: its view's affine map and identity (phase 2b)
-    s.first = o; o += s.view_slots * s.cell_stride;
-    s.second = o; o += any_hide ? s.view_slots * s.cell_stride : 0;
+    s.first = o; o += big ? 0 : s.view_slots * s.cell_stride;
+    s.second = o; o += any_hide && !big ? s.view_slots * s.cell_stride : 0;
     s.trow = o;  o += s.view_slots * s.trow_stride * 4;
     s.tmap_slots = stage_envs;
     s.tmap_stride = gather ? nv * vs * vs * 2 : round_up(nv * vs * vs * 2, 16);   // (gather: DENSE — band g of a group is entry g * vs)
@@ -217,7 +222,7 @@ __host__ __device__ inline RenderScratch render_scratch_for(const MgConfig& cfg,
     const int dyn = cfg.prestige_mask ? (cfg.any_hide ? 2 : 1) * n * 4 * ts * (mode == 2 ? render_gather_row_bytes(ts) : ts * 3) + (mode == 2 ? 32 : 0) : 0;
     // (`fixed`: what a workgroup holds besides its waves' scratch — exactly the launcher's sum, launch_render_t)
     const int atlas_b = render_atlas_lds_bytes(cfg, mode), fixed = render_shared_layout(cfg).total;
-    const bool gather = mode == 2;
+    const bool gather = mode == 2, big = mode == 3;
     int rows = 0, out = 0;
     if (!gather && !render_chunk_raster(cfg, mode)) {
         const int rb = 3 * vs * ts;
@@ -230,19 +235,19 @@ __host__ __device__ inline RenderScratch render_scratch_for(const MgConfig& cfg,
     // run once per group instead of once per env), full trips in the per-cell phases — with one slot of view scratch per
     // env of the group (see the kernel's pass 0); the recoloured tiles of a 'prestige' env keep their one slot (they are
     // made right before the env's raster)
-    const RenderScratch b = render_scratch_layout(cfg.cells_stride, n, nv, vs, 1, dyn, out, rows, true, 0, gather);
+    const RenderScratch b = render_scratch_layout(cfg.cells_stride, n, nv, vs, 1, dyn, out, rows, true, 0, gather, big);
     const int resident = (atlas_b + 4 * b.total + fixed <= 160 * 1024) ? atlas_b : 0;   // else the atlas is read in place
     // (a wave stages its batch's records with two per lane — mg_render_kernel.h, step_load_issue —: up to 8 envs of up to
     // 16 agents, 4 envs of more)
     const int kmax = n > 16 ? 4 : 8;
     // ('prestige' — 12-wave workgroups next to a large atlas —: fewer view slots before fewer staged envs or fewer waves)
     for (int slots = dyn ? kmax : 0; dyn && slots >= 1; slots >>= 1) {
-        const RenderScratch t = render_scratch_layout(cfg.cells_stride, n, nv, vs, kmax, dyn, out, rows, cfg.any_hide != 0, slots, gather);
+        const RenderScratch t = render_scratch_layout(cfg.cells_stride, n, nv, vs, kmax, dyn, out, rows, cfg.any_hide != 0, slots, gather, big);
         if (resident + wpb * t.total + fixed <= 160 * 1024) return t;
     }
     int k = kmax;
-    while (k > 1 && resident + wpb * render_scratch_layout(cfg.cells_stride, n, nv, vs, k, dyn, out, rows, cfg.any_hide != 0, dyn ? 1 : 0, gather).total + fixed > 160 * 1024) k >>= 1;
-    return render_scratch_layout(cfg.cells_stride, n, nv, vs, k, dyn, out, rows, cfg.any_hide != 0, dyn ? 1 : 0, gather);
+    while (k > 1 && resident + wpb * render_scratch_layout(cfg.cells_stride, n, nv, vs, k, dyn, out, rows, cfg.any_hide != 0, dyn ? 1 : 0, gather, big).total + fixed > 160 * 1024) k >>= 1;
+    return render_scratch_layout(cfg.cells_stride, n, nv, vs, k, dyn, out, rows, cfg.any_hide != 0, dyn ? 1 : 0, gather, big);
 }
 
 }  // namespace mg

@@ -153,8 +153,9 @@ int32_t mg_obs_place(const MgConfig* cfg, const MgState* st, int32_t n_buffers, 
         while (P0 < half) P0 <<= 1;                                   // the power of two >= half the buffer (>= 2 MiB)
         S.candidate_bytes = 3 * P0;
         // (the default time limit follows the candidate: memory nobody had before is cleared as it is handed out, ~0.02 s per GiB —
-        // a 24 GiB candidate of BASELINE configs[4] is half a second of hipMalloc, and 2 s would end the search after four)
-        if (default_seconds) seconds = std::min(8.0, std::max(2.0, 0.16 * (double)(3 * P0) / (double)(1ull << 30)));
+        // a 24 GiB candidate of BASELINE configs[4] is 0.5-0.8 s of hipMalloc + measurement: 2 s would end the search after
+        // three, 4 s after six — one box needed more than six: a third of a second per GiB of candidate, 12 s at most)
+        if (default_seconds) seconds = std::min(12.0, std::max(2.0, 0.33 * (double)(3 * P0) / (double)(1ull << 30)));
         const int max_level = (flags & MG_PLACE_THOROUGH) ? 2 : 0;
         const int passes = (flags & MG_PLACE_THOROUGH) ? 2 : 1;
         std::vector<Cand> cands;              // every candidate measured (base == nullptr: gone back to the driver)

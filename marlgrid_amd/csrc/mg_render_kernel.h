@@ -266,6 +266,11 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     static_assert(!kGather || (VS_ > 0 && TS_ >= 5 && (TS_ % 8) != 0 && (V_ == 0 || V_ == 9)), "gather raster: compile-time view and tile size, static atlas in LDS");
     typedef GatherGeom<kGather ? VS_ : 7, kGather ? TS_ : 5> Gm;
     constexpr bool kPadRows = kGather;                                // (the prologue pads the atlas as it copies it)
+    // RM_ == 3: a grid that does not fit LDS (beyond ~140 x 140) is read IN PLACE — the step works on its home in HBM, a view
+    // cell's object is a global load, and who stands on a view cell is searched among the env's agents instead of looked up in
+    // per-cell maps; the atlas is read in place too (V_ == 8), view and tile size are run-time values
+    constexpr bool kBigGrid = RM_ == 3;
+    static_assert(!kBigGrid || (VS_ == 0 && TS_ == 0 && V_ == 8), "grid read in place: the fully run-time instantiation");
     constexpr int kRowB = kGather ? Gm::RS : 0, kRowW = kRowB / 4;
     constexpr int kPadFrontW = Gm::FRONT / 4, kPadTailW = Gm::TAIL / 4;   // zero dwords in front of a row / behind the last
     constexpr int kPadQ = 6;                                         // padded dwords per thread in the prologue's first round trip
@@ -396,7 +401,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             const int T = WPB * 64;
             const uint32_t* gsrc = reinterpret_cast<const uint32_t*>(st.grid + (size_t)eb * cfg.cells_stride);
             const uint64_t* rsrc = st.agents + (size_t)eb * n;
-            const int nd = kb * gdw, nr = kb * n;
+            const int nd = kBigGrid ? 0 : kb * gdw, nr = kb * n;
             // (16 bytes per lane and request: a batch's grids are whole 16-byte chunks — cells_stride is a multiple of 16 —,
             // and every request costs its address, its bounds check and its exec mask: 2 instead of 8)
             static_assert(kSR % 4 == 0, "grid dwords per lane: whole uint4s");
@@ -547,13 +552,15 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 // only runs for an env whose agents' actions do depend on their order (step_par_commit says which);
                 // step_end on the env's lane (done agents, respawn, the episode's end and the reset that follows it).
                 StepCtx ctx;
-                uint8_t* const g_mine = w_stage_g + (size_t)(lane & 7) * cfg.cells_stride;
+                // (the staged grids of the batch — or, for a grid that is read in place, the batch's grids where they live)
+                uint8_t* const g_batch = kBigGrid ? st.grid + (size_t)eb * cfg.cells_stride : w_stage_g;
+                uint8_t* const g_mine = g_batch + (size_t)(lane & 7) * cfg.cells_stride;
                 if (lane < kb) ctx = step_begin(cfg, st, eb + lane, se, sc, g_mine);
                 bool loop = true;                       // this env's agents take the sequential loop
                 if (n <= 8) {
                     if (lane < kb) step_par_publish(cfg, sc, ctx);
                     wave_lds_sync();
-                    const ParLane P = step_par_resolve(cfg, sc, w_stage_g, kb, lane);
+                    const ParLane P = step_par_resolve(cfg, sc, g_batch, kb, lane);
                     wave_lds_sync();
                     loop = step_par_commit(cfg, st, fs.rewards, eb, sc, P, lane);
                     wave_lds_sync();
@@ -606,6 +613,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                         }
                     }
                 }
+                if constexpr (kBigGrid) todo = 0;       // (written where they live)
                 while (todo) {      // grid slices the step wrote: back to HBM, the whole wave per slice
                     const int j = __builtin_ctzll(todo);
                     todo &= todo - 1;
@@ -635,14 +643,16 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
         if (ej != ej0) continue;
         const int G = min(kb, ej0 + gd) - ej0;
         const int nvVV = nv * VV;
-        const uint8_t* g_grid = w_stage_g + (size_t)ej * cfg.cells_stride;      // env ej + g: + g * cells_stride
+        const uint8_t* g_grid = kBigGrid ? kernarg_again<MgState>(offsetof(RenderKernargs, st)).grid + (size_t)e * cfg.cells_stride
+                                         : w_stage_g + (size_t)ej * cfg.cells_stride;      // env ej + g: + g * cells_stride
         const uint64_t* g_rec = w_stage_r + (size_t)ej * rec_stride;            //            + g * rec_stride
         // 1. scratch of the G slots
         const bool has_second = cfg.any_hide;                    // (no `second` slots without hide_item_types)
-        for (int i = lane; i < G * (L.cell_stride / 4); i += kWave) {
-            reinterpret_cast<uint32_t*>(w_first)[i] = 0xFFFFFFFFu;
-            if (has_second) reinterpret_cast<uint32_t*>(w_second)[i] = 0xFFFFFFFFu;
-        }
+        if constexpr (!kBigGrid)
+            for (int i = lane; i < G * (L.cell_stride / 4); i += kWave) {
+                reinterpret_cast<uint32_t*>(w_first)[i] = 0xFFFFFFFFu;
+                if (has_second) reinterpret_cast<uint32_t*>(w_second)[i] = 0xFFFFFFFFu;
+            }
         for (int i = lane; i < G * L.trow_stride; i += kWave) w_trow[i] = 0;
         wave_lds_sync();
         if constexpr (V_ == 3 || V_ == 4) {
@@ -668,7 +678,8 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 else if (below == 1 && has_second) w_second[cell] = (uint8_t)a;   // only hide_item_types looks at it
             }
         };
-        for (int it = lane; it < G * n; it += kWave) { const int g = (int)by_n.div((uint32_t)it); first_of_cell(g, it - __mul24(g, n)); }
+        if constexpr (!kBigGrid)
+            for (int it = lane; it < G * n; it += kWave) { const int g = (int)by_n.div((uint32_t)it); first_of_cell(g, it - __mul24(g, n)); }
         // 2b. one lane per VIEWER: its view as an affine map of (column va, row vb) — SURVEY.md A.4's four cases
         //     folded into an origin, a swap bit and two signs — and who it is, so that phase 3 does no per-cell
         //     case analysis (as nested branches it ran every lane through all four headings):
@@ -709,9 +720,25 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             const bool inb = wx >= 0 && wx < W && wy >= 0 && wy < H;
             const int cell = __mul24(wx, H) + wy;
             uint32_t base = 0, show = 0xFF;
+            uint32_t big1 = 0xFF, big2 = 0xFF;          // kBigGrid: the first / second agent of the cell, searched
             if (inb) {
                 base = w_grid[cell];
-                show = w_first[gcell + cell];
+                if constexpr (kBigGrid) {
+                    // the lowest- and second-lowest-rank agents standing on the cell, among the env's n (what the per-cell maps
+                    // `first` / `second` hold for grids that fit LDS)
+                    const uint64_t* w_rec = g_rec + __umul24(g, (uint32_t)rec_stride);
+                    const uint32_t cxy = (uint32_t)wx | ((uint32_t)wy << 8);
+                    uint32_t r1 = 0xFF, r2 = 0xFF;
+                    for (int j = 0; j < n; j++) {
+                        const uint64_t rj = w_rec[j];
+                        if ((rec_byte(rj, MG_AG_FLAGS) & MG_AF_PLACED) && rec_xy(rj) == cxy) {
+                            const uint32_t rk = rec_byte(rj, MG_AG_RANK);
+                            if (rk < r1) { r2 = r1; big2 = big1; r1 = rk; big1 = (uint32_t)j; }
+                            else if (rk < r2) { r2 = rk; big2 = (uint32_t)j; }
+                        }
+                    }
+                    show = big1;
+                } else show = w_first[gcell + cell];
                 if (show != 0xFF && wx == x && wy == y && ((aff.y >> 26) & 1u)) show = k;   // viewer in the stack: base.py:282-291
             }
             if (s_oflags[base] & MG_OF_SEE_BEHIND)                     // opacity first
@@ -720,10 +747,10 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 // hide_item_types (base.py:441-449), applied after visibility: a hidden cell object is
                 // replaced by the first agent standing on it (or nothing) and that agent is drawn as
                 // a plain cell object — the "viewer is in the stack" rule no longer applies to it
-                const uint32_t first = w_first[gcell + cell];
+                const uint32_t first = kBigGrid ? big1 : (uint32_t)w_first[gcell + cell];
                 if (base && ((s_hideby[base] >> k) & 1u)) { base = 0; show = first; }
                 else if (base == 0 && first != 0xFF && first != k && ((cfg.hide_agent_mask >> k) & 1u))
-                    show = w_second[gcell + cell];
+                    show = kBigGrid ? big2 : (uint32_t)w_second[gcell + cell];
             }
             // tile selection (base.py:275-299) as if the cell were visible -> atlas offset of the view cell; phase 5
             // puts the shadow tile where it is not.  (Selected HERE, where the cell's object, agent and viewer are in
@@ -1241,7 +1268,7 @@ hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_t* obs,
     X(3, 8, 16, 0, 0) X(3, 8, 4, 0, 0) X(0, 8, 8, 0, 0) X(0, 8, 4, 0, 0)
 #define MG_RENDER_GROUP_B(X) /* tile 16 / 32, the atlas in global memory */                                                \
     X(7, 16, 16, 0, 0) X(7, 16, 4, 0, 0) X(7, 32, 16, 0, 0) X(7, 32, 4, 0, 0) X(0, 16, 8, 0, 0) X(0, 16, 4, 0, 0)               \
-    X(0, 32, 8, 0, 0) X(0, 32, 4, 0, 0) X(0, 8, 4, 8, 0) X(0, 16, 4, 8, 0) X(0, 32, 4, 8, 0) X(0, 0, 4, 8, 0)
+    X(0, 32, 8, 0, 0) X(0, 32, 4, 0, 0) X(0, 8, 4, 8, 0) X(0, 16, 4, 8, 0) X(0, 32, 4, 8, 0) X(0, 0, 4, 8, 0) X(0, 0, 4, 8, 3)
 #define MG_RENDER_GROUP_C(X) /* assemble-and-stream: any other tile size */                                                \
     X(7, 0, 16, 0, 0) X(7, 0, 4, 0, 0) X(0, 0, 8, 0, 0) X(0, 0, 4, 0, 0)
 #define MG_RENDER_GROUP_D(X) /* 'prestige': per-env recoloured tiles */                                                     \

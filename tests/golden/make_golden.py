@@ -70,6 +70,9 @@ TRAJ = {  # scenario -> (n_seeds, n_steps, n_full_obs_seeds)
     "Limit-3Agent100Kinds24x24": (4, 80, 1),
     "Limit-2Agent60Groups16x16": (4, 80, 1),
     "Limit-2AgentCluttered128x128": (3, 60, 1),        # a grid of 16 KiB per env (two of them per wave in LDS: grid + first-agent map)
+    # grids that do not fit LDS: the obs kernel reads them in place and searches the agents of a view cell (RM_ == 3)
+    "Limit-3AgentCluttered200x200-hide": (2, 50, 1),
+    "Limit-4AgentSpawnRect160x160-hide": (3, 60, 1),
 }
 # action distributions: navigation mostly, all 7 ids present — except where the reference cannot go: toggling a Box raises
 # TypeError (objects.py:381-382) and a closed Door's sprite NameError (objects.py:370), so the scenarios that hold Boxes and open

@@ -154,6 +154,10 @@ def ref_recipe(name):
         "Limit-24AgentEmpty20x20-view5": ("EmptyMultiGrid", dict(grid_size=20, max_steps=60)),
         "Limit-3Agent100Kinds24x24": ("KindsTestEnv", dict(grid_size=24, max_steps=80)),
         "Limit-2AgentCluttered128x128": ("ClutteredMultiGrid", dict(grid_size=128, n_clutter=600, max_steps=40)),
+        "Limit-3AgentCluttered200x200-hide": ("ClutteredMultiGrid", dict(grid_size=200, n_clutter=1500, max_steps=40)),
+        "Limit-4AgentSpawnRect160x160-hide": ("SpawnRectTestEnv", dict(grid_size=160, respawn=True, max_steps=40,
+                                                                       agent_spawn_kwargs=dict(top=(1, 1), size=(3, 3), max_tries=500))),
+        "Limit-2AgentEmpty255x255-view9-ts5": ("EmptyMultiGrid", dict(grid_size=255, max_steps=30)),
         "Limit-2Agent60Groups16x16": ("GroupsTestEnv", dict(grid_size=16, max_steps=60)),
         "Test-3AgentCluttered9x9-view6": ("ClutteredMultiGrid", dict(grid_size=9, n_clutter=7, max_steps=60)),
         "Test-2AgentEmpty8x8-view4-ts5": ("EmptyMultiGrid", dict(grid_size=8, max_steps=50)),
@@ -307,6 +311,20 @@ def groups_spec():
     return s
 
 
+def big_spawn_rect_spec(size):
+    """the spawn-rectangle scenario on a grid that does not fit LDS: four agents crowded into a 3 x 3 corner of a `size` x `size`
+    room (stacks, and with hide_item_types the second agent of a cell), respawning there — the obs kernel's grid-in-place variant
+    (tests/golden/refstate.py:_spawn_rect_env_class, base.py:411, 505, 643)"""
+    s = _base(4, size, 7, respawn=True, max_steps=40)
+    W = H = size
+    s["objects"] = [None, WALL, GOAL]
+    s["wall_obj"] = 1
+    prog = [("wall_rect", 0, 0, W, H), ("put", 2, 2, H - 2), ("place", 1, 4, 100)]
+    s["gen_ctor"], s["gen_reset"] = prog, prog
+    s["agent_spawn"] = dict(top=(1, 1), size=(3, 3), max_tries=500)
+    return _with_hide(s, [["Agent"], ["Wall"], [], ["Agent", "Goal"]])
+
+
 def _with_views(spec, views):
     """per-agent view geometry (agents.py:19-35); spec-level view_size / tile_size / ... stay the first agent's"""
     for a, v in zip(spec["agents"], views):
@@ -359,6 +377,10 @@ def registered(name):   # noqa: F811  (extends the table above with test-only sc
         "Limit-24AgentEmpty20x20-view5": lambda: empty_spec(24, 20, 5, colors=[ALL_COLORS[k % 12] for k in range(24)], max_steps=60),
         "Limit-3Agent100Kinds24x24": lambda: kinds_spec(),
         "Limit-2AgentCluttered128x128": lambda: cluttered_spec(2, 128, 7, n_clutter=600, max_steps=40),
+        "Limit-3AgentCluttered200x200-hide": lambda: _with_hide(cluttered_spec(3, 200, 7, n_clutter=1500, max_steps=40),
+                                                               [["Wall"], ["Agent", "Goal"], []]),
+        "Limit-4AgentSpawnRect160x160-hide": lambda: big_spawn_rect_spec(160),
+        "Limit-2AgentEmpty255x255-view9-ts5": lambda: empty_spec(2, 255, 9, tile_size=5, max_steps=30),
         "Limit-2Agent60Groups16x16": lambda: groups_spec(),
         # every agent its own view (agents.py:19-35): a 5x5 view at 8 px, a 7x7 view at 5 px looking through walls,
         # a 5x5 view at 8 px again (same group as the first) with the agent one row up

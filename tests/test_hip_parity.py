@@ -196,7 +196,15 @@ def test_rng_seeding_golden():
                                        ("Test-3AgentCluttered9x9-prestige-mixed", 256, 160),
                                        ("Edge-3AgentCluttered9x9-prestige-mixed-tile5", 4101, 70),
                                        ("Edge-3AgentCluttered9x9-prestige-mixed-tile5", 21, 120),
-                                       ("Edge-2AgentGoalcycle9x9-prestige-tile5", 300, 90)])
+                                       ("Edge-2AgentGoalcycle9x9-prestige-tile5", 300, 90),
+                                       # beyond round 5's limits: 24 agents (4 envs per staged batch, the sequential agent loop,
+                                       # iter_order in a scratch column), grids read in place (160 x 160 with crowded spawns and
+                                       # hide_item_types, 255 x 255: the largest a uint8 coordinate addresses)
+                                       ("Limit-24AgentEmpty20x20-view5", 70, 50),
+                                       ("Limit-24AgentEmpty20x20-view5", 4099, 12),
+                                       ("Limit-4AgentSpawnRect160x160-hide", 70, 60),
+                                       ("Limit-2AgentEmpty255x255-view9-ts5", 37, 40),
+                                       ("Limit-2AgentCluttered128x128", 130, 30)])
 def test_batch_vs_oracle(name, B, T):
     """same seeds, same actions: HIP batch == B oracle envs, every step, full observations."""
     import torch
