@@ -560,9 +560,14 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 if (n <= 8) {
                     if (lane < kb) step_par_publish(cfg, sc, ctx);
                     wave_lds_sync();
-                    const ParLane P = step_par_resolve(cfg, sc, g_batch, kb, lane);
+                    // (`lp`: the lane index, opaque to the compiler — what step_par_* derive from it, agent = lane / 8 and env =
+                    // lane % 8, is otherwise an invariant of the env loop: computed at the kernel's entry, spilled at the
+                    // register limit and fetched back from scratch memory four times per batch)
+                    int lp = lane;
+                    asm volatile("" : "+v"(lp));
+                    const ParLane P = step_par_resolve(cfg, sc, g_batch, kb, lp);
                     wave_lds_sync();
-                    loop = step_par_commit(cfg, st, fs.rewards, eb, sc, P, lane);
+                    loop = step_par_commit(cfg, st, fs.rewards, eb, sc, P, lp);
                     wave_lds_sync();
 #if defined(MG_AB_VARIANTS)
                     if (sc.stamp && !loop) sc.stamp[2] = wall_clock64();      // (the stamp step_agents sets when it runs)
@@ -702,47 +707,40 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
         };
         for (int it = lane; it < G * nv; it += kWave) { const int g = (int)by_nv.div((uint32_t)it); view_affine(g, it - __mul24(g, nv)); }
         wave_lds_sync();
-        // 3. egocentric crop + rotate: view cell (a = column, b = row) -> world cell.  All index
-        //    arithmetic in 24-bit multiplies (Div20; offsets of slot g are products of small numbers).
-        for (uint32_t it = (uint32_t)lane; it < (uint32_t)(G * nvVV); it += kWave) {
-            const uint32_t g = by_nvVV.div(it), iv = it - __umul24(g, (uint32_t)nvVV);
-            const uint32_t v = by_VV.template div<kExactVV>(iv), c = iv - __umul24(v, (uint32_t)VV);
-            const uint32_t vb = by_VS.template div<(VS_ > 0)>(c), va = c - __umul24(vb, (uint32_t)VS);
-            const uint8_t* w_grid = g_grid + __umul24(g, (uint32_t)cfg.cells_stride);
-            const uint32_t gcell = __umul24(g, (uint32_t)L.cell_stride);
-            const uint2 aff = w_vaff[__umul24(g, (uint32_t)nv) + v];
+        // 3. egocentric crop + rotate: view cell (a = column, b = row) -> world cell; the cell's object, the
+        //    agent shown on it, its transparency, and — tile selection (base.py:275-299) as if the cell were visible — the atlas
+        //    offset of the view cell (phase 5 puts the shadow tile where it is not).  All index arithmetic in 24-bit
+        //    multiplies (Div20; offsets of slot g are products of small numbers).
+        //    view_cell: ONE cell, everything about its slot and viewer handed in.  Written without branches around its
+        //    look-ups (an out-of-grid cell reads cell 0 and discards it): the row form below unrolls it over a view row, and the
+        //    look-ups of the row's cells then travel together instead of one dependent round trip after the other.
+        auto view_cell = [&](const uint32_t g, const uint32_t v, const uint32_t va, const uint32_t vb, const int wx, const int wy,
+                             const uint8_t* w_grid, const uint32_t gcell, const uint2 aff, const uint8_t* w_recb, uint16_t* tmap) -> bool {
             const uint32_t k = (aff.y >> 16) & 0xFFu;
             const int x = (int)(aff.y & 0xFFu), y = (int)((aff.y >> 8) & 0xFFu);
-            const bool swap = (aff.x >> 20) & 1u;
-            const int p = (int)(swap ? vb : va), q = (int)(swap ? va : vb);
-            const int wx = (int)(aff.x & 0x3FFu) - 256 + (((aff.x >> 21) & 1u) ? -p : p);
-            const int wy = (int)((aff.x >> 10) & 0x3FFu) - 256 + (((aff.x >> 22) & 1u) ? -q : q);
-            const bool inb = wx >= 0 && wx < W && wy >= 0 && wy < H;
-            const int cell = __mul24(wx, H) + wy;
-            uint32_t base = 0, show = 0xFF;
+            const bool inb = (uint32_t)wx < (uint32_t)W && (uint32_t)wy < (uint32_t)H;
+            const int cell = inb ? __mul24(wx, H) + wy : 0;
+            uint32_t base = w_grid[cell], show;
             uint32_t big1 = 0xFF, big2 = 0xFF;          // kBigGrid: the first / second agent of the cell, searched
-            if (inb) {
-                base = w_grid[cell];
-                if constexpr (kBigGrid) {
-                    // the lowest- and second-lowest-rank agents standing on the cell, among the env's n (what the per-cell maps
-                    // `first` / `second` hold for grids that fit LDS)
-                    const uint64_t* w_rec = g_rec + __umul24(g, (uint32_t)rec_stride);
-                    const uint32_t cxy = (uint32_t)wx | ((uint32_t)wy << 8);
-                    uint32_t r1 = 0xFF, r2 = 0xFF;
-                    for (int j = 0; j < n; j++) {
-                        const uint64_t rj = w_rec[j];
-                        if ((rec_byte(rj, MG_AG_FLAGS) & MG_AF_PLACED) && rec_xy(rj) == cxy) {
-                            const uint32_t rk = rec_byte(rj, MG_AG_RANK);
-                            if (rk < r1) { r2 = r1; big2 = big1; r1 = rk; big1 = (uint32_t)j; }
-                            else if (rk < r2) { r2 = rk; big2 = (uint32_t)j; }
-                        }
+            if constexpr (kBigGrid) {
+                // the lowest- and second-lowest-rank agents standing on the cell, among the env's n (what the per-cell maps
+                // `first` / `second` hold for grids that fit LDS)
+                const uint64_t* w_rec = g_rec + __umul24(g, (uint32_t)rec_stride);
+                const uint32_t cxy = (uint32_t)wx | ((uint32_t)wy << 8);
+                uint32_t r1 = 0xFF, r2 = 0xFF;
+                for (int j = 0; j < n; j++) {
+                    const uint64_t rj = w_rec[j];
+                    if (inb && (rec_byte(rj, MG_AG_FLAGS) & MG_AF_PLACED) && rec_xy(rj) == cxy) {
+                        const uint32_t rk = rec_byte(rj, MG_AG_RANK);
+                        if (rk < r1) { r2 = r1; big2 = big1; r1 = rk; big1 = (uint32_t)j; }
+                        else if (rk < r2) { r2 = rk; big2 = (uint32_t)j; }
                     }
-                    show = big1;
-                } else show = w_first[gcell + cell];
-                if (show != 0xFF && wx == x && wy == y && ((aff.y >> 26) & 1u)) show = k;   // viewer in the stack: base.py:282-291
-            }
-            if (s_oflags[base] & MG_OF_SEE_BEHIND)                     // opacity first
-                atomicOr(&w_trow[__umul24(g, (uint32_t)L.trow_stride) + __umul24(v, (uint32_t)VS) + vb], 1u << va);
+                }
+                show = big1;
+            } else show = w_first[gcell + cell];
+            if (!inb) { base = 0; show = 0xFF; }
+            if (show != 0xFF && wx == x && wy == y && ((aff.y >> 26) & 1u)) show = k;   // viewer in the stack: base.py:282-291
+            const bool see = (s_oflags[base] & MG_OF_SEE_BEHIND) != 0;                  // opacity first
             if (cfg.any_hide && inb) {
                 // hide_item_types (base.py:441-449), applied after visibility: a hidden cell object is
                 // replaced by the first agent standing on it (or nothing) and that agent is drawn as
@@ -752,16 +750,15 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 else if (base == 0 && first != 0xFF && first != k && ((cfg.hide_agent_mask >> k) & 1u))
                     show = kBigGrid ? big2 : (uint32_t)w_second[gcell + cell];
             }
-            // tile selection (base.py:275-299) as if the cell were visible -> atlas offset of the view cell; phase 5
-            // puts the shadow tile where it is not.  (Selected HERE, where the cell's object, agent and viewer are in
-            // registers: as a per-cell phase of its own behind the shadow cast it re-derived the cell's coordinates
-            // and re-read all of it — 82 instructions per trip, now 7 conditional stores per view ROW.)
+            // (the tile is selected HERE, where the cell's object, agent and viewer are in registers: as a per-cell phase of its
+            // own behind the shadow cast it re-derived the cell's coordinates and re-read all of it)
             const uint32_t orient = (aff.y >> 24) & 3u;                                 // -(dir+1) mod 4 of the viewer
-            const uint8_t* w_recb = reinterpret_cast<const uint8_t*>(g_rec + __umul24(g, (uint32_t)rec_stride));   // records, bytewise
             const uint32_t slot = s_oslot[base];
             const bool stacked = show != 0xFF && slot != 0xFF;                          // an agent on an overlappable object / an empty cell
+            const uint32_t sh = stacked ? show : 0u;
+            const uint32_t sdir = w_recb[sh * 8 + MG_AG_DIR];
             uint32_t tile = 1 + base;
-            if (stacked) tile = 1 + cfg.n_obj + (__umul24(slot, (uint32_t)n) + show) * 4 + w_recb[show * 8 + MG_AG_DIR];
+            if (stacked) tile = 1 + cfg.n_obj + (__umul24(slot, (uint32_t)n) + show) * 4 + sdir;
             uint32_t vt = __umul24(orient, (uint32_t)cfg.n_tiles) + tile;             // (virtual) tile index
             bool dyn = false;
             if constexpr (kPrestige) {
@@ -773,7 +770,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                     dyn = true;
                 }
             }
-            uint16_t* tmap = w_tmap + __umul24(g, (uint32_t)(L.tmap_stride / 2));
+            const uint32_t iv = __umul24(v, (uint32_t)VV) + __umul24(vb, (uint32_t)VS) + va;
             if constexpr (kChunkRaster && !kGlobalAtlas)                                // dword offset from the atlas base
                 tmap[iv] = (uint16_t)(dyn ? dyn_off / 4 + __umul24(vt - NT4, (uint32_t)(TS_ * TS_ * 3 / 4)) : __umul24(vt, (uint32_t)(TS_ * TS_ * 3 / 4)));
             else
@@ -782,6 +779,54 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 const size_t o = ((size_t)(e + (int)g) * nv + v) * VV + va * VS + vb;  // [i][j] like the reference
                 dbg_cells[o] = (uint8_t)base;
                 dbg_agent[o] = (uint8_t)show;
+            }
+            return see;
+        };
+        // Compile-time views: one lane per view ROW (G * nv * VS of them: 42 of 64 lanes for two envs of three 7 x 7 views, two
+        // trips for four) — the row's origin and step worked out once (along a view row the world cell moves by one column or
+        // one row: p = swap ? vb : va), its VS cells unrolled, the row's transparency mask assembled in a register and stored
+        // once.  Round 5's form — a lane per CELL: three divisions, the viewer's map decoded and an LDS atomic per cell — stays
+        // for run-time view sizes.
+        constexpr bool kRowViews = VS_ > 0;
+        if constexpr (kRowViews) {
+            const uint32_t rows = (uint32_t)(G * nv * VS);
+            for (uint32_t it = (uint32_t)lane; it < rows; it += kWave) {
+                const uint32_t gv = by_VS.template div<true>(it), vb = it - __umul24(gv, (uint32_t)VS);
+                const uint32_t g = by_nv.div(gv), v = gv - __umul24(g, (uint32_t)nv);
+                const uint8_t* w_grid = g_grid + __umul24(g, (uint32_t)cfg.cells_stride);
+                const uint32_t gcell = __umul24(g, (uint32_t)L.cell_stride);
+                const uint2 aff = w_vaff[__umul24(g, (uint32_t)nv) + v];
+                const uint8_t* w_recb = reinterpret_cast<const uint8_t*>(g_rec + __umul24(g, (uint32_t)rec_stride));   // records, bytewise
+                uint16_t* tmap = w_tmap + __umul24(g, (uint32_t)(L.tmap_stride / 2));
+                const bool swap = (aff.x >> 20) & 1u, negx = (aff.x >> 21) & 1u, negy = (aff.x >> 22) & 1u;
+                const int ox = (int)(aff.x & 0x3FFu) - 256, oy = (int)((aff.x >> 10) & 0x3FFu) - 256;
+                // column va = 0 of the row, and the step to the next column
+                int wx = ox + (swap ? (negx ? -(int)vb : (int)vb) : 0), wy = oy + (swap ? 0 : (negy ? -(int)vb : (int)vb));
+                const int dx = swap ? 0 : (negx ? -1 : 1), dy = swap ? (negy ? -1 : 1) : 0;
+                uint32_t bits = 0;
+#pragma unroll
+                for (int va = 0; va < VS_; va++) {
+                    if (view_cell(g, v, (uint32_t)va, vb, wx, wy, w_grid, gcell, aff, w_recb, tmap)) bits |= 1u << va;
+                    wx += dx; wy += dy;
+                }
+                w_trow[__umul24(g, (uint32_t)L.trow_stride) + __umul24(v, (uint32_t)VS) + vb] = bits;
+            }
+        } else {
+            for (uint32_t it = (uint32_t)lane; it < (uint32_t)(G * nvVV); it += kWave) {
+                const uint32_t g = by_nvVV.div(it), iv = it - __umul24(g, (uint32_t)nvVV);
+                const uint32_t v = by_VV.template div<kExactVV>(iv), c = iv - __umul24(v, (uint32_t)VV);
+                const uint32_t vb = by_VS.template div<(VS_ > 0)>(c), va = c - __umul24(vb, (uint32_t)VS);
+                const uint8_t* w_grid = g_grid + __umul24(g, (uint32_t)cfg.cells_stride);
+                const uint32_t gcell = __umul24(g, (uint32_t)L.cell_stride);
+                const uint2 aff = w_vaff[__umul24(g, (uint32_t)nv) + v];
+                const bool swap = (aff.x >> 20) & 1u;
+                const int p = (int)(swap ? vb : va), q = (int)(swap ? va : vb);
+                const int wx = (int)(aff.x & 0x3FFu) - 256 + (((aff.x >> 21) & 1u) ? -p : p);
+                const int wy = (int)((aff.x >> 10) & 0x3FFu) - 256 + (((aff.x >> 22) & 1u) ? -q : q);
+                const uint8_t* w_recb = reinterpret_cast<const uint8_t*>(g_rec + __umul24(g, (uint32_t)rec_stride));   // records, bytewise
+                uint16_t* tmap = w_tmap + __umul24(g, (uint32_t)(L.tmap_stride / 2));
+                if (view_cell(g, v, va, vb, wx, wy, w_grid, gcell, aff, w_recb, tmap))
+                    atomicOr(&w_trow[__umul24(g, (uint32_t)L.trow_stride) + __umul24(v, (uint32_t)VS) + vb], 1u << va);
             }
         }
         wave_lds_sync();
