@@ -786,9 +786,10 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
         // trips for four) — the row's origin and step worked out once (along a view row the world cell moves by one column or
         // one row: p = swap ? vb : va), its VS cells unrolled, the row's transparency mask assembled in a register and stored
         // once.  Round 5's form — a lane per CELL: three divisions, the viewer's map decoded and an LDS atomic per cell — stays
-        // for run-time view sizes.
+        // for run-time view sizes and for groups with fewer than 32 rows (one env of three viewers: 21 lanes walking 7 cells each
+        // is a longer chain than 147 cells over 64 lanes — measured: BASELINE configs[1], one env per wave, +0.9 % in row form).
         constexpr bool kRowViews = VS_ > 0;
-        if constexpr (kRowViews) {
+        if (kRowViews && G * nv * VS >= 32) {
             const uint32_t rows = (uint32_t)(G * nv * VS);
             for (uint32_t it = (uint32_t)lane; it < rows; it += kWave) {
                 const uint32_t gv = by_VS.template div<true>(it), vb = it - __umul24(gv, (uint32_t)VS);
@@ -805,7 +806,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 const int dx = swap ? 0 : (negx ? -1 : 1), dy = swap ? (negy ? -1 : 1) : 0;
                 uint32_t bits = 0;
 #pragma unroll
-                for (int va = 0; va < VS_; va++) {
+                for (int va = 0; va < (VS_ ? VS_ : 1); va++) {
                     if (view_cell(g, v, (uint32_t)va, vb, wx, wy, w_grid, gcell, aff, w_recb, tmap)) bits |= 1u << va;
                     wx += dx; wy += dy;
                 }
