@@ -19,7 +19,7 @@ B = int(os.environ.get("B", "32768"))
 if os.environ.get("TILE"):          # the bench scenario's shape with another view_tile_size
     from marlgrid_amd.agents import GridAgentInterface
     from marlgrid_amd.envs import ClutteredMultiGrid
-    env = ClutteredMultiGrid(agents=[GridAgentInterface(color=c, view_size=7, view_tile_size=int(os.environ["TILE"])) for c in ("red", "blue", "purple")],
+    env = ClutteredMultiGrid(agents=[GridAgentInterface(color=c, view_size=int(os.environ.get("VIEW", "7")), view_tile_size=int(os.environ["TILE"])) for c in ("red", "blue", "purple")],
                              grid_size=15, clutter_density=0.15, batch_size=B, strict=False, auto_reset=True)
 else:
     env = make(os.environ.get("WL", "MarlGrid-3AgentCluttered15x15-v0"), batch_size=B, auto_reset=True, strict=False)
