@@ -356,7 +356,11 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
         }
         // (the gather raster: groups of FOUR — measured against 1, 2, 3 and the whole batch of 8, raster alone: -4.0 % at tile 5,
         // -3.8 % at tile 6 against 8; with 8 the first store of a launch waits for 23 us of views, profiles/r05)
-        depth = depth_mode > 0 ? depth_mode : kGather ? 4 : !kChunkRaster ? L.tmap_slots : kPrestige ? (1 << (wave & 3)) : (TS_ == 8 ? 2 : 1);
+        // (round 6, with the views in row form — a lane per view row —: at 5-pixel tiles groups of TWO for views 7 and 9, whose four
+        // envs would be 84 / 108 rows — a full trip and a fifth of one —: raster alone 0.0727 -> 0.0711 ms at view 7, 0.0610 ->
+        // 0.0582 at view 9; every other gather geometry stays at four: `profiles/r06/ab_render_view_group_depth_sweep_v9.txt`)
+        constexpr int kGatherDepth = (TS_ == 5 && (VS_ == 7 || VS_ == 9) && !kPrestige) ? 2 : 4;
+        depth = depth_mode > 0 ? depth_mode : kGather ? kGatherDepth : !kChunkRaster ? L.tmap_slots : kPrestige ? (1 << (wave & 3)) : (TS_ == 8 ? 2 : 1);
         if (depth > L.tmap_slots) depth = L.tmap_slots;
         if (depth > L.view_slots) depth = L.view_slots;   // (a group's views need a scratch slot per env)
     }
@@ -786,10 +790,11 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
         // trips for four) — the row's origin and step worked out once (along a view row the world cell moves by one column or
         // one row: p = swap ? vb : va), its VS cells unrolled, the row's transparency mask assembled in a register and stored
         // once.  Round 5's form — a lane per CELL: three divisions, the viewer's map decoded and an LDS atomic per cell — stays
-        // for run-time view sizes and for groups with fewer than 32 rows (one env of three viewers: 21 lanes walking 7 cells each
-        // is a longer chain than 147 cells over 64 lanes — measured: BASELINE configs[1], one env per wave, +0.9 % in row form).
+        // for run-time view sizes and for groups with fewer than 24 rows (one env of three viewers: 21 lanes walking 7 cells each
+        // is a longer chain than 147 cells over 64 lanes — measured: BASELINE configs[1], one env per wave, +0.9 % in row form;
+        // four envs of ONE viewer, 28 rows — the reference's human_player example —: -1.4 %).
         constexpr bool kRowViews = VS_ > 0;
-        if (kRowViews && G * nv * VS >= 32) {
+        if (kRowViews && G * nv * VS >= 24) {
             const uint32_t rows = (uint32_t)(G * nv * VS);
             for (uint32_t it = (uint32_t)lane; it < rows; it += kWave) {
                 const uint32_t gv = by_VS.template div<true>(it), vb = it - __umul24(gv, (uint32_t)VS);
