@@ -63,7 +63,7 @@ extern "C" {
 #define MG_MAX_AGENTS 32  /* agents per env (the reference: any number, base.py:335-369; register_marl_env asserts <= 6) */
 #define MG_MAX_OBJ 256    /* object kinds incl. id 0 = None: the ids are uint8, as the reference's registry keys are (base.py:25,91) */
 #define MG_MAX_GEN 1024   /* ops of a reset program (device memory: a sanity bound, not a buffer size) */
-#define MG_MAX_VIEW 15
+#define MG_MAX_VIEW 31    /* view_size (agents.py:19-35: any; a view row is a 32-bit mask here) */
 #define MG_KEY_WORDS 2
 #define MG_MT_N 624
 #define MG_MT_HEAD 16

@@ -7,7 +7,7 @@ this module raises.  Build it with `python -c "import __graft_entry__ as g; g.bu
 import ctypes as C
 import os
 
-MAX_AGENTS, MAX_OBJ, MAX_GEN, MAX_VIEW, KEY_WORDS, MT_N, MT_HEAD = 32, 256, 1024, 15, 2, 624, 16
+MAX_AGENTS, MAX_OBJ, MAX_GEN, MAX_VIEW, KEY_WORDS, MT_N, MT_HEAD = 32, 256, 1024, 31, 2, 624, 16
 ABI_VERSION = 6
 
 OK = 0

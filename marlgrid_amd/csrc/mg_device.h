@@ -111,7 +111,7 @@ struct Div20 {
 
 // per-wave LDS scratch of the obs-render kernel (bytes), shared by host launch code and kernel
 struct RenderScratch {
-    int grid, rec, pres, pcol, vaff, first, second, trow, tmap, dyn, out, step, total;
+    int grid, rec, pres, pcol, vaff, first, second, trow, trow2, tmap, dyn, out, step, total;
     int stage_envs;    // envs whose inputs (grid + agent records) are staged per batch: 1..8
     int tmap_slots;    // tmaps a wave can hold at once (= stage_envs): the look-ahead depth of its env loop
     int tmap_stride;   // bytes per tmap slot
@@ -192,6 +192,8 @@ __host__ __device__ inline RenderScratch render_scratch_layout(int cells_stride,
     s.first = o; o += big ? 0 : s.view_slots * s.cell_stride;
     s.second = o; o += any_hide && !big ? s.view_slots * s.cell_stride : 0;
     s.trow = o;  o += s.view_slots * s.trow_stride * 4;
+    // (views of more than 15 rows: the shadow cast walks its rows in memory — mg_occlude.h —, the result next to the transparency)
+    s.trow2 = o; o += vs > 15 ? s.view_slots * s.trow_stride * 4 : 0;
     s.tmap_slots = stage_envs;
     s.tmap_stride = gather ? nv * vs * vs * 2 : round_up(nv * vs * vs * 2, 16);   // (gather: DENSE — band g of a group is entry g * vs)
     s.tmap = o;  o += round_up(s.tmap_slots * s.tmap_stride, 16);

@@ -77,7 +77,8 @@ __global__ __launch_bounds__(kBlock) void frame_kernel(MgConfig cfg, MgState st,
             if (rec_byte(r, MG_AG_FLAGS) & MG_AF_ACTIVE) {          // base.py:743
                 uint32_t m[MG_MAX_VIEW];
                 if (cfg.see_through_walls) { for (int j = 0; j < VS; j++) m[j] = (1u << VS) - 1u; }
-                else occlude_rows<0>(VS, off, &s_trow[tid * VS], m);
+                else if (VS <= kRegView) occlude_rows<0>(VS, off, &s_trow[tid * VS], m);
+                else occlude_rows_mem(VS, off, &s_trow[tid * VS], m);
                 for (int vb = 0; vb < VS; vb++)
                     for (int va = 0; va < VS; va++)
                         if ((m[vb] >> va) & 1u) {

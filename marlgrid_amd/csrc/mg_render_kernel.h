@@ -840,7 +840,15 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
         auto visibility = [&](const int g, const int v) {         // slot g, viewer v
             const uint64_t r = g_rec[__mul24(g, rec_stride) + s_vmap[v]];
             const int row0 = __mul24(g, L.trow_stride) + __mul24(v, VS);
-            uint32_t m[VS_ ? VS_ : MG_MAX_VIEW];
+            if (VS_ == 0 && VS > kRegView) {                            // views of 16 .. 31 rows: the rows stay in LDS
+                uint32_t* w_m = reinterpret_cast<uint32_t*>(ws + L.trow2) + row0;
+                if (!(rec_byte(r, MG_AG_FLAGS) & MG_AF_ACTIVE)) { for (int j = 0; j < VS; j++) w_m[j] = 0; }
+                else if (cfg.see_through_walls) { for (int j = 0; j < VS; j++) w_m[j] = (1u << VS) - 1u; }
+                else occlude_rows_mem(VS, off, &w_trow[row0], w_m);
+                for (int j = 0; j < VS; j++) w_vis[row0 + j] = w_m[j];
+                return;
+            }
+            uint32_t m[VS_ ? VS_ : kRegView];
             if (!(rec_byte(r, MG_AG_FLAGS) & MG_AF_ACTIVE)) {           // base.py:420-425
                 for (int j = 0; j < VS; j++) m[j] = 0;
             } else if (cfg.see_through_walls) {                          // agents.py:294-295

@@ -28,7 +28,7 @@ extern "C" {
 #define MGO_MAX_OBJ 256
 #define MGO_MAX_FILL 8
 #define MGO_MAX_GEN 192
-#define MGO_MAX_VIEW 15
+#define MGO_MAX_VIEW 31
 #define MGO_AGENT_BASE 1000 /* cell value >= this: the cell object is agent (value - base) */
 
 /* error codes (mirroring the reference's exceptions) */

@@ -154,6 +154,9 @@ def ref_recipe(name):
         "Limit-24AgentEmpty20x20-view5": ("EmptyMultiGrid", dict(grid_size=20, max_steps=60)),
         "Limit-3Agent100Kinds24x24": ("KindsTestEnv", dict(grid_size=24, max_steps=80)),
         "Limit-2AgentCluttered128x128": ("ClutteredMultiGrid", dict(grid_size=128, n_clutter=600, max_steps=40)),
+        "Limit-2AgentCluttered25x25-view21-tile5": ("ClutteredMultiGrid", dict(grid_size=25, n_clutter=90, max_steps=50)),
+        "Limit-3AgentCluttered33x33-view31-tile4": ("ClutteredMultiGrid", dict(grid_size=33, n_clutter=160, max_steps=50)),
+        "Limit-2AgentEmpty19x19-view17-tile8": ("EmptyMultiGrid", dict(grid_size=19, max_steps=50)),
         "Limit-3AgentCluttered200x200-hide": ("ClutteredMultiGrid", dict(grid_size=200, n_clutter=1500, max_steps=40)),
         "Limit-4AgentSpawnRect160x160-hide": ("SpawnRectTestEnv", dict(grid_size=160, respawn=True, max_steps=40,
                                                                        agent_spawn_kwargs=dict(top=(1, 1), size=(3, 3), max_tries=500))),
@@ -377,6 +380,9 @@ def registered(name):   # noqa: F811  (extends the table above with test-only sc
         "Limit-24AgentEmpty20x20-view5": lambda: empty_spec(24, 20, 5, colors=[ALL_COLORS[k % 12] for k in range(24)], max_steps=60),
         "Limit-3Agent100Kinds24x24": lambda: kinds_spec(),
         "Limit-2AgentCluttered128x128": lambda: cluttered_spec(2, 128, 7, n_clutter=600, max_steps=40),
+        "Limit-2AgentCluttered25x25-view21-tile5": lambda: cluttered_spec(2, 25, 21, n_clutter=90, tile_size=5, view_offset=2, max_steps=50),
+        "Limit-3AgentCluttered33x33-view31-tile4": lambda: cluttered_spec(3, 33, 31, n_clutter=160, tile_size=4, max_steps=50),
+        "Limit-2AgentEmpty19x19-view17-tile8": lambda: empty_spec(2, 19, 17, max_steps=50),
         "Limit-3AgentCluttered200x200-hide": lambda: _with_hide(cluttered_spec(3, 200, 7, n_clutter=1500, max_steps=40),
                                                                [["Wall"], ["Agent", "Goal"], []]),
         "Limit-4AgentSpawnRect160x160-hide": lambda: big_spawn_rect_spec(160),

@@ -204,7 +204,10 @@ def test_rng_seeding_golden():
                                        ("Limit-24AgentEmpty20x20-view5", 4099, 12),
                                        ("Limit-4AgentSpawnRect160x160-hide", 70, 60),
                                        ("Limit-2AgentEmpty255x255-view9-ts5", 37, 40),
-                                       ("Limit-2AgentCluttered128x128", 130, 30)])
+                                       ("Limit-2AgentCluttered128x128", 130, 30),
+                                       ("Limit-2AgentCluttered25x25-view21-tile5", 70, 50),
+                                       ("Limit-3AgentCluttered33x33-view31-tile4", 40, 40),
+                                       ("Limit-2AgentEmpty19x19-view17-tile8", 4100, 20)])
 def test_batch_vs_oracle(name, B, T):
     """same seeds, same actions: HIP batch == B oracle envs, every step, full observations."""
     import torch
