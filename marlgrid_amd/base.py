@@ -373,6 +373,12 @@ def _warn_generic_kernel(g, generic, prestige):
         return
     _GENERIC_WARNED.add(key)
     import warnings
+    if g.kernel_name.endswith(", 3>"):      # the grid-in-place variant: nothing about the view or the tiles would change it
+        warnings.warn("marlgrid_amd: this grid does not fit the observation kernel's LDS next to its per-cell agent maps (grids up "
+                      "to ~140 x 140, ~110 x 110 with hide_item_types, are staged there): it is read in place by the fully run-time "
+                      "instantiation (%s) — correct, every size up to 255 x 255, but slower per observation byte than a staged grid"
+                      % g.kernel_name, RuntimeWarning, stacklevel=4)
+        return
     near = []
     if prestige:
         near.append("'prestige' agents: view_size 7 with any view_tile_size (5, 8 and 11 fastest), or view_tile_size 8 / 16 / 32 with any view")
