@@ -35,6 +35,9 @@ __global__ __launch_bounds__(PC / 16) void encode_kernel(MgConfig cfg, MgState s
     constexpr int T = PC / 16;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x;
+#if defined(MG_AB_VARIANTS)
+    if (lc.aligned == 2) return;        // measurement build (MG_ENCODE_EMPTY): what a launch of this shape costs when it does nothing
+#endif
     const EncodePiece P = encode_piece(cfg, lc, (long long)blockIdx.x, PC);
     encode_stage(cfg, st, lc, P, smem, tid, T);
     __syncthreads();
@@ -50,7 +53,10 @@ hipError_t launch_encode(const MgConfig& cfg, const MgState& st, const uint8_t* 
 #if defined(MG_AB_VARIANTS)
     if (const char* f = getenv("MG_ENCODE_PC")) PC = atoi(f);      // measurement build: 1024 / 2048 / 4096 / 8192
 #endif
-    const EncodeLaunch lc = encode_launch(cfg, out, PC);
+    EncodeLaunch lc = encode_launch(cfg, out, PC);
+#if defined(MG_AB_VARIANTS)
+    if (const char* f = getenv("MG_ENCODE_EMPTY")) { if (atoi(f)) lc.aligned = 2; }
+#endif
     const size_t lds = kEncTab + (size_t)lc.nraw * (lc.two ? 2 : 1);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     const unsigned pieces = (unsigned)((lc.total + PC - 1) / PC);
