@@ -170,6 +170,8 @@ def ref_recipe(name):
                                                                  respawn=True, ghost_mode=True, reward_decay=False,
                                                                  n_bonus_tiles=3, initial_reward=True, penalty=-1.5)),
     }
+    if name.startswith("FuzzW-"):
+        return fuzz_wide_case(int(name[6:]))[1]
     if name.startswith("Fuzz-"):
         return fuzz_case(int(name[5:]))[1]
     return t[name]
@@ -457,6 +459,8 @@ def registered(name):   # noqa: F811  (extends the table above with test-only sc
     }
     if name in extra:
         return extra[name]()
+    if name.startswith("FuzzW-"):
+        return fuzz_wide_case(int(name[6:]))[0]
     if name.startswith("Fuzz-"):
         return fuzz_case(int(name[5:]))[0]
     return _registered_base(name)
@@ -499,6 +503,50 @@ def fuzz_case(i):
     if r2.random() < 0.25:
         ev = r2.choice([4, 6, 8])        # (a 2 x 2 view cannot be built upstream: MultiGrid needs >= 3)
         spec["view_size"], spec["view_offset"] = ev, min(spec["view_offset"], ev - 1)
+    if r.random() < 0.3:
+        _with_delays(spec, [r.choice([0, 0, 1, 3, 7]) for _ in range(n)])
+    if r.random() < 0.3:
+        types = ["Agent", "Wall", "Goal", "BonusTile"]
+        _with_hide(spec, [[t for t in types if r.random() < 0.35] for _ in range(n)])
+    return spec, recipe
+
+
+def fuzz_wide_case(i):
+    """(spec, reference recipe) of pseudo-random scenario `i` BEYOND round 5's limits: up to 32 agents,
+    views up to 31 x 31, grids up to 60 x 60 and — every seventh case — 130 ... 255 cells a side (the obs kernel's grid-in-place
+    variant), small tiles so that the images stay small.  The other knobs as in fuzz_case."""
+    import random
+    r = random.Random(880000 + i)
+    kind = r.choice(["empty", "cluttered", "cluttered", "goalcycle"])
+    big = i % 7 == 3
+    W = r.randint(130, 255) if big else r.randint(8, 60)
+    H = W if (kind == "goalcycle" or r.random() < 0.5) else (r.randint(130, 255) if big else r.randint(8, 60))
+    free = (W - 2) * (H - 2)
+    n = r.choice([1, 2, 3, 5, 9, 12, 17, 20, 24, 32])
+    n = max(1, min(n, free // 6))
+    vs = r.choice([3, 7, 10, 13, 16, 17, 19, 22, 25, 28, 31]) if not big else r.choice([5, 7, 9, 17])
+    if n > 12:
+        vs = min(vs, 9)                       # (many agents AND large views: images of megabytes per env; and LDS)
+    common = dict(ghost_mode=r.random() < 0.6, respawn=r.random() < 0.35, max_steps=r.randint(12, 45))
+    if r.random() < 0.5:
+        common["reward_decay"] = r.random() < 0.5
+    colors = [r.choice(_MANY) for _ in range(n)]
+    akw = dict(view_size=vs, tile_size=r.choice([3, 4, 5, 5, 6, 8]), view_offset=r.randint(0, vs - 1),
+               see_through_walls=r.random() < 0.25, colors=colors)
+    size = dict(grid_size=W) if W == H and r.random() < 0.5 else dict(width=W, height=H)
+    if kind == "empty":
+        spec = empty_spec(n, W, H=H, **akw, **common)
+        recipe = ("EmptyMultiGrid", dict(size, **common))
+    elif kind == "cluttered":
+        extra = dict(n_clutter=r.randint(0, min(free // 5, 2000)), randomize_goal=r.random() < 0.4)
+        spec = cluttered_spec(n, W, H=H, **extra, **akw, **common)
+        recipe = ("ClutteredMultiGrid", dict(size, **extra, **common))
+    else:
+        extra = dict(n_clutter=r.randint(0, min(free // 6, 2000)), n_bonus_tiles=r.randint(1, 4),
+                     reward=r.choice([1, 1, 2, 0.5]), penalty=r.choice([0.0, -0.5, -1.5]),
+                     initial_reward=r.random() < 0.6, reset_on_mistake=r.random() < 0.4)
+        spec = goalcycle_spec(n, W, **extra, **akw, **common)
+        recipe = ("ClutteredGoalCycleEnv", dict(grid_size=W, **extra, **common))
     if r.random() < 0.3:
         _with_delays(spec, [r.choice([0, 0, 1, 3, 7]) for _ in range(n)])
     if r.random() < 0.3:

@@ -246,6 +246,14 @@ def test_fuzz_vs_oracle(i):
     test_batch_vs_oracle("Fuzz-%d" % i, 40 + (i % 3) * 33, 70)
 
 
+@pytest.mark.parametrize("i", list(range(28)))
+def test_fuzz_beyond_the_old_limits_vs_oracle(i):
+    """scenarios.fuzz_wide_case — up to 32 agents, views up to 31 x 31, grids up to 255 x 255 (every seventh case: the grid
+    read in place), hide_item_types, spawn delays, all three scenario classes; the oracle is checked against the LIVE reference
+    on the same cases (test_oracle_vs_reference.py::test_live_fuzz_beyond_the_old_limits) —: HIP batch == oracle, every step"""
+    test_batch_vs_oracle("FuzzW-%d" % i, 9 + (i % 4) * 20, 45)
+
+
 def test_agent_objects_expose_batched_state_and_geometry():
     """env.agents[k].pos / .dir / .done / .active / .carrying and the view-geometry helpers
     (agents.py:141-288) are batched views of the device state: checked against the oracle's agents"""

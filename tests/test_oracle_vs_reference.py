@@ -57,11 +57,17 @@ def test_live_fuzz(i):
     test_live_side_by_side("Fuzz-%d" % i, 31000 + i, 90)
 
 
+@pytest.mark.parametrize("i", list(range(28)))
+def test_live_fuzz_beyond_the_old_limits(i):
+    """scenarios.fuzz_wide_case: up to 32 agents, views up to 31 x 31, grids up to 255 x 255 — reference == oracle, every step"""
+    test_live_side_by_side("FuzzW-%d" % i, 47000 + i, 45)
+
+
 def test_occlusion_live_random():
     m = refload.load()
     from marlgrid.agents import occlude_mask
     rng = np.random.RandomState(123)
-    for vs in (3, 5, 7, 9, 13, 2, 4, 6, 8):
+    for vs in (3, 5, 7, 9, 13, 2, 4, 6, 8, 16, 17, 22, 31):
         for off in (0, 1):
             for _ in range(150):
                 T = rng.rand(vs, vs) < rng.choice([0.6, 0.8, 0.95])
