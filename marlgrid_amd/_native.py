@@ -70,6 +70,7 @@ class GenProgram(C.Structure):
 PLACE_MAX, PLACE_ALL = 8, 136
 PLACE_STIR, PLACE_THOROUGH, PLACE_NO_REUSE = 1, 2, 4
 PLACE_STOP = {0: "", 1: "found", 2: "cap", 3: "time", 4: "memory", 5: "out of memory", 6: "small", 7: "not HBM-bound"}
+E_ARG, E_UNSUPPORTED, E_LAUNCH = -100, -101, -102
 E_NOMEM = -103
 
 
@@ -93,7 +94,7 @@ class PlaceStats(C.Structure):
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmarlgrid_hip.so")
 
 # every symbol include/marlgrid_hip.h declares
-SYMBOLS = ["mg_abi_version", "mg_struct_sizes", "mg_host_flag_alloc", "mg_host_flag_free", "mg_obs_alloc", "mg_obs_free", "mg_obs_place", "mg_obs_release", "mg_obs_trim", "mg_build_info", "mg_error_string", "mg_mt_seed", "mg_reset", "mg_step", "mg_step_render",
+SYMBOLS = ["mg_abi_version", "mg_struct_sizes", "mg_host_flag_alloc", "mg_host_flag_free", "mg_obs_alloc", "mg_obs_free", "mg_obs_place", "mg_obs_release", "mg_obs_trim", "mg_build_info", "mg_error_string", "mg_mt_seed", "mg_reset", "mg_step", "mg_step_render", "mg_step_render_encode",
            "mg_render_obs",
            "mg_encode", "mg_put_obj", "mg_place", "mg_render_frame", "mg_time_render_obs",
            "mg_render_obs_lds_bytes", "mg_render_kernel_name"]
@@ -164,6 +165,7 @@ def lib():
     L.mg_reset.argtypes = [C.POINTER(Config), C.POINTER(State), C.POINTER(GenProgram), vp, vp]
     L.mg_step.argtypes = [C.POINTER(Config), C.POINTER(State), vp, i32, vp, C.POINTER(GenProgram), vp]
     L.mg_step_render.argtypes = [C.POINTER(Config), C.POINTER(State), vp, i32, vp, C.POINTER(GenProgram), vp, vp]
+    L.mg_step_render_encode.argtypes = [C.POINTER(Config), C.POINTER(State), vp, i32, vp, C.POINTER(GenProgram), vp, vp, vp]
     L.mg_render_obs.argtypes = [C.POINTER(Config), C.POINTER(State), vp, vp, vp, vp, vp]
     L.mg_encode.argtypes = [C.POINTER(Config), C.POINTER(State), vp, vp, vp]
     L.mg_put_obj.argtypes = [C.POINTER(Config), C.POINTER(State), i32, i32, i32, vp, vp]

@@ -415,7 +415,7 @@ class MultiGridEnv(object):
     def __init__(self, agents=[], grid_size=None, width=None, height=None, max_steps=100,
                  reward_decay=True, seed=1337, respawn=False, ghost_mode=True, agent_spawn_kwargs={},
                  batch_size=1, device=None, seeds=None, auto_reset=False, strict=True, obs_buffers=2,
-                 fused_step=True, place_obs=True, _dry=False):
+                 fused_step=True, place_obs=True, encode_in_step=False, _dry=False):
         if grid_size is not None:
             assert width is None and height is None
             width, height = grid_size, grid_size
@@ -438,6 +438,12 @@ class MultiGridEnv(object):
         self.strict = strict
         self.obs_buffers = max(1, int(obs_buffers))
         self.fused_step = bool(fused_step)     # step() = one launch (mg_step_render) instead of mg_step + mg_render_obs
+        # encode_in_step=True: every step() (and reset()) also leaves `grid.encode()` of the batch — (B, W, H, 3) uint8,
+        # base.py:196-214 — in `self.grid_encoding`, written by the step's own launch where it can (mg_step_render_encode:
+        # +2.4 % bytes instead of a second launch), by an mg_encode launch behind it otherwise
+        self.encode_in_step = bool(encode_in_step)
+        self.grid_encoding = None
+        self._enc_fused = True                 # until the library says MG_E_UNSUPPORTED for this configuration
         # where the observation buffers live: "search" (= True) picks the fastest of a bounded set of candidate
         # allocations by timing the raster itself into each (_place_obs_buffers -> mg_obs_place: <= 2 s, candidates <=
         # min(a quarter of the free memory, 32 GiB)); "thorough": the long search (a second pass, larger candidates, one
@@ -1179,6 +1185,8 @@ class MultiGridEnv(object):
         N.check(self._lib.mg_reset(C.byref(self._cfg), C.byref(self._state), C.byref(prog),
                                    self._mask_ptr(env_mask), self._stream()))
         self._render()
+        if self.encode_in_step:
+            self._encode_into(self._encoding_buffer())
         if self.strict:
             self.check_errors()
         return self._package_obs()
@@ -1232,9 +1240,21 @@ class MultiGridEnv(object):
         if self.fused_step and not self._hetero:
             # the whole step — action loop, reset of finished episodes, observation raster — is ONE launch:
             # the wave that renders an env steps it first
-            N.check(self._lib.mg_step_render(C.byref(self._cfg), C.byref(self._state), actions.data_ptr(),
-                                             actions.element_size(), self.rewards.data_ptr(), prog,
-                                             self.obs.data_ptr(), stream))
+            enc_rc = N.E_UNSUPPORTED
+            if self.encode_in_step and self._enc_fused:
+                enc_rc = self._lib.mg_step_render_encode(C.byref(self._cfg), C.byref(self._state), actions.data_ptr(),
+                                                         actions.element_size(), self.rewards.data_ptr(), prog,
+                                                         self.obs.data_ptr(), self._encoding_buffer().data_ptr(), stream)
+                if enc_rc == N.E_UNSUPPORTED:      # (nothing was launched: more than 256 object ids + agent marks, or a grid read in place)
+                    self._enc_fused = False
+                else:
+                    N.check(enc_rc)
+            if enc_rc == N.E_UNSUPPORTED:
+                N.check(self._lib.mg_step_render(C.byref(self._cfg), C.byref(self._state), actions.data_ptr(),
+                                                 actions.element_size(), self.rewards.data_ptr(), prog,
+                                                 self.obs.data_ptr(), stream))
+                if self.encode_in_step:
+                    self._encode_into(self._encoding_buffer())
         else:
             N.check(self._lib.mg_step(C.byref(self._cfg), C.byref(self._state), actions.data_ptr(),
                                       actions.element_size(), self.rewards.data_ptr(), prog, stream))
@@ -1243,6 +1263,8 @@ class MultiGridEnv(object):
             for g in self._groups:       # one raster launch per view group (one group unless the agents' views differ)
                 N.check(self._lib.mg_render_obs(C.byref(g.cfg), C.byref(self._state), g.obs.data_ptr(), None,
                                                 None, None, stream))
+            if self.encode_in_step:
+                self._encode_into(self._encoding_buffer())
         if probe is not None:
             probe(2)
         if self.strict == "sync":
@@ -1333,9 +1355,19 @@ class MultiGridEnv(object):
         if vis_mask is not None:
             vm = torch.as_tensor(vis_mask, device=self.device).to(torch.uint8).expand(
                 self.batch_size, self.width, self.height).contiguous()
+        return self._encode_into(out, vm)
+
+    def _encode_into(self, out, vm=None):
         N.check(self._lib.mg_encode(C.byref(self._cfg), C.byref(self._state),
                                     None if vm is None else C.c_void_p(vm.data_ptr()), out.data_ptr(), self._stream()))
         return out
+
+    def _encoding_buffer(self):
+        """`grid_encoding` (encode_in_step): ONE tensor for the env's life — every step overwrites it"""
+        if self.grid_encoding is None:
+            import torch
+            self.grid_encoding = torch.empty((self.batch_size, self.width, self.height, 3), dtype=torch.uint8, device=self.device)
+        return self.grid_encoding
 
     @_on_device
     def check_errors(self):

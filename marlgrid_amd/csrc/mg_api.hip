@@ -137,14 +137,15 @@ int32_t mg_render_obs(const MgConfig* cfg, const MgState* st, uint8_t* obs, uint
     return rc(mg::launch_render(*cfg, *st, obs, view_cells, view_agent, vis_mask, (hipStream_t)stream));
 }
 
-int32_t mg_step_render(const MgConfig* cfg, const MgState* st, const void* actions, int32_t action_bytes, float* rewards,
-                       const MgGenProgram* auto_reset, uint8_t* obs, void* stream) {
+static int32_t step_render(const MgConfig* cfg, const MgState* st, const void* actions, int32_t action_bytes, float* rewards,
+                           const MgGenProgram* auto_reset, uint8_t* obs, uint8_t* encode_out, void* stream) {
     int e = check_both(cfg, st);
     if (e) return e;
     if (!actions || !rewards || !obs) return MG_E_ARG;
     if (action_bytes != 1 && action_bytes != 4 && action_bytes != 8) return MG_E_ARG;
     if (cfg->n_view != 0) return MG_E_ARG;   // one launch steps AND renders every agent: view groups take mg_step + mg_render_obs
     if (auto_reset && (e = check_prog(cfg, auto_reset))) return e;
+    if (encode_out && !mg::render_can_encode(*cfg)) return MG_E_UNSUPPORTED;
     mg::FusedStep fs;
     fs.actions = actions;
     fs.rewards = rewards;
@@ -152,8 +153,24 @@ int32_t mg_step_render(const MgConfig* cfg, const MgState* st, const void* actio
     fs.enabled = 1;
     fs.has_prog = auto_reset ? 1 : 0;
     if (auto_reset) fs.prog = *auto_reset;
-    else { fs.prog.template_grid = nullptr; fs.prog.n_ops = 0; fs.prog.reject = nullptr; fs.prog.n_reject = 0; }
+    else { fs.prog.template_grid = nullptr; fs.prog.n_ops = 0; fs.prog.ops = nullptr; fs.prog.reject = nullptr; fs.prog.n_reject = 0; }
+    fs.encode_out = encode_out;
+    const uint32_t cells = (uint32_t)(cfg->W * cfg->H), n = (uint32_t)cfg->n_agents;
+    fs.enc_m_cells = (uint32_t)((0x100000000ull + cells - 1) / cells);
+    fs.enc_m_n = (uint32_t)((0x100000000ull + n - 1) / n);
+    fs.enc_ne = 0;        // (launch_render fills it in for the instantiations that use it)
     return rc(mg::launch_render(*cfg, *st, obs, nullptr, nullptr, nullptr, (hipStream_t)stream, &fs));
+}
+
+int32_t mg_step_render(const MgConfig* cfg, const MgState* st, const void* actions, int32_t action_bytes, float* rewards,
+                       const MgGenProgram* auto_reset, uint8_t* obs, void* stream) {
+    return step_render(cfg, st, actions, action_bytes, rewards, auto_reset, obs, nullptr, stream);
+}
+
+int32_t mg_step_render_encode(const MgConfig* cfg, const MgState* st, const void* actions, int32_t action_bytes, float* rewards,
+                              const MgGenProgram* auto_reset, uint8_t* obs, uint8_t* encode_out, void* stream) {
+    if (!encode_out) return MG_E_ARG;
+    return step_render(cfg, st, actions, action_bytes, rewards, auto_reset, obs, encode_out, stream);
 }
 
 int32_t mg_encode(const MgConfig* cfg, const MgState* st, const uint8_t* vis_mask, uint8_t* out, void* stream) {

@@ -59,6 +59,10 @@ struct FusedStep {
     float* rewards;           // [B][n]
     int32_t action_bytes, enabled, has_prog;
     MgGenProgram prog;        // auto-reset program (has_prog)
+    uint8_t* encode_out;      // mg_step_render_encode: MultiGrid.encode of the stepped batch, [B][W][H][3] (null: not asked for)
+    uint32_t enc_m_cells, enc_m_n;   // ... its divide-by-multiply constants: ceil(2^32 / (W * H)), ceil(2^32 / n)
+    int32_t enc_ne;           // ... dwords of its LDS table — one per grid byte value: object kinds, then the agent codes n_obj +
+                              //     4 k + dir —, (n_obj + 4 n) rounded up to 16 (mg_render.hip: render_enc_entries; 0: none)
 };
 
 // Block-shared LDS of the obs-render kernel behind the atlas, sized by the configuration (object kinds in sixteens): per

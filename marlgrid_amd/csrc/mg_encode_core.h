@@ -257,6 +257,94 @@ MG_HD void encode_chunks(const MgConfig& cfg, const EncodeLaunch& lc, const Enco
     }
 }
 
+// ---- the same inside the obs kernel's fused step (mg_render_kernel.h: mg_step_render_encode) ----------------------------
+// A wave has its batch of kb envs staged in LDS anyway — the stepped grids (env j at raw + j * stride, HBM layout) and the
+// stepped records (env j's at recs + j * rec_stride) — and the batch is cells [cell0, cell0 + kb * cells) of the flat output
+// stream: the agents' marks go into the grid bytes themselves (n_obj + 4 n <= 256 is the caller's precondition) — and out again
+// when the caller still needs the grids —, the stream leaves as aligned 16-byte chunks between
+// a head and a tail of fewer than 16 single bytes each.  `tab`: one dword per byte value — object kinds, then the agent
+// codes n_obj + 4 k + dir — (type, colour, state).  Plain functions of `lane` (of `nl` >= 32 lanes) like the phases above.
+// (undo: take the marks out again — the caller still needs the grids as they were)
+MG_HD void encode_batch_mark(const MgConfig& cfg, uint8_t* raw, const uint64_t* recs, int rec_stride, int kb, uint32_t m_n, int lane, int nl,
+                             bool undo = false) {
+    const int n = cfg.n_agents, items = kb * n;
+    for (int it = lane; it < items; it += nl) {
+        const uint32_t e = enc_div((uint32_t)it, (uint32_t)n, m_n);
+        const int k = it - (int)e * n;
+        const uint64_t* rr = recs + (size_t)e * rec_stride;
+        const uint64_t r = rr[k];
+        if (!(rec_byte(r, MG_AG_FLAGS) & MG_AF_PLACED)) continue;
+        const uint32_t xy = rec_xy(r), rank = rec_byte(r, MG_AG_RANK);
+        bool first = true;
+        for (int j = 0; j < n; j++) {
+            const uint64_t rj = rr[j];
+            if ((rec_byte(rj, MG_AG_FLAGS) & MG_AF_PLACED) && rec_xy(rj) == xy && rec_byte(rj, MG_AG_RANK) < rank) first = false;
+        }
+        if (!first) continue;
+        const int addr = (int)e * cfg.cells_stride + (int)rec_byte(r, MG_AG_X) * cfg.H + (int)rec_byte(r, MG_AG_Y);
+        const uint8_t code = (uint8_t)((uint32_t)cfg.n_obj + 4u * (uint32_t)k + rec_byte(r, MG_AG_DIR));
+        if (!undo) { if (raw[addr] == 0) raw[addr] = code; }
+        else if (raw[addr] == code) raw[addr] = 0;           // (object ids are < n_obj: only a mark has this value)
+    }
+}
+MG_HD uint32_t encode_batch_byte(const uint8_t* raw, const uint32_t* tab, uint32_t s, int cells, int stride, uint32_t m_cells) {
+    const uint32_t f = enc_mulhi(s, 0xAAAAAAABu) >> 1, p = s - 3u * f;          // byte s of the batch: byte p of its cell f
+    const uint32_t e = enc_div(f, (uint32_t)cells, m_cells);
+    return (tab[raw[(int)e * stride + (int)(f - e * (uint32_t)cells)]] >> (8u * p)) & 0xFFu;
+}
+struct alignas(16) EncChunk { uint32_t v[4]; };
+// the aligned chunk that starts at byte s of the batch's stream
+MG_HD EncChunk encode_batch_chunk(const uint8_t* raw, const uint32_t* tab, uint32_t s, int cells, int stride, int len, uint32_t m_cells) {
+    const uint32_t f = enc_mulhi(s, 0xAAAAAAABu) >> 1, p = s - 3u * f;      // the chunk's first byte is byte p of cell f
+    const uint32_t e = enc_div(f, (uint32_t)cells, m_cells);
+    const int c = (int)f - (int)e * cells;
+    const int nA = cells - c;                                               // cells left in this env, this one included
+    const int addrA = (int)e * stride + c;
+    // six consecutive cells: a window of the env's bytes, continued — where the env ends inside it — by the next env's first
+    const bool needB = nA < 6 && (int)f + nA < len;
+    const int addrB = needB ? ((int)e + 1) * stride : 0;
+    MG_ENC_BOUNDS(addrA & ~3, 12);
+    MG_ENC_BOUNDS(addrB, 8);
+    const uint32_t sh = (uint32_t)addrA & 3u, s8 = 8u * (uint32_t)(nA < 7 ? nA : 7);
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(raw + (addrA & ~3));
+    const uint32_t* wb = reinterpret_cast<const uint32_t*>(raw + addrB);
+    const uint64_t A = (uint64_t)enc_align(w[1], w[0], sh) | ((uint64_t)enc_align(w[2], w[1], sh) << 32);
+    const uint64_t Bv = (uint64_t)wb[0] | ((uint64_t)wb[1] << 32);
+    const uint64_t X = needB ? ((A & ~(~0ull << s8)) | (Bv << s8)) : A;
+    uint32_t t[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) t[i] = tab[(uint32_t)(X >> (8 * i)) & 0xFFu];
+    // 18 bytes = 6 x 3, as five dwords; the chunk is bytes p .. p + 15 of them (as in encode_chunks)
+    const uint32_t d0 = enc_perm(t[1], t[0], 0x04020100u);
+    const uint32_t d1 = enc_perm(t[2], t[1], 0x05040201u);
+    const uint32_t d2 = enc_perm(t[3], t[2], 0x06050402u);
+    const uint32_t d3 = enc_perm(t[5], t[4], 0x04020100u);
+    const uint32_t d4 = enc_perm(0u, t[5], 0x0C0C0201u);
+    const EncChunk o = {{enc_align(d1, d0, p), enc_align(d2, d1, p), enc_align(d3, d2, p), enc_align(d4, d3, p)}};
+    return o;
+}
+MG_HD void encode_batch_chunks(const MgConfig& cfg, const uint8_t* raw, const uint32_t* tab, uint8_t* out, long long cell0, int kb,
+                               int cells, uint32_t m_cells, int lane, int nl) {
+    const int stride = cfg.cells_stride, len = kb * cells;
+    const uint32_t total = 3u * (uint32_t)len;
+    uint8_t* dst = out + 3 * cell0;
+    uint32_t head = (16u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u)) & 15u;
+    if (head > total) head = total;
+    const uint32_t nq = (total - head) >> 4, tail0 = head + 16u * nq;
+    if ((uint32_t)lane < head) dst[lane] = (uint8_t)encode_batch_byte(raw, tab, (uint32_t)lane, cells, stride, m_cells);
+    if (lane >= 16 && tail0 + (uint32_t)(lane - 16) < total && lane < 32)
+        dst[tail0 + (uint32_t)(lane - 16)] = (uint8_t)encode_batch_byte(raw, tab, tail0 + (uint32_t)(lane - 16), cells, stride, m_cells);
+    // two chunks per lane and trip: two independent chains of look-ups in flight (a trip is three dependent LDS round trips)
+    for (uint32_t q = (uint32_t)lane; q < nq; q += 2u * (uint32_t)nl) {
+        const uint32_t q2 = q + (uint32_t)nl;
+        const bool two = q2 < nq;
+        const EncChunk a = encode_batch_chunk(raw, tab, head + 16u * q, cells, stride, len, m_cells);
+        const EncChunk b = encode_batch_chunk(raw, tab, head + 16u * (two ? q2 : q), cells, stride, len, m_cells);
+        *reinterpret_cast<EncChunk*>(dst + head + 16u * q) = a;
+        if (two) *reinterpret_cast<EncChunk*>(dst + head + 16u * q2) = b;
+    }
+}
+
 // bytes of the raw plane a piece of PC cells can span in HBM layout (+ slack for the window reads past its end)
 inline int encode_raw_bytes(int cells, int stride, int PC) {
     const long long envs = cells >= PC ? 2 : (PC + cells - 2) / cells + 1;      // envs a piece can touch

@@ -19,6 +19,7 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
                          uint8_t* view_agent, uint8_t* vis_mask, hipStream_t s, const FusedStep* fused_step = nullptr,
                          RenderPick* pick = nullptr);
 int render_min_lds_bytes(const MgConfig& cfg);
+bool render_can_encode(const MgConfig& cfg);      // mg_step_render_encode: this configuration's step launch can write the encoding too
 hipError_t launch_encode(const MgConfig& cfg, const MgState& st, const uint8_t* vis_mask, uint8_t* out,
                          hipStream_t s);
 hipError_t launch_put_obj(const MgConfig& cfg, const MgState& st, int obj, int x, int y, const uint8_t* mask,

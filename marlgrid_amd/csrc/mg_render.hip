@@ -15,6 +15,7 @@ extern "C" int mg_ab_stamps(unsigned long long* p) { g_ab_stamps = p; return 0; 
 
 #if !defined(MG_DEV_ONLY)
 MG_RENDER_GROUP_A(MG_RENDER_EXTERN)
+MG_RENDER_GROUP_N(MG_RENDER_EXTERN)
 MG_RENDER_GROUP_B(MG_RENDER_EXTERN)
 MG_RENDER_GROUP_C(MG_RENDER_EXTERN)
 MG_RENDER_GROUP_D(MG_RENDER_EXTERN)
@@ -82,6 +83,52 @@ static int choose_wpb(const MgConfig& cfg, int mode) {
 #define MG_RENDER_DISPATCH_RT(TS, V)                                                                       \
     (wpb == 16 ? launch_render_t<0, TS, 8, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick)             \
                : launch_render_t<0, TS, 4, V>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick))
+// mg_step_render_encode: the instantiations with the encode compiled in (variant + 16, MG_RENDER_GROUP_N) — the shapes of the
+// BASELINE configs (views 7 and 9 at 8-pixel tiles), any other view at 8-pixel tiles, GridAgentInterface's defaults (view 7
+// at 5-pixel tiles) —, chosen as launch_render chooses among the plain ones.  Everything else (and what the fused encode
+// cannot do: a grid read in place, object ids and agent marks that do not share a byte, 'prestige' agents, an atlas in
+// global memory) is hipErrorNotSupported: nothing is launched, the C ABI answers MG_E_UNSUPPORTED, hosts call mg_step_render
+// and mg_encode.
+static int render_enc_entries(const MgConfig& cfg) { return cfg.n_obj + 4 * cfg.n_agents <= 256 ? ((cfg.n_obj + 4 * cfg.n_agents + 15) & ~15) : 0; }
+static hipError_t launch_render_enc(const MgConfig& cfg, const MgState& st, uint8_t* obs, hipStream_t s, const FusedStep* fs0,
+                                    RenderPick* pick) {
+    FusedStep fse = *fs0;
+    fse.enc_ne = render_enc_entries(cfg);
+    const FusedStep* fs = &fse;
+#if defined(MG_DEV_ONLY)
+    return launch_render_t<MG_DEV_ONLY>(cfg, st, obs, nullptr, nullptr, nullptr, s, fs, pick);
+#else
+    if (cfg.prestige_mask || render_big_grid(cfg) || fse.enc_ne == 0) return hipErrorNotSupported;
+    const int vs = cfg.view_size, ts = cfg.tile_size, mode = render_mode_for(cfg), wpb = choose_wpb(cfg, mode);
+    const size_t enc_lds = (size_t)fse.enc_ne * 4;
+    if (render_lds_bytes(cfg, 4, mode) + enc_lds > 160 * 1024) return hipErrorNotSupported;     // (incl. an atlas that stays in global memory)
+    const bool w16 = wpb == 16 && render_lds_bytes(cfg, 16, mode) + enc_lds <= 160 * 1024;
+    if (mode == 2) {
+        if (vs == 7 && ts == 5)
+            return w16 ? launch_render_t<7, 5, 16, 16, 2>(cfg, st, obs, nullptr, nullptr, nullptr, s, fs, pick)
+                       : launch_render_t<7, 5, 4, 16, 2>(cfg, st, obs, nullptr, nullptr, nullptr, s, fs, pick);
+        return hipErrorNotSupported;
+    }
+    if (ts != 8) return hipErrorNotSupported;
+    if (vs == 7)
+        return w16 ? launch_render_t<7, 8, 16, 16, 0>(cfg, st, obs, nullptr, nullptr, nullptr, s, fs, pick)
+                   : launch_render_t<7, 8, 4, 16, 0>(cfg, st, obs, nullptr, nullptr, nullptr, s, fs, pick);
+    if (vs == 9)
+        return w16 ? launch_render_t<9, 8, 16, 16, 0>(cfg, st, obs, nullptr, nullptr, nullptr, s, fs, pick)
+                   : launch_render_t<9, 8, 4, 16, 0>(cfg, st, obs, nullptr, nullptr, nullptr, s, fs, pick);
+    // (run-time view size: 8-wave workgroups, as MG_RENDER_DISPATCH_RT)
+    return wpb == 16 && render_lds_bytes(cfg, 8, mode) + enc_lds <= 160 * 1024
+               ? launch_render_t<0, 8, 8, 16, 0>(cfg, st, obs, nullptr, nullptr, nullptr, s, fs, pick)
+               : launch_render_t<0, 8, 4, 16, 0>(cfg, st, obs, nullptr, nullptr, nullptr, s, fs, pick);
+#endif
+}
+bool render_can_encode(const MgConfig& cfg) {
+    FusedStep f;
+    f.enabled = 1;
+    RenderPick p;
+    return launch_render_enc(cfg, MgState{}, nullptr, nullptr, &f, &p) == hipSuccess;
+}
+
 // The kernel launch of mg_render_obs / mg_step_render.
 hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, uint8_t* view_cells,
                          uint8_t* view_agent, uint8_t* vis_mask, hipStream_t s, const FusedStep* fs, RenderPick* pick) {
@@ -98,7 +145,14 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
     none.prog.ops = nullptr;
     none.prog.reject = nullptr;
     none.prog.n_reject = 0;
+    none.encode_out = nullptr;
+    none.enc_m_cells = none.enc_m_n = 0;
+    none.enc_ne = 0;
     if (!fs) fs = &none;
+    if (fs->encode_out) {
+        if (view_cells || view_agent || vis_mask || pick) return hipErrorInvalidValue;
+        return launch_render_enc(cfg, st, obs, s, fs, nullptr);
+    }
     if ((view_cells || view_agent || vis_mask) && !(view_cells && view_agent && vis_mask)) return hipErrorInvalidValue;
 #if defined(MG_DEV_ONLY)   // development: compile ONE instantiation (register / ISA checks without the other sixty),
     // e.g. -DMG_DEV_ONLY="7,5,16,0,0"

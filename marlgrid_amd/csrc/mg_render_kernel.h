@@ -37,6 +37,7 @@
 #endif
 #include "mg_occlude.h"
 #include "mg_gather.h"
+#include "mg_encode_core.h"
 
 namespace mg {
 
@@ -240,11 +241,16 @@ extern unsigned long long* g_ab_stamps;       // set through mg_ab_stamps (mg_re
 //     <7,8> only): 2 nontemporal stores, 3 raster only (phases 2-5 skipped), 4 stores only (no LDS
 //     look-ups), 6 no store bursts, 11 phases 2-5 executed twice.
 // WPB = waves per workgroup (4 or 16; MG_RENDER_WPB overrides the launcher's choice).
-template <int VS_, int TS_, int WPB, int V_ = 0, int RM_ = 0>
+// VX_ = V_ + 16: mg_step_render_encode's instantiations — the fused step also writes MultiGrid.encode of its batch (compiled
+//     in, not a flag of the launch: with the code in every instantiation the launches that do not ask for it lost 0.4 - 1.4 %
+//     off the fast path — `profiles/r06/ab_fused_encode_in_launch_as_a_flag_v23.txt`).
+template <int VS_, int TS_, int WPB, int VX_ = 0, int RM_ = 0>
 __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState st, uint8_t* __restrict__ obs,
                                                         uint8_t* __restrict__ dbg_cells,
                                                         uint8_t* __restrict__ dbg_agent,
                                                         uint8_t* __restrict__ dbg_vis, RenderLaunch lc, FusedStep fs) {
+    constexpr int V_ = VX_ & 15;                // the variant proper
+    constexpr bool kEnc = (VX_ & 16) != 0;      // + 16: mg_step_render_encode
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // the wave index is uniform: told to the compiler, everything derived from it (the wave's scratch
     // pointers, its run of envs, loop bounds) lives in SGPRs instead of one VGPR each
@@ -270,6 +276,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     // cell's object is a global load, and who stands on a view cell is searched among the env's agents instead of looked up in
     // per-cell maps; the atlas is read in place too (V_ == 8), view and tile size are run-time values
     constexpr bool kBigGrid = RM_ == 3;
+    static_assert(!kEnc || !kBigGrid, "mg_step_render_encode works on the staged grids");
     static_assert(!kBigGrid || (VS_ == 0 && TS_ == 0 && V_ == 8), "grid read in place: the fully run-time instantiation");
     constexpr int kRowB = kGather ? Gm::RS : 0, kRowW = kRowB / 4;
     constexpr int kPadFrontW = Gm::FRONT / 4, kPadTailW = Gm::TAIL / 4;   // zero dwords in front of a row / behind the last
@@ -297,6 +304,8 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     uint8_t* s_vmap = s_shared + lc.sh.vmap;                                            // [MG_MAX_AGENTS] viewer slot -> agent
     MgObjDesc* s_obj = reinterpret_cast<MgObjDesc*>(s_shared + lc.sh.obj);              // [NO] (fused step only)
     MgGenOp* s_ops = reinterpret_cast<MgGenOp*>(s_shared + lc.sh.ops);                  // [kOpsLds] the reset program's first ops (fused step)
+    // (mg_step_render_encode's instantiations) [fs.enc_ne] grid byte -> (type, colour, state): behind the last wave's scratch
+    uint32_t* s_enc = reinterpret_cast<uint32_t*>(s_shared + lc.sh.total + (size_t)WPB * lc.L.total);
     constexpr bool kChunkRaster = TS_ > 0 && (TS_ % 8) == 0 && RM_ == 0;
     constexpr bool kStreamRaster = !kChunkRaster && !kGather;     // assemble-and-stream
     // the rasters bound by instruction issue run at a raised wave priority (phase 6); measured per instantiation: the gather
@@ -432,7 +441,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             const int nops = fs.enabled && fs.has_prog ? min(fs.prog.n_ops, kOpsLds) * 2 : 0;   // ... and the reset program's first ops
             uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0, o0 = a0, o1 = a0, p0 = a0;
             uint8_t f = 0, sl = 0xFF, f2 = 0, vmap0 = 0;
-            uint32_t hide0 = 0;
+            uint32_t hide0 = 0, enc_raw = 0, enc_col = 0;
             double pscale0 = 0.;
             // padded tile rows (kPadRows): LDS dword d is 4 bytes of row d / kRowW, read as the 8 aligned bytes of the
             // atlas around them (pad_source, mg_gather.h) and cut out when they are stored
@@ -463,6 +472,12 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 if (tidl < MG_MAX_AGENTS) {     // the per-agent tables of the launch struct, requested with the rest
                     pscale0 = cfg.prestige_scale[tidl];
                     vmap0 = cfg.view_agent[tidl];
+                }
+                if constexpr (kEnc) {
+                    if (fs.encode_out && tidl < fs.enc_ne) {     // (mg_step_render_encode) the encode table's sources: T >= 256 >= enc_ne
+                        if (tidl < cfg.n_obj) enc_raw = *reinterpret_cast<const uint32_t*>(cfg.obj + tidl);
+                        else if (tidl - cfg.n_obj < 4 * cfg.n_agents) enc_col = cfg.agent_color_idx[(tidl - cfg.n_obj) >> 2];
+                    }
                 }
             }
             StepScratch sc;
@@ -527,6 +542,14 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                 if (tidl < MG_MAX_AGENTS) {
                     s_pscale[tidl] = pscale0;
                     s_vmap[tidl] = cfg.n_view ? vmap0 : (uint8_t)tidl;
+                }
+                if constexpr (kEnc) {
+                    if (fs.encode_out && tidl < fs.enc_ne) {
+                        // id 0 (None) and the padding encode as zeros; agent code 4 k + d: (agent_type_idx, colour of k, d)
+                        const int code = tidl - cfg.n_obj;
+                        s_enc[tidl] = tidl < cfg.n_obj ? (tidl ? enc_raw & 0xFFFFFFu : 0u)
+                                    : code < 4 * cfg.n_agents ? ((uint32_t)cfg.agent_type_idx | (enc_col << 8) | ((uint32_t)(code & 3) << 16)) : 0u;
+                    }
                 }
             }
             if (first) {
@@ -639,9 +662,36 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     // alone, so that the wave's first store leaves early, then groups of 2, 4, ... up to the wave's depth.
     const bool ramp = kChunkRaster && kPrestige && depth_mode <= 0 && eb == e0;
     int gd = ramp ? 1 : depth;                  // size of the current group
+    // mg_step_render_encode: MultiGrid.encode (base.py:196-214) of the batch this wave has just stepped — its stepped grids and
+    // records are staged: the first agent of an empty cell marks it in the grid bytes, then a lane per aligned 16-byte chunk of
+    // the batch's part of the flat output stream (mg_encode_core.h); +2.4 % bytes on the bench's shape.  WHEN: behind the
+    // rasters of the batch's first group — the wave's first image stores are out, the other waves' stores cover the look-ups'
+    // latency (at the end of the wave's run it was the launch's tail: +4.1 % instead of the bytes' +2.4 %), and the marks are
+    // taken out again for the views that follow; a batch of one group: when it is done.
+    bool enc_pending = false;
+    if constexpr (kEnc) enc_pending = fs.enabled && fs.encode_out != nullptr && kb > 0;
+    auto encode_batch = [&](const bool undo) {
+        if constexpr (!kEnc) { (void)undo; return; } else {
+        MG_REGION_LOCALS;
+        const FusedStep& fse = kernarg_again<FusedStep>(offsetof(RenderKernargs, fs));
+        int le = lane;
+        asm volatile("" : "+v"(le));
+        encode_batch_mark(cfg, w_stage_g, w_stage_r, rec_stride, kb, fse.enc_m_n, le, kWave);
+        wave_lds_sync();
+        encode_batch_chunks(cfg, w_stage_g, s_enc, fse.encode_out, (long long)eb * (W * H), kb, W * H, fse.enc_m_cells, le, kWave);
+        wave_lds_sync();
+        if (undo) {
+            encode_batch_mark(cfg, w_stage_g, w_stage_r, rec_stride, kb, fse.enc_m_n, le, kWave, true);
+            wave_lds_sync();
+        }
+        enc_pending = false;
+        }
+    };
+    (void)encode_batch; (void)enc_pending;
     for (int ej0 = 0; ej0 < kb; ej0 += gd, gd = ramp ? min(2 * gd, L.view_slots) : depth)
     for (int pass = 0; pass < 2; pass++)
     for (int ej = ej0; ej < min(kb, ej0 + gd); ej++) {
+        if constexpr (kEnc) { if (enc_pending && ej0 > 0) encode_batch(true); }
         MG_REGION_LOCALS;
         const int e = eb + ej;
         uint16_t* w_tmap = w_tmap0 + (size_t)(ej - ej0) * (L.tmap_stride / 2);
@@ -1242,9 +1292,11 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
         wave_lds_sync();   // scratch is reused by the next env
         if (e == e0) MG_STAMP(pass == 0 ? 4 : 5);
     }
+        if constexpr (kEnc) { if (enc_pending) encode_batch(false); }
     }
     MG_STAMP(6);
 }
+
 
 // Compute units of the current device (256 on a whole MI355X; 32 per partition in CPX mode): what the persistent
 // grid is sized for.  Asked once per device (hipDeviceGetAttribute is a host-side table look-up, no stream work).
@@ -1260,21 +1312,26 @@ inline int device_cus() {
     return cached[dev];
 }
 
-template <int VS_, int TS_, int WPB, int V_ = 0, int RM_ = 0>
+template <int VS_, int TS_, int WPB, int VX_ = 0, int RM_ = 0>
 hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_t* obs, uint8_t* c, uint8_t* a,
                                   uint8_t* v, hipStream_t s, const FusedStep* fs, RenderPick* pick) {
     static_assert(RM_ == 1 || TS_ == 0 || (TS_ % 8) != 0 || TS_ == 8 || TS_ == 16 || TS_ == 32, "see render_chunk_raster");
     const RenderScratch L = render_scratch_for(cfg, WPB, RM_);
+    constexpr int V_ = VX_ & 15;
     const size_t atlas_lds = (V_ == 8 || V_ == 12) ? 0 : (size_t)render_atlas_lds_bytes(cfg, RM_);
     const RenderShared sh = render_shared_layout(cfg);
-    size_t lds = atlas_lds + sh.total + WPB * (size_t)L.total;
+    // (mg_step_render_encode: its table — fs->enc_ne dwords — lies behind the block-shared tables, the waves' scratch behind it)
+    constexpr bool kEnc = (VX_ & 16) != 0;
+    if (kEnc && (!fs || fs->enc_ne <= 0)) return hipErrorInvalidValue;
+    const size_t enc_lds = kEnc ? (size_t)fs->enc_ne * 4 : 0;
+    size_t lds = atlas_lds + sh.total + enc_lds + WPB * (size_t)L.total;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (pick) {     // mg_render_kernel_name: which instantiation this configuration gets — nothing is launched
-        pick->vs = VS_; pick->ts = TS_; pick->wpb = WPB; pick->v = V_; pick->rm = RM_; pick->lds = (int)lds;
+        pick->vs = VS_; pick->ts = TS_; pick->wpb = WPB; pick->v = VX_; pick->rm = RM_; pick->lds = (int)lds;
         return hipSuccess;
     }
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<VS_, TS_, WPB, V_, RM_>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<VS_, TS_, WPB, VX_, RM_>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
@@ -1315,7 +1372,7 @@ hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_t* obs,
 #if defined(MG_AB_VARIANTS)
     if (const char* f = getenv("MG_RENDER_DEPTH")) lc.depth_mode = atoi(f);   // 1: every wave view -> raster env by env
 #endif
-    hipLaunchKernelGGL((render_kernel<VS_, TS_, WPB, V_, RM_>), dim3(blocks), dim3(WPB * 64), lds, s, cfg, st, obs, c, a, v,
+    hipLaunchKernelGGL((render_kernel<VS_, TS_, WPB, VX_, RM_>), dim3(blocks), dim3(WPB * 64), lds, s, cfg, st, obs, c, a, v,
                        lc, *fs);
     return hipGetLastError();
 }
@@ -1365,6 +1422,9 @@ hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_t* obs,
 #else
 #define MG_RENDER_GROUP_V(X)
 #endif
+#define MG_RENDER_GROUP_N(X) /* mg_step_render_encode (V + 16): the BASELINE configs' shapes, the default tile, any view at tile 8 */ \
+    X(7, 8, 16, 16, 0) X(7, 8, 4, 16, 0) X(9, 8, 16, 16, 0) X(9, 8, 4, 16, 0) X(0, 8, 8, 16, 0) X(0, 8, 4, 16, 0)                       \
+    X(7, 5, 16, 16, 2) X(7, 5, 4, 16, 2)
 #define MG_RENDER_EXTERN(VS, TS, WPB, V, RM)                                                                               \
     extern template hipError_t launch_render_t<VS, TS, WPB, V, RM>(const MgConfig&, const MgState&, uint8_t*, uint8_t*,     \
                                                                  uint8_t*, uint8_t*, hipStream_t, const FusedStep*, RenderPick*);

@@ -243,6 +243,45 @@ int emu_encode(const MgConfig* cfg, const MgState* st, const uint8_t* vis, uint8
     return (int)g_enc_oob;
 }
 
+// The fused step's encode (encode_batch_mark / encode_batch_chunks) as a wave of the obs kernel runs it: the wave's batch of
+// kb <= 8 envs staged in "LDS" — the grids in HBM layout, the records env by env —, 64 lanes, the table as the kernel's
+// prologue builds it.  per_wave: envs a wave walks (its batches follow each other).  slack: bytes of the staging buffer
+// behind the batch's grids that may be read (never used): what follows the grids in the wave's scratch.
+int emu_encode_batch(const MgConfig* cfg, const MgState* st, uint8_t* out, int per_wave, int rec_stride) {
+    const int n = cfg->n_agents, cells = cfg->W * cfg->H, stride = cfg->cells_stride;
+    if (cfg->n_obj + 4 * n > 256 || rec_stride < n) return -1;
+    std::vector<uint32_t> tab(256, 0xDEADBEEFu);
+    for (int o = 0; o < cfg->n_obj; o++)
+        tab[o] = o ? ((uint32_t)cfg->obj[o].type_idx | ((uint32_t)cfg->obj[o].color_idx << 8) | ((uint32_t)cfg->obj[o].state << 16)) : 0u;
+    for (int code = 0; code < 4 * n; code++)
+        tab[cfg->n_obj + code] = (uint32_t)cfg->agent_type_idx | ((uint32_t)cfg->agent_color_idx[code >> 2] << 8) | ((uint32_t)(code & 3) << 16);
+    const uint32_t m_cells = (uint32_t)((0x100000000ull + (uint32_t)cells - 1) / (uint32_t)cells);
+    const uint32_t m_n = (uint32_t)((0x100000000ull + (uint32_t)n - 1) / (uint32_t)n);
+    const int K = 8, slack = 16;
+    std::vector<uint8_t> raw((size_t)K * stride + slack + 16);
+    uint8_t* rw = raw.data() + ((16 - (reinterpret_cast<uintptr_t>(raw.data()) & 15)) & 15);
+    std::vector<uint64_t> recs((size_t)K * rec_stride);
+    g_enc_plane_bytes = (uint32_t)(K * stride + slack);
+    g_enc_oob = 0;
+    for (int e0 = 0; e0 < cfg->B; e0 += per_wave)
+        for (int eb = e0; eb < e0 + per_wave && eb < cfg->B; eb += K) {
+            int kb = e0 + per_wave - eb;
+            if (kb > K) kb = K;
+            if (kb > cfg->B - eb) kb = cfg->B - eb;
+            memset(rw, 0xA5, (size_t)K * stride + slack);
+            memcpy(rw, st->grid + (size_t)eb * stride, (size_t)kb * stride);
+            for (int j = 0; j < kb; j++)
+                for (int k = 0; k < n; k++) recs[(size_t)j * rec_stride + k] = st->agents[(size_t)(eb + j) * n + k];
+            for (int lane = 0; lane < 64; lane++) mg::encode_batch_mark(*cfg, rw, recs.data(), rec_stride, kb, m_n, lane, 64);
+            for (int lane = 0; lane < 64; lane++)
+                mg::encode_batch_chunks(*cfg, rw, tab.data(), out, (long long)eb * cells, kb, cells, m_cells, lane, 64);
+            // the marks taken out again: the staged grids are what they were (the views that follow read them)
+            for (int lane = 0; lane < 64; lane++) mg::encode_batch_mark(*cfg, rw, recs.data(), rec_stride, kb, m_n, lane, 64, true);
+            if (memcmp(rw, st->grid + (size_t)eb * stride, (size_t)kb * stride) != 0) return -3;
+        }
+    return (int)g_enc_oob;
+}
+
 int emu_sizeof(int which) {
     switch (which) {
     case 0: return (int)sizeof(MgConfig);

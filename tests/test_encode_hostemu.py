@@ -85,6 +85,21 @@ def run_case(rng, B, W, H, n, n_obj, pc=0, with_vis=False, misalign=0, crowd=Fal
         raise AssertionError("encode differs at (env, x, y) %s ... of %d cells; got %s want %s"
                              % (bad[:4].tolist(), len(bad), got[tuple(bad[0])], want[tuple(bad[0])]))
     assert (buf[:off] == 0x5A).all() and (buf[off + B * cells * 3:] == 0x5A).all(), "wrote outside `out`"
+    # the same batch through the fused step's encode (a wave's staged batch of <= 8 envs at a time: encode_batch_mark /
+    # encode_batch_chunks), walked with several envs-per-wave so that batches start at every phase of the 16-byte chunks
+    if vis is None and n_obj + 4 * n <= 256:
+        for per_wave in sorted({1, 3, 8, 13, 64} if B <= 64 else {8}):
+            buf2 = np.full(B * cells * 3 + 64, 0x5A, np.uint8)
+            off2 = (-buf2.ctypes.data) % 16 + misalign
+            out2 = buf2[off2:off2 + B * cells * 3]
+            rc = L.emu_encode_batch(C.byref(cfg), C.byref(st), C.c_void_p(out2.ctypes.data), per_wave, n + int(rng.randint(0, 3)))
+            assert rc == 0, "fused encode: out-of-range LDS offsets: %d" % rc
+            got2 = out2.reshape(B, W, H, 3)
+            if not np.array_equal(got2, want):
+                bad = np.argwhere((got2 != want).any(axis=-1))
+                raise AssertionError("fused encode (per_wave %d) differs at (env, x, y) %s ... of %d cells; got %s want %s"
+                                     % (per_wave, bad[:4].tolist(), len(bad), got2[tuple(bad[0])], want[tuple(bad[0])]))
+            assert (buf2[:off2] == 0x5A).all() and (buf2[off2 + B * cells * 3:] == 0x5A).all(), "fused encode wrote outside `out`"
 
 
 @pytest.mark.parametrize("W,H,n", [(15, 15, 3), (11, 11, 3), (9, 9, 4), (30, 30, 8), (3, 3, 1), (3, 5, 2), (7, 11, 3), (40, 40, 2),

@@ -455,6 +455,68 @@ def test_encode_whole_batch_and_through_the_c_abi(name, B):
         assert bool((buf[:shift] == 0x5A).all()) and bool((buf[shift + nb:] == 0x5A).all())
 
 
+@pytest.mark.parametrize("name,B", [("MarlGrid-3AgentCluttered15x15-v0", 32768), ("MarlGrid-3AgentCluttered15x15-v0", 4099),
+                                    ("MarlGrid-3AgentCluttered11x11-v0", 4096), ("Test-4AgentEmpty5x5-crowded", 1000),
+                                    ("Custom-8AgentCluttered30x30", 2051), ("Edge-2AgentCluttered40x40-view9-off3", 700),
+                                    ("Edge-16AgentEmpty6x6-view7", 333), ("Goalcycle-demo-solo-v0", 517),
+                                    ("Test-3AgentCluttered9x9-prestige-mixed", 300), ("Limit-24AgentEmpty20x20-view5", 77),
+                                    ("Limit-3Agent100Kinds24x24", 130), ("Limit-2AgentCluttered128x128", 9), ("Limit-3AgentCluttered200x200-hide", 5),
+                                    ("Limit-2Agent60Groups16x16", 203), ("FuzzW-0", 21), ("MarlGrid-2AgentEmpty9x9-v0", 1)])
+def test_encode_in_step(name, B):
+    """encode_in_step=True: `env.grid_encoding` after every step() (and reset()) is what `env.grid.encode()` — the
+    stand-alone mg_encode kernel, itself compared with the reference's encode at every step of every golden — returns at
+    that moment, and a twin without the option steps identically (observations, rewards, done, state).  Where the step's
+    own launch writes it (mg_step_render_encode: grids staged in LDS, object ids and agent marks in one byte) and where
+    the library declines and the host launches mg_encode behind the step (a 200 x 200 grid read in place; agents with
+    their own views), with auto-reset inside the launch, batches that end inside a wave's run of envs,
+    16 x 16-cell grids (no padding between the staged envs) and the flat stream at every 16-byte phase."""
+    import torch
+    seeds = 77 + np.arange(B)
+    env = product_envs.build(name, batch_size=B, seeds=seeds, place_obs=False, auto_reset=True, encode_in_step=True)
+    twin = product_envs.build(name, batch_size=B, seeds=seeds, place_obs=False, auto_reset=True)
+    o1, o2 = env.reset(), twin.reset()
+    assert torch.equal(env.grid_encoding, env.grid.encode())
+    rng = np.random.RandomState(3)
+    n = env.num_agents
+    T = 40 if B <= 4099 else 14
+    for t in range(T):
+        a = rng.randint(0, 7, size=(B, n))
+        if name in ("Limit-3Agent100Kinds24x24", "Limit-2Agent60Groups16x16"):
+            a[a == 5] = 6          # (toggling a Box is a TypeError upstream, objects.py: reproduced, and not this test's subject)
+        a = torch.from_numpy(a)
+        o1, r1, d1, _ = env.step(a)
+        o2, r2, d2, _ = twin.step(a)
+        want = env.grid.encode()
+        assert torch.equal(env.grid_encoding, want), (t, torch.nonzero((env.grid_encoding != want).any(dim=-1))[:5])
+        if t % 5 == 0 or t == T - 1:
+            assert torch.equal(want, _encode_reference_torch(env)), t
+            assert torch.equal(r1, r2) and torch.equal(d1, d2), t
+            assert all(torch.equal(x, y) for x, y in zip(_obs_list(o1), _obs_list(o2))), t
+    assert torch.equal(env.grid_state, twin.grid_state) and torch.equal(env.agent_state, twin.agent_state)
+    assert torch.equal(env.mt_pos, twin.mt_pos)
+    # who wrote it: the step's own launch for the shapes the library has the encode compiled into (views 7 / 9 / any at 8-pixel
+    # tiles, view 7 at 5-pixel tiles; MG_RENDER_GROUP_N) — the host's mg_encode launch behind the step where it declined
+    if env.fused_step and not env._hetero:
+        in_launch = {"MarlGrid-3AgentCluttered15x15-v0": True, "MarlGrid-3AgentCluttered11x11-v0": True, "Custom-8AgentCluttered30x30": True,
+                     "MarlGrid-2AgentEmpty9x9-v0": True, "Limit-3AgentCluttered200x200-hide": False,
+                     "Test-3AgentCluttered9x9-prestige-mixed": False}
+        if name in in_launch:
+            assert env._enc_fused == in_launch[name], (name, env.kernel_name, env._enc_fused)
+    env.check_errors()
+
+
+def _obs_list(o):
+    import torch
+    if torch.is_tensor(o):
+        return [o]
+    if isinstance(o, dict):
+        return [v for v in o.values() if torch.is_tensor(v)]
+    out = []
+    for x in o:
+        out.extend(_obs_list(x))
+    return out
+
+
 def test_obs_ring_longer_than_a_placement_call():
     """obs_buffers > MG_PLACE_MAX (8): the first eight buffers of the ring are placed by the library, the rest stay torch
     allocations, the ring rotates through all of them (the constructor used to fail with 'invalid argument')"""

@@ -65,7 +65,7 @@ def test_golden_trajectory(name):
     S, T, n = g["actions"].shape
     F = g["obs_full"].shape[0]
     Fh = g["obs_a0"].shape[0] if "obs_a0" in g.files else 0      # agents with their own views: per-agent arrays
-    env = product_envs.build(name, batch_size=S, seeds=g["seeds"])
+    env = product_envs.build(name, batch_size=S, seeds=g["seeds"], encode_in_step=True)
     # the product's own scenario description must equal the independent one the oracle was pinned with
     spec = scenarios.registered(name)
     ps = env.scenario_spec()
@@ -96,6 +96,7 @@ def test_golden_trajectory(name):
             _cmp_rich(o, g, t + 1, "%s step %d" % (name, t))
         o, r, dn = _pov(o), r.cpu().numpy(), dn.cpu().numpy()
         st = product_envs.canonical(env)
+        enc_step = env.grid_encoding.cpu().numpy()
         enc = env.grid.encode().cpu().numpy()
         for si in range(S):
             what = "%s seed %d step %d" % (name, si, t)
@@ -103,6 +104,7 @@ def test_golden_trajectory(name):
             assert np.abs(r[si].astype(np.float64) - g["rewards"][si, t]).max() <= REW_TOL, what
             assert bool(dn[si]) == bool(g["ep_done"][si, t]), what
             assert np.array_equal(enc[si], g["encode"][si, t]), what
+            assert np.array_equal(enc_step[si], g["encode"][si, t]), what       # (encode_in_step: written by the step's own launch)
             assert [refstate.crc(x) for x in o[si]] == list(g["obs_crc"][si, t]), what
             if si < F:
                 assert np.array_equal(o[si], g["obs_full"][si, t]), what
