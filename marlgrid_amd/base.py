@@ -1104,8 +1104,8 @@ class MultiGridEnv(object):
             if need < 0 or need > 160 * 1024:
                 raise NotImplementedError(
                     "this configuration needs %d KiB of LDS per workgroup for 4 waves of per-env scratch; the obs "
-                    "kernel has 160 KiB — with 'prestige' agents reduce the grid (their recolouring has no grid-in-place variant) "
-                    "or the tile size; otherwise the number of agents / the view size" % (need // 1024))
+                    "kernel has 160 KiB — with 'prestige' agents reduce their number or the tile size (every one of them has "
+                    "its four recoloured sprites there); otherwise the number of agents / the view size" % (need // 1024))
             g.obj_dev = torch.from_numpy(raw).to(self.device)
             g.atlas_dev = torch.from_numpy(flat).to(self.device)
             g.atlas = atlas

@@ -48,8 +48,8 @@ static int render_small_lds_bytes(const MgConfig& cfg) {
     return atlas_b + rest <= 160 * 1024 ? atlas_b + rest : rest;   // else the atlas is read in place
 }
 // A grid whose staged copy (and the per-cell first-agent maps beside it) does not fit LDS even then — beyond ~140 x 140, ~110 x
-// 110 with hide_item_types — takes the variant that reads the grid in place (RM_ == 3); 'prestige' agents have no such variant.
-static bool render_big_grid(const MgConfig& cfg) { return render_small_lds_bytes(cfg) > 160 * 1024 && cfg.prestige_mask == 0; }
+// 110 with hide_item_types — takes the variant that reads the grid in place (RM_ == 3; with 'prestige' agents: their recoloured tiles in LDS beside it).
+static bool render_big_grid(const MgConfig& cfg) { return render_small_lds_bytes(cfg) > 160 * 1024; }
 
 int render_min_lds_bytes(const MgConfig& cfg) {
     if (render_big_grid(cfg)) return render_shared_layout(cfg).total + 4 * render_scratch_for(cfg, 4, 3).total;
@@ -160,7 +160,8 @@ hipError_t launch_render(const MgConfig& cfg, const MgState& st, uint8_t* obs, u
 #else
     const int vs = cfg.view_size, ts = cfg.tile_size;
     if (render_big_grid(cfg))       // the grid read in place (everything about the view and the tiles at run time, 4-wave workgroups)
-        return launch_render_t<0, 0, 4, 8, 3>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick);
+        return cfg.prestige_mask ? launch_render_t<0, 0, 4, 12, 3>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick)
+                                 : launch_render_t<0, 0, 4, 8, 3>(cfg, st, obs, view_cells, view_agent, vis_mask, s, fs, pick);
     const int mode = render_mode_for(cfg);
     const int wpb = choose_wpb(cfg, mode);
     if (cfg.prestige_mask) {   // per-env recoloured agent tiles (LDS), 4-wave workgroups

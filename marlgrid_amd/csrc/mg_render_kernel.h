@@ -277,7 +277,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
     // per-cell maps; the atlas is read in place too (V_ == 8), view and tile size are run-time values
     constexpr bool kBigGrid = RM_ == 3;
     static_assert(!kEnc || !kBigGrid, "mg_step_render_encode works on the staged grids");
-    static_assert(!kBigGrid || (VS_ == 0 && TS_ == 0 && V_ == 8), "grid read in place: the fully run-time instantiation");
+    static_assert(!kBigGrid || (VS_ == 0 && TS_ == 0 && (V_ == 8 || V_ == 12)), "grid read in place: the fully run-time instantiations");
     constexpr int kRowB = kGather ? Gm::RS : 0, kRowW = kRowB / 4;
     constexpr int kPadFrontW = Gm::FRONT / 4, kPadTailW = Gm::TAIL / 4;   // zero dwords in front of a row / behind the last
     constexpr int kPadQ = 6;                                         // padded dwords per thread in the prologue's first round trip
@@ -949,7 +949,9 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             };
             const int tbytes = kGather ? Gm::TILE : tile_bytes;
             const uint8_t* abase = kGlobalAtlas ? cfg.atlas : s_atlas;
-            const uint8_t* w_grid = w_stage_g + (size_t)ej * cfg.cells_stride;      // (here, per env: the recoloured tiles have ONE slot;
+            // (a grid that is read in place: the object a 'prestige' agent stands on comes from where the grid lives)
+            const uint8_t* w_grid = kBigGrid ? kernarg_again<MgState>(offsetof(RenderKernargs, st)).grid + (size_t)e * cfg.cells_stride
+                                             : w_stage_g + (size_t)ej * cfg.cells_stride;      // (here, per env: the recoloured tiles have ONE slot;
             const uint64_t* w_rec = w_stage_r + (size_t)ej * rec_stride;            //  the views of the group are done, w_trow is free)
             uint32_t* w_col = w_trow;
             if (lane < n && ((cfg.prestige_mask >> lane) & 1u)) {
@@ -1392,7 +1394,7 @@ hipError_t launch_render_t(const MgConfig& cfg, const MgState& st, uint8_t* obs,
     X(0, 8, 4, 9, 0) X(0, 16, 4, 9, 0)
 #define MG_RENDER_GROUP_E(X)                                                                                               \
     X(7, 0, 12, 9, 0) X(7, 0, 8, 9, 0) X(7, 0, 4, 9, 0) X(0, 32, 4, 9, 0) X(0, 0, 4, 9, 0)                                      \
-    X(0, 8, 4, 12, 0) X(0, 16, 4, 12, 0) X(0, 32, 4, 12, 0) X(0, 0, 4, 12, 0)
+    X(0, 8, 4, 12, 0) X(0, 16, 4, 12, 0) X(0, 32, 4, 12, 0) X(0, 0, 4, 12, 0) X(0, 0, 4, 12, 3)
 #if defined(MG_EXP) && (MG_EXP & 8)
 #define MG_RENDER_GROUP_X(X) X(7, 8, 12, 0, 0)      /* experiment builds only (mg_render.hip) */
 #else

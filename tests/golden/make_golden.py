@@ -73,6 +73,7 @@ TRAJ = {  # scenario -> (n_seeds, n_steps, n_full_obs_seeds)
     # grids that do not fit LDS: the obs kernel reads them in place and searches the agents of a view cell (RM_ == 3)
     "Limit-3AgentCluttered200x200-hide": (2, 50, 1),
     "Limit-4AgentSpawnRect160x160-hide": (3, 60, 1),
+    "Limit-3AgentSpawnRect150x150-prestige": (3, 60, 1),   # ... with 'prestige' agents (variant 12 of it), the goal where they spawn
     # views beyond 15 x 15 (a view row is a 32-bit mask: up to 31)
     "Limit-2AgentCluttered25x25-view21-tile5": (4, 70, 1),
     "Limit-3AgentCluttered33x33-view31-tile4": (3, 60, 1),

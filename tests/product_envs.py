@@ -127,10 +127,14 @@ def _spawn_rect_env_class():
     from marlgrid_amd.objects import Goal, Wall
 
     class SpawnRectTestEnv(MultiGridEnv):
+        def __init__(self, *a, goal_at=None, **kw):
+            self._goal_at = goal_at
+            super().__init__(*a, **kw)
+
         def _gen_grid(self, width, height):
             self.grid = MultiGrid((width, height))
             self.grid.wall_rect(0, 0, width, height)
-            self.put_obj(Goal(color="green", reward=1), 2, height - 2)
+            self.put_obj(Goal(color="green", reward=1), *(self._goal_at or (2, height - 2)))
             for _ in range(4):
                 self.place_obj(Wall(), max_tries=100)
     return SpawnRectTestEnv

@@ -160,6 +160,8 @@ def ref_recipe(name):
         "Limit-3AgentCluttered200x200-hide": ("ClutteredMultiGrid", dict(grid_size=200, n_clutter=1500, max_steps=40)),
         "Limit-4AgentSpawnRect160x160-hide": ("SpawnRectTestEnv", dict(grid_size=160, respawn=True, max_steps=40,
                                                                        agent_spawn_kwargs=dict(top=(1, 1), size=(3, 3), max_tries=500))),
+        "Limit-3AgentSpawnRect150x150-prestige": ("SpawnRectTestEnv", dict(grid_size=150, respawn=True, max_steps=40, goal_at=(2, 2),
+                                                                           agent_spawn_kwargs=dict(top=(1, 1), size=(3, 3), max_tries=500))),
         "Limit-2AgentEmpty255x255-view9-ts5": ("EmptyMultiGrid", dict(grid_size=255, max_steps=30)),
         "Limit-2Agent60Groups16x16": ("GroupsTestEnv", dict(grid_size=16, max_steps=60)),
         "Test-3AgentCluttered9x9-view6": ("ClutteredMultiGrid", dict(grid_size=9, n_clutter=7, max_steps=60)),
@@ -330,6 +332,20 @@ def big_spawn_rect_spec(size):
     return _with_hide(s, [["Agent"], ["Wall"], [], ["Agent", "Goal"]])
 
 
+def big_prestige_spec(size):
+    """'prestige'-coloured agents on a grid that does not fit LDS (the grid-in-place variant with per-env recoloured tiles): three
+    agents — two of them 'prestige' — spawn in a 3 x 3 corner of a `size` x `size` room WITH the goal in it, so that rewards (and
+    with them the agents' colours, agents.py:92-119, 141-153) change every few steps; respawn=True"""
+    s = _base(3, size, 7, respawn=True, max_steps=40, colors=["prestige", "blue", "prestige"])
+    W = H = size
+    s["objects"] = [None, WALL, GOAL]
+    s["wall_obj"] = 1
+    prog = [("wall_rect", 0, 0, W, H), ("put", 2, 2, 2), ("place", 1, 4, 100)]
+    s["gen_ctor"], s["gen_reset"] = prog, prog
+    s["agent_spawn"] = dict(top=(1, 1), size=(3, 3), max_tries=500)
+    return s
+
+
 def _with_views(spec, views):
     """per-agent view geometry (agents.py:19-35); spec-level view_size / tile_size / ... stay the first agent's"""
     for a, v in zip(spec["agents"], views):
@@ -388,6 +404,7 @@ def registered(name):   # noqa: F811  (extends the table above with test-only sc
         "Limit-3AgentCluttered200x200-hide": lambda: _with_hide(cluttered_spec(3, 200, 7, n_clutter=1500, max_steps=40),
                                                                [["Wall"], ["Agent", "Goal"], []]),
         "Limit-4AgentSpawnRect160x160-hide": lambda: big_spawn_rect_spec(160),
+        "Limit-3AgentSpawnRect150x150-prestige": lambda: big_prestige_spec(150),
         "Limit-2AgentEmpty255x255-view9-ts5": lambda: empty_spec(2, 255, 9, tile_size=5, max_steps=30),
         "Limit-2Agent60Groups16x16": lambda: groups_spec(),
         # every agent its own view (agents.py:19-35): a 5x5 view at 8 px, a 7x7 view at 5 px looking through walls,

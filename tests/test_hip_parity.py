@@ -205,6 +205,7 @@ def test_rng_seeding_golden():
                                        ("Limit-24AgentEmpty20x20-view5", 70, 50),
                                        ("Limit-24AgentEmpty20x20-view5", 4099, 12),
                                        ("Limit-4AgentSpawnRect160x160-hide", 70, 60),
+                                       ("Limit-3AgentSpawnRect150x150-prestige", 70, 90),       # ... with 'prestige' agents: variant 12 of it
                                        ("Limit-2AgentEmpty255x255-view9-ts5", 37, 40),
                                        ("Limit-2AgentCluttered128x128", 130, 30),
                                        ("Limit-2AgentCluttered25x25-view21-tile5", 70, 50),

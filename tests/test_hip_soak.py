@@ -2,7 +2,8 @@
 MT19937 state), so the HIP path is stepped against the CPU oracle over MANY episodes here, with `auto_reset=True` (the
 reset of a finished episode runs inside the step launch; the oracle resets on `done`): >= 6 000 steps, >= 60 episodes
 per env, >= 25 wraps of the lazy MT regeneration and its LDS-DMA head refills.  Every step: rewards (<= 1e-6) and done;
-every `obs_every`-th step: the full observations; every 500th step and at the end: canonical state of every env (grid,
+every `obs_every`-th step: the full observations (and, for the two BASELINE workloads, `MultiGrid.encode` of the batch as the
+step's own launch writes it: `encode_in_step`); every 500th step and at the end: canonical state of every env (grid,
 agent records incl. stack order, step counter) and the numpy form of the RNG state.
 Reference: marlgrid/base.py:501-653 (step), :402-416 (reset), over many episodes."""
 import numpy as np
@@ -49,6 +50,10 @@ def soak(name, B, T, obs_every=50, seed0=424200, action_seed=5, p=None, **kw):
         episodes += dn2
         if look:
             assert np.array_equal(o.cpu().numpy(), o2), "%s obs step %d" % (name, t)
+            if env.encode_in_step:       # MultiGrid.encode of the batch as the step's own launch wrote it (mg_step_render_encode)
+                enc = env.grid_encoding.cpu().numpy()
+                for b in range(B):
+                    assert np.array_equal(enc[b], orc.envs[b].encode()), "%s encode env %d step %d" % (name, b, t)
         draws += (env.mt_pos - last_pos).long() % 624
         last_pos = env.mt_pos.clone()
         if t % 500 == 0 or t == T:
@@ -59,14 +64,14 @@ def soak(name, B, T, obs_every=50, seed0=424200, action_seed=5, p=None, **kw):
 
 def test_soak_headline_3agent_cluttered15x15():
     """the bench workload: 64 envs x 6 000 steps, >= 60 episodes per env, >= 25 MT wraps"""
-    s = soak("MarlGrid-3AgentCluttered15x15-v0", 64, 6000)
+    s = soak("MarlGrid-3AgentCluttered15x15-v0", 64, 6000, encode_in_step=True)
     assert s["episodes"].min() >= 60, s["episodes"].min()
     assert s["wraps"].min() >= 25, s["wraps"]
 
 
 def test_soak_config4_8agent_cluttered30x30():
     """BASELINE.json configs[4]: 16 envs x 6 000 steps (eight agents: ~10 shuffle draws per step)"""
-    s = soak("Custom-8AgentCluttered30x30", 16, 6000, seed0=77000, action_seed=6)
+    s = soak("Custom-8AgentCluttered30x30", 16, 6000, seed0=77000, action_seed=6, encode_in_step=True)
     assert s["episodes"].min() >= 60 and s["wraps"].min() >= 25, (s["episodes"].min(), s["wraps"])
 
 

@@ -256,8 +256,9 @@ def test_constructor_errors():
 
 def test_oversized_configuration_is_rejected_on_the_host():
     """a grid whose per-env scratch cannot fit the obs kernel's LDS budget is read in place since round 6 (the launcher's
-    pick says so, and a RuntimeWarning); what still cannot be rendered — 'prestige' agents on such a grid: their recolouring
-    has no grid-in-place variant — fails loudly at table build time (never a silent fallback)"""
+    pick says so, and a RuntimeWarning), with 'prestige' agents too (variant 12 of it: their recoloured tiles in LDS beside
+    it); what still cannot be rendered — sixteen 'prestige' agents at 32-pixel tiles: 196 KiB of recoloured sprites per env —
+    fails loudly at table build time (never a silent fallback)"""
     from marlgrid_amd import _native as N
     from marlgrid_amd import base as PB
     from marlgrid_amd.agents import GridAgentInterface
@@ -272,6 +273,10 @@ def test_oversized_configuration_is_rejected_on_the_host():
     with pytest.warns(RuntimeWarning, match="read in place"):
         PB._warn_generic_kernel(g, 3, False)
     env = EmptyMultiGrid(agents=[GridAgentInterface(view_tile_size=8, color="prestige")], grid_size=200, _dry=True)
+    cfg, _raw, _flat, _atlas = env._host_tables()
+    assert N.render_kernel_name(cfg) == ("mg::render_kernel<0, 0, 4, 12, 3>", 3)
+    assert 0 < N.lib().mg_render_obs_lds_bytes(ctypes.byref(cfg)) <= 160 * 1024
+    env = EmptyMultiGrid(agents=[GridAgentInterface(view_tile_size=32, color="prestige") for _ in range(16)], grid_size=20, _dry=True)
     env._dry = False                      # exercise the host-side budget check only
     env.device = None
     with pytest.raises(NotImplementedError, match="LDS"):
@@ -344,7 +349,8 @@ def test_object_registry_interface():
 def test_render_lds_query():
     """mg_render_obs_lds_bytes: the library reports what its obs kernel needs (the host never re-derives
     the layout): small for the bench config, atlas dropped from LDS for 32-px tiles, small again for a huge grid (read in
-    place since round 6), > 160 KiB only where no variant fits — 'prestige' agents on a huge grid"""
+    place since round 6, with 'prestige' agents too), > 160 KiB only where no variant fits — sixteen 'prestige' agents' recoloured
+    32-pixel sprites"""
     from marlgrid_amd import _native as N
     L = N.lib()
 
@@ -359,7 +365,8 @@ def test_render_lds_query():
     assert need(3, 7, 8, 240, 28, prestige=0b111, hide=1) > need(3, 7, 8, 240, 28, prestige=0b111)
     assert need(2, 3, 32, 96, 24) < 4 * 24 * 32 * 32 * 3                  # atlas (288 KiB) stays in HBM / L2
     assert need(1, 7, 8, 200 * 200, 12) < 64 * 1024                       # the grid-in-place variant
-    assert need(1, 7, 8, 200 * 200, 12, prestige=1) > 160 * 1024          # rejected by MultiGridEnv
+    assert need(1, 7, 8, 200 * 200, 12, prestige=1) < 64 * 1024           # ... with a 'prestige' agent
+    assert need(16, 7, 32, 400, 100, prestige=0xFFFF) > 160 * 1024        # rejected by MultiGridEnv
     assert need(0, 7, 8, 240, 28) < 0 and L.mg_render_obs_lds_bytes(None) < 0
 
 

@@ -96,6 +96,23 @@ for label, mk in cases:
             b.synchronize()
             enc.append(a.elapsed_time(b) / 50)
         del enc_out
+        # the step with MultiGrid.encode of the batch written by the SAME launch (encode_in_step: mg_step_render_encode where the
+        # library has it compiled in, an mg_encode launch behind the step elsewhere), interleaved with the plain step
+        env.encode_in_step = True
+        env.step(acts[0])
+        step_enc, step_again = [], []
+        for rep in range(5):
+            for flag, into in ((True, step_enc), (False, step_again)):
+                env.encode_in_step = flag
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                env.step(acts[0])
+                a.record()
+                for i in range(30):
+                    env.step(acts[i % 8])
+                b.record()
+                b.synchronize()
+                into.append(a.elapsed_time(b) / 30)
+        enc_in_launch = bool(env._enc_fused) and env.fused_step and not env._hetero
         enc_bytes = B * (env.cells_stride + 8 * env.num_agents + 3 * env.width * env.height)
         env.check_errors()
         nb = env.obs.numel()
@@ -107,6 +124,8 @@ for label, mk in cases:
                           "kernel": env.kernel_name, "place_obs": PLACE,
                           "encode_ms": statistics.median(enc), "encode_bytes": enc_bytes,
                           "encode_frac_of_8TBps": enc_bytes / statistics.median(enc) / 1e6 / 8000,
+                          "step_with_encode_ms": statistics.median(step_enc), "encode_in_the_step_launch": enc_in_launch,
+                          "step_with_encode_vs_step_pct": 100 * (statistics.median(step_enc) / statistics.median(step_again) - 1),
                           "obs_placement": {k: pm.get(k) for k in ("found", "kept", "candidates", "stopped", "seconds", "pinned_bytes",
                                                                    "budget_bytes", "median_ms", "candidate_bytes")}}), flush=True)
         del env
