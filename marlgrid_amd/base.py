@@ -1613,12 +1613,14 @@ class MultiGridEnv(object):
                 for d in range(4):
                     self._frame_amax |= int(fa[0, fa.shape[1] - 4 + d][..., 0].max()) << (8 * d)
         Hp, Wp = self.height * tile_size, self.width * tile_size
-        # (the frame kernel keeps the env's grid, its per-cell agent maps and the visibility highlight in one workgroup's LDS:
-        # 5 bytes per cell — grids up to ~180 x 180; the step path has no such limit, see mg_render_obs' grid-in-place variant)
-        if 3 * self.cells_stride + 2 * ((self.width * self.height + 7) // 8 * 8) + 4096 > 160 * 1024:
-            raise NotImplementedError("render(): the whole-grid image of a %d x %d grid needs more than the 160 KiB of LDS of a "
-                                      "workgroup (5 bytes per cell); observations, step() and encode() have no such limit"
-                                      % (self.width, self.height))
+        # (the frame kernel keeps two bytes per cell in one workgroup's LDS — the cell's tile index and its highlight bit; the grid
+        # is read where it lives —: every grid up to 255 x 255 fits, next to the recoloured sprites of up to ~10 'prestige' agents)
+        lds = 2 * ((self.width * self.height + 7) // 8 * 8) + 1024 + 4 * self.num_agents * self.view_size + (
+            self.num_agents * tile_size * tile_size * 3 if any(self._prestige) else 0)
+        if lds > 160 * 1024:
+            raise NotImplementedError("render(): the whole-grid image of a %d x %d grid with %d 'prestige' agents at %d-pixel tiles "
+                                      "needs more than the 160 KiB of LDS of a workgroup; use a smaller tile_size"
+                                      % (self.width, self.height, self.num_agents, tile_size))
         img = torch.empty((K, Hp, Wp, 3), dtype=torch.uint8, device=self.device)
         N.check(self._lib.mg_render_frame(C.byref(self._cfg), C.byref(self._state), ids.data_ptr(), K,
                                           self._frame_atlas.data_ptr(), tile_size, int(bool(highlight)),

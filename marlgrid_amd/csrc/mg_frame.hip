@@ -19,25 +19,26 @@ __global__ __launch_bounds__(kBlock) void frame_kernel(MgConfig cfg, MgState st,
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int W = cfg.W, H = cfg.H, n = cfg.n_agents, VS = cfg.view_size;
     const int cells = W * H;
-    uint8_t* s_grid = smem;                                   // [cells_stride]
-    uint8_t* s_first = s_grid + cfg.cells_stride;             // [cells_stride] lowest-rank agent or 0xFF
-    uint8_t* s_hl = s_first + cfg.cells_stride;               // [cells_stride] highlight flag
-    uint16_t* s_tile = reinterpret_cast<uint16_t*>(s_hl + cfg.cells_stride);   // [cells] tile index
+    // LDS: TWO bytes per cell — the cell's tile index, bit 15 = "some agent sees it" — so that every grid a uint8 coordinate
+    // addresses fits (255 x 255: 127 KiB; with a copy of the grid, a first-agent map and a highlight plane beside it, 5 bytes per
+    // cell, the frame ended at ~180 x 180).  The grid itself is read where it lives (twice per cell: L2).
+    uint16_t* s_tile = reinterpret_cast<uint16_t*>(smem);                      // [cells] tile index | kSeen
     uint64_t* s_rec = reinterpret_cast<uint64_t*>(s_tile + round_up(cells, 8));
     uint32_t* s_trow = reinterpret_cast<uint32_t*>(s_rec + MG_MAX_AGENTS);     // [n][VS]
     uint8_t* s_dyn = reinterpret_cast<uint8_t*>(s_trow + round_up(n * VS, 4));   // [n][ts*ts*3] recoloured tiles
+    constexpr uint32_t kSeen = 0x8000u;
     const int tid = threadIdx.x;
     const int e = env_ids[blockIdx.x];
     if (e < 0 || e >= cfg.B) return;
+    const uint8_t* __restrict__ g_grid = st.grid + (size_t)e * cfg.cells_stride;
+    const uint32_t n_tiles = (uint32_t)cfg.n_tiles;
 
-    for (int i = tid; i < cfg.cells_stride; i += kBlock) {
-        s_grid[i] = st.grid[(size_t)e * cfg.cells_stride + i];
-        s_first[i] = 0xFF;
-        s_hl[i] = 0;
-    }
+    // tile per world cell: render_tile(obj, top_agent=None) — base.py:275-299.  Every cell its object's plain tile ...
+    for (int c = tid; c < cells; c += kBlock) s_tile[c] = (uint16_t)(1u + g_grid[c]);
     if (tid < n) s_rec[tid] = st.agents[(size_t)e * n + tid];
     for (int i = tid; i < n * VS; i += kBlock) s_trow[i] = 0;
     __syncthreads();
+    // ... then the lowest-rank agent of a cell puts its own there (the cell object, or `obj.agents[0]` on an overlappable one)
     if (tid < n) {
         const uint64_t r = s_rec[tid];
         if (rec_byte(r, MG_AG_FLAGS) & MG_AF_PLACED) {
@@ -48,7 +49,15 @@ __global__ __launch_bounds__(kBlock) void frame_kernel(MgConfig cfg, MgState st,
                     rec_byte(rj, MG_AG_RANK) < rec_byte(r, MG_AG_RANK))
                     lowest = false;
             }
-            if (lowest) s_first[rec_byte(r, MG_AG_X) * H + rec_byte(r, MG_AG_Y)] = (uint8_t)tid;
+            const int c = (int)rec_byte(r, MG_AG_X) * H + (int)rec_byte(r, MG_AG_Y);
+            const uint32_t base = g_grid[c];
+            const uint32_t slot = base ? cfg.obj[base].ovl_slot : 0u;
+            if (lowest && slot != 0xFF) {
+                uint32_t tile;
+                if (((cfg.prestige_mask >> tid) & 1u) && (rec_byte(r, MG_AG_FLAGS) & MG_AF_ACTIVE)) tile = n_tiles + (uint32_t)tid;   // dynamic tile (LDS)
+                else tile = 1 + cfg.n_obj + (slot * n + (uint32_t)tid) * 4 + rec_byte(r, MG_AG_DIR);
+                s_tile[c] = (uint16_t)tile;
+            }
         }
     }
     __syncthreads();
@@ -67,7 +76,7 @@ __global__ __launch_bounds__(kBlock) void frame_kernel(MgConfig cfg, MgState st,
             int wx, wy;
             world(s_rec[k], va, vb, wx, wy);
             uint32_t base = 0;
-            if (wx >= 0 && wx < W && wy >= 0 && wy < H) base = s_grid[wx * H + wy];
+            if (wx >= 0 && wx < W && wy >= 0 && wy < H) base = g_grid[wx * H + wy];
             const bool transp = base == 0 || (cfg.obj[base].flags & MG_OF_SEE_BEHIND);
             if (transp) atomicOr(&s_trow[k * VS + vb], 1u << va);
         }
@@ -84,7 +93,10 @@ __global__ __launch_bounds__(kBlock) void frame_kernel(MgConfig cfg, MgState st,
                         if ((m[vb] >> va) & 1u) {
                             int wx, wy;
                             world(r, va, vb, wx, wy);
-                            if (wx >= 0 && wx < W && wy >= 0 && wy < H) s_hl[wx * H + wy] = 1;
+                            if (wx >= 0 && wx < W && wy >= 0 && wy < H) {     // (two cells share a dword: an atomic OR of the cell's half)
+                                const int c = wx * H + wy;
+                                atomicOr(reinterpret_cast<uint32_t*>(s_tile) + (c >> 1), kSeen << (16 * (c & 1)));
+                            }
                         }
             }
         }
@@ -97,7 +109,7 @@ __global__ __launch_bounds__(kBlock) void frame_kernel(MgConfig cfg, MgState st,
             if (!((cfg.prestige_mask >> X) & 1u)) continue;
             const uint64_t rx = s_rec[X];
             if ((rec_byte(rx, MG_AG_FLAGS) & (MG_AF_ACTIVE | MG_AF_PLACED)) != (MG_AF_ACTIVE | MG_AF_PLACED)) continue;
-            const uint32_t base = s_grid[rec_byte(rx, MG_AG_X) * H + rec_byte(rx, MG_AG_Y)];
+            const uint32_t base = g_grid[rec_byte(rx, MG_AG_X) * H + rec_byte(rx, MG_AG_Y)];
             const uint32_t sdir = rec_byte(rx, MG_AG_DIR);
             const PrestigeColor col = prestige_color(st.prestige[(size_t)e * n + X], cfg.prestige_scale[X]);
             const uint32_t amax = (amax4 >> (8 * sdir)) & 0xFFu;
@@ -111,18 +123,6 @@ __global__ __launch_bounds__(kBlock) void frame_kernel(MgConfig cfg, MgState st,
                                s_dyn + (size_t)X * tile_bytes + p * 3);
         }
     }
-    // tile per world cell: render_tile(obj, top_agent=None) — base.py:275-299
-    const uint32_t n_tiles = (uint32_t)cfg.n_tiles;
-    for (int c = tid; c < cells; c += kBlock) {
-        const uint32_t base = s_grid[c], show = s_first[c];
-        uint32_t tile;
-        const uint32_t slot = base ? cfg.obj[base].ovl_slot : 0u;
-        if (show == 0xFF || slot == 0xFF) tile = 1 + base;
-        else if (((cfg.prestige_mask >> show) & 1u) && (rec_byte(s_rec[show], MG_AG_FLAGS) & MG_AF_ACTIVE))
-            tile = n_tiles + show;                                   // dynamic tile (LDS)
-        else tile = 1 + cfg.n_obj + (slot * n + show) * 4 + rec_byte(s_rec[show], MG_AG_DIR);
-        s_tile[c] = (uint16_t)tile;
-    }
     __syncthreads();
     // raster: image [H*ts][W*ts][3]; row R -> world y = R / ts; dword d of the row -> world x = d / TD
     const int TD = ts * 3 / 4;                    // dwords per tile row (ts % 4 == 0)
@@ -134,10 +134,10 @@ __global__ __launch_bounds__(kBlock) void frame_kernel(MgConfig cfg, MgState st,
         const int R = q / row_dw, d = q - R * row_dw;
         const int j = R / ts, rr = R - j * ts, i = d / TD, kk = d - i * TD;
         const int c = i * H + j;
-        const uint32_t t = s_tile[c];
+        const uint32_t tc = s_tile[c], t = tc & (kSeen - 1u);
         uint32_t v = (t < n_tiles) ? atlas32[(size_t)t * tile_dw + rr * TD + kk]
                                    : reinterpret_cast<const uint32_t*>(s_dyn)[(size_t)(t - n_tiles) * tile_dw + rr * TD + kk];
-        if (s_hl[c]) {
+        if (tc & kSeen) {
             // (img*8 + 255*2) >> 3, clipped to 255 (base.py:327-329) == min(255, img + 63) per byte
             uint32_t o = 0;
 #pragma unroll
@@ -154,7 +154,8 @@ __global__ __launch_bounds__(kBlock) void frame_kernel(MgConfig cfg, MgState st,
 hipError_t launch_frame(const MgConfig& cfg, const MgState& st, const int32_t* env_ids, int K, const uint8_t* atlas,
                         int ts, int highlight, uint32_t amax, uint8_t* out, hipStream_t s) {
     if (K <= 0) return hipSuccess;
-    size_t lds = 3 * (size_t)cfg.cells_stride + 2 * (size_t)round_up(cfg.W * cfg.H, 8) + MG_MAX_AGENTS * 8 +
+    if ((size_t)cfg.n_tiles + (size_t)cfg.n_agents >= 0x8000u) return hipErrorInvalidValue;      // (bit 15 of a cell's tile index is its highlight)
+    size_t lds = 2 * (size_t)round_up(cfg.W * cfg.H, 8) + MG_MAX_AGENTS * 8 +
                  (size_t)round_up(cfg.n_agents * cfg.view_size, 4) * 4 + 64 +
                  (cfg.prestige_mask ? (size_t)cfg.n_agents * ts * ts * 3 : 0);
     if (lds > 160 * 1024) return hipErrorInvalidValue;

@@ -331,6 +331,43 @@ def gen_frames(out):
     np.savez_compressed(out, **d)
 
 
+FRAMES_BIG = {  # scenario -> (seed, steps, tile_size): whole-grid images too large to keep — their CRC32 and two crops are kept
+    "Limit-3AgentSpawnRect150x150-prestige": (1337, [0, 6, 30], 8),      # 1 200 x 1 200 px; 'prestige' sprites in the corner
+    "Limit-3AgentCluttered200x200-hide": (1337, [0, 9], 4),             # 800 x 800 px
+    "Limit-2AgentEmpty255x255-view9-ts5": (1338, [0, 5], 8),             # 2 040 x 2 040 px: the largest grid
+}
+
+
+def gen_frames_big(out):
+    """`MultiGridEnv.render(mode='rgb_array', tile_size=…, show_agent_views=False)` of grids beyond ~180 x 180 (base.py:714-759):
+    highlighted and bare; per image its shape, the CRC32 of its bytes, the crop around the first agent and the top-left corner."""
+    d = {}
+    for name, (seed, steps, ts) in FRAMES_BIG.items():
+        spec = scenarios.registered(name)
+        recipe = scenarios.ref_recipe(name)
+        n = len(spec["agents"])
+        env = refstate.make_ref_env(spec, recipe, seed=int(seed))
+        env.reset()
+        arng = np.random.RandomState(seed)
+        acts = arng.choice(3, size=(max(steps) + 1, n)).astype(np.int8)
+        d["%s/actions" % name] = acts
+        d["%s/seed" % name] = np.array(seed)
+        d["%s/tile_size" % name] = np.array(ts)
+        for t in range(max(steps) + 1):
+            if t in steps:
+                for tag, kw in (("full", dict()), ("bare", dict(highlight=False))):
+                    img = np.asarray(env.render(mode="rgb_array", tile_size=ts, show_agent_views=False, **kw)).astype(np.uint8)
+                    x, y = (int(v) for v in env.agents[0].pos)
+                    r0, c0 = max(0, y * ts - 48), max(0, x * ts - 48)
+                    d["%s/%d/%s/shape" % (name, t, tag)] = np.array(img.shape)
+                    d["%s/%d/%s/crc" % (name, t, tag)] = np.array(refstate.crc(img), dtype=np.uint32)
+                    d["%s/%d/%s/at" % (name, t, tag)] = np.array([r0, c0])
+                    d["%s/%d/%s/near_agent0" % (name, t, tag)] = img[r0:r0 + 96, c0:c0 + 96].copy()
+                    d["%s/%d/%s/corner" % (name, t, tag)] = img[:64, :64].copy()
+            env.step(acts[t])
+    np.savez_compressed(out, **d)
+
+
 def gen_interact(m, out):
     """Hand-built pickup/drop/toggle scenes (base.py:587-617 — 'TODO: verify' in the reference).
     Each scene: EmptyMultiGrid 7x7, 2 agents teleported via a fresh grid + put_obj; scripted
@@ -404,6 +441,8 @@ def main():
             print("traj", name, flush=True)
     if "frames" in which:
         gen_frames(os.path.join(HERE, "frames.npz"))
+    if "frames" in which or "frames_big" in which:
+        gen_frames_big(os.path.join(HERE, "frames_big.npz"))
     if "interact" in which:
         gen_interact(m, os.path.join(HERE, "interact.npz"))
     for f in sorted(os.listdir(HERE)):

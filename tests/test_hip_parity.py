@@ -487,6 +487,35 @@ def test_full_frame_render_golden():
             env.step(torch.from_numpy(acts[:, t].astype(np.int64)))
 
 
+def test_full_frame_render_of_grids_beyond_lds_golden():
+    """env.render() of grids beyond ~180 x 180 (the frame kernel keeps two bytes per cell in LDS and reads the grid where it
+    lives): 150 x 150 with 'prestige' agents, 200 x 200 with hide_item_types, 255 x 255 — against the reference's
+    MultiGridEnv.render(mode='rgb_array', tile_size=…, show_agent_views=False): shape, CRC32 of the whole image, the crop
+    around agent 0 and the top-left corner (tests/golden/frames_big.npz: the images themselves are up to 12 MB)."""
+    import torch
+    g = np.load(os.path.join(GOLD, "frames_big.npz"))
+    names = sorted({k.split("/")[0] for k in g.files})
+    assert len(names) == 3
+    for name in names:
+        seed, ts = int(g["%s/seed" % name]), int(g["%s/tile_size" % name])
+        acts = g["%s/actions" % name]
+        steps = sorted({int(k.split("/")[1]) for k in g.files if k.startswith(name + "/") and k.endswith("/full/crc")})
+        env = product_envs.build(name, batch_size=2, seeds=[seed, seed + 1000])
+        env.reset()
+        for t in range(max(steps) + 1):
+            if t in steps:
+                for tag, kw in (("full", dict()), ("bare", dict(highlight=False))):
+                    img = env.render(tile_size=ts, show_agent_views=False, **kw).cpu().numpy()
+                    what = (name, t, tag)
+                    assert list(img.shape) == list(g["%s/%d/%s/shape" % (name, t, tag)]), what
+                    r0, c0 = (int(v) for v in g["%s/%d/%s/at" % (name, t, tag)])
+                    assert np.array_equal(img[r0:r0 + 96, c0:c0 + 96], g["%s/%d/%s/near_agent0" % (name, t, tag)]), what
+                    assert np.array_equal(img[:64, :64], g["%s/%d/%s/corner" % (name, t, tag)]), what
+                    assert refstate.crc(img) == int(g["%s/%d/%s/crc" % (name, t, tag)]), what
+            a = np.stack([acts[t], acts[t]]).astype(np.int64)
+            env.step(torch.from_numpy(a))
+
+
 def test_rich_observations():
     """'rich' observation_style: per-agent dicts like the reference's (base.py:461-471)."""
     import torch
