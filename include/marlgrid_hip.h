@@ -251,7 +251,7 @@ int32_t mg_step_render(const MgConfig* cfg, const MgState* st, const void* actio
  * NULL, encode_out) would write right after it — from the same launch: the wave that has stepped and drawn its envs
  * still holds their grids and records.  encode_out: device uint8 [B][W][H][3] (any alignment).  +2.4 % bytes on
  * MarlGrid-3AgentCluttered15x15-v0 instead of a second launch.  Compiled into instantiations of the step kernel of their
- * own: view sizes 7, 9 (and, at run time, any other) with 8-pixel tiles, view 7 with 5-pixel tiles.  MG_E_UNSUPPORTED —
+ * own: view sizes 7, 9 and those above 9 with 8-pixel tiles, view 7 with 5-pixel tiles.  MG_E_UNSUPPORTED —
  * nothing launched, call mg_step_render and mg_encode — for every other shape, and when n_obj + 4 n_agents > 256 (object
  * ids and agent marks do not share a byte), with 'prestige' agents, or when the grid or the atlas does not fit LDS. */
 int32_t mg_step_render_encode(const MgConfig* cfg, const MgState* st, const void* actions, int32_t action_bytes,

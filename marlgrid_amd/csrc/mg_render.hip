@@ -116,6 +116,9 @@ static hipError_t launch_render_enc(const MgConfig& cfg, const MgState& st, uint
     if (vs == 9)
         return w16 ? launch_render_t<9, 8, 16, 16, 0>(cfg, st, obs, nullptr, nullptr, nullptr, s, fs, pick)
                    : launch_render_t<9, 8, 4, 16, 0>(cfg, st, obs, nullptr, nullptr, nullptr, s, fs, pick);
+    // the views whose plain launch is a specialised instantiation the encode set does not have (3 ... 6, 8 at 8-pixel tiles): a
+    // second launch costs them +7 %, the run-time-view instantiation would cost +40 %
+    if (vs <= 9) return hipErrorNotSupported;
     // (run-time view size: 8-wave workgroups, as MG_RENDER_DISPATCH_RT)
     return wpb == 16 && render_lds_bytes(cfg, 8, mode) + enc_lds <= 160 * 1024
                ? launch_render_t<0, 8, 8, 16, 0>(cfg, st, obs, nullptr, nullptr, nullptr, s, fs, pick)
