@@ -514,18 +514,45 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                         uint32_t cut = 0, keep = 0;
                         if (d < npd) adst[d] = pad_source<3 * TS_, kPadFrontW, kRowW>(d, pad_rows, raw16, cut, keep) >= 0 ? pad_cut(pw[q].x, pw[q].y, cut, keep) : 0u;
                     }
-                    for (int d = tidl + kPadQ * T; d < npd; d += T) {             // (larger atlases: the rest, a second trip)
-                        uint32_t cut = 0, keep = 0;
-                        const int a = pad_source<3 * TS_, kPadFrontW, kRowW>(d, pad_rows, raw16, cut, keep);
-                        uint2 w = make_uint2(0, 0);
-                        if (a >= 0) w = *reinterpret_cast<const uint2*>(cfg.atlas + a);
-                        adst[d] = a >= 0 ? pad_cut(w.x, w.y, cut, keep) : 0u;
+                    // (larger atlases: the rest, eight requests per thread and round trip — as one load and one store per iteration
+                    // the 45 dwords per thread of the reference's example, 11-pixel tiles with 'prestige' sprites, were 39 dependent
+                    // round trips: 13 us of a 134 us launch before its workgroups' barrier)
+                    constexpr int kPadU = 8;         // (12 or 16 per trip spill registers even in the 12-wave variants)
+                    for (int d0 = tidl + kPadQ * T; d0 < npd; d0 += kPadU * T) {
+                        uint2 w[kPadU];
+                        uint32_t cut[kPadU], keep[kPadU];
+                        int a[kPadU];
+#pragma unroll
+                        for (int u = 0; u < kPadU; u++) {
+                            const int d = d0 + u * T;
+                            cut[u] = keep[u] = 0;
+                            a[u] = d < npd ? pad_source<3 * TS_, kPadFrontW, kRowW>(d, pad_rows, raw16, cut[u], keep[u]) : -1;
+                            w[u] = make_uint2(0, 0);
+                            if (a[u] >= 0) w[u] = *reinterpret_cast<const uint2*>(cfg.atlas + a[u]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = 0; u < kPadU; u++) {
+                            const int d = d0 + u * T;
+                            if (d < npd) adst[d] = a[u] >= 0 ? pad_cut(w[u].x, w[u].y, cut[u], keep[u]) : 0u;
+                        }
                     }
                 } else {
                 uint4* adst = reinterpret_cast<uint4*>(s_atlas);
                 if (tidl < na) adst[tidl] = a0;
                 if (tidl + T < na) adst[tidl + T] = a1;
-                for (int i = tidl + 2 * T; i < na; i += T) adst[i] = asrc[i];    // (larger atlases: the rest, a second trip)
+                if constexpr (TS_ == 8) {      // (8-pixel tiles: 192 bytes per tile — the atlas of 28 tiles is 21 KB: no such rest unless there are 40 kinds)
+                    for (int i = tidl + 2 * T; i < na; i += T) adst[i] = asrc[i];
+                } else
+                for (int i0 = tidl + 2 * T; i0 < na; i0 += 4 * T) {             // (larger atlases: the rest, four requests per thread and round trip)
+                    uint4 w[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) w[u] = i0 + u * T < na ? asrc[i0 + u * T] : make_uint4(0, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        if (i0 + u * T < na) adst[i0 + u * T] = w[u];
+                }
                 }
                 if (tidl < no) reinterpret_cast<uint4*>(s_obj)[tidl] = o0;
                 if (tidl + T < no) reinterpret_cast<uint4*>(s_obj)[tidl + T] = o1;
