@@ -43,7 +43,15 @@ __global__ __launch_bounds__(PC / 16) void encode_kernel(MgConfig cfg, MgState s
     __syncthreads();
     encode_agents(cfg, st, lc, P, smem, tid, T);
     __syncthreads();
-    encode_chunks(cfg, lc, P, vis, out, smem, tid, T, PC);
+    // (by runs of 16 cells where nothing stands in the way; the chunk form finishes the batch's last cells — and does everything
+    // with a vis_mask, agent marks in their own plane, an `out` that is not 16-byte aligned, grids of fewer than 16 cells)
+    int q_first = 0;
+    if (lc.runs && !vis) {
+        q_first = encode_runs(cfg, lc, P, smem, tid, T);
+        __syncthreads();
+        encode_runs_store(lc, P, out, smem, tid, T);
+    }
+    encode_chunks(cfg, lc, P, vis, out, smem, tid, T, PC, q_first);
 }
 
 hipError_t launch_encode(const MgConfig& cfg, const MgState& st, const uint8_t* vis_mask, uint8_t* out,
@@ -51,21 +59,32 @@ hipError_t launch_encode(const MgConfig& cfg, const MgState& st, const uint8_t* 
     if (cfg.B <= 0) return hipSuccess;
     int PC = 0;
 #if defined(MG_AB_VARIANTS)
-    if (const char* f = getenv("MG_ENCODE_PC")) PC = atoi(f);      // measurement build: 1024 / 2048 / 4096 / 8192
+    if (const char* f = getenv("MG_ENCODE_PC")) PC = atoi(f);      // measurement build: 1024 / 2048 / 4096 / 8192 / 16384
 #endif
     EncodeLaunch lc = encode_launch(cfg, out, PC);
 #if defined(MG_AB_VARIANTS)
     if (const char* f = getenv("MG_ENCODE_EMPTY")) { if (atoi(f)) lc.aligned = 2; }
 #endif
-    const size_t lds = kEncTab + (size_t)lc.nraw * (lc.two ? 2 : 1);
-    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    const size_t lds = kEncTab + (size_t)lc.nraw * (lc.two ? 2 : 1) + (lc.runs ? 3 * (size_t)PC : 0);      // (+ the piece's output image: encode_runs)
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
     const unsigned pieces = (unsigned)((lc.total + PC - 1) / PC);
-    if (PC == 4096) hipLaunchKernelGGL((encode_kernel<4096>), dim3(pieces), dim3(256), lds, s, cfg, st, vis_mask, out, lc);
+#define MG_ENCODE_LAUNCH(N)                                                                                              \
+    do {                                                                                                                 \
+        if (lds > 64 * 1024) {                                                                                           \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_kernel<N>),                         \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
+            if (e != hipSuccess) return e;                                                                               \
+        }                                                                                                                \
+        hipLaunchKernelGGL((encode_kernel<N>), dim3(pieces), dim3(N / 16), lds, s, cfg, st, vis_mask, out, lc);          \
+    } while (0)
+    if (PC == 8192) MG_ENCODE_LAUNCH(8192);
+    else if (PC == 4096) MG_ENCODE_LAUNCH(4096);
 #if defined(MG_AB_VARIANTS)
-    else if (PC == 2048) hipLaunchKernelGGL((encode_kernel<2048>), dim3(pieces), dim3(128), lds, s, cfg, st, vis_mask, out, lc);
-    else if (PC == 8192) hipLaunchKernelGGL((encode_kernel<8192>), dim3(pieces), dim3(512), lds, s, cfg, st, vis_mask, out, lc);
+    else if (PC == 2048) MG_ENCODE_LAUNCH(2048);
+    else if (PC == 16384) MG_ENCODE_LAUNCH(16384);
 #endif
-    else hipLaunchKernelGGL((encode_kernel<1024>), dim3(pieces), dim3(64), lds, s, cfg, st, vis_mask, out, lc);
+    else MG_ENCODE_LAUNCH(1024);
+#undef MG_ENCODE_LAUNCH
     return hipGetLastError();
 }
 

@@ -34,6 +34,7 @@ struct EncodeLaunch {
     int cells, nraw;          // W * H; bytes of the raw grid plane in LDS (a multiple of 16)
     uint32_t m_cells, m_n;    // divide-by-multiply constants (32-bit mul_hi): ceil(2^32 / cells), ceil(2^32 / n)
     int two, aligned;         // agent marks in their own byte plane; `out` is 16-byte aligned
+    int runs;                 // phase C by runs of 16 cells (encode_runs): one byte plane, aligned `out`, W * H >= 16
 };
 
 MG_HD uint32_t enc_mulhi(uint32_t a, uint32_t b) {
@@ -188,7 +189,7 @@ MG_HD void encode_agents(const MgConfig& cfg, const MgState& st, const EncodeLau
 #define MG_ENC_BOUNDS(off, bytes) do {} while (0)
 #endif
 MG_HD void encode_chunks(const MgConfig& cfg, const EncodeLaunch& lc, const EncodePiece& P, const uint8_t* vis, uint8_t* out,
-                         const uint8_t* smem, int tid, int T, int PC) {
+                         const uint8_t* smem, int tid, int T, int PC, int q_first = 0) {
     const uint32_t* tab = reinterpret_cast<const uint32_t*>(smem);
     const uint32_t* tab2 = tab + 256;
     const uint8_t* raw = smem + kEncTab;
@@ -197,7 +198,7 @@ MG_HD void encode_chunks(const MgConfig& cfg, const EncodeLaunch& lc, const Enco
     uint8_t* dst = out + (size_t)P.g0 * 3;
     const int nbytes = P.len * 3;
     const int NQ = 3 * PC / 16;
-    for (int q = tid; q < NQ; q += T) {
+    for (int q = q_first + tid; q < NQ; q += T) {
         if (16 * q >= nbytes) break;
         const uint32_t qd = ((uint32_t)q * 21846u) >> 16;                   // q / 3 (q < 32768)
         const uint32_t p = (uint32_t)q - 3u * qd;                           // the chunk's first byte is byte p of its first cell
@@ -255,6 +256,79 @@ MG_HD void encode_chunks(const MgConfig& cfg, const EncodeLaunch& lc, const Enco
             for (int i = 0; i < 16 && 16 * q + i < nbytes; i++) dst[16 * q + i] = (uint8_t)(w4[i >> 2] >> (8 * (i & 3)));
         }
     }
+}
+
+// C'. The same output by RUNS: a lane per 16 consecutive cells = 48 output bytes = three whole aligned chunks (a piece starts at
+// a multiple of 16 cells), where object ids and agent marks share the byte plane, nothing is masked (no vis_mask) and a run
+// touches at most two envs (W * H >= 16): ONE division, ONE window of 16 grid bytes (five aligned dwords cut with v_alignbyte; a
+// second one, the next env's first bytes, merged in byte-wise with v_bfi where the env ends inside the run), sixteen table
+// look-ups, twelve v_perm_b32, three 16-byte LDS stores — 2.5 instructions per output byte where the chunk form (one division, one window
+// of 6 cells, 6 look-ups, 9 permutes per 16 bytes) spends 4.4: the kernel is bound by its instructions, not by its bytes
+// (measurement build: everything but the stores 8.4 of 10.5 us at 32 768 envs, 43.0 of 44.4 at 262 144; the stores alone 5.8
+// / 22.6).  Returns the first chunk it did NOT write: encode_chunks finishes the piece from there (the batch's last cells).
+// (a lane's 48 bytes go to the piece's OUTPUT IMAGE in LDS — `stg`, 48 bytes per run behind the planes —, and encode_runs_store
+// streams that image out with a lane per chunk, consecutive lanes consecutive chunks: stored straight from the run's lane, three
+// 16-byte stores 48 bytes apart per lane, every wave-store touched 24 cache lines a third each — slower than the chunk form)
+MG_HD int encode_runs(const MgConfig& cfg, const EncodeLaunch& lc, const EncodePiece& P, uint8_t* smem, int tid, int T) {
+    const uint32_t* tab = reinterpret_cast<const uint32_t*>(smem);
+    const uint8_t* raw = smem + kEncTab;
+    uint8_t* stg = smem + kEncTab + lc.nraw;
+    const int cells = lc.cells, stride = cfg.cells_stride;
+    const int nrun = P.len >> 4;
+    for (int r = tid; r < nrun; r += T) {
+        const int f = 16 * r;
+        const uint32_t cc = (uint32_t)(P.c0 + f);
+        const uint32_t e = enc_div(cc, (uint32_t)cells, lc.m_cells);
+        const int c = (int)cc - (int)e * cells;
+        const int nA = cells - c;                                           // cells left in this env, this one included
+        const int addrA = (int)e * stride + c - P.c0a;
+        MG_ENC_BOUNDS(addrA & ~3, 20);
+        uint32_t X[4];
+        {
+            const uint32_t sh = (uint32_t)addrA & 3u;
+            const uint32_t* w = reinterpret_cast<const uint32_t*>(raw + (addrA & ~3));
+            const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
+            X[0] = enc_align(w1, w0, sh); X[1] = enc_align(w2, w1, sh); X[2] = enc_align(w3, w2, sh); X[3] = enc_align(w4, w3, sh);
+        }
+        if (nA < 16 && f + nA < P.len) {     // the env ends inside the run: cells nA .. 15 are the next env's first
+            const int addrB = ((int)e + 1) * stride - P.c0a - nA;           // (its cell j - nA at byte j of this window)
+            MG_ENC_BOUNDS(addrB & ~3, 20);
+            const uint32_t sh = (uint32_t)addrB & 3u;
+            const uint32_t* w = reinterpret_cast<const uint32_t*>(raw + (addrB & ~3));
+            const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
+            const uint32_t Y[4] = {enc_align(w1, w0, sh), enc_align(w2, w1, sh), enc_align(w3, w2, sh), enc_align(w4, w3, sh)};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int t = nA - 4 * i;                                   // bytes of dword i that are still this env's
+                const uint32_t mA = t >= 4 ? 0xFFFFFFFFu : t <= 0 ? 0u : (1u << (8 * t)) - 1u;
+                X[i] = (X[i] & mA) | (Y[i] & ~mA);
+            }
+        }
+        uint32_t t[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) t[i] = tab[(X[i >> 2] >> (8 * (i & 3))) & 0xFFu];
+        typedef struct { uint32_t v[4]; } __attribute__((aligned(16))) q16;
+        q16 o[3];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {        // four cells -> three dwords
+            const uint32_t a = t[4 * k], b = t[4 * k + 1], cq = t[4 * k + 2], d = t[4 * k + 3];
+            const uint32_t d0 = enc_perm(b, a, 0x04020100u);        // a.0 a.1 a.2 b.0
+            const uint32_t d1 = enc_perm(cq, b, 0x05040201u);       // b.1 b.2 c.0 c.1
+            const uint32_t d2 = enc_perm(d, cq, 0x06050402u);       // c.2 d.0 d.1 d.2
+            const int j = 3 * k;
+            o[j >> 2].v[j & 3] = d0; o[(j + 1) >> 2].v[(j + 1) & 3] = d1; o[(j + 2) >> 2].v[(j + 2) & 3] = d2;
+        }
+        q16* d48 = reinterpret_cast<q16*>(stg + 48 * (size_t)r);
+        d48[0] = o[0]; d48[1] = o[1]; d48[2] = o[2];
+    }
+    return 3 * nrun;
+}
+MG_HD void encode_runs_store(const EncodeLaunch& lc, const EncodePiece& P, uint8_t* out, const uint8_t* smem, int tid, int T) {
+    typedef struct { uint32_t v[4]; } __attribute__((aligned(16))) q16;
+    const q16* stg = reinterpret_cast<const q16*>(smem + kEncTab + lc.nraw);
+    q16* dst = reinterpret_cast<q16*>(out + (size_t)P.g0 * 3);
+    const int nq = 3 * (P.len >> 4);
+    for (int q = tid; q < nq; q += T) dst[q] = stg[q];
 }
 
 // ---- the same inside the obs kernel's fused step (mg_render_kernel.h: mg_step_render_encode) ----------------------------
@@ -362,8 +436,10 @@ inline EncodeLaunch encode_launch(const MgConfig& cfg, const void* out, int& PC)
     lc.m_n = (uint32_t)((0x100000000ull + (uint32_t)cfg.n_agents - 1) / (uint32_t)cfg.n_agents);
     lc.two = cfg.n_obj + 4 * cfg.n_agents > 256 ? 1 : 0;
     lc.aligned = (reinterpret_cast<uintptr_t>(out) & 15) == 0 ? 1 : 0;
-    // pieces of 4096 cells (256 threads) where that makes a thousand workgroups, else of 1024 cells (one wave each)
-    if (PC == 0) PC = lc.total / 4096 >= 1024 ? 4096 : 1024;
+    lc.runs = (!lc.two && lc.aligned && lc.cells >= 16) ? 1 : 0;
+    // pieces of 8192 cells (512 threads: the tables and the three barriers of a workgroup per 24 KB of output) where that makes 512
+    // workgroups, of 4096 where that does, else of 1024 cells (one wave each)
+    if (PC == 0) PC = lc.total / 8192 >= 512 ? 8192 : lc.total / 4096 >= 512 ? 4096 : 1024;
     if (PC < 1024) PC = 1024;
     lc.nraw = encode_raw_bytes(lc.cells, cfg.cells_stride, PC);
     return lc;

@@ -220,13 +220,13 @@ int emu_gather(int vs, int ts, int n_vt, int n_dyn, const uint8_t* atlas_raw, co
 
 // mg_encode as its kernel runs it: piece by piece, phase by phase (a barrier between phases), thread by thread; the LDS
 // of a workgroup is a buffer of exactly the size the launcher asks for, filled with garbage first.  pc: 0 = the launcher's
-// choice, or 4096 / 1024.  Returns the number of out-of-range LDS offsets formed (0 = none), -1 for bad arguments.
+// choice, or 8192 / 4096 / 1024.  Returns the number of out-of-range LDS offsets formed (0 = none), -1 for bad arguments.
 int emu_encode(const MgConfig* cfg, const MgState* st, const uint8_t* vis, uint8_t* out, int pc) {
-    if (pc != 0 && pc != 4096 && pc != 1024) return -1;
+    if (pc != 0 && pc != 8192 && pc != 4096 && pc != 1024) return -1;
     int PC = pc;
     const mg::EncodeLaunch lc = mg::encode_launch(*cfg, out, PC);
     const int T = PC / 16;
-    const size_t lds = mg::kEncTab + (size_t)lc.nraw * (lc.two ? 2 : 1);
+    const size_t lds = mg::kEncTab + (size_t)lc.nraw * (lc.two ? 2 : 1) + (lc.runs ? 3 * (size_t)PC : 0);
     g_enc_plane_bytes = (uint32_t)lc.nraw;
     g_enc_oob = 0;
     const long long pieces = (lc.total + PC - 1) / PC;
@@ -238,7 +238,12 @@ int emu_encode(const MgConfig* cfg, const MgState* st, const uint8_t* vis, uint8
         if ((size_t)P.nd * 4 > (size_t)lc.nraw) return -2;
         for (int tid = 0; tid < T; tid++) mg::encode_stage(*cfg, *st, lc, P, sm, tid, T);
         for (int tid = 0; tid < T; tid++) mg::encode_agents(*cfg, *st, lc, P, sm, tid, T);
-        for (int tid = 0; tid < T; tid++) mg::encode_chunks(*cfg, lc, P, vis, out, sm, tid, T, PC);
+        int q_first = 0;        // (as the kernel: by runs of 16 cells where it can, the chunk form for the rest)
+        if (lc.runs && !vis) {
+            for (int tid = 0; tid < T; tid++) q_first = mg::encode_runs(*cfg, lc, P, sm, tid, T);
+            for (int tid = 0; tid < T; tid++) mg::encode_runs_store(lc, P, out, sm, tid, T);
+        }
+        for (int tid = 0; tid < T; tid++) mg::encode_chunks(*cfg, lc, P, vis, out, sm, tid, T, PC, q_first);
     }
     return (int)g_enc_oob;
 }

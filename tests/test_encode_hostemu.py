@@ -109,7 +109,7 @@ def test_encode_kernel_on_the_host(W, H, n):
     for B in (1, 2, 7, 19, 64):
         if B * W * H > 120000:
             continue
-        for pc in (1024, 4096):
+        for pc in (1024, 4096, 8192):
             run_case(rng, B, W, H, n, n_obj=int(rng.randint(2, 40)), pc=pc)
     run_case(rng, 33, W, H, n, n_obj=12, with_vis=True)
     run_case(rng, 9, W, H, n, n_obj=12, misalign=int(rng.randint(1, 16)))
@@ -128,4 +128,5 @@ def test_encode_agent_marks_in_their_own_plane():
 def test_encode_launcher_piece_choice():
     """the launcher's own choice of piece size (0): a batch large enough for 4096-cell pieces"""
     rng = np.random.RandomState(6)
-    run_case(rng, 19000, 15, 15, 3, n_obj=3)          # 4.3 M cells: 1 043 pieces of 4 096
+    run_case(rng, 19000, 15, 15, 3, n_obj=3)          # 4.3 M cells: 522 pieces of 8 192
+    run_case(rng, 9500, 15, 15, 3, n_obj=3)           # 2.1 M cells: 522 pieces of 4 096

@@ -22,7 +22,7 @@ for i in range(10):
     env.step(torch.randint(0, 7, (B, env.num_agents), generator=g).cuda())
 outs = {}
 res = {}
-sizes = [0, 1024, 2048, 4096, 8192, "empty"]      # "empty": the launcher's shape with a kernel that returns at once
+sizes = [0, 1024, 2048, 4096, 8192, 16384, "empty"]      # "empty": the launcher's shape with a kernel that returns at once
 for rep in range(7):
     for pc in sizes:
         os.environ["MG_ENCODE_EMPTY"] = "1" if pc == "empty" else "0"
