@@ -1,0 +1,33 @@
+#!/usr/bin/env python
+"""An ad-hoc sweep beyond the fuzz cases the suite runs: HIP batch == oracle, every step (tests/test_hip_parity.py::
+test_batch_vs_oracle) for scenarios.fuzz_case(i) / fuzz_wide_case(i), i in the given ranges.  The oracle is pinned against the
+LIVE reference for i < 51 (narrow) and i < 28 (wide) by the CPU suite; a mismatch found here is first re-checked there
+(tests/test_oracle_vs_reference.py) before anybody blames the kernel.
+usage: fuzz_sweep.py [narrow_lo narrow_hi wide_lo wide_hi]"""
+import os
+import sys
+import time
+import traceback
+import warnings
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+warnings.simplefilter("ignore")
+import test_hip_parity as T  # noqa: E402
+
+a = [int(x) for x in sys.argv[1:5]] if len(sys.argv) >= 5 else [51, 300, 28, 100]
+bad, t0, n = [], time.time(), 0
+for name, lo, hi, Bf, steps in (("Fuzz-%d", a[0], a[1], lambda i: 40 + (i % 3) * 33, 70), ("FuzzW-%d", a[2], a[3], lambda i: 9 + (i % 4) * 20, 45)):
+    for i in range(lo, hi):
+        try:
+            T.test_batch_vs_oracle(name % i, Bf(i), steps)
+        except NotImplementedError as e:          # a configuration the host rejects loudly (LDS budget): not a parity matter
+            print("skip", name % i, str(e)[:90], flush=True)
+        except Exception as e:                    # noqa: BLE001
+            bad.append(name % i)
+            print("FAIL", name % i, type(e).__name__, str(e)[:300], flush=True)
+            traceback.print_exc(limit=3)
+        n += 1
+print("%d cases in %.0f s; failures: %s" % (n, time.time() - t0, bad or "none"))
