@@ -27,6 +27,7 @@ How the line is measured (one self-consistent measurement, not a collage):
   * `clocks` holds rocm-smi samples before the first and after the last block; `roofline.traffic`
     is measured in this run (tools/pmc.py: rocprofv3 --pmc passes in a child process, N = 1 only).
   * `extra.strong_n1`: the full headline batch (262 144 envs) on ONE GPU, same fields.
+  * `extra.step_with_encode`: the step with `MultiGrid.encode` of the batch written by its own launch, against the step alone.
   * `extra.pipelined_shards`: the per-GPU batch (and twice it) as TWO envs on two streams, stepped without a join
     (marlgrid_amd.sharding.ShardPipeline): what overlapping launches of independent shards are worth, next to the
     same number of envs as one env.  The contract line itself is ONE env on one stream.
@@ -567,6 +568,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic = null)")
     ap.add_argument("--no-strong", action="store_true", help="skip the 262 144-env single-GPU point")
     ap.add_argument("--no-pipeline", action="store_true", help="skip extra.pipelined_shards (two envs on two streams)")
+    ap.add_argument("--no-encode-leg", action="store_true", help="skip extra.step_with_encode (the step with MultiGrid.encode from its own launch)")
     ap.add_argument("--unfused", action="store_true",
                     help="env.step() as two launches (mg_step, mg_render_obs) instead of one (mg_step_render): A/B only")
     ap.add_argument("--oversubscribe", action="store_true",
@@ -802,6 +804,58 @@ def main():
                     "stores of the other); same trajectories env by env; the contract line above is ONE env, one stream",
             "points": pts}
         out["value_pipelined_shards"] = pts[0]["value"]       # the same batch as two envs on two streams (extra.pipelined_shards)
+
+    # MultiGrid.encode of the stepped batch from the step's own launch (mg_step_render_encode; `encode_in_step=True`): what it adds
+    # to a step, against a second launch (VERDICT r05 item 3's "or inside the launch": asked <= +3 %)
+    def _with_encode():
+        import statistics
+        from marlgrid_amd.envs import make as mk
+        seeds_e = sharding.shard_seeds(1337, B, 0, 1)
+        env_e = mk(wl, batch_size=B, seeds=seeds_e, auto_reset=True, strict=False)
+        env_e.reset()
+        g = torch.Generator().manual_seed(11)
+        acts = [torch.randint(0, 7, (B, n), generator=g).to(dev) for _ in range(16)]
+        env_e.encode_in_step = True
+        for i in range(30):                      # identity first: the launch's encoding == mg_encode behind the step
+            env_e.step(acts[i % 16])
+            if not torch.equal(env_e.grid_encoding, env_e.grid.encode()):
+                raise RuntimeError("mg_step_render_encode differs from mg_encode at step %d" % i)
+        in_launch = bool(env_e._enc_fused) and env_e.fused_step and not env_e._hetero
+        enc2 = torch.empty_like(env_e.grid_encoding)
+        t = {"step": [], "step_with_encode": [], "step_then_mg_encode": []}
+        for rnd in range(7):
+            for mode in t:
+                env_e.encode_in_step = mode == "step_with_encode"
+                for i in range(10):
+                    env_e.step(acts[i % 16])
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for i in range(100):
+                    env_e.step(acts[i % 16])
+                    if mode == "step_then_mg_encode":
+                        env_e._encode_into(enc2)
+                e1.record()
+                torch.cuda.synchronize()
+                t[mode].append(e0.elapsed_time(e1) / 100)
+        env_e.check_errors()
+        med = {k: statistics.median(v) for k, v in t.items()}
+        res = {"what": "one env.step() of the contract workload with MultiGrid.encode of the batch (base.py:196-214) written by the "
+                       "step's own launch (encode_in_step=True -> mg_step_render_encode), against the step alone and against a second "
+                       "launch (mg_encode) behind it; interleaved rounds of 100 steps, medians of 7; identity with mg_encode checked "
+                       "over 30 steps first",
+               "ms": med, "encoding_written_by_the_step_launch": in_launch,
+               "step_with_encode_vs_step_pct": 100 * (med["step_with_encode"] / med["step"] - 1),
+               "step_then_mg_encode_vs_step_pct": 100 * (med["step_then_mg_encode"] / med["step"] - 1),
+               "encoding_bytes": int(enc2.numel()), "observation_bytes": int(env_e.obs.numel())}
+        del env_e
+        torch.cuda.empty_cache()
+        return res
+
+    if n_gpus == 1 and not args.no_encode_leg and wl == WORKLOAD:
+        res = leg("step_with_encode", _with_encode)
+        if res is not None:
+            out.setdefault("extra", {})["step_with_encode"] = res
 
     if rank == 0:
         if not args.no_cpu_baseline:
