@@ -39,7 +39,7 @@ class Config(C.Structure):
                 ("max_steps", C.c_int32), ("reward_decay", C.c_int32), ("ghost_mode", C.c_int32),
                 ("respawn", C.c_int32),
                 ("cells_stride", C.c_int32), ("n_obj", C.c_int32), ("n_ovl_slots", C.c_int32),
-                ("n_tiles", C.c_int32), ("agent_type_idx", C.c_int32), ("auto_reset", C.c_int32),
+                ("n_tiles", C.c_int32), ("agent_type_idx", C.c_int32), ("atlas_gather_off", C.c_int32),
                 ("spawn_x0", C.c_int32), ("spawn_y0", C.c_int32), ("spawn_x1", C.c_int32), ("spawn_y1", C.c_int32),
                 ("spawn_max_tries", C.c_int32),
                 ("n_view", C.c_int32), ("view_agent", C.c_uint8 * MAX_AGENTS),

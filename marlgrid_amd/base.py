@@ -26,6 +26,7 @@ Differences from the reference that the batch forces (documented in DESIGN.md):
 """
 import ctypes as C
 import functools
+import os
 import threading
 
 import numpy as np
@@ -1040,7 +1041,6 @@ class MultiGridEnv(object):
         # (base.py:683): they differ for falsy non-False values such as 0 or None
         cfg.ghost_mode = (1 if self.ghost_mode is not False else 0) | (2 if self.ghost_mode else 0)
         cfg.respawn = int(bool(self.respawn))
-        cfg.auto_reset = int(self.auto_reset)
         # place_obj(agent, **agent_spawn_kwargs) (base.py:411, 505, 643)
         kw = dict(self.agent_spawn_kwargs or {})
         reject_fn = kw.pop("reject_fn", None)
@@ -1107,6 +1107,22 @@ class MultiGridEnv(object):
                     "kernel has 160 KiB — with 'prestige' agents reduce their number or the tile size (every one of them has "
                     "its four recoloured sprites there); otherwise the number of agents / the view size" % (need // 1024))
             g.obj_dev = torch.from_numpy(raw).to(self.device)
+            # the 'prestige' gather instantiations (variant 9, raster 2: examples/human_player.py's shape) take the atlas in the
+            # raster's own LDS layout when the host has it ready — behind the plain one, `atlas_gather_off` bytes on —: building it
+            # per workgroup was 5 us of a 130 us launch (20 instructions per dword, 45 dwords per thread)
+            cfg.atlas_gather_off = 0
+            name0 = N.render_kernel_name(cfg)[0]
+            if name0.endswith(", 9, 2>") and not os.environ.get("MG_NO_GATHER_ATLAS"):
+                ts, seg = g.tile_size, 3 * g.tile_size
+                rs = (16 + seg + 3) // 4 * 4
+                rows = np.ascontiguousarray(flat[:4 * cfg.n_tiles * ts * seg]).reshape(-1, seg)
+                padded = np.zeros((rows.shape[0], rs), np.uint8)
+                padded[:, 16:16 + seg] = rows
+                pb = np.concatenate([padded.reshape(-1), np.zeros(32, np.uint8)])
+                pb = np.concatenate([pb, np.zeros((-pb.size) % 16, np.uint8)])
+                off = (flat.size + 15) // 16 * 16
+                flat = np.concatenate([flat, np.zeros(off - flat.size, np.uint8), pb])
+                cfg.atlas_gather_off = off
             g.atlas_dev = torch.from_numpy(flat).to(self.device)
             g.atlas = atlas
             cfg.obj, cfg.atlas = g.obj_dev.data_ptr(), g.atlas_dev.data_ptr()

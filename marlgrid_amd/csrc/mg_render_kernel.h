@@ -450,13 +450,29 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             uint2 pw[kPadQ];
 #pragma unroll
             for (int q = 0; q < kPadQ; q++) pw[q] = make_uint2(0, 0);
+            // ('prestige' gather instantiations: the host's copy of the atlas in this layout, when there is one — MgConfig::
+            // atlas_gather_off —, as plain 16-byte pieces: three per thread in this round trip, in the same registers)
+            const int goff = (kPadRows && kPrestige) ? cfg.atlas_gather_off : 0;
+            const int npq = (npd + 3) / 4;
+            static_assert(kPadQ == 6, "three uint4 of the ready-made atlas ride in pw[0..5]");
             if (first) {
                 if constexpr (kPadRows) {
+                    if (kPrestige && goff) {
+                        const uint4* psrc = reinterpret_cast<const uint4*>(cfg.atlas + goff);
+#pragma unroll
+                        for (int j = 0; j < 3; j++)
+                            if (tidl + j * T < npq) {
+                                const uint4 t4 = psrc[tidl + j * T];
+                                pw[2 * j] = make_uint2(t4.x, t4.y);
+                                pw[2 * j + 1] = make_uint2(t4.z, t4.w);
+                            }
+                    } else {
 #pragma unroll
                     for (int q = 0; q < kPadQ; q++) {
                         uint32_t cut, keep;
                         const int a = tidl + q * T < npd ? pad_source<3 * TS_, kPadFrontW, kRowW>(tidl + q * T, pad_rows, raw16, cut, keep) : -1;
                         if (a >= 0) pw[q] = *reinterpret_cast<const uint2*>(cfg.atlas + a);
+                    }
                     }
                 } else {
                     if (tidl < na) a0 = asrc[tidl];
@@ -507,6 +523,22 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             }
             if (first) {
                 if constexpr (kPadRows) {
+                    if (kPrestige && goff) {
+                        uint4* adst4 = reinterpret_cast<uint4*>(s_atlas);
+                        const uint4* psrc = reinterpret_cast<const uint4*>(cfg.atlas + goff);
+#pragma unroll
+                        for (int j = 0; j < 3; j++)
+                            if (tidl + j * T < npq) adst4[tidl + j * T] = make_uint4(pw[2 * j].x, pw[2 * j].y, pw[2 * j + 1].x, pw[2 * j + 1].y);
+                        for (int i0 = tidl + 3 * T; i0 < npq; i0 += 4 * T) {
+                            uint4 w[4];
+#pragma unroll
+                            for (int u = 0; u < 4; u++) w[u] = i0 + u * T < npq ? psrc[i0 + u * T] : make_uint4(0, 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int u = 0; u < 4; u++)
+                                if (i0 + u * T < npq) adst4[i0 + u * T] = w[u];
+                        }
+                    } else {
                     uint32_t* adst = reinterpret_cast<uint32_t*>(s_atlas);
 #pragma unroll
                     for (int q = 0; q < kPadQ; q++) {
@@ -536,6 +568,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
                             const int d = d0 + u * T;
                             if (d < npd) adst[d] = a[u] >= 0 ? pad_cut(w[u].x, w[u].y, cut[u], keep[u]) : 0u;
                         }
+                    }
                     }
                 } else {
                 uint4* adst = reinterpret_cast<uint4*>(s_atlas);
