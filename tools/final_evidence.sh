@@ -20,7 +20,7 @@ python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; tail -c 600
 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver.json 2> $OUT/bench_driver.err
 fi
 if [[ " $PARTS " == *" prof "* ]]; then
-( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rocprof -o bench -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-strong --no-pipeline --no-pmc --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err )
+( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rocprof -o bench -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-strong --no-pipeline --no-encode-leg --no-pmc --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err )
 find $OUT/rocprof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
 head -4 $OUT/kernel_stats.csv
 bash tools/step_counters.sh $OUT/pmc > /dev/null 2>&1; cp $OUT/pmc/step_counters.txt $OUT/ 2>/dev/null
