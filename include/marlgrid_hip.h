@@ -140,8 +140,8 @@ typedef struct MgConfig {
                                                                    * the atlas in the gather raster's LDS layout — per tile row 16 zero
                                                                    * bytes, its 3 * tile_size bytes, zeros up to a multiple of 4; 32 zero
                                                                    * bytes behind the last row; the whole rounded up to 16 —: the
-                                                                   * 'prestige' gather instantiations then copy it as it is instead of
-                                                                   * building it per workgroup (was: reserved) */
+                                                                   * gather instantiations (mg_render_kernel_name: <.., 2>) then copy it as
+                                                                   * it is instead of building it per workgroup (was: reserved) */
     int32_t spawn_x0, spawn_y0, spawn_x1, spawn_y1;               /* agent_spawn_kwargs top / size clamped to the
                                                                    * grid like base.py:692-695: agents are placed
                                                                    * in [x0,x1) x [y0,y1) (base.py:411, 505, 643) */

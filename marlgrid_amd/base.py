@@ -1107,12 +1107,13 @@ class MultiGridEnv(object):
                     "kernel has 160 KiB — with 'prestige' agents reduce their number or the tile size (every one of them has "
                     "its four recoloured sprites there); otherwise the number of agents / the view size" % (need // 1024))
             g.obj_dev = torch.from_numpy(raw).to(self.device)
-            # the 'prestige' gather instantiations (variant 9, raster 2: examples/human_player.py's shape) take the atlas in the
-            # raster's own LDS layout when the host has it ready — behind the plain one, `atlas_gather_off` bytes on —: building it
-            # per workgroup was 5 us of a 130 us launch (20 instructions per dword, 45 dwords per thread)
+            # the gather instantiations (raster 2: 5-, 6-, 7-, 9- ... 12-pixel tiles; examples/human_player.py's shape) take the atlas
+            # in the raster's own LDS layout when the host has it ready — behind the plain one, `atlas_gather_off` bytes on —: building
+            # it per workgroup was 5 us of human_player's 130 us launch (20 instructions per dword, 45 dwords per thread), 1 - 1.6 %
+            # of the others'
             cfg.atlas_gather_off = 0
             name0 = N.render_kernel_name(cfg)[0]
-            if name0.endswith(", 9, 2>") and not os.environ.get("MG_NO_GATHER_ATLAS"):
+            if name0.endswith(", 2>") and not os.environ.get("MG_NO_GATHER_ATLAS"):
                 ts, seg = g.tile_size, 3 * g.tile_size
                 rs = (16 + seg + 3) // 4 * 4
                 rows = np.ascontiguousarray(flat[:4 * cfg.n_tiles * ts * seg]).reshape(-1, seg)

@@ -450,14 +450,14 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             uint2 pw[kPadQ];
 #pragma unroll
             for (int q = 0; q < kPadQ; q++) pw[q] = make_uint2(0, 0);
-            // ('prestige' gather instantiations: the host's copy of the atlas in this layout, when there is one — MgConfig::
+            // (the host's copy of the atlas in this layout, when there is one — MgConfig::
             // atlas_gather_off —, as plain 16-byte pieces: three per thread in this round trip, in the same registers)
-            const int goff = (kPadRows && kPrestige) ? cfg.atlas_gather_off : 0;
+            const int goff = kPadRows ? cfg.atlas_gather_off : 0;
             const int npq = (npd + 3) / 4;
             static_assert(kPadQ == 6, "three uint4 of the ready-made atlas ride in pw[0..5]");
             if (first) {
                 if constexpr (kPadRows) {
-                    if (kPrestige && goff) {
+                    if (goff) {
                         const uint4* psrc = reinterpret_cast<const uint4*>(cfg.atlas + goff);
 #pragma unroll
                         for (int j = 0; j < 3; j++)
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(WPB * 64) void render_kernel(MgConfig cfg, MgState 
             }
             if (first) {
                 if constexpr (kPadRows) {
-                    if (kPrestige && goff) {
+                    if (goff) {
                         uint4* adst4 = reinterpret_cast<uint4*>(s_atlas);
                         const uint4* psrc = reinterpret_cast<const uint4*>(cfg.atlas + goff);
 #pragma unroll

@@ -116,11 +116,12 @@ def test_golden_trajectory(name):
         assert seeding.same_stream(env.numpy_rng_state(si), (g["mt_final"][si], g["mt_final_pos"][si])), (name, si)
 
 
-@pytest.mark.parametrize("name", ["Test-1AgentGoalcycle11x11-prestige-ts11", "Edge-2AgentGoalcycle9x9-prestige-tile5"])
+@pytest.mark.parametrize("name", ["Test-1AgentGoalcycle11x11-prestige-ts11", "Test-2AgentCluttered9x9-offset2-ts5",
+                                  "Edge-2AgentGoalcycle9x9-prestige-tile5"])
 def test_without_the_ready_made_gather_atlas(name, monkeypatch):
-    """the 'prestige' gather instantiations take the atlas in the raster's LDS layout from the host when it is there
-    (MgConfig.atlas_gather_off; marlgrid_amd/base.py builds it) — a C host that does not provide one gets the layout built per
-    workgroup, as before: the reference's golden (11-pixel tiles) / the oracle (5-pixel tiles) on that path"""
+    """the gather instantiations take the atlas in the raster's LDS layout from the host when it is there (MgConfig.
+    atlas_gather_off; marlgrid_amd/base.py builds it) — a C host that does not provide one gets the layout built per workgroup,
+    as before: the reference's goldens (11-pixel tiles with a 'prestige' agent; 5-pixel tiles) / the oracle on that path"""
     monkeypatch.setenv("MG_NO_GATHER_ATLAS", "1")
     if name.startswith("Test-"):
         test_golden_trajectory(name)
@@ -128,7 +129,7 @@ def test_without_the_ready_made_gather_atlas(name, monkeypatch):
         test_batch_vs_oracle(name, 300, 90)
     monkeypatch.delenv("MG_NO_GATHER_ATLAS")
     env = product_envs.build(name, batch_size=2)
-    assert env._cfg.atlas_gather_off > 0 and env.kernel_name.endswith(", 9, 2>")
+    assert env._cfg.atlas_gather_off > 0 and env.kernel_name.endswith(", 2>")
 
 
 def test_rng_seeding_golden():
