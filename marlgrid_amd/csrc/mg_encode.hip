@@ -48,7 +48,8 @@ __global__ __launch_bounds__(PC / 16) void encode_kernel(MgConfig cfg, MgState s
     int q_first = 0;
     if (lc.runs && !vis) {
         q_first = encode_runs(cfg, lc, P, smem, tid, T);
-        __syncthreads();
+        if (lc.runs == 2) wave_lds_sync();
+        else __syncthreads();
         encode_runs_store(lc, P, out, smem, tid, T);
     }
     encode_chunks(cfg, lc, P, vis, out, smem, tid, T, PC, q_first);

@@ -221,10 +221,13 @@ int emu_gather(int vs, int ts, int n_vt, int n_dyn, const uint8_t* atlas_raw, co
 // mg_encode as its kernel runs it: piece by piece, phase by phase (a barrier between phases), thread by thread; the LDS
 // of a workgroup is a buffer of exactly the size the launcher asks for, filled with garbage first.  pc: 0 = the launcher's
 // choice, or 8192 / 4096 / 1024.  Returns the number of out-of-range LDS offsets formed (0 = none), -1 for bad arguments.
+static int g_enc_force_runs = 0;      // 1 / 2: the store phase of encode_runs as large / small batches take it (0: as the launcher decides)
+void emu_encode_force_runs(int v) { g_enc_force_runs = v; }
 int emu_encode(const MgConfig* cfg, const MgState* st, const uint8_t* vis, uint8_t* out, int pc) {
     if (pc != 0 && pc != 8192 && pc != 4096 && pc != 1024) return -1;
     int PC = pc;
-    const mg::EncodeLaunch lc = mg::encode_launch(*cfg, out, PC);
+    mg::EncodeLaunch lc = mg::encode_launch(*cfg, out, PC);
+    if (lc.runs && g_enc_force_runs) lc.runs = g_enc_force_runs;
     const int T = PC / 16;
     const size_t lds = mg::kEncTab + (size_t)lc.nraw * (lc.two ? 2 : 1) + (lc.runs ? 3 * (size_t)PC : 0);
     g_enc_plane_bytes = (uint32_t)lc.nraw;

@@ -76,7 +76,12 @@ def run_case(rng, B, W, H, n, n_obj, pc=0, with_vis=False, misalign=0, crowd=Fal
     buf = np.full(B * cells * 3 + 64, 0x5A, np.uint8)
     off = (-buf.ctypes.data) % 16 + misalign
     out = buf[off:off + B * cells * 3]
+    # (the runs' store phase as large batches take it — a barrier, a lane per chunk of the piece — and as small ones do — a wave
+    # streams its own runs out —: the launcher picks by the number of pieces, the test takes turns)
+    run_case.turn = getattr(run_case, "turn", 0) + 1
+    L.emu_encode_force_runs(1 + run_case.turn % 2)
     rc = L.emu_encode(C.byref(cfg), C.byref(st), None if vis is None else C.c_void_p(vis.ctypes.data), C.c_void_p(out.ctypes.data), pc)
+    L.emu_encode_force_runs(0)
     assert rc == 0, "out-of-range LDS offsets: %d" % rc
     want = encode_reference(grid, rec, W, H, n_obj, obj_enc, 13, colors, vis)
     got = out.reshape(B, W, H, 3)
