@@ -412,6 +412,7 @@ def _encode_reference_torch(env):
 
 
 @pytest.mark.parametrize("name,B", [("MarlGrid-3AgentCluttered15x15-v0", 32768), ("MarlGrid-3AgentCluttered11x11-v0", 4096),
+                                    ("MarlGrid-3AgentCluttered15x15-v0", 80001),      # 2 198 pieces: the workgroup-wide store phase
                                     ("Test-4AgentEmpty5x5-crowded", 1000), ("Custom-8AgentCluttered30x30", 4099),
                                     ("Edge-2AgentCluttered40x40-view9-off3", 700), ("Edge-16AgentEmpty6x6-view7", 333),
                                     ("MarlGrid-2AgentEmpty9x9-v0", 1)])
